@@ -1,0 +1,197 @@
+/*
+ * rawdtw.h -- C ABI of the MI355X-native DTW alignment engine (librawdtw.so).
+ *
+ * This is the drop-in boundary for RawAlign's DTW hot path.  The reference has
+ * no plugin API; its boundary is the C++ free-function interface of
+ * src/dtw.hpp:21-29, called from exactly one place, align_chain
+ * (src/rmap.cpp:211,215,221,273,277,284).  Each entry point below names the
+ * reference interface it replaces.  Plain pointers and sizes only; every
+ * function returns a status code (no exceptions cross the ABI, no abort()).
+ *
+ * Threading: a rawdtw_ctx owns one HIP stream and is NOT re-entrant; use one
+ * ctx per host thread (or serialise).  Different ctxs are independent.
+ *
+ * Arithmetic contract: fp32, local distance |x-y|, cell = min3 + dist, sentinel
+ * = float(1e10); device code is built with -ffp-contract=off.  Costs are
+ * bit-identical to the reference for finite inputs (NaN inputs: unspecified).
+ */
+#ifndef RAWDTW_H
+#define RAWDTW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAWDTW_ABI_VERSION 1
+
+typedef enum {
+    RAWDTW_OK = 0,
+    RAWDTW_ERR_INVALID = 1,     /* zero length / negative radius: the reference assert()s (dtw.cpp:79,274-277) */
+    RAWDTW_ERR_DEVICE = 2,      /* HIP runtime error; see rawdtw_last_error */
+    RAWDTW_ERR_OOM = 3,
+    RAWDTW_ERR_RANGE = 4,       /* a job window lies outside the uploaded arenas */
+    RAWDTW_ERR_UNSUPPORTED = 5, /* e.g. traceback of a banded global job (rmap.cpp:223-225 assert(false)) */
+    RAWDTW_ERR_NO_DEVICE = 6
+} rawdtw_status;
+
+#define RAWDTW_FULL (-1) /* band_radius value selecting DTW_global (dtw.hpp:21) */
+
+/* One DTW sub-problem = one call of DTW_global / DTW_global_slantedbanded_antidiagonalwise
+ * (dtw.hpp:21,25) as align_chain issues it: a = read events window, b = reference
+ * signal window.  32 bytes. */
+typedef struct {
+    uint64_t ref_off;      /* element offset of b[0] in the reference arena (rawdtw_reference_offset) */
+    uint32_t read_off;     /* element offset of a[0] in the batch's event arena */
+    uint32_t n;            /* a_length: read events in the window (>=1) */
+    uint32_t m;            /* b_length: reference signals in the window (>=1) */
+    int32_t band_radius;   /* the band_radius argument (>=0), or RAWDTW_FULL */
+    uint32_t exclude_last; /* exclude_last_element */
+    uint32_t reserved;     /* 0 */
+} rawdtw_job_t;
+
+typedef struct rawdtw_ctx rawdtw_ctx;
+typedef struct rawdtw_plan rawdtw_plan;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int rawdtw_abi_version(void);
+int rawdtw_device_count(int *count);
+int rawdtw_create(int device_ordinal, rawdtw_ctx **out);
+int rawdtw_destroy(rawdtw_ctx *ctx);
+const char *rawdtw_last_error(const rawdtw_ctx *ctx);
+const char *rawdtw_status_string(int status);
+int rawdtw_sync(rawdtw_ctx *ctx);
+/* the ctx's hipStream_t, as void* (for event timing on the stream kernels run on) */
+int rawdtw_stream(rawdtw_ctx *ctx, void **stream);
+
+/* ---- reference signals: replaces ri_idx_t.forward_signals / reverse_signals
+ * (src/rawindex.h:32-34) as the `b` operand.  Uploaded once, resident in HBM.
+ * strand uses the reference's convention: chain.strand==1 selects fwd
+ * (rmap.cpp:182-188). ---- */
+int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const *fwd,
+                            const float *const *rev, const uint32_t *len);
+int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uint64_t *off);
+/* Adopt a device-resident arena instead (caller keeps ownership; 16-byte aligned). */
+int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats);
+
+/* ---- read events: the `a` operand (p->events[read].values, rmap.cpp:517) of all
+ * reads of a batch, concatenated by the caller. ---- */
+int rawdtw_upload_events(rawdtw_ctx *ctx, const float *h_events, uint64_t n_floats);
+int rawdtw_set_events_device(rawdtw_ctx *ctx, const float *d_events, uint64_t n_floats);
+
+/* ---- score-only batches: replaces the calls at rmap.cpp:211,215,273,277 ---- */
+/* One shot: upload events, bin + launch, copy costs back (out_cost[k] for jobs[k]). */
+int rawdtw_score_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs,
+                       const float *h_events, uint64_t n_events, float *out_cost);
+
+/* Split form, for callers that keep inputs resident (and for benchmarking):
+ * plan_create validates and size-bins the jobs and uploads device descriptors;
+ * plan_run only launches kernels on the ctx stream (asynchronous); costs stay in
+ * HBM in PLAN ORDER; plan_fetch waits and returns them in JOB order. */
+typedef struct {
+    uint64_t n_jobs;
+    uint64_t cells;            /* DP cells the batch evaluates (exact, band cell sets counted) */
+    uint64_t algorithmic_bytes; /* sum over jobs of 4(n+m)+4+32 */
+    uint64_t n_lane_jobs;      /* jobs on the lane-per-job banded kernel */
+    uint64_t n_wave_band_jobs; /* jobs on the wave-per-job banded kernel */
+    uint64_t n_full_jobs;      /* jobs on the full-matrix wavefront kernel */
+    uint64_t workspace_bytes;
+    uint32_t n_launches;
+} rawdtw_plan_info_t;
+
+int rawdtw_plan_create(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs,
+                       rawdtw_plan **out);
+int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info);
+int rawdtw_plan_run(rawdtw_ctx *ctx, rawdtw_plan *plan);
+int rawdtw_plan_fetch(rawdtw_ctx *ctx, rawdtw_plan *plan, float *out_cost);
+/* device pointer to the plan-order costs and the plan-order -> job index map */
+int rawdtw_plan_device_costs(const rawdtw_plan *plan, const float **d_cost,
+                             const uint32_t **h_order);
+/* per-launch kernel names and HIP-event durations (ms) of the most recent
+ * rawdtw_plan_run_timed; arrays hold up to n_launches entries */
+int rawdtw_plan_run_timed(rawdtw_ctx *ctx, rawdtw_plan *plan, float *launch_ms,
+                          uint32_t *launch_kind, uint32_t cap);
+int rawdtw_plan_destroy(rawdtw_plan *plan);
+
+/* ---- traceback batches: replaces DTW_global_tb (dtw.hpp:28) at rmap.cpp:221,284.
+ * Jobs must have band_radius == RAWDTW_FULL.  The direction matrix is kept as a
+ * packed 2-bit buffer in HBM and walked on the GPU.  path_off[k] (caller
+ * supplied, elements) locates job k's path inside path_i/path_j/path_d, which
+ * must have room for n+m-1 entries per job; entries come out in forward order,
+ * i indexing a (read window), j indexing b (reference window). ---- */
+int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs,
+                           const float *h_events, uint64_t n_events, float *out_cost,
+                           const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
+                           uint32_t *path_j, float *path_d);
+
+/* ---- single-call drop-ins with the reference's own signatures flattened
+ * (dtw.hpp:21,25,28).  Host pointers; convenient, not fast. ---- */
+int rawdtw_dtw_global(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m,
+                      int exclude_last, float *cost);
+int rawdtw_dtw_global_slantedbanded_antidiagonalwise(rawdtw_ctx *ctx, const float *a, uint32_t n,
+                                                     const float *b, uint32_t m, int band_radius,
+                                                     int exclude_last, float *cost);
+int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m,
+                         int exclude_last, float *cost, uint32_t *path_len, uint32_t *path_i,
+                         uint32_t *path_j, float *path_d);
+
+/* ---- host-side mirror of align_chain / the DTW block of gen_chains
+ * (src/rmap.cpp:181-313, 509-530): job decomposition and exact replay.  Pure
+ * host code, no device work. ---- */
+typedef struct {
+    uint32_t target_position;
+    uint32_t query_position;
+} rawdtw_anchor_t; /* ri_anchor_t, rmap.h:21-27; stored end-first like the reference */
+
+typedef struct {
+    int border_constraint;  /* 0 global, 1 sparse (roptions.h:21-23) */
+    int fill_method;        /* 0 full, 1 banded (roptions.h:25-26) */
+    float band_radius_frac; /* roptions.c:51 */
+    float match_bonus;      /* roptions.c:52 */
+    float min_score;        /* roptions.c:53 */
+    int fused_score;        /* 1: score = fmaf(n, bonus, -cost) as the reference's -O3 -march=native build contracts it */
+} rawdtw_align_opt_t;
+
+/* Number of DTW jobs align_chain issues for a chain (before any early exit). */
+uint32_t rawdtw_chain_job_count(const rawdtw_align_opt_t *opt, uint32_t n_anchors);
+/* Emit those jobs. ref_base = arena offset of the chain's strand array
+ * (rawdtw_reference_offset), read_base = arena offset of the read's events. */
+int rawdtw_chain_build_jobs(const rawdtw_align_opt_t *opt, const rawdtw_anchor_t *anchors,
+                            uint32_t n_anchors, uint64_t ref_base, uint32_t read_base, int cigar,
+                            rawdtw_job_t *jobs_out);
+/* Fold per-job costs back into align_chain's result, replaying its early exits
+ * (rmap.cpp:205-209, 265-268) with min_score. Returns the alignment score. */
+float rawdtw_chain_replay(const rawdtw_align_opt_t *opt, const rawdtw_anchor_t *anchors,
+                          uint32_t n_anchors, const float *job_cost, float min_score);
+/* The sequential loop of rmap.cpp:515-524 over one read's chains, given in
+ * evaluation order; chain c owns job_cost[job_off[c]..job_off[c+1]).  Writes
+ * score[c], keep[c]; returns the number kept. */
+uint32_t rawdtw_read_replay(const rawdtw_align_opt_t *opt, uint32_t n_chains,
+                            const uint32_t *anchor_off, const rawdtw_anchor_t *anchors,
+                            const uint64_t *job_off, const float *job_cost, float *score,
+                            uint8_t *keep);
+
+
+/* The evaluation order of one read's chains: the permutation std::sort (libstdc++, unstable)
+ * produces for the comparator a.chaining_score > b.chaining_score (rmap.cpp:512). */
+int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out);
+
+/* Batched forms over many reads (what rmap.cpp's per-read worker does for every read of a
+ * mini-batch, hoisted around one GPU submission).  Chains are listed read by read, each read's
+ * chains already in the reference's evaluation order (std::sort by chaining_score descending,
+ * rmap.cpp:512).  chain c owns anchors[anchor_off[c]..anchor_off[c+1]); read r owns chains
+ * [chain_off[r], chain_off[r+1]).  ref_base[c]/read_base[c]: arena offsets for chain c.
+ * job_off (n_chains+1 entries) is written by build and read by replay. */
+int rawdtw_batch_build_jobs(const rawdtw_align_opt_t *opt, uint64_t n_chains, const uint64_t *anchor_off,
+                            const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                            const uint32_t *read_base, uint64_t *job_off, rawdtw_job_t *jobs_out,
+                            uint64_t jobs_cap, uint64_t *n_jobs_out);
+int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
+                        const uint64_t *job_off, const float *job_cost, float *score, uint8_t *keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAWDTW_H */

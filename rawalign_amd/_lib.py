@@ -1,0 +1,104 @@
+"""ctypes binding to librawdtw.so (the C ABI declared in include/rawdtw.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class RawDTWError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"rawdtw status {status}: {msg}")
+        self.status = status
+
+
+def library_path() -> str:
+    return os.environ.get("RAWDTW_LIBRARY", os.path.join(HERE, "librawdtw.so"))
+
+
+class AlignOpt(C.Structure):
+    _fields_ = [
+        ("border_constraint", C.c_int),
+        ("fill_method", C.c_int),
+        ("band_radius_frac", C.c_float),
+        ("match_bonus", C.c_float),
+        ("min_score", C.c_float),
+        ("fused_score", C.c_int),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("n_jobs", C.c_uint64),
+        ("cells", C.c_uint64),
+        ("algorithmic_bytes", C.c_uint64),
+        ("n_lane_jobs", C.c_uint64),
+        ("n_wave_band_jobs", C.c_uint64),
+        ("n_full_jobs", C.c_uint64),
+        ("workspace_bytes", C.c_uint64),
+        ("n_launches", C.c_uint32),
+    ]
+
+
+# every symbol include/rawdtw.h declares: name -> (restype, argtypes)
+VP, U64, U32, I32, F32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float
+SYMBOLS = {
+    "rawdtw_abi_version": (I32, []),
+    "rawdtw_device_count": (I32, [C.POINTER(I32)]),
+    "rawdtw_create": (I32, [I32, C.POINTER(VP)]),
+    "rawdtw_destroy": (I32, [VP]),
+    "rawdtw_last_error": (C.c_char_p, [VP]),
+    "rawdtw_status_string": (C.c_char_p, [I32]),
+    "rawdtw_sync": (I32, [VP]),
+    "rawdtw_stream": (I32, [VP, C.POINTER(VP)]),
+    "rawdtw_upload_reference": (I32, [VP, U32, VP, VP, VP]),
+    "rawdtw_reference_offset": (I32, [VP, U32, I32, C.POINTER(U64)]),
+    "rawdtw_set_reference_device": (I32, [VP, VP, U64]),
+    "rawdtw_upload_events": (I32, [VP, VP, U64]),
+    "rawdtw_set_events_device": (I32, [VP, VP, U64]),
+    "rawdtw_score_batch": (I32, [VP, VP, U64, VP, U64, VP]),
+    "rawdtw_plan_create": (I32, [VP, VP, U64, C.POINTER(VP)]),
+    "rawdtw_plan_info": (I32, [VP, C.POINTER(PlanInfo)]),
+    "rawdtw_plan_run": (I32, [VP, VP]),
+    "rawdtw_plan_fetch": (I32, [VP, VP, VP]),
+    "rawdtw_plan_device_costs": (I32, [VP, C.POINTER(VP), C.POINTER(VP)]),
+    "rawdtw_plan_run_timed": (I32, [VP, VP, VP, VP, U32]),
+    "rawdtw_plan_destroy": (I32, [VP]),
+    "rawdtw_traceback_batch": (I32, [VP, VP, U64, VP, U64, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_dtw_global": (I32, [VP, VP, U32, VP, U32, I32, C.POINTER(F32)]),
+    "rawdtw_dtw_global_slantedbanded_antidiagonalwise": (I32, [VP, VP, U32, VP, U32, I32, I32, C.POINTER(F32)]),
+    "rawdtw_dtw_global_tb": (I32, [VP, VP, U32, VP, U32, I32, C.POINTER(F32), C.POINTER(U32), VP, VP, VP]),
+    "rawdtw_chain_job_count": (U32, [C.POINTER(AlignOpt), U32]),
+    "rawdtw_chain_build_jobs": (I32, [C.POINTER(AlignOpt), VP, U32, U64, U32, I32, VP]),
+    "rawdtw_chain_replay": (F32, [C.POINTER(AlignOpt), VP, U32, VP, F32]),
+    "rawdtw_read_replay": (U32, [C.POINTER(AlignOpt), U32, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_sort_by_chaining_score": (I32, [VP, U32, VP]),
+    "rawdtw_batch_build_jobs": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, U64, C.POINTER(U64)]),
+    "rawdtw_batch_replay": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, VP]),
+}
+
+
+def load_library():
+    """Load librawdtw.so; raises LibraryMissing (never falls back to anything else)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LibraryMissing(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rawalign_amd/csrc` (hipcc, --offload-arch=gfx950)"
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

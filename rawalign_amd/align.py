@@ -1,0 +1,200 @@
+"""Host-side mirror of align_chain (src/rmap.cpp:181-313) and of the DTW block of gen_chains
+(src/rmap.cpp:509-530), driving the GPU engine: build every chain's DTW jobs, score them in one
+batch on the device, then replay the reference's sequential accept/cut logic on the host.
+
+Names follow the reference: MapOpt fields are ri_mapopt_t's (src/roptions.h:61-65), Chain fields
+are ri_chain_t's (src/rmap.h:29-46)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import AlignOpt
+from .dtw import ANCHOR_DTYPE, JOB_DTYPE, DtwResult, Engine
+
+# src/roptions.h:13-15,21-26
+RI_M_DTW_EVALUATE_CHAINS = 0x2
+RI_M_DTW_OUTPUT_CIGAR = 0x4
+RI_M_DTW_LOG_SCORES = 0x8
+RI_M_DTW_BORDER_CONSTRAINT_GLOBAL = 0
+RI_M_DTW_BORDER_CONSTRAINT_SPARSE = 1
+RI_M_DTW_BORDER_CONSTRAINT_LOCAL = 2
+RI_M_DTW_FILL_METHOD_FULL = 0
+RI_M_DTW_FILL_METHOD_BANDED = 1
+
+
+@dataclass
+class MapOpt:
+    """The ri_mapopt_t fields the hot path reads, with the defaults of src/roptions.c:49-53."""
+
+    dtw_border_constraint: int = RI_M_DTW_BORDER_CONSTRAINT_SPARSE
+    dtw_fill_method: int = RI_M_DTW_FILL_METHOD_BANDED
+    dtw_band_radius_frac: float = 0.10
+    dtw_match_bonus: float = 0.4
+    dtw_min_score: float = 20.0
+    flag: int = RI_M_DTW_EVALUATE_CHAINS
+    # rmap.cpp:306 compiles to one fused multiply-subtract with the reference's flags on an FMA host
+    fused_score: bool = True
+
+    def c_struct(self) -> AlignOpt:
+        if self.dtw_border_constraint not in (0, 1):
+            # rmap.cpp:301-304: fprintf(stderr, "ERROR: invalid border constraint") + exit(EXIT_FAILURE)
+            raise SystemExit("ERROR: invalid border constraint")
+        return AlignOpt(self.dtw_border_constraint, self.dtw_fill_method, self.dtw_band_radius_frac,
+                        self.dtw_match_bonus, self.dtw_min_score, int(self.fused_score))
+
+
+@dataclass
+class Chain:
+    chaining_score: float
+    reference_sequence_index: int
+    strand: int
+    anchors: np.ndarray  # ANCHOR_DTYPE, end-first: anchors[n-1] is the chain start (rmap.cpp:193-196)
+    alignment_score: float = 0.0
+    dtw_result: DtwResult | None = None
+
+    @property
+    def n_anchors(self) -> int:
+        return len(self.anchors)
+
+
+@dataclass
+class ReadCandidates:
+    """One read at one chunk round: its global event array and the chains gen_chains produced."""
+
+    events: np.ndarray
+    chains: list = field(default_factory=list)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def evaluation_order(engine: Engine, chaining_scores) -> np.ndarray:
+    s = np.ascontiguousarray(chaining_scores, dtype=np.float32)
+    perm = np.zeros(len(s), np.uint32)
+    engine._check(engine.lib.rawdtw_sort_by_chaining_score(_ptr(s), len(s), _ptr(perm)))
+    return perm
+
+
+def evaluate_reads(engine: Engine, reads, opt: MapOpt):
+    """The DTW block of gen_chains for a whole batch of reads (rmap.cpp:509-530).
+
+    The reference reference-signal arrays must already be uploaded (engine.upload_reference).
+    Returns, per read, the list of surviving chains (post_alignment_chains, in evaluation order)
+    with alignment_score filled in, plus batch statistics."""
+    copt = opt.c_struct()
+    lib = engine.lib
+    # flatten
+    ev_parts, read_base = [], []
+    acc = 0
+    for r in reads:
+        ev = np.ascontiguousarray(r.events, dtype=np.float32)
+        ev_parts.append(ev)
+        read_base.append(acc)
+        acc += len(ev)
+    events = np.concatenate(ev_parts) if ev_parts else np.zeros(0, np.float32)
+    order_per_read, chain_list = [], []
+    chain_off = np.zeros(len(reads) + 1, np.uint64)
+    for ri, r in enumerate(reads):
+        perm = evaluation_order(engine, [c.chaining_score for c in r.chains])
+        order_per_read.append(perm)
+        for k in perm:
+            chain_list.append((ri, r.chains[int(k)]))
+        chain_off[ri + 1] = len(chain_list)
+    n_chains = len(chain_list)
+    anchor_off = np.zeros(n_chains + 1, np.uint64)
+    ref_base = np.zeros(n_chains, np.uint64)
+    rbase = np.zeros(n_chains, np.uint32)
+    for c, (ri, ch) in enumerate(chain_list):
+        anchor_off[c + 1] = anchor_off[c] + np.uint64(ch.n_anchors)
+        ref_base[c] = engine.reference_offset(ch.reference_sequence_index, ch.strand)
+        rbase[c] = read_base[ri]
+    anchors = (np.concatenate([np.ascontiguousarray(ch.anchors, dtype=ANCHOR_DTYPE) for _, ch in chain_list])
+               if n_chains else np.zeros(0, ANCHOR_DTYPE))
+    job_off = np.zeros(n_chains + 1, np.uint64)
+    n_jobs = C.c_uint64()
+    engine._check(lib.rawdtw_batch_build_jobs(C.byref(copt), n_chains, _ptr(anchor_off), _ptr(anchors),
+                                              _ptr(ref_base), _ptr(rbase), _ptr(job_off), None, 0,
+                                              C.byref(n_jobs)))
+    jobs = np.zeros(n_jobs.value, JOB_DTYPE)
+    engine._check(lib.rawdtw_batch_build_jobs(C.byref(copt), n_chains, _ptr(anchor_off), _ptr(anchors),
+                                              _ptr(ref_base), _ptr(rbase), _ptr(job_off), _ptr(jobs),
+                                              len(jobs), C.byref(n_jobs)))
+    cost = engine.score_batch(jobs, events)
+    score = np.zeros(n_chains, np.float32)
+    keep = np.zeros(n_chains, np.uint8)
+    engine._check(lib.rawdtw_batch_replay(C.byref(copt), len(reads), _ptr(chain_off), _ptr(anchor_off),
+                                          _ptr(anchors), _ptr(job_off), _ptr(cost), _ptr(score), _ptr(keep)))
+    out = []
+    for ri in range(len(reads)):
+        kept = []
+        for c in range(int(chain_off[ri]), int(chain_off[ri + 1])):
+            ch = chain_list[c][1]
+            ch.alignment_score = float(score[c])
+            if keep[c]:
+                kept.append(ch)
+        out.append(kept)
+    stats = {"n_chains": n_chains, "n_jobs": int(n_jobs.value), "jobs": jobs, "job_cost": cost,
+             "scores": score, "keep": keep}
+    return out, stats
+
+
+def align_chain(engine: Engine, chain: Chain, read_events, opt: MapOpt, cigar: bool = False,
+                min_score: float = -1e10) -> Chain:
+    """align_chain for one chain (rmap.cpp:181-313).  With cigar=True the traceback jobs run on the
+    GPU and chain.dtw_result is assembled with the reference's quirks (SURVEY.md 8 a-4 i, ii)."""
+    copt = opt.c_struct()
+    lib = engine.lib
+    anchors = np.ascontiguousarray(chain.anchors, dtype=ANCHOR_DTYPE)
+    na = len(anchors)
+    nj = lib.rawdtw_chain_job_count(C.byref(copt), na)
+    jobs = np.zeros(max(nj, 1), JOB_DTYPE)
+    ref_base = engine.reference_offset(chain.reference_sequence_index, chain.strand)
+    st = lib.rawdtw_chain_build_jobs(C.byref(copt), _ptr(anchors), na, ref_base, 0, int(cigar), _ptr(jobs))
+    if st == 5:
+        # rmap.cpp:223-225: assert(false) //not implemented
+        raise AssertionError("banded global alignment with --dtw-output-cigar is not implemented")
+    engine._check(st)
+    jobs = jobs[:nj]
+    ev = np.ascontiguousarray(read_events, dtype=np.float32)
+    if not cigar:
+        cost = engine.score_batch(jobs, ev)
+        chain.alignment_score = float(lib.rawdtw_chain_replay(C.byref(copt), _ptr(anchors), na, _ptr(cost),
+                                                               C.c_float(min_score)))
+        return chain
+    results = engine.traceback_batch(jobs, ev)
+    cost = np.array([r.cost for r in results], np.float32)
+    # rmap.cpp:306 with the summed sub-costs; no early exit on this path (min_score defaults to -1e10)
+    chain.alignment_score = float(lib.rawdtw_chain_replay(C.byref(copt), _ptr(anchors), na, _ptr(cost),
+                                                           C.c_float(-1e10)))
+    if opt.dtw_border_constraint == RI_M_DTW_BORDER_CONSTRAINT_GLOBAL:
+        r = results[0]
+        pi = r.i.astype(np.uint64)
+        pj = r.j.astype(np.uint64)
+        # rmap.cpp:230-233: the loop adds the anchor offsets to alignment.back() once per element
+        if len(pi):
+            pi[-1] += np.uint64(len(pi)) * np.uint64(anchors[na - 1]["query_position"])
+            pj[-1] += np.uint64(len(pj)) * np.uint64(anchors[na - 1]["target_position"])
+        chain.dtw_result = DtwResult(np.float32(r.cost), pi, pj, r.difference)
+    else:
+        parts = na - 1
+        pis, pjs, pds = [], [], []
+        total = np.float32(0.0)
+        for p, r in enumerate(results):
+            s = anchors[parts - p]
+            pis.append(r.i.astype(np.uint64) + np.uint64(s["query_position"]))   # rmap.cpp:287
+            pjs.append(r.j.astype(np.uint64) + np.uint64(s["target_position"]))  # rmap.cpp:288
+            pds.append(r.difference)
+            total = np.float32(total + r.cost)                                    # rmap.cpp:290
+        chain.dtw_result = DtwResult(total, np.concatenate(pis) if pis else np.zeros(0, np.uint64),
+                                     np.concatenate(pjs) if pjs else np.zeros(0, np.uint64),
+                                     np.concatenate(pds) if pds else np.zeros(0, np.float32))
+    return chain
+
+
+def dtwresult_to_string(res: DtwResult) -> str:
+    """rmap.cpp:580-592: "(i,j,diff)" per element, diff through ostream<<float (== %g)."""
+    return "".join("(%d,%d,%s)" % (int(i), int(j), "%g" % float(d)) for i, j, d in zip(res.i, res.j, res.difference))

@@ -1,0 +1,718 @@
+// rawdtw_capi.cpp -- the C ABI of librawdtw.so (include/rawdtw.h): context, arenas, the
+// batch planner and the launch sequences.  Host code only; kernels live in rawdtw_kernels.hip.
+//
+// There is NO CPU fallback in here: every scoring entry point runs the HIP kernels or
+// returns an error status.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rawdtw_internal.h"
+
+using namespace rawdtw;
+
+struct rawdtw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // reference arena
+    float *d_ref = nullptr;
+    uint64_t n_ref = 0;
+    bool own_ref = false;
+    std::vector<uint64_t> ref_off; // 2*n_seq entries: [seq*2 + 0] = forward (strand 1), [seq*2 + 1] = reverse
+    std::vector<uint32_t> ref_len;
+    // event arena
+    float *d_ev = nullptr;
+    uint64_t n_ev = 0, cap_ev = 0;
+    bool own_ev = false;
+    std::string err;
+};
+
+struct rawdtw_plan {
+    rawdtw_ctx *ctx = nullptr;
+    uint64_t n_jobs = 0;
+    std::vector<uint32_t> order;   // plan position -> job index
+    std::vector<Launch> launches;
+    std::vector<int32_t> launch_rpl;
+    DevJob *d_jobs = nullptr;
+    FullAux *d_aux = nullptr;      // indexed like d_jobs (only meaningful for full-matrix jobs)
+    float *d_cost = nullptr;
+    float *d_bnd = nullptr;
+    uint8_t *d_dir = nullptr;
+    uint64_t bnd_floats = 0, dir_bytes = 0;
+    std::vector<DevJob> h_jobs;    // plan order (kept for traceback + info)
+    std::vector<FullAux> h_aux;
+    rawdtw_plan_info_t info{};
+    bool cells_counted = false;
+};
+
+namespace {
+
+int fail(rawdtw_ctx *ctx, int status, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return status;
+}
+
+int hip_fail(rawdtw_ctx *ctx, hipError_t e, const char *what)
+{
+    int st = (e == hipErrorOutOfMemory) ? RAWDTW_ERR_OOM : RAWDTW_ERR_DEVICE;
+    return fail(ctx, st, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr);                                      \
+    } while (0)
+
+// post-slant radius, dtw.cpp:298-300 (unsigned 32-bit arithmetic for the correction)
+inline int slanted_radius(uint32_t n, uint32_t m, int r0)
+{
+    uint32_t N = n > m ? n : m, M = n > m ? m : n;
+    uint32_t extra = ((N - M) * (uint32_t)r0 + N - 1u) / N;
+    return r0 + (int)extra;
+}
+
+// exact size of the band's cell set (same walk as the kernels; host side, for reporting)
+uint64_t banded_cells(uint32_t n, uint32_t m, int R)
+{
+    const uint32_t N = n > m ? n : m, M = n > m ? m : n;
+    const int P = R + ((R % 2 == 0) ? 1 : 0), S = R + ((R % 2 == 1) ? 1 : 0);
+    uint64_t cells = 1;
+    int row = 0;
+    uint32_t rem = 0;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        if (adv) { rem -= N; row++; }
+        for (int pass = adv ? 0 : 1; pass < 2; pass++) {
+            const int len = pass == 0 ? S : P;
+            const int si = pass == 0 ? (int)col + S / 2 - 1 : (int)col + P / 2;
+            const int sj = pass == 0 ? row - S / 2 : row - P / 2;
+            int lo = 0, hi = len;
+            lo = std::max(lo, si - (int)N + 1);
+            lo = std::max(lo, -sj);
+            hi = std::min(hi, si + 1);
+            hi = std::min(hi, (int)M - sj);
+            if (hi > lo) cells += (uint64_t)(hi - lo);
+        }
+    }
+    return cells;
+}
+
+inline int full_rpl(uint32_t ny)
+{
+    return ny <= 64 ? 1 : ny <= 128 ? 2 : ny <= 256 ? 4 : 8;
+}
+
+inline uint64_t dir_bytes_for(uint32_t n, uint32_t m, int rpl)
+{
+    const uint32_t NX = n > m ? n : m, NY = n > m ? m : n;
+    const uint64_t strips = (NY + 64ull * rpl - 1) / (64ull * rpl);
+    const uint64_t word = rpl == 8 ? 2 : 1;
+    return strips * ((uint64_t)NX + 63) * 64 * word;
+}
+
+template <typename T> int dev_alloc(rawdtw_ctx *ctx, T **p, uint64_t count)
+{
+    *p = nullptr;
+    if (count == 0) return RAWDTW_OK;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return RAWDTW_OK;
+}
+
+int ensure_events_capacity(rawdtw_ctx *ctx, uint64_t n)
+{
+    if (ctx->own_ev && ctx->cap_ev >= n) return RAWDTW_OK;
+    if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
+    ctx->d_ev = nullptr;
+    ctx->own_ev = true;
+    uint64_t cap = std::max<uint64_t>(n + (n >> 2), 1024);
+    cap = (cap + 63) & ~63ull;
+    int st = dev_alloc(ctx, &ctx->d_ev, cap);
+    if (st != RAWDTW_OK) { ctx->cap_ev = 0; return st; }
+    ctx->cap_ev = cap;
+    return RAWDTW_OK;
+}
+
+// Build a plan. traceback=true: every job must be a full-matrix job and gets a direction buffer.
+int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool traceback,
+               rawdtw_plan **out)
+{
+    *out = nullptr;
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (n_jobs > 0 && !jobs) return fail(ctx, RAWDTW_ERR_INVALID, "jobs is NULL");
+    if (n_jobs >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "more than 2^32-1 jobs in one batch");
+    rawdtw_plan *pl = new (std::nothrow) rawdtw_plan;
+    if (!pl) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    pl->ctx = ctx;
+    pl->n_jobs = n_jobs;
+
+    // sort key: class in the top bits, then descending length so long jobs start first
+    //   banded lane : class = R (0..12)
+    //   banded wave : class = 16 + lds bucket
+    //   full        : class = 32 + log2(rpl)
+    struct Keyed { uint64_t key; uint32_t idx; int32_t R; };
+    std::vector<Keyed> keyed(n_jobs);
+    uint64_t alg_bytes = 0;
+    for (uint64_t k = 0; k < n_jobs; k++) {
+        const rawdtw_job_t &j = jobs[k];
+        if (j.n == 0 || j.m == 0 || j.band_radius < RAWDTW_FULL ||
+            j.n >= 0x7fffffffu || j.m >= 0x7fffffffu) {
+            delete pl;
+            return fail(ctx, RAWDTW_ERR_INVALID,
+                        "job " + std::to_string(k) + ": zero length or negative band radius (dtw.cpp:274-277 asserts)");
+        }
+        if ((uint64_t)j.read_off + j.n > ctx->n_ev || j.ref_off + j.m > ctx->n_ref) {
+            delete pl;
+            return fail(ctx, RAWDTW_ERR_RANGE, "job " + std::to_string(k) + ": window outside the uploaded arenas");
+        }
+        alg_bytes += 4ull * ((uint64_t)j.n + j.m) + 4 + 32;
+        const uint32_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m);
+        uint64_t cls;
+        int32_t R = -1;
+        if (j.band_radius == RAWDTW_FULL) {
+            const int rpl = full_rpl(NY);
+            cls = 32 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
+        } else {
+            if (traceback) {
+                delete pl;
+                return fail(ctx, RAWDTW_ERR_UNSUPPORTED,
+                            "traceback of a banded job is not implemented (rmap.cpp:223-225 assert(false))");
+            }
+            R = slanted_radius(j.n, j.m, j.band_radius);
+            if (R < 0 || R + 1 > kMaxWaveBandK) {
+                delete pl;
+                return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
+            }
+            if (R <= kMaxLaneRadius) cls = (uint64_t)R;
+            else {
+                const uint32_t K = (uint32_t)R + 1;
+                // LDS buckets: 3K floats <= 1.5K, 6K, 24K, 40K floats
+                cls = 16 + (K <= 512 ? 0 : K <= 2048 ? 1 : K <= 8192 ? 2 : 3);
+            }
+        }
+        keyed[k].key = (cls << 40) | (uint64_t)(0xffffffffffull - N);
+        keyed[k].idx = (uint32_t)k;
+        keyed[k].R = R;
+    }
+    std::sort(keyed.begin(), keyed.end(), [](const Keyed &x, const Keyed &y) {
+        return x.key != y.key ? x.key < y.key : x.idx < y.idx;
+    });
+
+    pl->order.resize(n_jobs);
+    pl->h_jobs.resize(n_jobs);
+    pl->h_aux.assign(n_jobs, FullAux{0, 0});
+    uint64_t bnd = 0, dirb = 0;
+    for (uint64_t p = 0; p < n_jobs; p++) {
+        const rawdtw_job_t &j = jobs[keyed[p].idx];
+        pl->order[p] = keyed[p].idx;
+        DevJob &d = pl->h_jobs[p];
+        d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
+        d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = (uint32_t)p;
+        const uint64_t cls = keyed[p].key >> 40;
+        if (cls >= 32) {
+            const int rpl = 1 << (cls - 32);
+            const uint32_t NX = std::max(j.n, j.m), NY = std::min(j.n, j.m);
+            if (NY > 64u * rpl) { // multi-strip: needs a boundary row
+                pl->h_aux[p].bnd_off = bnd;
+                bnd += ((uint64_t)NX + 63) & ~63ull;
+            }
+            if (traceback) {
+                pl->h_aux[p].dir_off = dirb;
+                dirb += (dir_bytes_for(j.n, j.m, rpl) + 255) & ~255ull;
+            }
+        }
+        // launches: maximal runs of equal class
+        if (pl->launches.empty() || (keyed[p - 1].key >> 40) != cls) {
+            Launch L{};
+            L.first = p; L.count = 0;
+            if (cls < 16) { L.kind = kKindBandLane; L.param = (int32_t)cls; }
+            else if (cls < 32) {
+                static const int32_t lds_f[4] = {3 * 512, 3 * 2048, 3 * 8192, 3 * kMaxWaveBandK};
+                L.kind = kKindBandWave; L.param = lds_f[cls - 16];
+            } else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 32); }
+            pl->launches.push_back(L);
+        }
+        pl->launches.back().count++;
+    }
+    // a banded-wave launch only needs LDS for its own largest K (jobs are sorted by N, not K)
+    for (Launch &L : pl->launches)
+        if (L.kind == kKindBandWave) {
+            int32_t kmax = 0;
+            for (uint64_t p = L.first; p < L.first + L.count; p++) kmax = std::max(kmax, pl->h_jobs[p].R + 1);
+            L.param = 3 * kmax;
+        }
+    pl->bnd_floats = bnd;
+    pl->dir_bytes = dirb;
+
+    rawdtw_plan_info_t &I = pl->info;
+    I.n_jobs = n_jobs;
+    I.algorithmic_bytes = alg_bytes;
+    I.n_launches = (uint32_t)pl->launches.size();
+    for (const Launch &L : pl->launches) {
+        if (L.kind == kKindBandLane) I.n_lane_jobs += L.count;
+        else if (L.kind == kKindBandWave) I.n_wave_band_jobs += L.count;
+        else I.n_full_jobs += L.count;
+    }
+    I.workspace_bytes = bnd * 4 + dirb + n_jobs * (sizeof(DevJob) + sizeof(FullAux) + 4);
+
+    int st;
+    if ((st = dev_alloc(ctx, &pl->d_jobs, n_jobs)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_aux, n_jobs)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_bnd, bnd)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_dir, dirb)) != RAWDTW_OK) {
+        rawdtw_plan_destroy(pl);
+        return st;
+    }
+    if (n_jobs) {
+        hipError_t e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data(), n_jobs * sizeof(DevJob),
+                                      hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data(), n_jobs * sizeof(FullAux), hipMemcpyHostToDevice,
+                               ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            rawdtw_plan_destroy(pl);
+            return hip_fail(ctx, e, "uploading job descriptors");
+        }
+    }
+    *out = pl;
+    return RAWDTW_OK;
+}
+
+int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L)
+{
+    const DevJob *jobs = pl->d_jobs + L.first;
+    float *out = pl->d_cost + L.first;
+    hipError_t e = hipSuccess;
+    switch (L.kind) {
+    case kKindBandLane:
+        e = launch_band_lane(L.param, jobs, L.count, ctx->d_ev, ctx->d_ref, out, ctx->stream);
+        break;
+    case kKindBandWave:
+        e = launch_band_wave(jobs, L.count, (uint32_t)L.param, ctx->d_ev, ctx->d_ref, out, ctx->stream);
+        break;
+    case kKindFullWave:
+    case kKindFullTb:
+        e = launch_full_wave(L.param, L.kind == kKindFullTb, jobs, L.count, pl->d_aux + L.first, ctx->d_ev,
+                             ctx->d_ref, out, pl->d_bnd, pl->d_dir, ctx->stream);
+        break;
+    default:
+        return fail(ctx, RAWDTW_ERR_INVALID, "unknown launch kind");
+    }
+    if (e != hipSuccess) return hip_fail(ctx, e, "kernel launch");
+    return RAWDTW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rawdtw_abi_version(void) { return RAWDTW_ABI_VERSION; }
+
+const char *rawdtw_status_string(int status)
+{
+    switch (status) {
+    case RAWDTW_OK: return "ok";
+    case RAWDTW_ERR_INVALID: return "invalid argument";
+    case RAWDTW_ERR_DEVICE: return "HIP runtime error";
+    case RAWDTW_ERR_OOM: return "out of memory";
+    case RAWDTW_ERR_RANGE: return "job window out of range";
+    case RAWDTW_ERR_UNSUPPORTED: return "unsupported";
+    case RAWDTW_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+    }
+}
+
+int rawdtw_device_count(int *count)
+{
+    if (!count) return RAWDTW_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return RAWDTW_OK;
+}
+
+int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
+{
+    if (!out) return RAWDTW_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RAWDTW_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return RAWDTW_ERR_INVALID;
+    rawdtw_ctx *ctx = new (std::nothrow) rawdtw_ctx;
+    if (!ctx) return RAWDTW_ERR_OOM;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return RAWDTW_ERR_DEVICE;
+    }
+    *out = ctx;
+    return RAWDTW_OK;
+}
+
+int rawdtw_destroy(rawdtw_ctx *ctx)
+{
+    if (!ctx) return RAWDTW_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
+    delete ctx;
+    return RAWDTW_OK;
+}
+
+const char *rawdtw_last_error(const rawdtw_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rawdtw_sync(rawdtw_ctx *ctx)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RAWDTW_OK;
+}
+
+int rawdtw_stream(rawdtw_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return RAWDTW_ERR_INVALID;
+    *stream = (void *)ctx->stream;
+    return RAWDTW_OK;
+}
+
+int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const *fwd,
+                            const float *const *rev, const uint32_t *len)
+{
+    if (!ctx || (n_seq && (!fwd || !rev || !len))) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    ctx->d_ref = nullptr; ctx->own_ref = true; ctx->n_ref = 0;
+    ctx->ref_off.assign(2ull * n_seq, 0);
+    ctx->ref_len.assign(len, len + n_seq);
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < n_seq; s++) {
+        // every array starts on a 16-byte boundary so 128-bit loads of window chunks stay aligned
+        ctx->ref_off[2 * s] = total; total += ((uint64_t)len[s] + 3) & ~3ull;
+        ctx->ref_off[2 * s + 1] = total; total += ((uint64_t)len[s] + 3) & ~3ull;
+    }
+    int st = dev_alloc(ctx, &ctx->d_ref, std::max<uint64_t>(total, 4));
+    if (st != RAWDTW_OK) return st;
+    ctx->n_ref = total;
+    for (uint32_t s = 0; s < n_seq; s++) {
+        if (len[s] == 0) continue;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref + ctx->ref_off[2 * s], fwd[s], (size_t)len[s] * 4,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref + ctx->ref_off[2 * s + 1], rev[s], (size_t)len[s] * 4,
+                                    hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RAWDTW_OK;
+}
+
+int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uint64_t *off)
+{
+    if (!ctx || !off || 2ull * seq + 1 >= ctx->ref_off.size() + 0ull) return RAWDTW_ERR_INVALID;
+    // rmap.cpp:182-188: strand==1 -> forward_signals, otherwise reverse_signals
+    *off = ctx->ref_off[2ull * seq + (strand == 1 ? 0 : 1)];
+    return RAWDTW_OK;
+}
+
+int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats)
+{
+    if (!ctx || (!d_ref && n_floats)) return fail(ctx, RAWDTW_ERR_INVALID, "null reference arena");
+    if (((uintptr_t)d_ref & 15u) != 0) return fail(ctx, RAWDTW_ERR_INVALID, "reference arena must be 16-byte aligned");
+    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    ctx->d_ref = const_cast<float *>(d_ref);
+    ctx->n_ref = n_floats;
+    ctx->own_ref = false;
+    ctx->ref_off.clear();
+    ctx->ref_len.clear();
+    return RAWDTW_OK;
+}
+
+int rawdtw_upload_events(rawdtw_ctx *ctx, const float *h_events, uint64_t n_floats)
+{
+    if (!ctx || (!h_events && n_floats)) return fail(ctx, RAWDTW_ERR_INVALID, "null events");
+    if (n_floats >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "event arena limited to 2^32-1 floats per batch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->own_ev) { ctx->d_ev = nullptr; ctx->cap_ev = 0; ctx->own_ev = true; }
+    int st = ensure_events_capacity(ctx, n_floats);
+    if (st != RAWDTW_OK) return st;
+    if (n_floats)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ev, h_events, n_floats * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_ev = n_floats;
+    return RAWDTW_OK;
+}
+
+int rawdtw_set_events_device(rawdtw_ctx *ctx, const float *d_events, uint64_t n_floats)
+{
+    if (!ctx || (!d_events && n_floats)) return fail(ctx, RAWDTW_ERR_INVALID, "null event arena");
+    if (((uintptr_t)d_events & 15u) != 0) return fail(ctx, RAWDTW_ERR_INVALID, "event arena must be 16-byte aligned");
+    if (n_floats >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "event arena limited to 2^32-1 floats per batch");
+    if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
+    ctx->d_ev = const_cast<float *>(d_events);
+    ctx->n_ev = n_floats;
+    ctx->cap_ev = 0;
+    ctx->own_ev = false;
+    return RAWDTW_OK;
+}
+
+int rawdtw_plan_create(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, rawdtw_plan **out)
+{
+    if (!out) return RAWDTW_ERR_INVALID;
+    if (ctx) { hipError_t e = hipSetDevice(ctx->device); if (e != hipSuccess) return hip_fail(ctx, e, "hipSetDevice"); }
+    return build_plan(ctx, jobs, n_jobs, false, out);
+}
+
+int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info)
+{
+    if (!plan || !info) return RAWDTW_ERR_INVALID;
+    rawdtw_plan *pl = const_cast<rawdtw_plan *>(plan);
+    if (!pl->cells_counted) {
+        uint64_t cells = 0;
+        for (const DevJob &d : pl->h_jobs)
+            cells += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
+        pl->info.cells = cells;
+        pl->cells_counted = true;
+    }
+    *info = pl->info;
+    return RAWDTW_OK;
+}
+
+int rawdtw_plan_run(rawdtw_ctx *ctx, rawdtw_plan *plan)
+{
+    if (!ctx || !plan || plan->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "plan does not belong to this context");
+    for (const Launch &L : plan->launches) {
+        int st = run_launch(ctx, plan, L);
+        if (st != RAWDTW_OK) return st;
+    }
+    return RAWDTW_OK;
+}
+
+int rawdtw_plan_run_timed(rawdtw_ctx *ctx, rawdtw_plan *plan, float *launch_ms, uint32_t *launch_kind,
+                          uint32_t cap)
+{
+    if (!ctx || !plan || plan->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "plan does not belong to this context");
+    const size_t nl = plan->launches.size();
+    std::vector<hipEvent_t> ev(nl + 1, nullptr);
+    for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    int st = RAWDTW_OK;
+    for (size_t i = 0; i < nl && st == RAWDTW_OK; i++) {
+        st = run_launch(ctx, plan, plan->launches[i]);
+        if (st == RAWDTW_OK && hipEventRecord(ev[i + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    }
+    if (st == RAWDTW_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    for (size_t i = 0; i < nl && st == RAWDTW_OK; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) { st = RAWDTW_ERR_DEVICE; break; }
+        if (i < cap) {
+            if (launch_ms) launch_ms[i] = ms;
+            if (launch_kind) launch_kind[i] = plan->launches[i].kind | ((uint32_t)plan->launches[i].param << 8);
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (st != RAWDTW_OK && ctx->err.empty()) ctx->err = "timed run failed";
+    return st;
+}
+
+int rawdtw_plan_fetch(rawdtw_ctx *ctx, rawdtw_plan *plan, float *out_cost)
+{
+    if (!ctx || !plan || plan->ctx != ctx || (!out_cost && plan->n_jobs))
+        return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to plan_fetch");
+    if (plan->n_jobs == 0) return RAWDTW_OK;
+    std::vector<float> tmp(plan->n_jobs);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), plan->d_cost, plan->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t p = 0; p < plan->n_jobs; p++) out_cost[plan->order[p]] = tmp[p];
+    return RAWDTW_OK;
+}
+
+int rawdtw_plan_device_costs(const rawdtw_plan *plan, const float **d_cost, const uint32_t **h_order)
+{
+    if (!plan) return RAWDTW_ERR_INVALID;
+    if (d_cost) *d_cost = plan->d_cost;
+    if (h_order) *h_order = plan->order.data();
+    return RAWDTW_OK;
+}
+
+int rawdtw_plan_destroy(rawdtw_plan *plan)
+{
+    if (!plan) return RAWDTW_OK;
+    if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
+    if (plan->d_jobs) (void)hipFree(plan->d_jobs);
+    if (plan->d_aux) (void)hipFree(plan->d_aux);
+    if (plan->d_cost) (void)hipFree(plan->d_cost);
+    if (plan->d_bnd) (void)hipFree(plan->d_bnd);
+    if (plan->d_dir) (void)hipFree(plan->d_dir);
+    delete plan;
+    return RAWDTW_OK;
+}
+
+int rawdtw_score_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, const float *h_events,
+                       uint64_t n_events, float *out_cost)
+{
+    int st = rawdtw_upload_events(ctx, h_events, n_events);
+    if (st != RAWDTW_OK) return st;
+    rawdtw_plan *pl = nullptr;
+    st = rawdtw_plan_create(ctx, jobs, n_jobs, &pl);
+    if (st != RAWDTW_OK) return st;
+    st = rawdtw_plan_run(ctx, pl);
+    if (st == RAWDTW_OK) st = rawdtw_plan_fetch(ctx, pl, out_cost);
+    rawdtw_plan_destroy(pl);
+    return st;
+}
+
+int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, const float *h_events,
+                           uint64_t n_events, float *out_cost, const uint64_t *path_off, uint32_t *path_len,
+                           uint32_t *path_i, uint32_t *path_j, float *path_d)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (n_jobs && (!jobs || !out_cost || !path_off || !path_len || !path_i || !path_j || !path_d))
+        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    int st = rawdtw_upload_events(ctx, h_events, n_events);
+    if (st != RAWDTW_OK) return st;
+
+    // sub-batches bounded by the direction-buffer budget
+    uint64_t budget = 16ull << 30;
+    if (const char *e = getenv("RAWDTW_TB_WORKSPACE_MB")) budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
+    uint64_t begin = 0;
+    while (begin < n_jobs) {
+        uint64_t end = begin, bytes = 0, path_elems = 0;
+        while (end < n_jobs) {
+            const rawdtw_job_t &j = jobs[end];
+            if (j.n == 0 || j.m == 0) return fail(ctx, RAWDTW_ERR_INVALID, "zero-length traceback job");
+            const uint64_t b = dir_bytes_for(j.n, j.m, full_rpl(std::min(j.n, j.m))) + 256;
+            if (end > begin && bytes + b > budget) break;
+            bytes += b;
+            path_elems += (uint64_t)j.n + j.m - 1;
+            end++;
+        }
+        const uint64_t cnt = end - begin;
+        rawdtw_plan *pl = nullptr;
+        st = build_plan(ctx, jobs + begin, cnt, true, &pl);
+        if (st != RAWDTW_OK) return st;
+        // device path buffers in plan order
+        std::vector<uint64_t> h_poff(cnt);
+        uint64_t acc = 0;
+        for (uint64_t p = 0; p < cnt; p++) {
+            h_poff[p] = acc;
+            acc += (uint64_t)pl->h_jobs[p].n + pl->h_jobs[p].m - 1;
+        }
+        uint64_t *d_poff = nullptr;
+        uint32_t *d_plen = nullptr, *d_pi = nullptr, *d_pj = nullptr;
+        float *d_pd = nullptr;
+        auto cleanup = [&]() {
+            if (d_poff) (void)hipFree(d_poff);
+            if (d_plen) (void)hipFree(d_plen);
+            if (d_pi) (void)hipFree(d_pi);
+            if (d_pj) (void)hipFree(d_pj);
+            if (d_pd) (void)hipFree(d_pd);
+            rawdtw_plan_destroy(pl);
+        };
+        if ((st = dev_alloc(ctx, &d_poff, cnt)) != RAWDTW_OK || (st = dev_alloc(ctx, &d_plen, cnt)) != RAWDTW_OK ||
+            (st = dev_alloc(ctx, &d_pi, acc)) != RAWDTW_OK || (st = dev_alloc(ctx, &d_pj, acc)) != RAWDTW_OK ||
+            (st = dev_alloc(ctx, &d_pd, acc)) != RAWDTW_OK) {
+            cleanup();
+            return st;
+        }
+        hipError_t e = hipMemcpyAsync(d_poff, h_poff.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "path offsets upload"); }
+        st = rawdtw_plan_run(ctx, pl);
+        if (st != RAWDTW_OK) { cleanup(); return st; }
+        for (const Launch &L : pl->launches) {
+            e = launch_tb_walk(pl->d_jobs + L.first, L.count, pl->d_aux + L.first, L.param, ctx->d_ev, ctx->d_ref,
+                               pl->d_dir, d_poff + L.first, d_plen + L.first, d_pi, d_pj, d_pd, ctx->stream);
+            if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback walk launch"); }
+        }
+        std::vector<float> h_cost(cnt), h_pd(acc);
+        std::vector<uint32_t> h_plen(cnt), h_pi(acc), h_pj(acc);
+        e = hipMemcpyAsync(h_cost.data(), pl->d_cost, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_plen.data(), d_plen, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && acc) e = hipMemcpyAsync(h_pi.data(), d_pi, acc * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && acc) e = hipMemcpyAsync(h_pj.data(), d_pj, acc * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && acc) e = hipMemcpyAsync(h_pd.data(), d_pd, acc * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback download"); }
+        for (uint64_t p = 0; p < cnt; p++) {
+            const uint64_t k = begin + pl->order[p];
+            out_cost[k] = h_cost[p];
+            const uint32_t len = h_plen[p];
+            // device paths are end-first; the reference returns them start-first (dtw.cpp:656-657)
+            // and pops the last element when exclude_last_element is set (dtw.cpp:659-663)
+            const uint32_t outlen = jobs[k].exclude_last ? len - 1 : len;
+            const uint64_t src = h_poff[p], dst = path_off[k];
+            for (uint32_t q = 0; q < outlen; q++) {
+                path_i[dst + q] = h_pi[src + len - 1 - q];
+                path_j[dst + q] = h_pj[src + len - 1 - q];
+                path_d[dst + q] = h_pd[src + len - 1 - q];
+            }
+            path_len[k] = outlen;
+        }
+        cleanup();
+        begin = end;
+    }
+    return RAWDTW_OK;
+}
+
+// ---- single-call drop-ins ----------------------------------------------------------------------
+static int single_call(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m, int radius,
+                       int excl, float *cost)
+{
+    if (!ctx || !a || !b || !cost) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (n == 0 || m == 0 || radius < RAWDTW_FULL) return fail(ctx, RAWDTW_ERR_INVALID, "zero length or negative radius");
+    // b goes to a private reference arena for the duration of the call
+    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; bool saved_own = ctx->own_ref;
+    float *d_b = nullptr;
+    int st = dev_alloc(ctx, &d_b, ((uint64_t)m + 3) & ~3ull);
+    if (st != RAWDTW_OK) return st;
+    hipError_t e = hipMemcpyAsync(d_b, b, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(ctx, e, "operand upload"); }
+    ctx->d_ref = d_b; ctx->n_ref = m; ctx->own_ref = false;
+    rawdtw_job_t j{0, 0, n, m, radius, excl ? 1u : 0u, 0};
+    st = rawdtw_score_batch(ctx, &j, 1, a, n, cost);
+    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n; ctx->own_ref = saved_own;
+    (void)hipFree(d_b);
+    return st;
+}
+
+int rawdtw_dtw_global(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m, int exclude_last,
+                      float *cost)
+{
+    return single_call(ctx, a, n, b, m, RAWDTW_FULL, exclude_last, cost);
+}
+
+int rawdtw_dtw_global_slantedbanded_antidiagonalwise(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b,
+                                                     uint32_t m, int band_radius, int exclude_last, float *cost)
+{
+    if (band_radius < 0) return fail(ctx, RAWDTW_ERR_INVALID, "negative band radius (dtw.cpp:277 asserts)");
+    return single_call(ctx, a, n, b, m, band_radius, exclude_last, cost);
+}
+
+int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m, int exclude_last,
+                         float *cost, uint32_t *path_len, uint32_t *path_i, uint32_t *path_j, float *path_d)
+{
+    if (!ctx || !a || !b || !cost || !path_len || !path_i || !path_j || !path_d)
+        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (n == 0 || m == 0) return fail(ctx, RAWDTW_ERR_INVALID, "zero length (dtw.cpp:596 asserts)");
+    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; bool saved_own = ctx->own_ref;
+    float *d_b = nullptr;
+    int st = dev_alloc(ctx, &d_b, ((uint64_t)m + 3) & ~3ull);
+    if (st != RAWDTW_OK) return st;
+    hipError_t e = hipMemcpyAsync(d_b, b, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(ctx, e, "operand upload"); }
+    ctx->d_ref = d_b; ctx->n_ref = m; ctx->own_ref = false;
+    rawdtw_job_t j{0, 0, n, m, RAWDTW_FULL, exclude_last ? 1u : 0u, 0};
+    uint64_t off = 0;
+    st = rawdtw_traceback_batch(ctx, &j, 1, a, n, cost, &off, path_len, path_i, path_j, path_d);
+    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n; ctx->own_ref = saved_own;
+    (void)hipFree(d_b);
+    return st;
+}
+
+} // extern "C"

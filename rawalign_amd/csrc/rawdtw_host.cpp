@@ -1,0 +1,207 @@
+// rawdtw_host.cpp -- host-side mirror of align_chain (src/rmap.cpp:181-313) and of the DTW block
+// of gen_chains (src/rmap.cpp:509-530), split in two so that the DTW calls in the middle can be
+// executed as one GPU batch:
+//
+//   rawdtw_chain_build_jobs : the decomposition of a chain into DTW sub-problems
+//   rawdtw_chain_replay     : the fold of the per-job costs, including the early exits that
+//                             depend on the running best score (rmap.cpp:205-209, 265-268)
+//   rawdtw_read_replay      : the sequential best-so-far loop over one read's chains
+//
+// The GPU evaluates every job of every chain speculatively; the replay then reproduces exactly
+// which chains the reference would have cut, so the filtered chain set (and everything
+// downstream: primary chains, MAPQ, the stop rule) is unchanged.  No device code here.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rawdtw.h"
+
+namespace {
+
+inline int band_radius_for(uint32_t read_region_size, float frac)
+{
+    // rmap.cpp:214,276: std::max(1, (int)(read_region_size * opt->dtw_band_radius_frac)), fp32 product
+    int r = (int)((float)read_region_size * frac);
+    return r > 1 ? r : 1;
+}
+
+inline float final_score(uint32_t num_aligned, const rawdtw_align_opt_t *opt, float cost)
+{
+    // rmap.cpp:306.  With the reference's flags (-O3 -march=native, GCC's default
+    // -ffp-contract=fast) this statement is a single fused multiply-subtract on FMA hosts.
+    if (opt->fused_score) return std::fmaf((float)num_aligned, opt->match_bonus, -cost);
+    volatile float prod = (float)num_aligned * opt->match_bonus; // keep the product rounded
+    return prod - cost;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rawdtw_chain_job_count(const rawdtw_align_opt_t *opt, uint32_t n_anchors)
+{
+    if (!opt || n_anchors == 0) return 0;
+    return opt->border_constraint == 0 ? 1u : n_anchors - 1;
+}
+
+int rawdtw_chain_build_jobs(const rawdtw_align_opt_t *opt, const rawdtw_anchor_t *anchors, uint32_t n_anchors,
+                            uint64_t ref_base, uint32_t read_base, int cigar, rawdtw_job_t *jobs_out)
+{
+    if (!opt || !anchors || n_anchors == 0 || !jobs_out) return RAWDTW_ERR_INVALID;
+    if (opt->border_constraint != 0 && opt->border_constraint != 1)
+        return RAWDTW_ERR_INVALID; // rmap.cpp:301-304: "invalid border constraint" -> exit
+    const bool banded = opt->fill_method != 0;
+    if (opt->border_constraint == 0) {
+        const rawdtw_anchor_t &s = anchors[n_anchors - 1]; // chain start (rmap.cpp:195)
+        const rawdtw_anchor_t &e = anchors[0];             // chain end   (rmap.cpp:196)
+        rawdtw_job_t &j = jobs_out[0];
+        j.ref_off = ref_base + s.target_position;
+        j.read_off = read_base + s.query_position;
+        j.m = e.target_position - s.target_position + 1;
+        j.n = e.query_position - s.query_position + 1;
+        j.exclude_last = 0;
+        j.reserved = 0;
+        if (cigar) {
+            if (banded) return RAWDTW_ERR_UNSUPPORTED; // rmap.cpp:223-225 assert(false)
+            j.band_radius = RAWDTW_FULL;
+        } else {
+            j.band_radius = banded ? band_radius_for(j.n, opt->band_radius_frac) : RAWDTW_FULL;
+        }
+        return RAWDTW_OK;
+    }
+    const uint32_t parts = n_anchors - 1;
+    for (uint32_t p = 0; p < parts; p++) {
+        const rawdtw_anchor_t &s = anchors[parts - p];     // rmap.cpp:253
+        const rawdtw_anchor_t &e = anchors[parts - p - 1]; // rmap.cpp:254
+        rawdtw_job_t &j = jobs_out[p];
+        j.ref_off = ref_base + s.target_position;
+        j.read_off = read_base + s.query_position;
+        j.m = e.target_position - s.target_position + 1;
+        j.n = e.query_position - s.query_position + 1;
+        j.reserved = 0;
+        if (cigar) {
+            // rmap.cpp:283-284: always DTW_global_tb, exclude_last_element never passed
+            j.band_radius = RAWDTW_FULL;
+            j.exclude_last = 0;
+        } else {
+            j.band_radius = banded ? band_radius_for(j.n, opt->band_radius_frac) : RAWDTW_FULL;
+            j.exclude_last = (p != parts - 1) ? 1u : 0u; // rmap.cpp:270
+        }
+    }
+    return RAWDTW_OK;
+}
+
+float rawdtw_chain_replay(const rawdtw_align_opt_t *opt, const rawdtw_anchor_t *anchors, uint32_t n_anchors,
+                          const float *job_cost, float min_score)
+{
+    float cost = 0.0f;
+    uint32_t num_aligned = 0;
+    const rawdtw_anchor_t &first = anchors[n_anchors - 1];
+    const rawdtw_anchor_t &last = anchors[0];
+    if (opt->border_constraint == 0) {
+        const uint32_t rn = last.query_position - first.query_position + 1;
+        const float attainable = (float)rn * opt->match_bonus; // rmap.cpp:205
+        if (attainable < min_score) return -1e10f;             // rmap.cpp:206-209
+        cost = job_cost[0];
+        num_aligned = rn;
+    } else {
+        const uint32_t parts = n_anchors - 1;
+        const uint32_t span = last.query_position - first.query_position + 1;
+        float attainable = (float)span * opt->match_bonus; // rmap.cpp:246
+        for (uint32_t p = 0; p < parts; p++) {
+            const rawdtw_anchor_t &s = anchors[parts - p];
+            const rawdtw_anchor_t &e = anchors[parts - p - 1];
+            if (attainable < min_score) return -1e10f; // rmap.cpp:265-268
+            const float sub = job_cost[p];
+            cost += sub;       // rmap.cpp:279 (fp32, in part order)
+            attainable -= sub; // rmap.cpp:280
+            num_aligned += e.query_position - s.query_position + 1; // rmap.cpp:292
+        }
+    }
+    return final_score(num_aligned, opt, cost);
+}
+
+uint32_t rawdtw_read_replay(const rawdtw_align_opt_t *opt, uint32_t n_chains, const uint32_t *anchor_off,
+                            const rawdtw_anchor_t *anchors, const uint64_t *job_off, const float *job_cost,
+                            float *score, uint8_t *keep)
+{
+    float best = 0.0f; // rmap.cpp:515
+    uint32_t kept = 0;
+    for (uint32_t c = 0; c < n_chains; c++) {
+        const uint32_t na = anchor_off[c + 1] - anchor_off[c];
+        const float s = rawdtw_chain_replay(opt, anchors + anchor_off[c], na, job_cost + job_off[c], best);
+        score[c] = s;
+        keep[c] = 0;
+        if (s >= opt->min_score) {  // rmap.cpp:518
+            if (s > best) best = s; // rmap.cpp:519-521
+            keep[c] = 1;
+            kept++;
+        }
+    }
+    return kept;
+}
+
+int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out)
+{
+    if ((!chaining_score || !perm_out) && n_chains) return RAWDTW_ERR_INVALID;
+    struct Item { float score; uint32_t idx; };
+    std::vector<Item> v(n_chains);
+    for (uint32_t c = 0; c < n_chains; c++) v[c] = Item{chaining_score[c], c};
+    // same algorithm, same comparator outcomes as rmap.cpp:512 => same permutation, ties included
+    std::sort(v.begin(), v.end(), [](const Item &a, const Item &b) { return a.score > b.score; });
+    for (uint32_t c = 0; c < n_chains; c++) perm_out[c] = v[c].idx;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_build_jobs(const rawdtw_align_opt_t *opt, uint64_t n_chains, const uint64_t *anchor_off,
+                            const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
+                            uint64_t *job_off, rawdtw_job_t *jobs_out, uint64_t jobs_cap, uint64_t *n_jobs_out)
+{
+    if (!opt || !anchor_off || !anchors || !ref_base || !read_base || !job_off || !n_jobs_out)
+        return RAWDTW_ERR_INVALID;
+    uint64_t total = 0;
+    for (uint64_t c = 0; c < n_chains; c++) {
+        const uint32_t na = (uint32_t)(anchor_off[c + 1] - anchor_off[c]);
+        const uint32_t nj = rawdtw_chain_job_count(opt, na);
+        job_off[c] = total;
+        if (jobs_out) {
+            if (total + nj > jobs_cap) return RAWDTW_ERR_RANGE;
+            if (nj) {
+                int st = rawdtw_chain_build_jobs(opt, anchors + anchor_off[c], na, ref_base[c], read_base[c], 0,
+                                                 jobs_out + total);
+                if (st != RAWDTW_OK) return st;
+            }
+        }
+        total += nj;
+    }
+    job_off[n_chains] = total;
+    *n_jobs_out = total;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *job_off,
+                        const float *job_cost, float *score, uint8_t *keep)
+{
+    if (!opt || !chain_off || !anchor_off || !anchors || !job_off || !job_cost || !score || !keep)
+        return RAWDTW_ERR_INVALID;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        float best = 0.0f; // rmap.cpp:515
+        for (uint64_t c = chain_off[r]; c < chain_off[r + 1]; c++) {
+            const uint32_t na = (uint32_t)(anchor_off[c + 1] - anchor_off[c]);
+            float s;
+            if (na < 1) s = 0.0f;
+            else s = rawdtw_chain_replay(opt, anchors + anchor_off[c], na, job_cost + job_off[c], best);
+            score[c] = s;
+            keep[c] = 0;
+            if (s >= opt->min_score) {  // rmap.cpp:518
+                if (s > best) best = s; // rmap.cpp:519-521
+                keep[c] = 1;
+            }
+        }
+    }
+    return RAWDTW_OK;
+}
+
+} // extern "C"

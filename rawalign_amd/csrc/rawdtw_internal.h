@@ -1,0 +1,66 @@
+// rawdtw_internal.h -- types shared by the HIP kernels and the host-side planner.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "../../include/rawdtw.h"
+
+namespace rawdtw {
+
+constexpr float kInf = 1e10f; // dtw.cpp:38,310-313: the float nearest 1e10
+
+// Device job record, 32 bytes, in PLAN order.  Written by the planner.
+struct DevJob {
+    uint64_t ref_off;  // element offset of b[0] in the reference arena
+    uint32_t read_off; // element offset of a[0] in the event arena
+    uint32_t n;        // a_length
+    uint32_t m;        // b_length
+    int32_t R;         // banded: radius AFTER the slant correction (dtw.cpp:298-300); full: -1
+    uint32_t flags;    // bit0: exclude_last_element
+    uint32_t aux;      // kernel-specific (full kernels: index into the per-job workspace tables)
+};
+static_assert(sizeof(DevJob) == 32, "DevJob must stay 32 bytes");
+
+enum : uint32_t { kFlagExcludeLast = 1u };
+
+// launch kinds (also reported by rawdtw_plan_run_timed)
+enum LaunchKind : uint32_t {
+    kKindBandLane = 1,  // lane-per-job banded kernel, one launch per radius class
+    kKindBandWave = 2,  // wave-per-job banded kernel
+    kKindFullWave = 3,  // wave-per-job full-matrix wavefront (score only)
+    kKindFullTb = 4,    // same, writing packed directions
+    kKindTbWalk = 5,    // traceback walk
+};
+
+constexpr int kMaxLaneRadius = 12;     // lane-per-job kernel handles R in [0, 12]
+constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
+
+struct Launch {
+    uint32_t kind;
+    int32_t param;      // band lane: R ; full: rows per lane ; band wave: LDS floats
+    uint64_t first;     // first plan-order job
+    uint64_t count;     // jobs in this launch
+};
+
+// per-job workspace for the full-matrix kernels
+struct FullAux {
+    uint64_t bnd_off; // float offset of the strip-boundary row in the workspace (multi-strip jobs)
+    uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
+};
+
+hipError_t launch_band_lane(int R, const DevJob *jobs, uint64_t count, const float *ev,
+                            const float *ref, float *out, hipStream_t s);
+hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats,
+                            const float *ev, const float *ref, float *out, hipStream_t s);
+hipError_t launch_full_wave(int rows_per_lane, bool traceback, const DevJob *jobs, uint64_t count,
+                            const FullAux *aux, const float *ev, const float *ref, float *out,
+                            float *bnd_ws, uint8_t *dir_ws, hipStream_t s);
+hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux, int rows_per_lane,
+                          const float *ev, const float *ref, const uint8_t *dir_ws,
+                          const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
+                          uint32_t *path_j, float *path_d, hipStream_t s);
+
+// geometry helpers shared with the planner
+inline uint32_t full_strip_rows(int rpl) { return 64u * (uint32_t)rpl; }
+
+} // namespace rawdtw

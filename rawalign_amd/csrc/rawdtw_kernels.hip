@@ -1,0 +1,500 @@
+// rawdtw_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for RawAlign's DTW hot path.
+//
+// What they replace (reference file:line):
+//   k_band_lane / k_band_wave : DTW_global_slantedbanded_antidiagonalwise  src/dtw.cpp:273-520
+//   k_full_wave<.,false>      : DTW_global                                 src/dtw.cpp:37-66
+//   k_full_wave<.,true> + k_tb_walk : DTW_global_tb                        src/dtw.cpp:595-667
+//
+// All of them are scalar fp32 min/add recurrences (no MFMA: nothing here is a contraction).
+// Cell values do not depend on evaluation order (min is exact, each cell is one rounded
+// subtract and one rounded add), so any wavefront order reproduces the reference bit for
+// bit as long as the same cell set and the same neighbour rules are used.  Built with
+// -ffp-contract=off.
+#include "rawdtw_internal.h"
+
+namespace rawdtw {
+
+__device__ __forceinline__ float min3f(float top, float left, float tl)
+{
+    // std::min(std::min(top,left),topleft); identical for non-NaN operands, one v_min3_f32
+    return __builtin_fminf(__builtin_fminf(top, left), tl);
+}
+
+__device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
+
+// ---------------------------------------------------------------------------------------------
+// Lane-per-job banded kernel.  Sparse-mode segments are tiny (2..~100 events, radius 1..12):
+// intra-job parallelism is a handful of cells per antidiagonal, so each lane owns one job and
+// the three rotating antidiagonal buffers of dtw.cpp:305-314 live in registers (radius is a
+// template parameter, every buffer index is a compile-time constant).  Operand windows slide
+// through registers too: one new a-value per column, one new b-value when the centre row moves.
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jobs, uint32_t count,
+                                                   const float *__restrict__ ev,
+                                                   const float *__restrict__ ref,
+                                                   float *__restrict__ out)
+{
+    constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
+    constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
+    constexpr int K = (P > S) ? P : S;
+    constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
+    constexpr int HP = P / 2, HS = S / 2;
+    constexpr bool EVEN = (R % 2 == 0);
+
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= count) return;
+    const DevJob jb = jobs[g];
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) { // dtw.cpp:284-292
+        const float *tp = A; A = B; B = tp;
+        uint32_t tn = N; N = M; M = tn;
+    }
+
+    float d0[K], d1[K], d2[K];
+    float aw[K];     // aw[x] = A[col + HP - x]
+    float bw[K + 1]; // bw[x] = B[row - HP - 1 + x]
+#pragma unroll
+    for (int x = 0; x < K; x++) {
+        d0[x] = kInf; d1[x] = kInf; d2[x] = kInf;
+        int ia = HP - x;
+        aw[x] = A[ia < 0 ? 0 : (ia >= (int)N ? (int)N - 1 : ia)];
+    }
+#pragma unroll
+    for (int x = 0; x <= K; x++) {
+        int ib = x - HP - 1;
+        bw[x] = B[ib < 0 ? 0 : (ib >= (int)M ? (int)M - 1 : ib)];
+    }
+
+    // column 0: only the corner (dtw.cpp:317-347), then the first rotation
+    d1[HP + SH] = dist(A[0], B[0]);
+
+    int row = 0;
+    uint32_t rem = 0; // M*col - row*N, so "row advances" <=> rem + M >= N  (dtw.cpp:352-359)
+    bool prev_adv = false;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        if (adv) { rem -= N; row++; }
+
+        // slide the operand windows
+#pragma unroll
+        for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
+        {
+            uint32_t ia = col + HP;
+            aw[0] = A[ia < N ? ia : N - 1];
+        }
+        if (adv) {
+#pragma unroll
+            for (int x = 0; x < K; x++) bw[x] = bw[x + 1];
+            int ib = row - HP - 1 + K;
+            bw[K] = B[ib < 0 ? 0 : (ib >= (int)M ? (int)M - 1 : ib)];
+        }
+
+        if (adv) { // secondary antidiagonal (dtw.cpp:361-414)
+#pragma unroll
+            for (int o = 0; o < S; o++) {
+                const int i = (int)col + HS - 1 - o;
+                const int j = row - HS + o;
+                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+                const float av = EVEN ? aw[o + 1 < K ? o + 1 : K - 1] : aw[o];
+                const float bv = EVEN ? bw[o + 1] : bw[o];
+                float top, tl, left;
+                if (SH == 0) {
+                    top = d1[o]; tl = d0[o]; left = d1[o + 1 < K ? o + 1 : K - 1];
+                } else {
+                    top = (o == 0) ? kInf : d1[o];
+                    tl = (o == 0 && !prev_adv) ? kInf : d0[o];
+                    left = (o == S - 1) ? kInf : d1[o + 1 < K ? o + 1 : K - 1];
+                }
+                const float v = min3f(top, left, tl) + dist(av, bv);
+                if (valid) d2[o] = v;
+            }
+#pragma unroll
+            for (int x = 0; x < K; x++) { float t = d0[x]; d0[x] = d1[x]; d1[x] = d2[x]; d2[x] = t; }
+        }
+
+        // primary antidiagonal (dtw.cpp:416-485)
+#pragma unroll
+        for (int o = 0; o < P; o++) {
+            const int i = (int)col + HP - o;
+            const int j = row - HP + o;
+            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+            const float av = aw[o];
+            const float bv = bw[o + 1];
+            float top, tl, left;
+            if (SH == 0) {
+                top = (o == 0) ? kInf : d1[o > 0 ? o - 1 : 0];
+                const float tl_flat = (o == 0) ? kInf : d0[o > 0 ? o - 1 : 0];
+                tl = adv ? d0[o] : tl_flat;
+                left = (o == P - 1 && adv) ? kInf : d1[o];
+                const float v = min3f(top, left, tl) + dist(av, bv);
+                if (valid) d2[o] = v;
+            } else {
+                top = (o == 0 && !adv) ? kInf : d1[o];
+                const float tl_flat = (o == 0 && !prev_adv) ? kInf : d0[o];
+                tl = adv ? d0[o + 1 < K ? o + 1 : K - 1] : tl_flat;
+                left = d1[o + 1 < K ? o + 1 : K - 1];
+                const float v = min3f(top, left, tl) + dist(av, bv);
+                if (valid) d2[o + 1 < K ? o + 1 : K - 1] = v;
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < K; x++) { float t = d0[x]; d0[x] = d1[x]; d1[x] = d2[x]; d2[x] = t; }
+        prev_adv = adv;
+    }
+
+    float res = d1[HP + SH]; // dtw.cpp:506-512
+    if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+    out[g] = res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-job banded kernel (any radius whose three buffers fit LDS).  The 64 lanes sweep the
+// offsets of one antidiagonal; the three rotating buffers are LDS arrays with the reference's
+// physical indexing, so stale-slot behaviour is the reference's too.  All control values are
+// wave-uniform.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_band_wave(const DevJob *__restrict__ jobs,
+                                                  const float *__restrict__ ev,
+                                                  const float *__restrict__ ref,
+                                                  float *__restrict__ out)
+{
+    extern __shared__ float lds[];
+    const DevJob jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        uint32_t tn = N; N = M; M = tn;
+    }
+    const int R = jb.R;
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int K = P > S ? P : S;
+    const int SH = P > S ? 0 : 1;
+    float *d0 = lds, *d1 = lds + K, *d2 = lds + 2 * K;
+    for (int x = lane; x < 3 * K; x += 64) lds[x] = kInf;
+    __syncthreads();
+    if (lane == 0) d1[P / 2 + SH] = dist(A[0], B[0]);
+    __syncthreads();
+
+    int row = 0;
+    uint32_t rem = 0;
+    int prev_adv = 0;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const int adv = rem >= N;
+        if (adv) { rem -= N; row++; }
+        for (int pass = adv ? 0 : 1; pass < 2; pass++) {
+            const int len = pass == 0 ? S : P;
+            const int si = pass == 0 ? (int)col + S / 2 - 1 : (int)col + P / 2;
+            const int sj = pass == 0 ? row - S / 2 : row - P / 2;
+            int lo = 0, hi = len;
+            if (si - (int)N + 1 > lo) lo = si - (int)N + 1;
+            if (-sj > lo) lo = -sj;
+            if (si + 1 < hi) hi = si + 1;
+            if ((int)M - sj < hi) hi = (int)M - sj;
+            // neighbour rule of this antidiagonal kind (see oracle RULES / dtw.cpp:368-485)
+            int dt, dtl, dl, ds, g_top_first, g_tl_first, g_left_last;
+            if (SH == 0) {
+                if (pass == 0) { dt = 0; dtl = 0; dl = 1; ds = 0; g_top_first = 0; g_tl_first = 0; g_left_last = 0; }
+                else if (adv)  { dt = -1; dtl = 0; dl = 0; ds = 0; g_top_first = 1; g_tl_first = 0; g_left_last = 1; }
+                else           { dt = -1; dtl = -1; dl = 0; ds = 0; g_top_first = 1; g_tl_first = 1; g_left_last = 0; }
+            } else {
+                if (pass == 0) { dt = 0; dtl = 0; dl = 1; ds = 0; g_top_first = 1; g_tl_first = !prev_adv; g_left_last = 1; }
+                else if (adv)  { dt = 0; dtl = 1; dl = 1; ds = 1; g_top_first = 0; g_tl_first = 0; g_left_last = 0; }
+                else           { dt = 0; dtl = 0; dl = 1; ds = 1; g_top_first = 1; g_tl_first = !prev_adv; g_left_last = 0; }
+            }
+            for (int o = lo + lane; o < hi; o += 64) {
+                const bool first = (o == 0), last = (o == len - 1);
+                const float top = (g_top_first && first) ? kInf : d1[o + dt];
+                const float tl = (g_tl_first && first) ? kInf : d0[o + dtl];
+                const float left = (g_left_last && last) ? kInf : d1[o + dl];
+                d2[o + ds] = min3f(top, left, tl) + dist(A[si - o], B[sj + o]);
+            }
+            __syncthreads();
+            float *t = d0; d0 = d1; d1 = d2; d2 = t;
+        }
+        prev_adv = adv;
+    }
+    if (lane == 0) {
+        float res = d1[P / 2 + SH];
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[blockIdx.x] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Full-matrix wavefront (DTW_global / DTW_global_tb fill).  One wave per job.  The shorter
+// sequence Y is laid over lanes, RPL consecutive rows per lane, 64*RPL rows per strip; the
+// longer sequence X is swept column by column with a one-column skew per lane (lane l works on
+// column t-l at step t), so every step advances a 64-cell-wide anti-diagonal wavefront whose
+// cells exchange values through DPP wave shifts only.  The DTW recurrence is symmetric under
+// transposition, so which operand is "a" does not change any cell value.  Strips hand their
+// last row to the next strip through a boundary row in HBM, read and written in 64-float
+// chunks.  With TB the 2-bit move of dtw.cpp:633-646 is decided at fill time from the same
+// three values and packed RPL codes per lane per step.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_shr1(float v, float fill)
+{
+    // lane l receives lane l-1's value; lane 0 keeps `fill`  (DPP wave_shr:1 = 0x138)
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                        0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
+__device__ __forceinline__ float read_lane(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+template <int RPL> struct DirWord { using type = uint8_t; };
+template <> struct DirWord<8> { using type = uint16_t; };
+
+template <int RPL, bool TB>
+__global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ jobs,
+                                                  const FullAux *__restrict__ aux,
+                                                  const float *__restrict__ ev,
+                                                  const float *__restrict__ ref,
+                                                  float *__restrict__ out, float *__restrict__ bnd_ws,
+                                                  uint8_t *__restrict__ dir_ws)
+{
+    using word_t = typename DirWord<RPL>::type;
+    const DevJob jb = jobs[blockIdx.x];
+    const FullAux ax = aux[blockIdx.x];
+    const int lane = threadIdx.x;
+    const float *a = ev + jb.read_off;
+    const float *b = ref + jb.ref_off;
+    const bool swapped = jb.n > jb.m; // the longer sequence is swept
+    const float *X = swapped ? a : b;
+    const float *Y = swapped ? b : a;
+    const uint32_t NX = swapped ? jb.n : jb.m;
+    const uint32_t NY = swapped ? jb.m : jb.n;
+    constexpr uint32_t STRIP = 64u * RPL;
+    const uint32_t nstrips = (NY + STRIP - 1) / STRIP;
+    const uint32_t TX = NX + 63; // step stride of one strip in the direction buffer
+    float *bnd = bnd_ws + ax.bnd_off;
+    word_t *dirs = reinterpret_cast<word_t *>(dir_ws + ax.dir_off);
+
+    float result = 0.0f;
+    for (uint32_t s = 0; s < nstrips; s++) {
+        const uint32_t y0 = (s * 64u + lane) * RPL;
+        float yv[RPL], v[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++) {
+            uint32_t y = y0 + k;
+            yv[k] = Y[y < NY ? y : NY - 1];
+            v[k] = kInf; // column -1
+        }
+        const uint32_t rows_here = (NY - s * STRIP) < STRIP ? (NY - s * STRIP) : STRIP;
+        const uint32_t lanes_here = (rows_here + RPL - 1) / RPL;
+        const uint32_t steps = NX + lanes_here - 1;
+        const bool has_rows = y0 < NY;
+        const bool hands_down = (s + 1 < nstrips); // then the strip is full and lane 63 owns its last row
+        // virtual row above row 0 is +inf, its corner D[-1][-1] is 0 so that D[0][0] = dist
+        float diag_in = (s == 0 && lane == 0) ? 0.0f : kInf;
+        float last_out = kInf, xval = 0.0f, xchunk = 0.0f, bchunk = kInf, wchunk = 0.0f;
+
+        for (uint32_t t = 0; t < steps; t++) {
+            if ((t & 63u) == 0) {
+                const uint32_t idx = t + lane;
+                xchunk = X[idx < NX ? idx : NX - 1];
+                if (s > 0) bchunk = idx < NX ? bnd[idx] : kInf;
+            }
+            const float x0 = read_lane(xchunk, (int)(t & 63u));
+            const float b0 = read_lane(bchunk, (int)(t & 63u));
+            const float up_in = wave_shr1(last_out, b0);
+            xval = wave_shr1(xval, x0);
+            const uint32_t x = t - (uint32_t)lane;
+            if (x < NX) {
+                float d = diag_in, ab = up_in;
+                uint32_t code = 0;
+#pragma unroll
+                for (int k = 0; k < RPL; k++) {
+                    const float left = v[k];
+                    const float nv = min3f(ab, left, d) + dist(xval, yv[k]);
+                    if (TB) {
+                        // reference names: left = D[i-1][j], top = D[i][j-1] with i over a, j over b.
+                        // Y rows are a-indices unless swapped.
+                        const float rl = swapped ? left : ab; // D[i-1][j]
+                        const float rt = swapped ? ab : left; // D[i][j-1]
+                        uint32_t c = 0;
+                        if (rl < __builtin_fminf(rt, d)) c = 1u;
+                        else if (rt < __builtin_fminf(rl, d)) c = 2u;
+                        code |= c << (2 * k);
+                    }
+                    d = left; ab = nv; v[k] = nv;
+                }
+                diag_in = up_in;
+                last_out = v[RPL - 1];
+                if (TB && has_rows) dirs[((uint64_t)s * TX + t) * 64u + lane] = (word_t)code;
+            }
+            if (hands_down && t >= 63u) {
+                // lane 63 finished column c = t-63 in this step; gather 64 of them, store coalesced
+                const uint32_t c = t - 63u;
+                const float v63 = read_lane(last_out, 63);
+                if ((uint32_t)lane == (c & 63u)) wchunk = v63;
+                if ((c & 63u) == 63u || c == NX - 1) {
+                    const uint32_t base = c & ~63u;
+                    if (base + lane <= c) bnd[base + lane] = wchunk;
+                }
+            }
+        }
+        if (s + 1 == nstrips) {
+            const uint32_t yl = NY - 1;
+            const uint32_t owner = (yl / RPL) & 63u;
+            float mine = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                if ((yl % RPL) == (uint32_t)k) mine = v[k];
+            result = read_lane(mine, (int)owner);
+        }
+        __threadfence_block();
+    }
+    if (lane == 0) {
+        if (jb.flags & kFlagExcludeLast) result = result - dist(a[jb.n - 1], b[jb.m - 1]);
+        out[blockIdx.x] = result;
+    }
+}
+
+// Traceback walk over the packed direction buffer: one lane per job, end-first output.
+__global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs, uint32_t count,
+                                                const FullAux *__restrict__ aux, int rpl,
+                                                const float *__restrict__ ev,
+                                                const float *__restrict__ ref,
+                                                const uint8_t *__restrict__ dir_ws,
+                                                const uint64_t *__restrict__ path_off,
+                                                uint32_t *__restrict__ path_len,
+                                                uint32_t *__restrict__ path_i,
+                                                uint32_t *__restrict__ path_j,
+                                                float *__restrict__ path_d)
+{
+    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (g >= count) return;
+    const DevJob jb = jobs[g];
+    const FullAux ax = aux[g];
+    const float *a = ev + jb.read_off;
+    const float *b = ref + jb.ref_off;
+    const bool swapped = jb.n > jb.m;
+    const uint32_t NX = swapped ? jb.n : jb.m;
+    const uint64_t TX = (uint64_t)NX + 63u;
+    const uint8_t *d8 = dir_ws + ax.dir_off;
+    const uint16_t *d16 = reinterpret_cast<const uint16_t *>(d8);
+    const uint64_t po = path_off[g];
+    uint32_t i = jb.n - 1, j = jb.m - 1, k = 0;
+    path_i[po] = i; path_j[po] = j; path_d[po] = dist(a[i], b[j]);
+    k = 1;
+    while (i > 0 || j > 0) {
+        if (i == 0) j--;
+        else if (j == 0) i--;
+        else {
+            const uint32_t y = swapped ? j : i, x = swapped ? i : j;
+            const uint32_t s = y / (64u * rpl), l = (y / rpl) & 63u, kk = y % rpl;
+            const uint64_t at = ((uint64_t)s * TX + x + l) * 64u + l;
+            const uint32_t word = (rpl == 8) ? d16[at] : d8[at];
+            const uint32_t code = (word >> (2 * kk)) & 3u;
+            if (code == 1u) i--;
+            else if (code == 2u) j--;
+            else { i--; j--; }
+        }
+        path_i[po + k] = i; path_j[po + k] = j; path_d[po + k] = dist(a[i], b[j]);
+        k++;
+    }
+    path_len[g] = k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <int R>
+static hipError_t launch_lane_r(const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
+                                float *out, hipStream_t s)
+{
+    const uint32_t blocks = (uint32_t)((count + 255) / 256);
+    hipLaunchKernelGGL(k_band_lane<R>, dim3(blocks), dim3(256), 0, s, jobs, (uint32_t)count, ev, ref, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_band_lane(int R, const DevJob *jobs, uint64_t count, const float *ev,
+                            const float *ref, float *out, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    switch (R) {
+    case 0: return launch_lane_r<0>(jobs, count, ev, ref, out, s);
+    case 1: return launch_lane_r<1>(jobs, count, ev, ref, out, s);
+    case 2: return launch_lane_r<2>(jobs, count, ev, ref, out, s);
+    case 3: return launch_lane_r<3>(jobs, count, ev, ref, out, s);
+    case 4: return launch_lane_r<4>(jobs, count, ev, ref, out, s);
+    case 5: return launch_lane_r<5>(jobs, count, ev, ref, out, s);
+    case 6: return launch_lane_r<6>(jobs, count, ev, ref, out, s);
+    case 7: return launch_lane_r<7>(jobs, count, ev, ref, out, s);
+    case 8: return launch_lane_r<8>(jobs, count, ev, ref, out, s);
+    case 9: return launch_lane_r<9>(jobs, count, ev, ref, out, s);
+    case 10: return launch_lane_r<10>(jobs, count, ev, ref, out, s);
+    case 11: return launch_lane_r<11>(jobs, count, ev, ref, out, s);
+    case 12: return launch_lane_r<12>(jobs, count, ev, ref, out, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats, const float *ev,
+                            const float *ref, float *out, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_wave),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_band_wave, dim3((uint32_t)count), dim3(64), lds_bytes, s, jobs, ev, ref, out);
+    return hipGetLastError();
+}
+
+template <int RPL, bool TB>
+static hipError_t launch_full_t(const DevJob *jobs, uint64_t count, const FullAux *aux, const float *ev,
+                                const float *ref, float *out, float *bnd_ws, uint8_t *dir_ws,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL((k_full_wave<RPL, TB>), dim3((uint32_t)count), dim3(64), 0, s, jobs, aux, ev, ref,
+                       out, bnd_ws, dir_ws);
+    return hipGetLastError();
+}
+
+hipError_t launch_full_wave(int rpl, bool tb, const DevJob *jobs, uint64_t count, const FullAux *aux,
+                            const float *ev, const float *ref, float *out, float *bnd_ws,
+                            uint8_t *dir_ws, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+#define RAWDTW_FULL_CASE(r)                                                                           \
+    case r:                                                                                           \
+        return tb ? launch_full_t<r, true>(jobs, count, aux, ev, ref, out, bnd_ws, dir_ws, s)         \
+                  : launch_full_t<r, false>(jobs, count, aux, ev, ref, out, bnd_ws, dir_ws, s);
+    switch (rpl) {
+        RAWDTW_FULL_CASE(1)
+        RAWDTW_FULL_CASE(2)
+        RAWDTW_FULL_CASE(4)
+        RAWDTW_FULL_CASE(8)
+    default: return hipErrorInvalidValue;
+    }
+#undef RAWDTW_FULL_CASE
+}
+
+hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl,
+                          const float *ev, const float *ref, const uint8_t *dir_ws,
+                          const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
+                          uint32_t *path_j, float *path_d, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((count + 63) / 64);
+    hipLaunchKernelGGL(k_tb_walk, dim3(blocks), dim3(64), 0, s, jobs, (uint32_t)count, aux, rpl, ev, ref,
+                       dir_ws, path_off, path_len, path_i, path_j, path_d);
+    return hipGetLastError();
+}
+
+} // namespace rawdtw

@@ -1,0 +1,199 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+Bit-exact: the DP is add/sub/abs/min in fp32 with no reassociation."""
+import numpy as np
+import pytest
+
+import rawalign_amd as ra
+from rawalign_amd.dtw import JOB_DTYPE
+from tests.golden_util import bits
+from tests.util import assert_bits_equal, default_radius, make_arena_jobs, oracle_costs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    return ra.Engine(0)
+
+
+def run(engine, jobs, events, ref):
+    pad = np.zeros(8, np.float32)
+    engine.upload_reference([np.concatenate([ref, pad])], [np.concatenate([ref, pad])])
+    jobs = jobs.copy()
+    jobs["ref_off"] += engine.reference_offset(0, 1)
+    return engine.score_batch(jobs, events)
+
+
+def test_golden_banded_and_full(engine, golden):
+    cases = [(c.a, c.b, c.R0, c.exclude_last) for c in golden] + [(c.a, c.b, -1, c.exclude_last) for c in golden]
+    jobs, ev, rf = make_arena_jobs(cases)
+    got = run(engine, jobs, ev, rf)
+    want = np.array([c.banded_bits for c in golden] + [c.global_bits for c in golden], np.uint32).view(np.float32)
+    assert_bits_equal(got, want, "golden")
+
+
+def test_golden_traceback(engine, golden):
+    cs = [c for c in golden if c.tb is not None]
+    jobs, ev, rf = make_arena_jobs([(c.a, c.b, -1, c.exclude_last) for c in cs])
+    engine.upload_reference([rf], [rf])
+    jobs["ref_off"] += engine.reference_offset(0, 1)
+    res = engine.traceback_batch(jobs, ev)
+    for c, r in zip(cs, res):
+        assert bits(r.cost) == c.tb[0]
+        assert np.array_equal(r.i, c.tb[1]) and np.array_equal(r.j, c.tb[2])
+        assert np.array_equal(r.difference.view(np.uint32), c.tb[3])
+
+
+def test_reference_function_names(engine, oracle):
+    """Reads like src/check_dtw.cpp:138-181: same inputs through every DTW variant."""
+    rng = np.random.default_rng(11)
+    for n, m in [(4, 4), (10, 10), (20, 10), (25, 10), (100, 100), (200, 50), (200, 30), (1, 1), (1, 9), (9, 1)]:
+        a = rng.uniform(-2.5, 2.5, n).astype(np.float32)
+        b = rng.uniform(-2.5, 2.5, m).astype(np.float32)
+        for ex in (False, True):
+            assert bits(engine.DTW_global(a, b, ex)) == bits(oracle.dtw_global(a, b, ex))
+            for R in (0, 1, 2, 5, 13, 40):
+                assert bits(engine.DTW_global_slantedbanded_antidiagonalwise(a, b, R, ex)) == bits(
+                    oracle.dtw_banded(a, b, R, ex))
+            tb = engine.DTW_global_tb(a, b, ex)
+            c, pi, pj, pd = oracle.dtw_global_tb(a, b, ex)
+            assert bits(tb.cost) == bits(c)
+            assert np.array_equal(tb.i, pi) and np.array_equal(tb.j, pj)
+            assert np.array_equal(tb.difference.view(np.uint32), pd.view(np.uint32))
+
+
+def test_random_sparse_like_batch(engine, oracle):
+    """Thousands of tiny segments, default radius, every radius class of the lane kernel."""
+    rng = np.random.default_rng(3)
+    cases = []
+    for t in range(6000):
+        n = int(rng.integers(1, 130))
+        m = max(1, int(round(n * rng.uniform(0.3, 1.6))))
+        R0 = default_radius(n) if t % 3 else int(rng.integers(0, 9))
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), R0, t & 1))
+    jobs, ev, rf = make_arena_jobs(cases)
+    assert_bits_equal(run(engine, jobs, ev, rf), oracle_costs(oracle, jobs, ev, rf), "sparse-like")
+
+
+def test_random_wave_band(engine, oracle):
+    """Radii beyond the lane kernel (wave-per-job kernel), including bands that clip the optimum."""
+    rng = np.random.default_rng(4)
+    cases = []
+    for t in range(160):
+        n = int(rng.integers(100, 1500))
+        m = max(1, int(round(n * rng.uniform(0.5, 1.4))))
+        R0 = default_radius(n) if t % 2 else int(rng.integers(13, 90))
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), R0, t & 1))
+    cases.append((rng.normal(size=6000).astype(np.float32), rng.normal(size=5200).astype(np.float32), 600, 0))
+    cases.append((rng.normal(size=3000).astype(np.float32), rng.normal(size=9000).astype(np.float32), 2100, 1))
+    jobs, ev, rf = make_arena_jobs(cases)
+    assert_bits_equal(run(engine, jobs, ev, rf), oracle_costs(oracle, jobs, ev, rf), "wave band")
+
+
+def test_random_full(engine, oracle):
+    """DTW_global through every rows-per-lane class and across strip boundaries."""
+    rng = np.random.default_rng(5)
+    shapes = [(1, 1), (2, 2), (1, 50), (50, 1), (63, 64), (64, 65), (65, 64), (128, 200), (129, 300), (256, 256),
+              (257, 256), (511, 700), (512, 512), (513, 514), (700, 520), (1025, 1100), (1600, 1030), (40, 3000)]
+    cases = []
+    for n, m in shapes:
+        for ex in (0, 1):
+            cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), -1, ex))
+    for _ in range(300):
+        n, m = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), -1, 0))
+    jobs, ev, rf = make_arena_jobs(cases)
+    assert_bits_equal(run(engine, jobs, ev, rf), oracle_costs(oracle, jobs, ev, rf), "full")
+
+
+def test_random_traceback(engine, oracle):
+    rng = np.random.default_rng(6)
+    shapes = [(1, 1), (1, 7), (7, 1), (2, 2), (30, 20), (64, 64), (65, 100), (130, 129), (260, 300), (513, 600),
+              (600, 513), (900, 1100)]
+    cases = [(rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), -1, k & 1)
+             for k, (n, m) in enumerate(shapes)]
+    jobs, ev, rf = make_arena_jobs(cases)
+    engine.upload_reference([rf], [rf])
+    jobs["ref_off"] += engine.reference_offset(0, 1)
+    res = engine.traceback_batch(jobs, ev)
+    for (a, b, _, ex), r in zip(cases, res):
+        c, pi, pj, pd = oracle.dtw_global_tb(a, b, ex)
+        assert bits(r.cost) == bits(c), (len(a), len(b))
+        assert np.array_equal(r.i, pi) and np.array_equal(r.j, pj), (len(a), len(b))
+        assert np.array_equal(r.difference.view(np.uint32), pd.view(np.uint32))
+
+
+def test_quantised_inputs_force_ties(engine, oracle):
+    """Equal neighbours everywhere: the diagonal-wins tie rule (dtw.cpp:633-646) decides the path."""
+    rng = np.random.default_rng(8)
+    for n, m in [(40, 40), (70, 55), (300, 280)]:
+        a = rng.integers(-2, 3, n).astype(np.float32)
+        b = rng.integers(-2, 3, m).astype(np.float32)
+        tb = engine.DTW_global_tb(a, b)
+        c, pi, pj, _ = oracle.dtw_global_tb(a, b)
+        assert bits(tb.cost) == bits(c) and np.array_equal(tb.i, pi) and np.array_equal(tb.j, pj)
+        R0 = default_radius(n)
+        assert bits(engine.DTW_global_slantedbanded_antidiagonalwise(a, b, R0)) == bits(oracle.dtw_banded(a, b, R0))
+
+
+def test_error_behaviour(engine):
+    ev = np.zeros(16, np.float32)
+    engine.upload_reference([np.zeros(16, np.float32)], [np.zeros(16, np.float32)])
+    bad = np.zeros(1, JOB_DTYPE)
+    bad[0] = (0, 0, 0, 4, 1, 0, 0)  # zero length: dtw.cpp:274 asserts
+    with pytest.raises(ra.RawDTWError) as e:
+        engine.score_batch(bad, ev)
+    assert e.value.status == 1
+    bad[0] = (0, 0, 4, 4, -5, 0, 0)  # negative radius: dtw.cpp:277 asserts
+    with pytest.raises(ra.RawDTWError):
+        engine.score_batch(bad, ev)
+    bad[0] = (10, 0, 4, 10, 1, 0, 0)  # window past the arena
+    with pytest.raises(ra.RawDTWError) as e:
+        engine.score_batch(bad, ev)
+    assert e.value.status == 4
+    bad[0] = (0, 0, 4, 4, 2, 0, 0)  # traceback of a banded job: rmap.cpp:223-225
+    with pytest.raises(ra.RawDTWError) as e:
+        engine.traceback_batch(bad, ev)
+    assert e.value.status == 5
+    assert len(engine.score_batch(np.zeros(0, JOB_DTYPE), ev)) == 0  # empty batch
+
+
+def test_properties_at_scale(engine):
+    """Size-independent properties on a batch too large to check cell by cell on the CPU:
+    DTW(x,x)=0, symmetry of the full DP, band never beats the full DP, identical jobs agree."""
+    rng = np.random.default_rng(9)
+    ref = rng.normal(size=1 << 20).astype(np.float32)
+    events = ref[: 1 << 19].copy() + rng.normal(scale=0.3, size=1 << 19).astype(np.float32)
+    engine.upload_reference([ref], [ref])
+    base = engine.reference_offset(0, 1)
+    nj = 200000
+    n = rng.integers(2, 60, nj).astype(np.uint32)
+    off = rng.integers(0, (1 << 19) - 64, nj).astype(np.uint32)
+    jobs = np.zeros(4 * nj, JOB_DTYPE)
+    R0 = np.maximum(1, (n.astype(np.float32) * np.float32(0.1)).astype(np.int32))
+    for q in range(4):
+        s = slice(q * nj, (q + 1) * nj)
+        jobs["read_off"][s] = off
+        jobs["ref_off"][s] = off.astype(np.uint64) + base
+        jobs["n"][s] = n
+        jobs["m"][s] = n
+    jobs["band_radius"][:nj] = R0
+    jobs["band_radius"][nj:2 * nj] = R0          # duplicate batch
+    jobs["band_radius"][2 * nj:3 * nj] = -1      # full
+    jobs["band_radius"][3 * nj:] = -1            # full, on (ref, ref): x against itself
+    cost = engine.score_batch(jobs, events)
+    banded, dup, full = cost[:nj], cost[nj:2 * nj], cost[2 * nj:3 * nj]
+    assert np.array_equal(banded.view(np.uint32), dup.view(np.uint32))
+    assert np.all(banded >= full)
+    # x vs x: upload ref as events too
+    self_jobs = jobs[3 * nj:].copy()
+    c0 = engine.score_batch(self_jobs, ref[: 1 << 19])
+    assert np.all(c0 == 0.0)
+    # symmetry of the full DP: swap roles of the two arenas
+    sym = engine.score_batch(jobs[2 * nj:2 * nj + 20000], events)
+    engine.upload_reference([events], [events])
+    b2 = engine.reference_offset(0, 1)
+    j2 = jobs[2 * nj:2 * nj + 20000].copy()
+    j2["ref_off"] = j2["read_off"].astype(np.uint64) + b2
+    sym2 = engine.score_batch(j2, ref[: 1 << 19])
+    assert np.array_equal(sym.view(np.uint32), sym2.view(np.uint32))
