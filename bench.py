@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- DTW hot path of RawAlign on MI355X: DTW GCUPS (+ reads/s) and % of the HBM roofline.
+
+One "step" = one pass of the hot path over one batch: every DTW job of every candidate chain of
+every read of a chunk round (sparse border constraint, banded=0.10 fill: BASELINE.json configs[1]),
+the align_chain fold and the per-read accept/cut loop -- all on the device, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: reads shard across ranks (each rank holds a full replica of the reference signal and
+its own reads); no data-path collective; RCCL is used only for the final counters and the
+max-over-ranks time.  Weak scaling: per-GPU work is fixed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+WORKLOAD = "ecoli_k12_4.6Mb_r9.4_sparse_banded0.10"
+SEED = 20231005 + 2  # seed = 20231005 + config id
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
+    ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify a sample of the device results against the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(jobs, events, ref_arena, cells, threads, target_s=1.5):
+    """The same job list on the host cores, through the REFERENCE's own compiled dtw.cpp when
+    oracle/_ref is present ("reference"), else through the oracle's C restatement ("port")."""
+    from oracle.loader import Oracle, RefDTW, build_oracle
+
+    if RefDTW.available():
+        impl, kind = RefDTW(), "reference"
+    else:
+        build_oracle(march_native=True)
+        impl, kind = Oracle(), "port"
+    # bounded sample: the whole batch if it is small enough, else a prefix of whole reads' jobs
+    n = len(jobs)
+    t0 = time.perf_counter()
+    impl.batch_costs(jobs[: min(n, 200000)], events, ref_arena, threads)
+    probe = time.perf_counter() - t0
+    per_job = probe / min(n, 200000)
+    take = int(min(n, max(200000, target_s / max(per_job, 1e-9))))
+    reps = max(1, int(round(target_s / max(per_job * take, 1e-6))))
+    reps = min(reps, 50)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = impl.batch_costs(jobs[:take], events, ref_arena, threads)
+    dt = (time.perf_counter() - t0) / reps
+    frac = take / n
+    return {
+        "value": cells * frac / dt / 1e9,
+        "unit": "GCUPS",
+        "cores": threads,
+        "kind": kind,
+        "sample": f"first {take} of {n} DTW jobs of the same batch ({frac * 100:.0f}% of its cells, cells pro-rated by job count), "
+                  f"{reps} repetition(s), {threads} threads pulling jobs from a shared counter, {dt * reps:.1f} s wall",
+        "jobs_per_s": take / dt,
+    }, out, take
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import rawalign_amd as ra
+    from rawalign_amd import synth
+    from rawalign_amd.shard import rank_seed
+
+    eng = ra.Engine(local_rank)
+    # reference signal replica (same on every rank), resident in HBM
+    ref = synth.make_reference([args.genome], seed=SEED)
+    eng.upload_reference(ref.forward, ref.reverse)
+    offs = {(s, st): eng.reference_offset(s, st) for s in range(ref.n_seq) for st in (0, 1)}
+    # this rank's reads
+    cb, sinfo = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=args.reads), seed=rank_seed(SEED, rank))
+    eng.upload_events(cb.events)
+    opt = ra.MapOpt()  # sparse, banded=0.10, bonus 0.4, min score 20 (roptions.c:49-53)
+    batch = ra.Batch(eng, opt, cb)
+    info = batch.info()
+    eng.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    batch.run_reps(max(args.warmup, 0), timed=False) if args.warmup > 0 else None
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    launches = batch.run_reps(args.steps, timed=True)  # K steps back to back, one sync at the end
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    score, keep, job_cost = batch.fetch(with_job_costs=True)
+    read_of_chain = np.repeat(np.arange(cb.n_reads), np.diff(cb.chain_off.astype(np.int64)))
+    mapped = int(len(np.unique(read_of_chain[keep.astype(bool)])))  # reads with >= 1 surviving chain
+
+    from rawalign_amd.shard import reduce_counters
+
+    # the path's only collective: final counters (sum) and the step time (max over ranks)
+    (reads_t, chains_t, jobs_t, cells_t, mapped_t, bytes_t), T = reduce_counters(
+        dist, [args.reads, info["n_chains"], info["n_jobs"], info["cells"], mapped, info["algorithmic_bytes"]],
+        elapsed, device=torch.device("cuda", local_rank) if dist is not None else None)
+
+    if rank == 0:
+        stats = batch.launch_stats(with_cells=False)
+        # dominant kernel = the launch with the largest mean duration
+        dom = max(range(len(launches)), key=lambda i: launches[i][2])
+        dkind, dparam, dms = launches[dom]
+        dbytes = stats[dom]["algorithmic_bytes"]
+        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == WORKLOAD and tj.get("reads") == args.reads:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        kname = ra.Engine.KIND_NAMES.get(dkind, {6: "chain_fold", 7: "read_select"}.get(dkind, str(dkind)))
+        out = {
+            "metric": "DTW GCUPS",
+            "value": cells_t * args.steps / T / 1e9,
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": T / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": WORKLOAD, "reads_per_gpu": args.reads, "genome_bp": args.genome,
+                       "border_constraint": "sparse", "fill_method": "banded=0.10",
+                       "sharding": f"reads over {world} gpu(s), reference replicated"},
+            "reads_per_s": reads_t * args.steps / T,
+            "mapped_reads_per_s": mapped_t * args.steps / T,
+            "jobs_per_s": jobs_t * args.steps / T,
+            "batch": {"reads": reads_t, "chains": chains_t, "dtw_jobs": jobs_t, "cells": cells_t,
+                      "mapped_reads": mapped_t, "algorithmic_bytes": bytes_t},
+            "whole_step_hbm_frac": bytes_t * args.steps / T / 1e9 / (HBM_PEAK_GBS * world),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": f"{kname}(param={dparam})", "launch_ms": dms,
+                         "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": stats[dom]["n_jobs"]},
+            "launches": [{"kernel": ra.Engine.KIND_NAMES.get(k, {6: "chain_fold", 7: "read_select"}.get(k, str(k))),
+                          "param": p, "ms": round(ms, 5), "jobs": stats[i]["n_jobs"]} for i, (k, p, ms) in enumerate(launches)],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # rebuild the job list exactly as the device batch built it
+            import ctypes as C
+
+            lib = eng.lib
+            copt = opt.c_struct()
+            p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            job_off = np.zeros(cb.n_chains + 1, np.uint64)
+            nj = C.c_uint64()
+            jobs = np.zeros(info["n_jobs"], ra.JOB_DTYPE)
+            lib.rawdtw_batch_build_jobs(C.byref(copt), cb.n_chains, p(cb.anchor_off), p(cb.anchors), p(cb.ref_base),
+                                        p(cb.read_base), p(job_off), p(jobs), len(jobs), C.byref(nj))
+            n = len(ref.forward[0])
+            pad = (n + 3) & ~3
+            arena = np.zeros(2 * pad, np.float32)
+            arena[:n] = ref.forward[0]
+            arena[pad:pad + n] = ref.reverse[0]
+            base, cpu_costs, take = cpu_baseline(jobs, cb.events, arena, info["cells"], args.cpu_threads)
+            out["cpu_baseline"] = base
+            # free check: the CPU leg and the device leg computed the same jobs
+            same = bool(np.array_equal(cpu_costs.view(np.uint32), job_cost[:take].view(np.uint32)))
+            out["cpu_gpu_costs_identical"] = same
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,7 +88,7 @@ int rawdtw_score_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_job
 /* Split form, for callers that keep inputs resident (and for benchmarking):
  * plan_create validates and size-bins the jobs and uploads device descriptors;
  * plan_run only launches kernels on the ctx stream (asynchronous); costs stay in
- * HBM in PLAN ORDER; plan_fetch waits and returns them in JOB order. */
+ * HBM, out[k] for jobs[k]; plan_fetch waits and copies them to the host. */
 typedef struct {
     uint64_t n_jobs;
     uint64_t cells;            /* DP cells the batch evaluates (exact, band cell sets counted) */
@@ -105,7 +105,7 @@ int rawdtw_plan_create(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_job
 int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info);
 int rawdtw_plan_run(rawdtw_ctx *ctx, rawdtw_plan *plan);
 int rawdtw_plan_fetch(rawdtw_ctx *ctx, rawdtw_plan *plan, float *out_cost);
-/* device pointer to the plan-order costs and the plan-order -> job index map */
+/* device pointer to the costs (job order) and the host array mapping launch order -> job index */
 int rawdtw_plan_device_costs(const rawdtw_plan *plan, const float **d_cost,
                              const uint32_t **h_order);
 /* per-launch kernel names and HIP-event durations (ms) of the most recent
@@ -190,6 +190,36 @@ int rawdtw_batch_build_jobs(const rawdtw_align_opt_t *opt, uint64_t n_chains, co
 int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
                         const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
                         const uint64_t *job_off, const float *job_cost, float *score, uint8_t *keep);
+
+
+/* ---- whole-batch form: the DTW block of gen_chains (rmap.cpp:509-530) for every read of a
+ * mini-batch in one submission -- job decomposition on the host, DTW scoring, the align_chain
+ * fold and the per-read accept/cut loop all on the device.  Inputs as rawdtw_batch_build_jobs;
+ * events and reference arenas must already be set on the ctx.  Outputs per chain: score[c]
+ * (chain.alignment_score, -1e10 when cut) and keep[c] (survives dtw_min_score). ---- */
+typedef struct rawdtw_batch rawdtw_batch;
+int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads,
+                        const uint64_t *chain_off, const uint64_t *anchor_off,
+                        const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out);
+int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint64_t *n_chains);
+int rawdtw_batch_run(rawdtw_ctx *ctx, rawdtw_batch *batch);
+/* as rawdtw_plan_run_timed, with two more launches (kinds 6, 7) for fold and select */
+int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms,
+                           uint32_t *launch_kind, uint32_t cap, uint32_t *n_launches);
+/* `reps` back-to-back runs with no host synchronisation in between, one at the end.  When
+ * launch_ms != NULL a HIP event pair brackets every launch on the ctx stream and launch_ms[i]
+ * receives launch i's MEAN duration over the reps. */
+int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, float *launch_ms,
+                          uint32_t *launch_kind, uint32_t cap, uint32_t *n_launches);
+/* static facts about launch i of the batch (same indexing as launch_ms): kind, parameter
+ * (band radius / rows per lane / LDS floats), jobs, their algorithmic bytes and DP cells */
+int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *kind, int32_t *param,
+                              uint64_t *n_jobs, uint64_t *algorithmic_bytes, uint64_t *cells);
+/* job_cost may be NULL; otherwise receives the per-job costs too */
+int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep,
+                       float *job_cost);
+int rawdtw_batch_destroy(rawdtw_batch *batch);
 
 #ifdef __cplusplus
 }

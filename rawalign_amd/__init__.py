@@ -14,6 +14,8 @@ from .align import (  # noqa: F401
     RI_M_DTW_BORDER_CONSTRAINT_SPARSE,
     RI_M_DTW_FILL_METHOD_BANDED,
     RI_M_DTW_FILL_METHOD_FULL,
+    Batch,
+    CandidateBatch,
     Chain,
     MapOpt,
     ReadCandidates,
@@ -23,6 +25,6 @@ from .align import (  # noqa: F401
 
 __all__ = [
     "Engine", "Plan", "DtwResult", "JOB_DTYPE", "ANCHOR_DTYPE", "RAWDTW_FULL",
-    "MapOpt", "Chain", "ReadCandidates", "align_chain", "evaluate_reads",
+    "MapOpt", "Chain", "Batch", "CandidateBatch", "ReadCandidates", "align_chain", "evaluate_reads",
     "load_library", "library_path", "LibraryMissing", "RawDTWError",
 ]

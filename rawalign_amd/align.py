@@ -198,3 +198,119 @@ def align_chain(engine: Engine, chain: Chain, read_events, opt: MapOpt, cigar: b
 def dtwresult_to_string(res: DtwResult) -> str:
     """rmap.cpp:580-592: "(i,j,diff)" per element, diff through ostream<<float (== %g)."""
     return "".join("(%d,%d,%s)" % (int(i), int(j), "%g" % float(d)) for i, j, d in zip(res.i, res.j, res.difference))
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-batch form (flat arrays; what a chunk round of the mapper hands to the device)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class CandidateBatch:
+    """All candidate chains of all reads of one submission, flattened.
+
+    Read r owns chains [chain_off[r], chain_off[r+1]) -- already in evaluation order (rmap.cpp:512);
+    chain c owns anchors[anchor_off[c]:anchor_off[c+1]] (end-first); ref_base[c] / read_base[c] are
+    the arena offsets of the chain's strand array and of its read's event array."""
+
+    events: np.ndarray
+    chain_off: np.ndarray
+    anchor_off: np.ndarray
+    anchors: np.ndarray
+    ref_base: np.ndarray
+    read_base: np.ndarray
+
+    @property
+    def n_reads(self):
+        return len(self.chain_off) - 1
+
+    @property
+    def n_chains(self):
+        return len(self.anchor_off) - 1
+
+
+class Batch:
+    """rawdtw_batch: DTW scoring + align_chain fold + per-read selection, all on the device."""
+
+    def __init__(self, engine: Engine, opt: MapOpt, cb: CandidateBatch):
+        self.engine = engine
+        self.cb = cb
+        self._copt = opt.c_struct()
+        self._arrays = [
+            np.ascontiguousarray(cb.chain_off, np.uint64), np.ascontiguousarray(cb.anchor_off, np.uint64),
+            np.ascontiguousarray(cb.anchors, ANCHOR_DTYPE), np.ascontiguousarray(cb.ref_base, np.uint64),
+            np.ascontiguousarray(cb.read_base, np.uint32),
+        ]
+        h = C.c_void_p()
+        a = self._arrays
+        engine._check(engine.lib.rawdtw_batch_create(engine._ctx, C.byref(self._copt), cb.n_reads, _ptr(a[0]),
+                                                     _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), C.byref(h)))
+        self._h = h
+
+    def info(self) -> dict:
+        from ._lib import PlanInfo
+
+        pi = PlanInfo()
+        nc = C.c_uint64()
+        self.engine._check(self.engine.lib.rawdtw_batch_info(self._h, C.byref(pi), C.byref(nc)))
+        d = {k: int(getattr(pi, k)) for k, _ in PlanInfo._fields_}
+        d["n_chains"] = int(nc.value)
+        d["n_reads"] = self.cb.n_reads
+        return d
+
+    def run(self):
+        self.engine._check(self.engine.lib.rawdtw_batch_run(self.engine._ctx, self._h))
+
+    def run_timed(self):
+        cap = 64
+        ms = np.zeros(cap, np.float32)
+        kind = np.zeros(cap, np.uint32)
+        n = C.c_uint32()
+        self.engine._check(self.engine.lib.rawdtw_batch_run_timed(self.engine._ctx, self._h, _ptr(ms), _ptr(kind),
+                                                                  cap, C.byref(n)))
+        return [(int(kind[k] & 0xFF), int(kind[k] >> 8), float(ms[k])) for k in range(min(n.value, cap))]
+
+    def run_reps(self, reps: int, timed: bool = True):
+        """`reps` back-to-back runs, one sync at the end; returns [(kind, param, mean_ms)] when timed."""
+        cap = 64
+        ms = np.zeros(cap, np.float32)
+        kind = np.zeros(cap, np.uint32)
+        n = C.c_uint32()
+        self.engine._check(self.engine.lib.rawdtw_batch_run_reps(
+            self.engine._ctx, self._h, int(reps), _ptr(ms) if timed else None, _ptr(kind), cap, C.byref(n)))
+        if not timed:
+            return []
+        return [(int(kind[k] & 0xFF), int(kind[k] >> 8), float(ms[k])) for k in range(min(n.value, cap))]
+
+    def launch_stats(self, with_cells=True):
+        out = []
+        i = 0
+        while True:
+            kind, param = C.c_uint32(), C.c_int32()
+            nj, ab, cl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            st = self.engine.lib.rawdtw_batch_launch_stats(self._h, i, C.byref(kind), C.byref(param), C.byref(nj),
+                                                           C.byref(ab), C.byref(cl) if with_cells else None)
+            if st != 0:
+                break
+            out.append({"kind": int(kind.value), "param": int(param.value), "n_jobs": int(nj.value),
+                        "algorithmic_bytes": int(ab.value), "cells": int(cl.value)})
+            i += 1
+        return out
+
+    def fetch(self, with_job_costs=False):
+        nc = self.cb.n_chains
+        score = np.zeros(nc, np.float32)
+        keep = np.zeros(nc, np.uint8)
+        jc = np.zeros(self.info()["n_jobs"], np.float32) if with_job_costs else None
+        self.engine._check(self.engine.lib.rawdtw_batch_fetch(self.engine._ctx, self._h, _ptr(score), _ptr(keep),
+                                                              _ptr(jc) if jc is not None else None))
+        return (score, keep, jc) if with_job_costs else (score, keep)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self.engine.lib.rawdtw_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

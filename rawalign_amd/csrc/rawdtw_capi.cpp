@@ -49,6 +49,17 @@ struct rawdtw_plan {
     bool cells_counted = false;
 };
 
+struct rawdtw_batch {
+    rawdtw_ctx *ctx = nullptr;
+    rawdtw_plan *plan = nullptr;
+    rawdtw_align_opt_t opt{};
+    uint64_t n_reads = 0, n_chains = 0;
+    ChainDesc *d_chains = nullptr;
+    uint64_t *d_chain_off = nullptr;
+    float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
+    uint8_t *d_keep = nullptr;
+};
+
 namespace {
 
 int fail(rawdtw_ctx *ctx, int status, const std::string &msg)
@@ -213,7 +224,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         pl->order[p] = keyed[p].idx;
         DevJob &d = pl->h_jobs[p];
         d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
-        d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = (uint32_t)p;
+        d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = keyed[p].idx;
         const uint64_t cls = keyed[p].key >> 40;
         if (cls >= 32) {
             const int rpl = 1 << (cls - 32);
@@ -289,7 +300,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
 int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L)
 {
     const DevJob *jobs = pl->d_jobs + L.first;
-    float *out = pl->d_cost + L.first;
+    float *out = pl->d_cost; // job order: every kernel stores at out[job.aux]
     hipError_t e = hipSuccess;
     switch (L.kind) {
     case kKindBandLane:
@@ -526,10 +537,8 @@ int rawdtw_plan_fetch(rawdtw_ctx *ctx, rawdtw_plan *plan, float *out_cost)
     if (!ctx || !plan || plan->ctx != ctx || (!out_cost && plan->n_jobs))
         return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to plan_fetch");
     if (plan->n_jobs == 0) return RAWDTW_OK;
-    std::vector<float> tmp(plan->n_jobs);
-    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), plan->d_cost, plan->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_cost, plan->d_cost, plan->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint64_t p = 0; p < plan->n_jobs; p++) out_cost[plan->order[p]] = tmp[p];
     return RAWDTW_OK;
 }
 
@@ -641,7 +650,7 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback download"); }
         for (uint64_t p = 0; p < cnt; p++) {
             const uint64_t k = begin + pl->order[p];
-            out_cost[k] = h_cost[p];
+            out_cost[k] = h_cost[pl->order[p]];
             const uint32_t len = h_plen[p];
             // device paths are end-first; the reference returns them start-first (dtw.cpp:656-657)
             // and pops the last element when exclude_last_element is set (dtw.cpp:659-663)
@@ -713,6 +722,225 @@ int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const floa
     ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n; ctx->own_ref = saved_own;
     (void)hipFree(d_b);
     return st;
+}
+
+// ---- whole-batch form ----------------------------------------------------------------------------
+int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out)
+{
+    if (!out) return RAWDTW_ERR_INVALID;
+    *out = nullptr;
+    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && n_reads) || !ref_base || !read_base)
+        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (opt->border_constraint != 0 && opt->border_constraint != 1)
+        return fail(ctx, RAWDTW_ERR_INVALID, "invalid border constraint (rmap.cpp:301-304)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_chains = chain_off[n_reads];
+    std::vector<uint64_t> job_off(n_chains + 1);
+    uint64_t n_jobs = 0;
+    int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
+                                     0, &n_jobs);
+    if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
+    std::vector<rawdtw_job_t> jobs(n_jobs);
+    st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), jobs.data(),
+                                 n_jobs, &n_jobs);
+    if (st != RAWDTW_OK) return fail(ctx, st, "job building failed");
+    std::vector<ChainDesc> desc(n_chains);
+    for (uint64_t c = 0; c < n_chains; c++) {
+        const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+        ChainDesc &d = desc[c];
+        d.job_first = job_off[c];
+        d.n_jobs = (uint32_t)(job_off[c + 1] - job_off[c]);
+        d.reserved = 0;
+        if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
+        const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
+        d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
+        uint32_t na = 0;
+        for (uint64_t k = job_off[c]; k < job_off[c + 1]; k++) na += jobs[k].n; // rmap.cpp:236,292
+        d.num_aligned = na;
+    }
+    rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
+    if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
+    st = build_plan(ctx, jobs.data(), n_jobs, false, &b->plan);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chains, n_chains);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chain_off, n_reads + 1);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_full, n_chains);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_gate, n_chains);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_score, n_chains);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_keep, n_chains);
+    if (st == RAWDTW_OK) {
+        hipError_t e = hipSuccess;
+        if (n_chains) e = hipMemcpyAsync(b->d_chains, desc.data(), n_chains * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(b->d_chain_off, chain_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = hip_fail(ctx, e, "uploading chain descriptors");
+    }
+    if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
+    *out = b;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint64_t *n_chains)
+{
+    if (!batch) return RAWDTW_ERR_INVALID;
+    if (n_chains) *n_chains = batch->n_chains;
+    if (info) return rawdtw_plan_info(batch->plan, info);
+    return RAWDTW_OK;
+}
+
+static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
+{
+    hipError_t e;
+    if (which == 0)
+        e = launch_chain_fold(b->d_chains, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
+                              b->d_full, b->d_gate, ctx->stream);
+    else
+        e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
+                               b->d_keep, ctx->stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, which == 0 ? "chain fold launch" : "read select launch");
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_run(rawdtw_ctx *ctx, rawdtw_batch *batch)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    int st = rawdtw_plan_run(ctx, batch->plan);
+    if (st == RAWDTW_OK) st = batch_tail(ctx, batch, 0);
+    if (st == RAWDTW_OK) st = batch_tail(ctx, batch, 1);
+    return st;
+}
+
+int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms, uint32_t *launch_kind, uint32_t cap,
+                           uint32_t *n_launches)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    const uint32_t nl = (uint32_t)batch->plan->launches.size();
+    if (n_launches) *n_launches = nl + 2;
+    int st = rawdtw_plan_run_timed(ctx, batch->plan, launch_ms, launch_kind, cap);
+    if (st != RAWDTW_OK) return st;
+    hipEvent_t ev[3];
+    for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    st = batch_tail(ctx, batch, 0);
+    if (st == RAWDTW_OK) { HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream)); st = batch_tail(ctx, batch, 1); }
+    if (st == RAWDTW_OK) { HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+        if (nl + k < cap) {
+            if (launch_ms) launch_ms[nl + k] = ms;
+            if (launch_kind) launch_kind[nl + k] = (k == 0 ? kKindChainFold : kKindReadSelect);
+        }
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return st;
+}
+
+int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, float *launch_ms, uint32_t *launch_kind,
+                          uint32_t cap, uint32_t *n_launches)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    rawdtw_plan *pl = batch->plan;
+    const uint32_t nl = (uint32_t)pl->launches.size() + 2;
+    if (n_launches) *n_launches = nl;
+    const bool timed = launch_ms != nullptr;
+    std::vector<hipEvent_t> ev;
+    if (timed) {
+        ev.assign((size_t)reps * (nl + 1), nullptr);
+        for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    int st = RAWDTW_OK;
+    for (uint32_t r = 0; r < reps && st == RAWDTW_OK; r++) {
+        hipEvent_t *e = timed ? &ev[(size_t)r * (nl + 1)] : nullptr;
+        if (timed && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        for (uint32_t i = 0; i < nl && st == RAWDTW_OK; i++) {
+            if (i + 2 < nl) st = run_launch(ctx, pl, pl->launches[i]);
+            else st = batch_tail(ctx, batch, (int)(i + 2 - nl));
+            if (st == RAWDTW_OK && timed && hipEventRecord(e[i + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
+    if (timed && st == RAWDTW_OK) {
+        for (uint32_t i = 0; i < nl && i < cap; i++) {
+            double acc = 0;
+            for (uint32_t r = 0; r < reps; r++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev[(size_t)r * (nl + 1) + i], ev[(size_t)r * (nl + 1) + i + 1]) != hipSuccess)
+                    st = RAWDTW_ERR_DEVICE;
+                acc += ms;
+            }
+            launch_ms[i] = reps ? (float)(acc / reps) : 0.f;
+            if (launch_kind)
+                launch_kind[i] = i + 2 < nl ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
+                                            : (i + 2 == nl ? kKindChainFold : kKindReadSelect);
+        }
+    }
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (st != RAWDTW_OK && ctx->err.empty()) ctx->err = "run_reps failed";
+    return st;
+}
+
+int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *kind, int32_t *param, uint64_t *n_jobs,
+                              uint64_t *algorithmic_bytes, uint64_t *cells)
+{
+    if (!batch) return RAWDTW_ERR_INVALID;
+    const rawdtw_plan *pl = batch->plan;
+    const uint32_t nl = (uint32_t)pl->launches.size();
+    if (i >= nl + 2) return RAWDTW_ERR_INVALID;
+    if (i >= nl) {
+        if (kind) *kind = i == nl ? kKindChainFold : kKindReadSelect;
+        if (param) *param = 0;
+        if (n_jobs) *n_jobs = i == nl ? batch->n_chains : batch->n_reads;
+        // fold: one 4-byte cost per job + a 24-byte descriptor and two 4-byte results per chain;
+        // select: 8 bytes read and 5 written per chain
+        if (algorithmic_bytes)
+            *algorithmic_bytes = i == nl ? pl->n_jobs * 4 + batch->n_chains * 32 : batch->n_chains * 13 + batch->n_reads * 8;
+        if (cells) *cells = 0;
+        return RAWDTW_OK;
+    }
+    const Launch &L = pl->launches[i];
+    uint64_t bytes = 0, cl = 0;
+    for (uint64_t p = L.first; p < L.first + L.count; p++) {
+        const DevJob &d = pl->h_jobs[p];
+        bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
+        if (cells) cl += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
+    }
+    if (kind) *kind = L.kind;
+    if (param) *param = L.param;
+    if (n_jobs) *n_jobs = L.count;
+    if (algorithmic_bytes) *algorithmic_bytes = bytes;
+    if (cells) *cells = cl;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep, float *job_cost)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    if (batch->n_chains) {
+        if (score) HIP_TRY(ctx, hipMemcpyAsync(score, batch->d_score, batch->n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (keep) HIP_TRY(ctx, hipMemcpyAsync(keep, batch->d_keep, batch->n_chains, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (job_cost && batch->plan->n_jobs)
+        HIP_TRY(ctx, hipMemcpyAsync(job_cost, batch->plan->d_cost, batch->plan->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_destroy(rawdtw_batch *b)
+{
+    if (!b) return RAWDTW_OK;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    rawdtw_plan_destroy(b->plan);
+    if (b->d_chains) (void)hipFree(b->d_chains);
+    if (b->d_chain_off) (void)hipFree(b->d_chain_off);
+    if (b->d_full) (void)hipFree(b->d_full);
+    if (b->d_gate) (void)hipFree(b->d_gate);
+    if (b->d_score) (void)hipFree(b->d_score);
+    if (b->d_keep) (void)hipFree(b->d_keep);
+    delete b;
+    return RAWDTW_OK;
 }
 
 } // extern "C"

@@ -17,7 +17,7 @@ struct DevJob {
     uint32_t m;        // b_length
     int32_t R;         // banded: radius AFTER the slant correction (dtw.cpp:298-300); full: -1
     uint32_t flags;    // bit0: exclude_last_element
-    uint32_t aux;      // kernel-specific (full kernels: index into the per-job workspace tables)
+    uint32_t aux;      // the job's index in the caller's batch: kernels store their cost at out[aux]
 };
 static_assert(sizeof(DevJob) == 32, "DevJob must stay 32 bytes");
 
@@ -30,7 +30,19 @@ enum LaunchKind : uint32_t {
     kKindFullWave = 3,  // wave-per-job full-matrix wavefront (score only)
     kKindFullTb = 4,    // same, writing packed directions
     kKindTbWalk = 5,    // traceback walk
+    kKindChainFold = 6, // per-chain fold of the part costs (align_chain)
+    kKindReadSelect = 7 // per-read accept/cut loop (gen_chains DTW block)
 };
+
+// One candidate chain as the replay kernels see it (24 bytes).
+struct ChainDesc {
+    uint64_t job_first;   // first job of the chain in the batch's job order
+    uint32_t n_jobs;      // 1 (global) or n_anchors-1 (sparse)
+    uint32_t span;        // read events between the chain's first and last anchor, inclusive (rmap.cpp:245)
+    uint32_t num_aligned; // sum of the parts' read_region_size (rmap.cpp:236,292)
+    uint32_t reserved;
+};
+static_assert(sizeof(ChainDesc) == 24, "ChainDesc must stay 24 bytes");
 
 constexpr int kMaxLaneRadius = 12;     // lane-per-job kernel handles R in [0, 12]
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
@@ -59,6 +71,12 @@ hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux
                           const float *ev, const float *ref, const uint8_t *dir_ws,
                           const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                           uint32_t *path_j, float *path_d, hipStream_t s);
+
+hipError_t launch_chain_fold(const ChainDesc *chains, uint64_t n_chains, const float *job_cost, float bonus,
+                             int fused, float *full_score, float *att_last, hipStream_t s);
+hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const float *full_score,
+                              const float *att_last, float min_score, float *score, uint8_t *keep,
+                              hipStream_t s);
 
 // geometry helpers shared with the planner
 inline uint32_t full_strip_rows(int rpl) { return 64u * (uint32_t)rpl; }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jo
 
     float res = d1[HP + SH]; // dtw.cpp:506-512
     if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
-    out[g] = res;
+    out[jb.aux] = res; // job order (aux = the job's index in the caller's batch)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void k_band_wave(const DevJob *__restrict__ job
     if (lane == 0) {
         float res = d1[P / 2 + SH];
         if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
-        out[blockIdx.x] = res;
+        out[jb.aux] = res;
     }
 }
 
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
     }
     if (lane == 0) {
         if (jb.flags & kFlagExcludeLast) result = result - dist(a[jb.n - 1], b[jb.m - 1]);
-        out[blockIdx.x] = result;
+        out[jb.aux] = result;
     }
 }
 
@@ -409,8 +409,78 @@ __global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-candidate selection: the fold of align_chain (rmap.cpp:238-306) and the best-so-far loop of
+// gen_chains (rmap.cpp:515-524), on the device.  A chain's running `current_max_attainable_score`
+// (rmap.cpp:246,280) never increases (every sub-cost is >= 0), so "some check before part p
+// fails" <=> "the check before the LAST part fails"; the fold therefore does not depend on the
+// running best and runs one lane per chain, and only the tiny accept/cut loop is sequential per
+// read.  All arithmetic is fp32 in the reference's order; the final score is a single fma when the
+// reference build contracts it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict__ chains, uint64_t n_chains,
+                                                    const float *__restrict__ job_cost, float bonus,
+                                                    int fused, float *__restrict__ full_score,
+                                                    float *__restrict__ att_last)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_chains) return;
+    const ChainDesc d = chains[c];
+    float attainable = (float)d.span * bonus; // rmap.cpp:205,246
+    float gate = attainable;                  // value tested before the last (or only) DTW call
+    float cost = 0.0f;
+    const float *jc = job_cost + d.job_first;
+    for (uint32_t p = 0; p < d.n_jobs; p++) {
+        gate = attainable;
+        const float sub = jc[p];
+        cost += sub;       // rmap.cpp:279
+        attainable -= sub; // rmap.cpp:280
+    }
+    if (d.n_jobs == 0) gate = __builtin_inff(); // no DTW call, no check
+    float score;
+    if (fused) score = __builtin_fmaf((float)d.num_aligned, bonus, -cost);
+    else { const float prod = (float)d.num_aligned * bonus; score = prod - cost; }
+    full_score[c] = score;
+    att_last[c] = gate;
+}
+
+__global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict__ chain_off, uint64_t n_reads,
+                                                     const float *__restrict__ full_score,
+                                                     const float *__restrict__ att_last, float min_score,
+                                                     float *__restrict__ score, uint8_t *__restrict__ keep)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    float best = 0.0f; // rmap.cpp:515
+    for (uint64_t c = chain_off[r]; c < chain_off[r + 1]; c++) {
+        const float s = (att_last[c] < best) ? -1e10f : full_score[c]; // rmap.cpp:206-209, 265-268
+        const bool k = s >= min_score;                                  // rmap.cpp:518
+        if (k && s > best) best = s;                                    // rmap.cpp:519-521
+        score[c] = s;
+        keep[c] = k ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+hipError_t launch_chain_fold(const ChainDesc *chains, uint64_t n_chains, const float *job_cost, float bonus,
+                             int fused, float *full_score, float *att_last, hipStream_t s)
+{
+    if (n_chains == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 255) / 256)), dim3(256), 0, s, chains, n_chains,
+                       job_cost, bonus, fused, full_score, att_last);
+    return hipGetLastError();
+}
+
+hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const float *full_score,
+                              const float *att_last, float min_score, float *score, uint8_t *keep, hipStream_t s)
+{
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_read_select, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, s, chain_off, n_reads,
+                       full_score, att_last, min_score, score, keep);
+    return hipGetLastError();
+}
+
 template <int R>
 static hipError_t launch_lane_r(const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
                                 float *out, hipStream_t s)

@@ -147,7 +147,7 @@ def test_error_behaviour(engine):
     bad[0] = (0, 0, 4, 4, -5, 0, 0)  # negative radius: dtw.cpp:277 asserts
     with pytest.raises(ra.RawDTWError):
         engine.score_batch(bad, ev)
-    bad[0] = (10, 0, 4, 10, 1, 0, 0)  # window past the arena
+    bad[0] = (28, 0, 4, 10, 1, 0, 0)  # window past the arena (fwd + rev = 32 floats)
     with pytest.raises(ra.RawDTWError) as e:
         engine.score_batch(bad, ev)
     assert e.value.status == 4
@@ -197,3 +197,76 @@ def test_properties_at_scale(engine):
     j2["ref_off"] = j2["read_off"].astype(np.uint64) + b2
     sym2 = engine.score_batch(j2, ref[: 1 << 19])
     assert np.array_equal(sym.view(np.uint32), sym2.view(np.uint32))
+
+
+@pytest.mark.parametrize("border,fill", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_batch_matches_oracle_loop(engine, oracle, border, fill):
+    """rawdtw_batch (DTW kernels + device fold + device select) == the reference's sequential loop
+    (rmap.cpp:515-524 calling align_chain with the running best), chain by chain, bit for bit."""
+    from oracle.loader import OrcOpt
+    from rawalign_amd import synth
+
+    ref = synth.make_reference([120000], seed=77)
+    engine.upload_reference(ref.forward, ref.reverse)
+    offs = {(0, st): engine.reference_offset(0, st) for st in (0, 1)}
+    cb, info = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=96, max_chunks=3, decoys_per_read=3.0),
+                                          seed=1234 + border * 2 + fill)
+    engine.upload_events(cb.events)
+    opt = ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill)
+    batch = ra.Batch(engine, opt, cb)
+    batch.run()
+    score, keep = batch.fetch()
+    oopt = OrcOpt(border, fill, 0.10, 0.4, 20.0, 1)
+    arrays = {1: ref.forward[0], 0: ref.reverse[0]}
+    strand_of = {offs[(0, 1)]: 1, offs[(0, 0)]: 0}
+    n_cut = n_keep = 0
+    for r in range(cb.n_reads):
+        best = np.float32(0.0)
+        for c in range(int(cb.chain_off[r]), int(cb.chain_off[r + 1])):
+            a = cb.anchors[int(cb.anchor_off[c]):int(cb.anchor_off[c + 1])]
+            ev = cb.events[int(cb.read_base[c]):]
+            want = oracle.align_chain(a, arrays[strand_of[int(cb.ref_base[c])]], ev, oopt, float(best))
+            assert bits(score[c]) == bits(want), (r, c, score[c], want)
+            k = want >= np.float32(20.0)
+            assert bool(keep[c]) == bool(k)
+            if k and want > best:
+                best = want
+            n_cut += want == np.float32(-1e10)
+            n_keep += bool(k)
+    assert n_keep > 0 and n_cut > 0  # both the accept and the early-cut path were exercised
+    # evaluate_reads (object API) agrees with the flat batch
+    st = batch.info()
+    assert st["n_chains"] == cb.n_chains and st["n_jobs"] > 0 and st["cells"] > 0
+
+
+def test_align_chain_cigar_quirks(engine, oracle):
+    """--dtw-output-cigar path: sparse (parts never exclude their last element, anchors counted
+    twice) and global+full (offsets added to the last tuple only), SURVEY.md 8 a-4 (i)(ii)."""
+    from oracle.loader import OrcOpt
+
+    rng = np.random.default_rng(31)
+    refsig = rng.normal(size=5000).astype(np.float32)
+    engine.upload_reference([refsig], [refsig[::-1].copy()])
+    q = np.array([3, 9, 14, 30, 31, 47, 80])
+    t = np.array([100, 105, 111, 125, 126, 140, 171])
+    anchors = np.zeros(len(q), ra.ANCHOR_DTYPE)
+    anchors["query_position"] = q[::-1]
+    anchors["target_position"] = t[::-1]
+    events = (refsig[97:97 + 90] + rng.normal(scale=0.2, size=90)).astype(np.float32)
+    for border, fill in [(1, 1), (1, 0), (0, 0)]:
+        opt = ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill)
+        ch = ra.Chain(50.0, 0, 1, anchors)
+        ra.align_chain(engine, ch, events, opt, cigar=True)
+        oopt = OrcOpt(border, fill, 0.10, 0.4, 20.0, 1)
+        sc, cost, pi, pj, pd = oracle.align_chain_cigar(anchors, refsig, events, oopt)
+        assert bits(ch.alignment_score) == bits(sc)
+        assert bits(ch.dtw_result.cost) == bits(cost)
+        assert np.array_equal(ch.dtw_result.i, pi) and np.array_equal(ch.dtw_result.j, pj)
+        assert np.array_equal(ch.dtw_result.difference.view(np.uint32), pd.view(np.uint32))
+    with pytest.raises(AssertionError):  # rmap.cpp:223-225
+        ra.align_chain(engine, ra.Chain(50.0, 0, 1, anchors), events, ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=1), cigar=True)
+    # score-only single chain, every min_score regime
+    for ms in (-1e10, 0.0, 25.0, 1e6):
+        opt = ra.MapOpt()
+        ch = ra.align_chain(engine, ra.Chain(50.0, 0, 1, anchors), events, opt, cigar=False, min_score=ms)
+        assert bits(ch.alignment_score) == bits(oracle.align_chain(anchors, refsig, events, OrcOpt(1, 1, 0.10, 0.4, 20.0, 1), ms))
