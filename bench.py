@@ -123,6 +123,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # a second, untimed pass with the launches serialised: clean per-kernel durations
+    eng.set_option("serial_launches", 1)
+    isolated = batch.run_reps(max(3, min(args.steps, 10)), timed=True)
+    eng.set_option("serial_launches", 0)
+
     score, keep, job_cost = batch.fetch(with_job_costs=True)
     read_of_chain = np.repeat(np.arange(cb.n_reads), np.diff(cb.chain_off.astype(np.int64)))
     mapped = int(len(np.unique(read_of_chain[keep.astype(bool)])))  # reads with >= 1 surviving chain
@@ -136,8 +141,9 @@ def main():
 
     if rank == 0:
         stats = batch.launch_stats(with_cells=False)
-        # dominant kernel = the launch with the largest mean duration
-        dom = max(range(len(launches)), key=lambda i: launches[i][2])
+        # dominant kernel = the launch with the largest duration when run alone; its duration inside the
+        # timed region (where launches overlap on several streams) is what `achieved` is priced with
+        dom = max(range(len(isolated)), key=lambda i: isolated[i][2])
         dkind, dparam, dms = launches[dom]
         dbytes = stats[dom]["algorithmic_bytes"]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
@@ -150,7 +156,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kname = ra.Engine.KIND_NAMES.get(dkind, {6: "chain_fold", 7: "read_select"}.get(dkind, str(dkind)))
+        kname = ra.Engine.KIND_NAMES.get(dkind, str(dkind))
         out = {
             "metric": "DTW GCUPS",
             "value": cells_t * args.steps / T / 1e9,
@@ -176,9 +182,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"{kname}(param={dparam})", "launch_ms": dms,
+                         "launch_ms_isolated": isolated[dom][2],
+                         "achieved_isolated": dbytes / (isolated[dom][2] * 1e-3) / 1e9 if isolated[dom][2] > 0 else 0.0,
                          "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": stats[dom]["n_jobs"]},
-            "launches": [{"kernel": ra.Engine.KIND_NAMES.get(k, {6: "chain_fold", 7: "read_select"}.get(k, str(k))),
-                          "param": p, "ms": round(ms, 5), "jobs": stats[i]["n_jobs"]} for i, (k, p, ms) in enumerate(launches)],
+            "launches": [{"kernel": ra.Engine.KIND_NAMES.get(k, str(k)),
+                          "param": p, "ms": round(ms, 5), "ms_isolated": round(isolated[i][2], 5),
+                          "jobs": stats[i]["n_jobs"], "algorithmic_bytes": stats[i]["algorithmic_bytes"]}
+                         for i, (k, p, ms) in enumerate(launches)],
         }
         if world == 1 and not args.no_cpu_baseline:
             # rebuild the job list exactly as the device batch built it

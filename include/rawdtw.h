@@ -62,6 +62,10 @@ int rawdtw_destroy(rawdtw_ctx *ctx);
 const char *rawdtw_last_error(const rawdtw_ctx *ctx);
 const char *rawdtw_status_string(int status);
 int rawdtw_sync(rawdtw_ctx *ctx);
+/* tuning knobs: "serial_launches" (0/1: run a batch's launches one after another on the main
+ * stream instead of concurrently -- for per-kernel timing), "lane_max_radius" (0..8: largest
+ * post-slant band radius handled by the lane-per-job kernel) */
+int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);
 /* the ctx's hipStream_t, as void* (for event timing on the stream kernels run on) */
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream);
 

@@ -56,6 +56,7 @@ SYMBOLS = {
     "rawdtw_last_error": (C.c_char_p, [VP]),
     "rawdtw_status_string": (C.c_char_p, [I32]),
     "rawdtw_sync": (I32, [VP]),
+    "rawdtw_set_option": (I32, [VP, C.c_char_p, C.c_int64]),
     "rawdtw_stream": (I32, [VP, C.POINTER(VP)]),
     "rawdtw_upload_reference": (I32, [VP, U32, VP, VP, VP]),
     "rawdtw_reference_offset": (I32, [VP, U32, I32, C.POINTER(U64)]),

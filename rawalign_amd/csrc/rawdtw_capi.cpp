@@ -18,6 +18,12 @@ using namespace rawdtw;
 struct rawdtw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // side streams: independent launches of one batch run concurrently (fork/join around the main stream)
+    static constexpr int kSide = 3;
+    hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
+    bool serial_launches = false;
+    int lane_max_radius = 6; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
     // reference arena
     float *d_ref = nullptr;
     uint64_t n_ref = 0;
@@ -36,6 +42,7 @@ struct rawdtw_plan {
     uint64_t n_jobs = 0;
     std::vector<uint32_t> order;   // plan position -> job index
     std::vector<Launch> launches;
+    std::vector<uint32_t> run_order; // launch indices, heaviest first
     std::vector<int32_t> launch_rpl;
     DevJob *d_jobs = nullptr;
     FullAux *d_aux = nullptr;      // indexed like d_jobs (only meaningful for full-matrix jobs)
@@ -164,9 +171,10 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     pl->n_jobs = n_jobs;
 
     // sort key: class in the top bits, then descending length so long jobs start first
-    //   banded lane : class = R (0..12)
-    //   banded wave : class = 16 + lds bucket
-    //   full        : class = 32 + log2(rpl)
+    //   banded lane          : class = 3*R + (2 - tier)  (R in 0..lane_max_radius, longer side <= 73)
+    //   banded wave, register: class = 32 + log2(chunks)      (radius+1 <= 64*chunks, chunks <= 32)
+    //   banded wave, LDS     : class = 40 + lds bucket
+    //   full                 : class = 48 + log2(rpl)
     struct Keyed { uint64_t key; uint32_t idx; int32_t R; };
     std::vector<Keyed> keyed(n_jobs);
     uint64_t alg_bytes = 0;
@@ -188,7 +196,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         int32_t R = -1;
         if (j.band_radius == RAWDTW_FULL) {
             const int rpl = full_rpl(NY);
-            cls = 32 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
+            cls = 48 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
         } else {
             if (traceback) {
                 delete pl;
@@ -200,11 +208,17 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 delete pl;
                 return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
             }
-            if (R <= kMaxLaneRadius) cls = (uint64_t)R;
-            else {
-                const uint32_t K = (uint32_t)R + 1;
-                // LDS buckets: 3K floats <= 1.5K, 6K, 24K, 40K floats
-                cls = 16 + (K <= 512 ? 0 : K <= 2048 ? 1 : K <= 8192 ? 2 : 3);
+            const uint32_t K = (uint32_t)R + 1;
+            if (R <= ctx->lane_max_radius && N <= (uint32_t)kLaneMaxN[kLaneTiers - 1]) {
+                const int tier = N <= (uint32_t)kLaneMaxN[0] ? 0 : N <= (uint32_t)kLaneMaxN[1] ? 1 : 2;
+                cls = 3ull * (uint64_t)R + (uint64_t)(2 - tier); // widest tier (longest jobs) first
+            }
+            else if (K <= 64u * kMaxWregChunks) {
+                uint32_t chunks = 1, lg = 0;
+                while (64u * chunks < K) { chunks <<= 1; lg++; }
+                cls = 32 + lg;
+            } else {
+                cls = 40 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
             }
         }
         keyed[k].key = (cls << 40) | (uint64_t)(0xffffffffffull - N);
@@ -226,8 +240,8 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
         d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = keyed[p].idx;
         const uint64_t cls = keyed[p].key >> 40;
-        if (cls >= 32) {
-            const int rpl = 1 << (cls - 32);
+        if (cls >= 48) {
+            const int rpl = 1 << (cls - 48);
             const uint32_t NX = std::max(j.n, j.m), NY = std::min(j.n, j.m);
             if (NY > 64u * rpl) { // multi-strip: needs a boundary row
                 pl->h_aux[p].bnd_off = bnd;
@@ -242,11 +256,10 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         if (pl->launches.empty() || (keyed[p - 1].key >> 40) != cls) {
             Launch L{};
             L.first = p; L.count = 0;
-            if (cls < 16) { L.kind = kKindBandLane; L.param = (int32_t)cls; }
-            else if (cls < 32) {
-                static const int32_t lds_f[4] = {3 * 512, 3 * 2048, 3 * 8192, 3 * kMaxWaveBandK};
-                L.kind = kKindBandWave; L.param = lds_f[cls - 16];
-            } else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 32); }
+            if (cls < 32) { L.kind = kKindBandLane; L.param = (int32_t)(cls / 3) | ((int32_t)(2 - cls % 3) << 7); }
+            else if (cls < 40) { L.kind = kKindBandWreg; L.param = 1 << (cls - 32); }
+            else if (cls < 48) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
+            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 48); }
             pl->launches.push_back(L);
         }
         pl->launches.back().count++;
@@ -260,6 +273,23 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         }
     pl->bnd_floats = bnd;
     pl->dir_bytes = dirb;
+    {   // rough work per launch: sum over jobs of (longer side) x (band width or shorter side)
+        std::vector<double> work(pl->launches.size(), 0.0);
+        for (size_t i = 0; i < pl->launches.size(); i++) {
+            const Launch &L = pl->launches[i];
+            for (uint64_t p = L.first; p < L.first + L.count; p++) {
+                const DevJob &d = pl->h_jobs[p];
+                const double N = std::max(d.n, d.m), M = std::min(d.n, d.m);
+                const double w = d.R < 0 ? M : std::min<double>(2.0 * d.R + 1.0, M);
+                // wave-per-job kernels spend a whole wave on one job
+                work[i] += N * (L.kind == kKindBandLane ? w : std::max(w, 64.0));
+            }
+        }
+        pl->run_order.resize(pl->launches.size());
+        for (uint32_t i = 0; i < pl->run_order.size(); i++) pl->run_order[i] = i;
+        std::stable_sort(pl->run_order.begin(), pl->run_order.end(),
+                         [&](uint32_t x, uint32_t y) { return work[x] > work[y]; });
+    }
 
     rawdtw_plan_info_t &I = pl->info;
     I.n_jobs = n_jobs;
@@ -267,7 +297,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     I.n_launches = (uint32_t)pl->launches.size();
     for (const Launch &L : pl->launches) {
         if (L.kind == kKindBandLane) I.n_lane_jobs += L.count;
-        else if (L.kind == kKindBandWave) I.n_wave_band_jobs += L.count;
+        else if (L.kind == kKindBandWave || L.kind == kKindBandWreg) I.n_wave_band_jobs += L.count;
         else I.n_full_jobs += L.count;
     }
     I.workspace_bytes = bnd * 4 + dirb + n_jobs * (sizeof(DevJob) + sizeof(FullAux) + 4);
@@ -297,28 +327,60 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     return RAWDTW_OK;
 }
 
-int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L)
+int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t stream)
 {
     const DevJob *jobs = pl->d_jobs + L.first;
     float *out = pl->d_cost; // job order: every kernel stores at out[job.aux]
     hipError_t e = hipSuccess;
     switch (L.kind) {
     case kKindBandLane:
-        e = launch_band_lane(L.param, jobs, L.count, ctx->d_ev, ctx->d_ref, out, ctx->stream);
+        e = launch_band_lane(L.param & 127, L.param >> 7, jobs, L.count, ctx->d_ev, ctx->d_ref, out, stream);
+        break;
+    case kKindBandWreg:
+        e = launch_band_wreg(L.param, jobs, L.count, ctx->d_ev, ctx->d_ref, out, stream);
         break;
     case kKindBandWave:
-        e = launch_band_wave(jobs, L.count, (uint32_t)L.param, ctx->d_ev, ctx->d_ref, out, ctx->stream);
+        e = launch_band_wave(jobs, L.count, (uint32_t)L.param, ctx->d_ev, ctx->d_ref, out, stream);
         break;
     case kKindFullWave:
     case kKindFullTb:
         e = launch_full_wave(L.param, L.kind == kKindFullTb, jobs, L.count, pl->d_aux + L.first, ctx->d_ev,
-                             ctx->d_ref, out, pl->d_bnd, pl->d_dir, ctx->stream);
+                             ctx->d_ref, out, pl->d_bnd, pl->d_dir, stream);
         break;
     default:
         return fail(ctx, RAWDTW_ERR_INVALID, "unknown launch kind");
     }
     if (e != hipSuccess) return hip_fail(ctx, e, "kernel launch");
     return RAWDTW_OK;
+}
+
+// All launches of a plan are independent: fork them over the main and side streams (heaviest
+// first), join back on the main stream.  `ev`, when given, receives a start/stop event pair per
+// launch (2*n entries), recorded on the stream that launch runs on.
+int run_all_launches(rawdtw_ctx *ctx, rawdtw_plan *pl, hipEvent_t *ev)
+{
+    const size_t nl = pl->launches.size();
+    if (nl == 0) return RAWDTW_OK;
+    const bool fork = nl > 1 && !ctx->serial_launches;
+    if (fork) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int k = 0; k < rawdtw_ctx::kSide; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+    }
+    int st = RAWDTW_OK;
+    for (size_t q = 0; q < nl && st == RAWDTW_OK; q++) {
+        const size_t i = pl->run_order[q];
+        const int sl = fork ? (int)(q % (rawdtw_ctx::kSide + 1)) : 0;
+        hipStream_t s = sl == 0 ? ctx->stream : ctx->side[sl - 1];
+        if (ev && hipEventRecord(ev[2 * i], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK) st = run_launch(ctx, pl, pl->launches[i], s);
+        if (st == RAWDTW_OK && ev && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    }
+    if (fork)
+        for (int k = 0; k < rawdtw_ctx::kSide; k++) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k], ctx->side[k]));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
+        }
+    return st;
 }
 
 } // namespace
@@ -365,6 +427,15 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
         delete ctx;
         return RAWDTW_ERR_DEVICE;
     }
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < rawdtw_ctx::kSide && ok; k++)
+        ok = hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { rawdtw_destroy(ctx); return RAWDTW_ERR_DEVICE; }
+    if (const char *e = getenv("RAWDTW_LANE_MAX_R")) {
+        int v = atoi(e);
+        ctx->lane_max_radius = v < 0 ? 0 : (v > kMaxLaneRadius ? kMaxLaneRadius : v);
+    }
     *out = ctx;
     return RAWDTW_OK;
 }
@@ -373,7 +444,13 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
 {
     if (!ctx) return RAWDTW_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    for (int k = 0; k < rawdtw_ctx::kSide; k++) {
+        if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
+        if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
     delete ctx;
@@ -387,6 +464,17 @@ int rawdtw_sync(rawdtw_ctx *ctx)
     if (!ctx) return RAWDTW_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RAWDTW_OK;
+}
+
+int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name) return RAWDTW_ERR_INVALID;
+    if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "lane_max_radius")) {
+        ctx->lane_max_radius = value < 0 ? 0 : (value > kMaxLaneRadius ? kMaxLaneRadius : (int)value);
+        return RAWDTW_OK;
+    }
+    return fail(ctx, RAWDTW_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream)
@@ -498,11 +586,7 @@ int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info)
 int rawdtw_plan_run(rawdtw_ctx *ctx, rawdtw_plan *plan)
 {
     if (!ctx || !plan || plan->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "plan does not belong to this context");
-    for (const Launch &L : plan->launches) {
-        int st = run_launch(ctx, plan, L);
-        if (st != RAWDTW_OK) return st;
-    }
-    return RAWDTW_OK;
+    return run_all_launches(ctx, plan, nullptr);
 }
 
 int rawdtw_plan_run_timed(rawdtw_ctx *ctx, rawdtw_plan *plan, float *launch_ms, uint32_t *launch_kind,
@@ -510,18 +594,13 @@ int rawdtw_plan_run_timed(rawdtw_ctx *ctx, rawdtw_plan *plan, float *launch_ms, 
 {
     if (!ctx || !plan || plan->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "plan does not belong to this context");
     const size_t nl = plan->launches.size();
-    std::vector<hipEvent_t> ev(nl + 1, nullptr);
+    std::vector<hipEvent_t> ev(2 * nl, nullptr);
     for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    int st = RAWDTW_OK;
-    for (size_t i = 0; i < nl && st == RAWDTW_OK; i++) {
-        st = run_launch(ctx, plan, plan->launches[i]);
-        if (st == RAWDTW_OK && hipEventRecord(ev[i + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-    }
-    if (st == RAWDTW_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    int st = run_all_launches(ctx, plan, ev.data());
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
     for (size_t i = 0; i < nl && st == RAWDTW_OK; i++) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) { st = RAWDTW_ERR_DEVICE; break; }
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { st = RAWDTW_ERR_DEVICE; break; }
         if (i < cap) {
             if (launch_ms) launch_ms[i] = ms;
             if (launch_kind) launch_kind[i] = plan->launches[i].kind | ((uint32_t)plan->launches[i].param << 8);
@@ -815,26 +894,9 @@ int rawdtw_batch_run(rawdtw_ctx *ctx, rawdtw_batch *batch)
 int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms, uint32_t *launch_kind, uint32_t cap,
                            uint32_t *n_launches)
 {
-    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
-    const uint32_t nl = (uint32_t)batch->plan->launches.size();
-    if (n_launches) *n_launches = nl + 2;
-    int st = rawdtw_plan_run_timed(ctx, batch->plan, launch_ms, launch_kind, cap);
-    if (st != RAWDTW_OK) return st;
-    hipEvent_t ev[3];
-    for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-    HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    st = batch_tail(ctx, batch, 0);
-    if (st == RAWDTW_OK) { HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream)); st = batch_tail(ctx, batch, 1); }
-    if (st == RAWDTW_OK) { HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
-    for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
-        float ms = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-        if (nl + k < cap) {
-            if (launch_ms) launch_ms[nl + k] = ms;
-            if (launch_kind) launch_kind[nl + k] = (k == 0 ? kKindChainFold : kKindReadSelect);
-        }
-    }
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    std::vector<float> tmp(64, 0.f);
+    int st = rawdtw_batch_run_reps(ctx, batch, 1, launch_ms ? launch_ms : tmp.data(), launch_kind,
+                                   launch_ms ? cap : 64, n_launches);
     return st;
 }
 
@@ -843,22 +905,22 @@ int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, f
 {
     if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
     rawdtw_plan *pl = batch->plan;
-    const uint32_t nl = (uint32_t)pl->launches.size() + 2;
+    const uint32_t np = (uint32_t)pl->launches.size(), nl = np + 2;
     if (n_launches) *n_launches = nl;
     const bool timed = launch_ms != nullptr;
     std::vector<hipEvent_t> ev;
     if (timed) {
-        ev.assign((size_t)reps * (nl + 1), nullptr);
+        ev.assign((size_t)reps * 2 * nl, nullptr);
         for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
     }
     int st = RAWDTW_OK;
     for (uint32_t r = 0; r < reps && st == RAWDTW_OK; r++) {
-        hipEvent_t *e = timed ? &ev[(size_t)r * (nl + 1)] : nullptr;
-        if (timed && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        for (uint32_t i = 0; i < nl && st == RAWDTW_OK; i++) {
-            if (i + 2 < nl) st = run_launch(ctx, pl, pl->launches[i]);
-            else st = batch_tail(ctx, batch, (int)(i + 2 - nl));
-            if (st == RAWDTW_OK && timed && hipEventRecord(e[i + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        hipEvent_t *e = timed ? &ev[(size_t)r * 2 * nl] : nullptr;
+        st = run_all_launches(ctx, pl, e);
+        for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
+            if (timed && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+            if (st == RAWDTW_OK) st = batch_tail(ctx, batch, k);
+            if (st == RAWDTW_OK && timed && hipEventRecord(e[2 * (np + k) + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         }
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
@@ -867,14 +929,14 @@ int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, f
             double acc = 0;
             for (uint32_t r = 0; r < reps; r++) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ev[(size_t)r * (nl + 1) + i], ev[(size_t)r * (nl + 1) + i + 1]) != hipSuccess)
-                    st = RAWDTW_ERR_DEVICE;
+                const size_t b = (size_t)r * 2 * nl + 2 * i;
+                if (hipEventElapsedTime(&ms, ev[b], ev[b + 1]) != hipSuccess) st = RAWDTW_ERR_DEVICE;
                 acc += ms;
             }
             launch_ms[i] = reps ? (float)(acc / reps) : 0.f;
             if (launch_kind)
-                launch_kind[i] = i + 2 < nl ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
-                                            : (i + 2 == nl ? kKindChainFold : kKindReadSelect);
+                launch_kind[i] = i < np ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
+                                        : (i == np ? kKindChainFold : kKindReadSelect);
         }
     }
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);

@@ -31,7 +31,8 @@ enum LaunchKind : uint32_t {
     kKindFullTb = 4,    // same, writing packed directions
     kKindTbWalk = 5,    // traceback walk
     kKindChainFold = 6, // per-chain fold of the part costs (align_chain)
-    kKindReadSelect = 7 // per-read accept/cut loop (gen_chains DTW block)
+    kKindReadSelect = 7, // per-read accept/cut loop (gen_chains DTW block)
+    kKindBandWreg = 8    // wave-per-job banded kernel, band in registers (param = registers per lane per buffer)
 };
 
 // One candidate chain as the replay kernels see it (24 bytes).
@@ -44,12 +45,23 @@ struct ChainDesc {
 };
 static_assert(sizeof(ChainDesc) == 24, "ChainDesc must stay 24 bytes");
 
-constexpr int kMaxLaneRadius = 12;     // lane-per-job kernel handles R in [0, 12]
+constexpr int kMaxLaneRadius = 8;      // lane-per-job kernel is instantiated for R in [0, 8]
+// lane kernel LDS tiles, by the longer side of the job (a window of L floats needs L+3 floats of its
+// CAP because it is copied in 16-byte aligned chunks):
+//   tier 0 "narrow": 256 jobs x  36 floats, longer side <= 13
+//   tier 1 "medium": 128 jobs x  76 floats, longer side <= 33
+//   tier 2 "wide"  :  64 jobs x 156 floats, longer side <= 73
+constexpr int kLaneTiers = 3;
+constexpr int kLaneJobs[kLaneTiers] = {256, 128, 64};
+constexpr int kLaneCap[kLaneTiers] = {16, 36, 76};
+constexpr int kLaneStride[kLaneTiers] = {36, 76, 156};
+constexpr int kLaneMaxN[kLaneTiers] = {13, 33, 73};
+constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
 
 struct Launch {
     uint32_t kind;
-    int32_t param;      // band lane: R ; full: rows per lane ; band wave: LDS floats
+    int32_t param;      // band lane: R | tier<<7 ; wreg: registers per lane ; full: rows per lane ; band wave: LDS floats
     uint64_t first;     // first plan-order job
     uint64_t count;     // jobs in this launch
 };
@@ -60,7 +72,9 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-hipError_t launch_band_lane(int R, const DevJob *jobs, uint64_t count, const float *ev,
+hipError_t launch_band_lane(int R, int tier, const DevJob *jobs, uint64_t count, const float *ev,
+                            const float *ref, float *out, hipStream_t s);
+hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev,
                             const float *ref, float *out, hipStream_t s);
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats,
                             const float *ev, const float *ref, float *out, hipStream_t s);

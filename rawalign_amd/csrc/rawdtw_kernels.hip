@@ -22,18 +22,46 @@ __device__ __forceinline__ float min3f(float top, float left, float tl)
 
 __device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
 
+__device__ __forceinline__ float wave_shr1(float v, float fill)
+{
+    // lane l receives lane l-1's value; lane 0 keeps `fill`  (DPP wave_shr:1 = 0x138)
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                        0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
+__device__ __forceinline__ float read_lane(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ float wave_shl1(float v, float fill)
+{
+    // lane l receives lane l+1's value; lane 63 keeps `fill`  (DPP wave_shl:1 = 0x130)
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                        0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Lane-per-job banded kernel.  Sparse-mode segments are tiny (2..~100 events, radius 1..12):
+// Lane-per-job banded kernel.  Sparse-mode segments are tiny (2..~70 events, radius 1..6):
 // intra-job parallelism is a handful of cells per antidiagonal, so each lane owns one job and
 // the three rotating antidiagonal buffers of dtw.cpp:305-314 live in registers (radius is a
-// template parameter, every buffer index is a compile-time constant).  Operand windows slide
-// through registers too: one new a-value per column, one new b-value when the centre row moves.
+// template parameter, every buffer index is a compile-time constant).
+//
+// Operands: the workgroup first stages the windows of its JOBS jobs from HBM into LDS with
+// coalesced 16-byte loads (a lane reading its own window 4 bytes at a time would pull a whole
+// 128-byte line per element through L2).  Each job owns STRIDE floats of LDS: the 16-byte
+// aligned chunks covering its longer window at [0, CAP) and its shorter one at [CAP, 2*CAP);
+// STRIDE/4 is odd so that lanes spread over the banks.  The DP then slides both windows through
+// registers -- one new a-value per column, one new b-value when the centre row moves -- fetched
+// from LDS one step ahead of their use.
 // ---------------------------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jobs, uint32_t count,
-                                                   const float *__restrict__ ev,
-                                                   const float *__restrict__ ref,
-                                                   float *__restrict__ out)
+template <int R, int JOBS, int CAP, int STRIDE>
+__global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ jobs, uint32_t count,
+                                                    const float *__restrict__ ev,
+                                                    const float *__restrict__ ref,
+                                                    float *__restrict__ out)
 {
     constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
     constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
@@ -41,10 +69,17 @@ __global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jo
     constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
     constexpr int HP = P / 2, HS = S / 2;
     constexpr bool EVEN = (R % 2 == 0);
+    constexpr int CW = CAP / 4;         // 16-byte chunks per window
+    static_assert(CAP % 4 == 0 && STRIDE % 4 == 0 && (STRIDE / 4) % 2 == 1 && STRIDE >= 2 * CAP, "LDS layout");
 
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= count) return;
-    const DevJob jb = jobs[g];
+    __shared__ __attribute__((aligned(16))) float win[JOBS * STRIDE];
+    __shared__ unsigned long long win_src[JOBS * 2]; // 16-byte aligned global address of each window
+    __shared__ int win_chunks[JOBS * 2];             // chunks to copy for each window
+
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x * (uint32_t)JOBS + tid;
+    const bool active = g < count;
+    DevJob jb = jobs[active ? g : count - 1];
     const float *A = ev + jb.read_off;
     const float *B = ref + jb.ref_off;
     uint32_t N = jb.n, M = jb.m;
@@ -52,6 +87,28 @@ __global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jo
         const float *tp = A; A = B; B = tp;
         uint32_t tn = N; N = M; M = tn;
     }
+    const uint32_t misA = (uint32_t)(((uintptr_t)A >> 2) & 3u), misB = (uint32_t)(((uintptr_t)B >> 2) & 3u);
+    win_src[2 * tid] = (unsigned long long)((uintptr_t)A & ~(uintptr_t)15);
+    win_src[2 * tid + 1] = (unsigned long long)((uintptr_t)B & ~(uintptr_t)15);
+    win_chunks[2 * tid] = active ? (int)((misA + N + 3) >> 2) : 0;
+    win_chunks[2 * tid + 1] = active ? (int)((misB + M + 3) >> 2) : 0;
+    __syncthreads();
+    // cooperative copy: consecutive threads take consecutive chunks of the same window
+#pragma unroll 2
+    for (int cidx = tid; cidx < JOBS * 2 * CW; cidx += JOBS) {
+        const int w = cidx / CW;          // window index = job*2 + which
+        const int k = cidx - w * CW;      // chunk inside the window
+        if (k < win_chunks[w]) {
+            const float4 v = *reinterpret_cast<const float4 *>(win_src[w] + 16ull * (unsigned)k);
+            const int job = w >> 1;
+            *reinterpret_cast<float4 *>(&win[job * STRIDE + (w & 1) * CAP + 4 * k]) = v;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float *LA = &win[tid * STRIDE + misA];
+    const float *LB = &win[tid * STRIDE + CAP + misB];
+    const int iN = (int)N, iM = (int)M;
 
     float d0[K], d1[K], d2[K];
     float aw[K];     // aw[x] = A[col + HP - x]
@@ -59,38 +116,49 @@ __global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jo
 #pragma unroll
     for (int x = 0; x < K; x++) {
         d0[x] = kInf; d1[x] = kInf; d2[x] = kInf;
-        int ia = HP - x;
-        aw[x] = A[ia < 0 ? 0 : (ia >= (int)N ? (int)N - 1 : ia)];
+        const int ia = HP - x;
+        aw[x] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
     }
 #pragma unroll
     for (int x = 0; x <= K; x++) {
-        int ib = x - HP - 1;
-        bw[x] = B[ib < 0 ? 0 : (ib >= (int)M ? (int)M - 1 : ib)];
+        const int ib = x - HP - 1;
+        bw[x] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
     }
+    const float a_first = LA[0], b_first = LB[0], a_last = LA[iN - 1], b_last = LB[iM - 1];
 
-    // column 0: only the corner (dtw.cpp:317-347), then the first rotation
-    d1[HP + SH] = dist(A[0], B[0]);
+    // column 0: only the corner (dtw.cpp:317-347), already rotated into place
+    d1[HP + SH] = dist(a_first, b_first);
 
     int row = 0;
     uint32_t rem = 0; // M*col - row*N, so "row advances" <=> rem + M >= N  (dtw.cpp:352-359)
     bool prev_adv = false;
+    // one-ahead operand fetch: a_next = A[col + HP] for the coming column,
+    // b_next = B[row + 1 - HP - 1 + K] for the coming row advance
+    float a_next, b_next;
+    {
+        const int ia = 1 + HP, ib = 1 - HP - 1 + K;
+        a_next = LA[ia >= iN ? iN - 1 : ia];
+        b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+    }
     for (uint32_t col = 1; col < N; col++) {
         rem += M;
         const bool adv = rem >= N;
         if (adv) { rem -= N; row++; }
 
-        // slide the operand windows
+        // slide the operand windows, then issue the next fetches
 #pragma unroll
         for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
+        aw[0] = a_next;
         {
-            uint32_t ia = col + HP;
-            aw[0] = A[ia < N ? ia : N - 1];
+            const int ia = (int)col + 1 + HP;
+            a_next = LA[ia >= iN ? iN - 1 : ia];
         }
         if (adv) {
 #pragma unroll
             for (int x = 0; x < K; x++) bw[x] = bw[x + 1];
-            int ib = row - HP - 1 + K;
-            bw[K] = B[ib < 0 ? 0 : (ib >= (int)M ? (int)M - 1 : ib)];
+            bw[K] = b_next;
+            const int ib = row + 1 - HP - 1 + K;
+            b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
         }
 
         if (adv) { // secondary antidiagonal (dtw.cpp:361-414)
@@ -147,7 +215,7 @@ __global__ __launch_bounds__(256) void k_band_lane(const DevJob *__restrict__ jo
     }
 
     float res = d1[HP + SH]; // dtw.cpp:506-512
-    if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+    if (jb.flags & kFlagExcludeLast) res = res - dist(a_last, b_last);
     out[jb.aux] = res; // job order (aux = the job's index in the caller's batch)
 }
 
@@ -240,17 +308,137 @@ __global__ __launch_bounds__(64) void k_band_wave(const DevJob *__restrict__ job
 // chunks.  With TB the 2-bit move of dtw.cpp:633-646 is decided at fill time from the same
 // three values and packed RPL codes per lane per step.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_shr1(float v, float fill)
+// ---------------------------------------------------------------------------------------------
+// Register-resident wave-per-job banded kernel, band offsets laid across lanes (physical buffer
+// index p = c*64 + lane, C registers per lane per buffer, radius + 1 <= 64*C).  The three
+// rotating antidiagonal buffers, and the operand windows, never leave registers: a neighbour at
+// p-1 / p+1 is a DPP wave shift (plus one v_readlane to carry across a 64-lane boundary), the
+// a-window slides one lane per column, the b-window one lane per centre-row advance, and the
+// single fresh value each of them needs comes out of a 64-wide chunk prefetched one chunk ahead
+// -- so no memory access sits on the antidiagonal-to-antidiagonal dependency chain.
+// Same physical indexing, guards and stale-slot behaviour as dtw.cpp:305-491.
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ jobs,
+                                                  const float *__restrict__ ev,
+                                                  const float *__restrict__ ref,
+                                                  float *__restrict__ out)
 {
-    // lane l receives lane l-1's value; lane 0 keeps `fill`  (DPP wave_shr:1 = 0x138)
-    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
-                                        0x138, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, r);
-}
+    const DevJob jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        uint32_t tn = N; N = M; M = tn;
+    }
+    const int R = jb.R;
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int SH = P > S ? 0 : 1;
+    const int HP = P / 2;
+    const int iN = (int)N, iM = (int)M;
+    auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
+    auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
 
-__device__ __forceinline__ float read_lane(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+    float d0[C], d1[C], d2[C], ap[C], bp[C];
+    // windows at column 0 / row 0:  ap(p) = A[col + HP + SH - p],  bp(p) = B[row - HP - SH + p]
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int p = c * 64 + lane;
+        d0[c] = kInf; d1[c] = kInf; d2[c] = kInf;
+        ap[c] = ldA(HP + SH - p);
+        bp[c] = ldB(p - HP - SH);
+        if (p == HP + SH) d1[c] = dist(A[0], B[0]); // the corner, already rotated into place
+    }
+    // fresh-value chunks: column col needs A[col + HP + SH]; the r-th row advance needs B[b0 + r - 1]
+    const int a0 = HP + SH + 1, b0 = 64 * C - HP - SH;
+    float acur = ldA(a0 + lane), anxt = ldA(a0 + 64 + lane);
+    float bcur = ldB(b0 + lane), bnxt = ldB(b0 + 64 + lane);
+
+    int row = 0;
+    uint32_t rem = 0;
+    bool prev_adv = false;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        const uint32_t ca = (col - 1) & 63u;
+        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 64 + lane); }
+        const float fresh_a = read_lane(acur, (int)ca);
+        if (adv) {
+            rem -= N;
+            row++;
+            const uint32_t cb = (uint32_t)(row - 1) & 63u;
+            if (cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 64 + lane); }
+            const float fresh_b = read_lane(bcur, (int)cb);
+            // b-window: every lane takes its right neighbour's value
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float fill = (c + 1 < C) ? read_lane(bp[c + 1 < C ? c + 1 : c], 0) : fresh_b;
+                bp[c] = wave_shl1(bp[c], fill);
+            }
+            // secondary antidiagonal (dtw.cpp:361-414): cell of lane p is (si - p, sj + p)
+            const int si = (int)col - 1 + HP + SH, sj = row - HP - SH;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int p = c * 64 + lane;
+                const float fill = (c + 1 < C) ? read_lane(d1[c + 1 < C ? c + 1 : c], 0) : kInf;
+                float left = wave_shl1(d1[c], fill); // dp1[p+1]
+                float top = d1[c], tl = d0[c];
+                if (SH) {
+                    if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
+                    if (p == S - 1) left = kInf;
+                }
+                const float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
+                const bool valid = p < S && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
+                if (valid) d2[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) { const float t = d0[c]; d0[c] = d1[c]; d1[c] = d2[c]; d2[c] = t; }
+        }
+        // a-window: every lane takes its left neighbour's value
+#pragma unroll
+        for (int c = C - 1; c >= 0; c--) {
+            const float fill = (c > 0) ? read_lane(ap[c > 0 ? c - 1 : 0], 63) : fresh_a;
+            ap[c] = wave_shr1(ap[c], fill);
+        }
+        // primary antidiagonal (dtw.cpp:416-485): offset o = p - SH, cell (si - p, sj + p)
+        {
+            const int si = (int)col + HP + SH, sj = row - HP - SH;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int p = c * 64 + lane;
+                const int o = p - SH;
+                const float f1 = (c > 0) ? read_lane(d1[c > 0 ? c - 1 : 0], 63) : kInf;
+                float top = wave_shr1(d1[c], f1); // dp1[p-1]
+                float tl, left = d1[c];
+                if (adv) {
+                    tl = d0[c];
+                    if (!SH && p == P - 1) left = kInf;
+                } else {
+                    const float f0 = (c > 0) ? read_lane(d0[c > 0 ? c - 1 : 0], 63) : kInf;
+                    tl = wave_shr1(d0[c], f0); // dp0[p-1]
+                    if (o == 0) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
+                }
+                const float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
+                const bool valid = o >= 0 && o < P && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
+                if (valid) d2[c] = v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) { const float t = d0[c]; d0[c] = d1[c]; d1[c] = d2[c]; d2[c] = t; }
+        prev_adv = adv;
+    }
+    const int pstar = P / 2 + SH; // dtw.cpp:506-512
+    float res = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        if ((pstar >> 6) == c) res = read_lane(d1[c], pstar & 63);
+    if (lane == 0) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
 }
 
 template <int RPL> struct DirWord { using type = uint8_t; };
@@ -422,25 +610,46 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
                                                     int fused, float *__restrict__ full_score,
                                                     float *__restrict__ att_last)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    // one wave per chain: the part costs are fetched 64 at a time (coalesced), the fp32 fold itself
+    // is inherently sequential and runs on wave-uniform values taken out of the chunk with readlane
+    const uint64_t c = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (c >= n_chains) return;
     const ChainDesc d = chains[c];
     float attainable = (float)d.span * bonus; // rmap.cpp:205,246
-    float gate = attainable;                  // value tested before the last (or only) DTW call
     float cost = 0.0f;
     const float *jc = job_cost + d.job_first;
-    for (uint32_t p = 0; p < d.n_jobs; p++) {
-        gate = attainable;
-        const float sub = jc[p];
-        cost += sub;       // rmap.cpp:279
-        attainable -= sub; // rmap.cpp:280
+    // all parts but the last: cost += sub; attainable -= sub (two independent fp32 chains)
+    const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0;
+    uint32_t base = 0;
+    for (; base + 64 <= body; base += 64) {
+        const float chunk = jc[base + lane];
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            const float sub = read_lane(chunk, k);
+            cost += sub;       // rmap.cpp:279
+            attainable -= sub; // rmap.cpp:280
+        }
     }
+    {
+        const uint32_t cnt = d.n_jobs - base; // 0..64 parts left, the last one included
+        const float chunk = ((uint32_t)lane < cnt) ? jc[base + lane] : 0.0f;
+        for (uint32_t k = 0; k + 1 < cnt; k++) {
+            const float sub = read_lane(chunk, (int)k);
+            cost += sub;
+            attainable -= sub;
+        }
+        if (cnt) cost += read_lane(chunk, (int)(cnt - 1));
+    }
+    float gate = attainable; // the value tested before the last (or only) DTW call (rmap.cpp:205,265)
     if (d.n_jobs == 0) gate = __builtin_inff(); // no DTW call, no check
     float score;
     if (fused) score = __builtin_fmaf((float)d.num_aligned, bonus, -cost);
     else { const float prod = (float)d.num_aligned * bonus; score = prod - cost; }
-    full_score[c] = score;
-    att_last[c] = gate;
+    if (lane == 0) {
+        full_score[c] = score;
+        att_last[c] = gate;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict__ chain_off, uint64_t n_reads,
@@ -467,7 +676,7 @@ hipError_t launch_chain_fold(const ChainDesc *chains, uint64_t n_chains, const f
                              int fused, float *full_score, float *att_last, hipStream_t s)
 {
     if (n_chains == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 255) / 256)), dim3(256), 0, s, chains, n_chains,
+    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 3) / 4)), dim3(256), 0, s, chains, n_chains,
                        job_cost, bonus, fused, full_score, att_last);
     return hipGetLastError();
 }
@@ -481,33 +690,42 @@ hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const
     return hipGetLastError();
 }
 
-template <int R>
-static hipError_t launch_lane_r(const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
-                                float *out, hipStream_t s)
+template <int R, int T>
+static hipError_t launch_lane_rt(const DevJob *jobs, uint64_t count, const float *ev, const float *ref, float *out,
+                                 hipStream_t s)
 {
-    const uint32_t blocks = (uint32_t)((count + 255) / 256);
-    hipLaunchKernelGGL(k_band_lane<R>, dim3(blocks), dim3(256), 0, s, jobs, (uint32_t)count, ev, ref, out);
+    const uint32_t blocks = (uint32_t)((count + kLaneJobs[T] - 1) / kLaneJobs[T]);
+    hipLaunchKernelGGL((k_band_lane<R, kLaneJobs[T], kLaneCap[T], kLaneStride[T]>), dim3(blocks), dim3(kLaneJobs[T]), 0,
+                       s, jobs, (uint32_t)count, ev, ref, out);
     return hipGetLastError();
 }
 
-hipError_t launch_band_lane(int R, const DevJob *jobs, uint64_t count, const float *ev,
+template <int R>
+static hipError_t launch_lane_r(int tier, const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
+                                float *out, hipStream_t s)
+{
+    switch (tier) {
+    case 0: return launch_lane_rt<R, 0>(jobs, count, ev, ref, out, s);
+    case 1: return launch_lane_rt<R, 1>(jobs, count, ev, ref, out, s);
+    case 2: return launch_lane_rt<R, 2>(jobs, count, ev, ref, out, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_band_lane(int R, int tier, const DevJob *jobs, uint64_t count, const float *ev,
                             const float *ref, float *out, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
     switch (R) {
-    case 0: return launch_lane_r<0>(jobs, count, ev, ref, out, s);
-    case 1: return launch_lane_r<1>(jobs, count, ev, ref, out, s);
-    case 2: return launch_lane_r<2>(jobs, count, ev, ref, out, s);
-    case 3: return launch_lane_r<3>(jobs, count, ev, ref, out, s);
-    case 4: return launch_lane_r<4>(jobs, count, ev, ref, out, s);
-    case 5: return launch_lane_r<5>(jobs, count, ev, ref, out, s);
-    case 6: return launch_lane_r<6>(jobs, count, ev, ref, out, s);
-    case 7: return launch_lane_r<7>(jobs, count, ev, ref, out, s);
-    case 8: return launch_lane_r<8>(jobs, count, ev, ref, out, s);
-    case 9: return launch_lane_r<9>(jobs, count, ev, ref, out, s);
-    case 10: return launch_lane_r<10>(jobs, count, ev, ref, out, s);
-    case 11: return launch_lane_r<11>(jobs, count, ev, ref, out, s);
-    case 12: return launch_lane_r<12>(jobs, count, ev, ref, out, s);
+    case 0: return launch_lane_r<0>(tier, jobs, count, ev, ref, out, s);
+    case 1: return launch_lane_r<1>(tier, jobs, count, ev, ref, out, s);
+    case 2: return launch_lane_r<2>(tier, jobs, count, ev, ref, out, s);
+    case 3: return launch_lane_r<3>(tier, jobs, count, ev, ref, out, s);
+    case 4: return launch_lane_r<4>(tier, jobs, count, ev, ref, out, s);
+    case 5: return launch_lane_r<5>(tier, jobs, count, ev, ref, out, s);
+    case 6: return launch_lane_r<6>(tier, jobs, count, ev, ref, out, s);
+    case 7: return launch_lane_r<7>(tier, jobs, count, ev, ref, out, s);
+    case 8: return launch_lane_r<8>(tier, jobs, count, ev, ref, out, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -524,6 +742,29 @@ hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_flo
     }
     hipLaunchKernelGGL(k_band_wave, dim3((uint32_t)count), dim3(64), lds_bytes, s, jobs, ev, ref, out);
     return hipGetLastError();
+}
+
+template <int C>
+static hipError_t launch_wreg_c(const DevJob *jobs, uint64_t count, const float *ev, const float *ref, float *out,
+                                hipStream_t s)
+{
+    hipLaunchKernelGGL(k_band_wreg<C>, dim3((uint32_t)count), dim3(64), 0, s, jobs, ev, ref, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
+                            float *out, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    switch (chunks) {
+    case 1: return launch_wreg_c<1>(jobs, count, ev, ref, out, s);
+    case 2: return launch_wreg_c<2>(jobs, count, ev, ref, out, s);
+    case 4: return launch_wreg_c<4>(jobs, count, ev, ref, out, s);
+    case 8: return launch_wreg_c<8>(jobs, count, ev, ref, out, s);
+    case 16: return launch_wreg_c<16>(jobs, count, ev, ref, out, s);
+    case 32: return launch_wreg_c<32>(jobs, count, ev, ref, out, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int RPL, bool TB>

@@ -96,7 +96,8 @@ class Plan:
 class Engine:
     """One rawdtw_ctx (one HIP device, one stream)."""
 
-    KIND_NAMES = {1: "band_lane", 2: "band_wave", 3: "full_wave", 4: "full_tb", 5: "tb_walk"}
+    KIND_NAMES = {1: "band_lane", 2: "band_wave_lds", 3: "full_wave", 4: "full_tb", 5: "tb_walk", 6: "chain_fold",
+                  7: "read_select", 8: "band_wreg"}
 
     def __init__(self, device: int = 0):
         self.lib = load_library()
@@ -127,6 +128,9 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.rawdtw_sync(self._ctx))
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.rawdtw_set_option(self._ctx, name.encode(), int(value)))
 
     def stream_handle(self) -> int:
         s = C.c_void_p()

@@ -84,6 +84,12 @@ def test_random_wave_band(engine, oracle):
         m = max(1, int(round(n * rng.uniform(0.5, 1.4))))
         R0 = default_radius(n) if t % 2 else int(rng.integers(13, 90))
         cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), R0, t & 1))
+    # radii on both sides of every registers-per-lane class boundary (K = R+1 = 64, 65, 128, 129, ... 2048, 2049)
+    for K in (64, 65, 128, 129, 256, 257, 512, 513, 1024, 1025, 2048, 2049):
+        n = int(K * 1.6) + 7
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32), K - 1, K & 1))
+    for R0 in range(5, 16):  # around the lane-kernel / wave-kernel hand-over
+        cases.append((rng.normal(size=150).astype(np.float32), rng.normal(size=140).astype(np.float32), R0, R0 & 1))
     cases.append((rng.normal(size=6000).astype(np.float32), rng.normal(size=5200).astype(np.float32), 600, 0))
     cases.append((rng.normal(size=3000).astype(np.float32), rng.normal(size=9000).astype(np.float32), 2100, 1))
     jobs, ev, rf = make_arena_jobs(cases)
