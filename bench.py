@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify a sample of the device results against the oracle")
+    ap.add_argument("--serial-launches", action="store_true",
+                    help="run the launches of a step one after another (profiling: per-kernel counters without overlap)")
     return ap.parse_args()
 
 
@@ -97,6 +98,8 @@ def main():
     from rawalign_amd.shard import rank_seed
 
     eng = ra.Engine(local_rank)
+    if args.serial_launches:
+        eng.set_option("serial_launches", 1)
     # reference signal replica (same on every rank), resident in HBM
     ref = synth.make_reference([args.genome], seed=SEED)
     eng.upload_reference(ref.forward, ref.reverse)
@@ -126,7 +129,7 @@ def main():
     # a second, untimed pass with the launches serialised: clean per-kernel durations
     eng.set_option("serial_launches", 1)
     isolated = batch.run_reps(max(3, min(args.steps, 10)), timed=True)
-    eng.set_option("serial_launches", 0)
+    eng.set_option("serial_launches", 1 if args.serial_launches else 0)
 
     score, keep, job_cost = batch.fetch(with_job_costs=True)
     read_of_chain = np.repeat(np.arange(cb.n_reads), np.diff(cb.chain_off.astype(np.int64)))

@@ -44,7 +44,13 @@ struct rawdtw_plan {
     std::vector<Launch> launches;
     std::vector<uint32_t> run_order; // launch indices, heaviest first
     std::vector<int32_t> launch_rpl;
-    DevJob *d_jobs = nullptr;
+    DevJob *d_jobs = nullptr;      // records of the jobs NOT handled by the tile kernel (plan order, after the tile jobs)
+    uint64_t n_tile_jobs = 0;      // plan positions [0, n_tile_jobs) are tile-kernel jobs, in job order
+    TileDesc *d_tiles = nullptr;
+    TileSpan *d_spans = nullptr;
+    TileJob *d_tjobs = nullptr;
+    uint64_t n_tiles = 0;
+    uint32_t tile_lds_floats = 0;
     FullAux *d_aux = nullptr;      // indexed like d_jobs (only meaningful for full-matrix jobs)
     float *d_cost = nullptr;
     float *d_bnd = nullptr;
@@ -171,10 +177,11 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     pl->n_jobs = n_jobs;
 
     // sort key: class in the top bits, then descending length so long jobs start first
-    //   banded lane          : class = 3*R + (2 - tier)  (R in 0..lane_max_radius, longer side <= 73)
-    //   banded wave, register: class = 32 + log2(chunks)      (radius+1 <= 64*chunks, chunks <= 32)
-    //   banded wave, LDS     : class = 40 + lds bucket
-    //   full                 : class = 48 + log2(rpl)
+    //   banded tile (lane DP): class = 0, kept in JOB order (R in 0..lane_max_radius, longer side <= 73)
+    //   banded wave, register: class = 40 + log2(chunks)      (radius+1 <= 64*chunks, chunks <= 32)
+    //   banded wave, LDS     : class = 48 + lds bucket
+    //   full                 : class = 56 + log2(rpl)
+    // inside a class: longer side descending, then shorter side descending (waves share one shape)
     struct Keyed { uint64_t key; uint32_t idx; int32_t R; };
     std::vector<Keyed> keyed(n_jobs);
     uint64_t alg_bytes = 0;
@@ -196,7 +203,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         int32_t R = -1;
         if (j.band_radius == RAWDTW_FULL) {
             const int rpl = full_rpl(NY);
-            cls = 48 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
+            cls = 56 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
         } else {
             if (traceback) {
                 delete pl;
@@ -209,19 +216,20 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
             }
             const uint32_t K = (uint32_t)R + 1;
-            if (R <= ctx->lane_max_radius && N <= (uint32_t)kLaneMaxN[kLaneTiers - 1]) {
-                const int tier = N <= (uint32_t)kLaneMaxN[0] ? 0 : N <= (uint32_t)kLaneMaxN[1] ? 1 : 2;
-                cls = 3ull * (uint64_t)R + (uint64_t)(2 - tier); // widest tier (longest jobs) first
-            }
+            if (R <= ctx->lane_max_radius && N <= (uint32_t)kLaneMaxN) cls = 0;
             else if (K <= 64u * kMaxWregChunks) {
                 uint32_t chunks = 1, lg = 0;
                 while (64u * chunks < K) { chunks <<= 1; lg++; }
-                cls = 32 + lg;
+                cls = 40 + lg;
             } else {
-                cls = 40 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
+                cls = 48 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
             }
         }
-        keyed[k].key = (cls << 40) | (uint64_t)(0xffffffffffull - N);
+        if (cls == 0) keyed[k].key = k; // tile jobs stay in job order: consecutive parts share their spans
+        else {
+            const uint64_t lim = (1ull << 28) - 1;
+            keyed[k].key = (cls << 56) | ((lim - std::min<uint64_t>(N, lim)) << 28) | (lim - std::min<uint64_t>(NY, lim));
+        }
         keyed[k].idx = (uint32_t)k;
         keyed[k].R = R;
     }
@@ -239,9 +247,9 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         DevJob &d = pl->h_jobs[p];
         d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
         d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = keyed[p].idx;
-        const uint64_t cls = keyed[p].key >> 40;
-        if (cls >= 48) {
-            const int rpl = 1 << (cls - 48);
+        const uint64_t cls = keyed[p].key >> 56;
+        if (cls >= 56) {
+            const int rpl = 1 << (cls - 56);
             const uint32_t NX = std::max(j.n, j.m), NY = std::min(j.n, j.m);
             if (NY > 64u * rpl) { // multi-strip: needs a boundary row
                 pl->h_aux[p].bnd_off = bnd;
@@ -253,16 +261,108 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             }
         }
         // launches: maximal runs of equal class
-        if (pl->launches.empty() || (keyed[p - 1].key >> 40) != cls) {
+        if (pl->launches.empty() || (keyed[p - 1].key >> 56) != cls) {
             Launch L{};
             L.first = p; L.count = 0;
-            if (cls < 32) { L.kind = kKindBandLane; L.param = (int32_t)(cls / 3) | ((int32_t)(2 - cls % 3) << 7); }
-            else if (cls < 40) { L.kind = kKindBandWreg; L.param = 1 << (cls - 32); }
-            else if (cls < 48) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
-            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 48); }
+            if (cls == 0) { L.kind = kKindBandLane; L.param = 0; }
+            else if (cls < 48) { L.kind = kKindBandWreg; L.param = 1 << (cls - 40); }
+            else if (cls < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
+            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 56); }
             pl->launches.push_back(L);
         }
         pl->launches.back().count++;
+    }
+    // ---- tiles for the lane-eligible jobs (plan positions [0, n_tile_jobs), job order) ----
+    std::vector<TileDesc> tiles;
+    std::vector<TileSpan> spans;
+    std::vector<TileJob> tjobs;
+    uint32_t tile_lds_max = 0;
+    if (!pl->launches.empty() && pl->launches[0].kind == kKindBandLane) {
+        const uint64_t nt = pl->launches[0].count;
+        pl->n_tile_jobs = nt;
+        tjobs.resize(nt);
+        struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
+        std::vector<Sp> cur;
+        struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
+        std::vector<Pend> pend;
+        uint64_t t_first = 0;
+        uint32_t lds_used = 0;
+        auto span_cost = [](const Sp &s) { return (uint32_t)(((s.end - s.start) + 3) & ~3ull); };
+        auto close_tile = [&](uint64_t t_end) {
+            if (t_end == t_first) return;
+            uint32_t off = 0;
+            const uint32_t span_first = (uint32_t)spans.size();
+            for (Sp &s : cur) {
+                s.lds = off;
+                const uint32_t len4 = span_cost(s);
+                spans.push_back(TileSpan{s.start, off, (len4 / 4) | (s.is_ref ? 0x80000000u : 0u)});
+                off += len4;
+            }
+            tile_lds_max = std::max(tile_lds_max, off);
+            for (uint64_t p = t_first; p < t_end; p++) {
+                const Pend &pe = pend[p - t_first];
+                TileJob &tj = tjobs[p];
+                tj.offA = (uint16_t)(cur[pe.spA].lds + (pe.a0 - cur[pe.spA].start));
+                tj.offB = (uint16_t)(cur[pe.spB].lds + (pe.b0 - cur[pe.spB].start));
+            }
+            // order the tile's records by (radius, longer side, shorter side): waves get one shape
+            std::sort(tjobs.begin() + t_first, tjobs.begin() + t_end, [](const TileJob &x, const TileJob &y) {
+                if (x.R != y.R) return x.R < y.R;
+                if (x.N != y.N) return x.N > y.N;
+                if (x.M != y.M) return x.M > y.M;
+                return x.aux < y.aux;
+            });
+            tiles.push_back(TileDesc{(uint32_t)t_first, (uint32_t)(t_end - t_first), span_first, (uint32_t)cur.size()});
+            cur.clear(); pend.clear(); lds_used = 0; t_first = t_end;
+        };
+        // find (or make) the span that holds window [w0, w0+len) of the given arena; returns its index or -1
+        auto place = [&](uint64_t w0, uint32_t len, bool is_ref, uint32_t &extra) -> int {
+            extra = 0;
+            for (int q = (int)cur.size() - 1; q >= 0 && q >= (int)cur.size() - 8; q--) {
+                Sp &s = cur[q];
+                if (s.is_ref != is_ref || w0 < s.start || w0 > s.end) continue;
+                if (w0 + len <= s.end) return q; // already covered
+                const uint32_t before = span_cost(s);
+                Sp grown = s; grown.end = w0 + len;
+                extra = span_cost(grown) - before;
+                return q; // caller extends after the budget check
+            }
+            extra = (uint32_t)((((w0 & 3ull) + len) + 3) & ~3ull);
+            return -1;
+        };
+        for (uint64_t p = 0; p < nt; p++) {
+            const DevJob &d = pl->h_jobs[p];
+            const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
+            const uint64_t a0 = swap ? d.ref_off : d.read_off, b0 = swap ? d.read_off : d.ref_off;
+            const uint32_t NA = swap ? d.m : d.n, NB = swap ? d.n : d.m;
+            const bool a_ref = swap, b_ref = !swap;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                uint32_t ea = 0, eb = 0;
+                int qa = place(a0, NA, a_ref, ea);
+                // place B after tentatively accounting for A (a fresh span for A cannot serve B: other arena)
+                int qb = place(b0, NB, b_ref, eb);
+                const uint32_t new_spans = (qa < 0) + (qb < 0);
+                if (attempt == 0 && (lds_used + ea + eb > kTileLdsFloats || cur.size() + new_spans > kTileMaxSpans ||
+                                     p - t_first >= kTileMaxJobs)) {
+                    close_tile(p);
+                    continue; // retry in the fresh tile
+                }
+                if (qa < 0) { cur.push_back(Sp{a0 & ~3ull, a0 + NA, a_ref, 0}); qa = (int)cur.size() - 1; }
+                else cur[qa].end = std::max(cur[qa].end, a0 + NA);
+                if (qb < 0) { cur.push_back(Sp{b0 & ~3ull, b0 + NB, b_ref, 0}); qb = (int)cur.size() - 1; }
+                else cur[qb].end = std::max(cur[qb].end, b0 + NB);
+                lds_used += ea + eb;
+                pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
+                TileJob &tj = tjobs[p];
+                tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.R = (uint8_t)d.R; tj.flags = (uint8_t)d.flags;
+                tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
+                break;
+            }
+        }
+        close_tile(nt);
+        pl->n_tiles = tiles.size();
+        pl->tile_lds_floats = tile_lds_max;
+        pl->launches[0].param = (int32_t)tile_lds_max;
     }
     // a banded-wave launch only needs LDS for its own largest K (jobs are sorted by N, not K)
     for (Launch &L : pl->launches)
@@ -300,11 +400,16 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         else if (L.kind == kKindBandWave || L.kind == kKindBandWreg) I.n_wave_band_jobs += L.count;
         else I.n_full_jobs += L.count;
     }
-    I.workspace_bytes = bnd * 4 + dirb + n_jobs * (sizeof(DevJob) + sizeof(FullAux) + 4);
+    I.workspace_bytes = bnd * 4 + dirb + (n_jobs - pl->n_tile_jobs) * (sizeof(DevJob) + sizeof(FullAux)) + n_jobs * 4 +
+                        tiles.size() * sizeof(TileDesc) + spans.size() * sizeof(TileSpan) + tjobs.size() * sizeof(TileJob);
 
     int st;
-    if ((st = dev_alloc(ctx, &pl->d_jobs, n_jobs)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_aux, n_jobs)) != RAWDTW_OK ||
+    const uint64_t n_dev_jobs = n_jobs - pl->n_tile_jobs;
+    if ((st = dev_alloc(ctx, &pl->d_jobs, n_dev_jobs)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_tiles, (uint64_t)tiles.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_spans, (uint64_t)spans.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_tjobs, (uint64_t)tjobs.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_aux, n_dev_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_bnd, bnd)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_dir, dirb)) != RAWDTW_OK) {
@@ -312,11 +417,19 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         return st;
     }
     if (n_jobs) {
-        hipError_t e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data(), n_jobs * sizeof(DevJob),
-                                      hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data(), n_jobs * sizeof(FullAux), hipMemcpyHostToDevice,
-                               ctx->stream);
+        hipError_t e = hipSuccess;
+        if (n_dev_jobs)
+            e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data() + pl->n_tile_jobs, n_dev_jobs * sizeof(DevJob),
+                               hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && n_dev_jobs)
+            e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data() + pl->n_tile_jobs, n_dev_jobs * sizeof(FullAux),
+                               hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !tiles.empty())
+            e = hipMemcpyAsync(pl->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !spans.empty())
+            e = hipMemcpyAsync(pl->d_spans, spans.data(), spans.size() * sizeof(TileSpan), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !tjobs.empty())
+            e = hipMemcpyAsync(pl->d_tjobs, tjobs.data(), tjobs.size() * sizeof(TileJob), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             rawdtw_plan_destroy(pl);
@@ -329,12 +442,15 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
 
 int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t stream)
 {
-    const DevJob *jobs = pl->d_jobs + L.first;
+    // device job records exist only for the non-tile jobs (plan positions >= n_tile_jobs)
+    const DevJob *jobs = pl->d_jobs + (L.first >= pl->n_tile_jobs ? L.first - pl->n_tile_jobs : 0);
+    const FullAux *aux = pl->d_aux + (L.first >= pl->n_tile_jobs ? L.first - pl->n_tile_jobs : 0);
     float *out = pl->d_cost; // job order: every kernel stores at out[job.aux]
     hipError_t e = hipSuccess;
     switch (L.kind) {
     case kKindBandLane:
-        e = launch_band_lane(L.param & 127, L.param >> 7, jobs, L.count, ctx->d_ev, ctx->d_ref, out, stream);
+        e = launch_band_tile(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->tile_lds_floats, ctx->d_ev,
+                             ctx->d_ref, out, stream);
         break;
     case kKindBandWreg:
         e = launch_band_wreg(L.param, jobs, L.count, ctx->d_ev, ctx->d_ref, out, stream);
@@ -344,7 +460,7 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
         break;
     case kKindFullWave:
     case kKindFullTb:
-        e = launch_full_wave(L.param, L.kind == kKindFullTb, jobs, L.count, pl->d_aux + L.first, ctx->d_ev,
+        e = launch_full_wave(L.param, L.kind == kKindFullTb, jobs, L.count, aux, ctx->d_ev,
                              ctx->d_ref, out, pl->d_bnd, pl->d_dir, stream);
         break;
     default:
@@ -635,6 +751,9 @@ int rawdtw_plan_destroy(rawdtw_plan *plan)
     if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
     if (plan->d_jobs) (void)hipFree(plan->d_jobs);
     if (plan->d_aux) (void)hipFree(plan->d_aux);
+    if (plan->d_tiles) (void)hipFree(plan->d_tiles);
+    if (plan->d_spans) (void)hipFree(plan->d_spans);
+    if (plan->d_tjobs) (void)hipFree(plan->d_tjobs);
     if (plan->d_cost) (void)hipFree(plan->d_cost);
     if (plan->d_bnd) (void)hipFree(plan->d_bnd);
     if (plan->d_dir) (void)hipFree(plan->d_dir);

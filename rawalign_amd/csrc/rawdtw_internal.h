@@ -25,7 +25,7 @@ enum : uint32_t { kFlagExcludeLast = 1u };
 
 // launch kinds (also reported by rawdtw_plan_run_timed)
 enum LaunchKind : uint32_t {
-    kKindBandLane = 1,  // lane-per-job banded kernel, one launch per radius class
+    kKindBandLane = 1,  // lane-per-job banded DP inside the tile kernel (one launch for all eligible jobs)
     kKindBandWave = 2,  // wave-per-job banded kernel
     kKindFullWave = 3,  // wave-per-job full-matrix wavefront (score only)
     kKindFullTb = 4,    // same, writing packed directions
@@ -34,6 +34,21 @@ enum LaunchKind : uint32_t {
     kKindReadSelect = 7, // per-read accept/cut loop (gen_chains DTW block)
     kKindBandWreg = 8    // wave-per-job banded kernel, band in registers (param = registers per lane per buffer)
 };
+
+// Tile kernel records (planner output)
+struct TileDesc { uint32_t job_first, n_jobs, span_first, n_spans; };
+struct TileSpan {
+    uint64_t src;          // float index of the span's first (16-byte aligned) element in its arena
+    uint32_t lds_off;      // float offset in the tile's LDS image (multiple of 4)
+    uint32_t chunks_arena; // 16-byte chunks to copy | (1u<<31 when the span lies in the reference arena)
+};
+struct TileJob {
+    uint16_t offA, offB;   // LDS float offsets of the longer / shorter window
+    uint8_t N, M, R, flags; // longer side, shorter side, slant-corrected radius, kFlagExcludeLast
+    uint32_t aux;          // job index in the caller's batch
+    uint32_t pad;
+};
+static_assert(sizeof(TileDesc) == 16 && sizeof(TileSpan) == 16 && sizeof(TileJob) == 16, "tile records are 16 bytes");
 
 // One candidate chain as the replay kernels see it (24 bytes).
 struct ChainDesc {
@@ -45,23 +60,18 @@ struct ChainDesc {
 };
 static_assert(sizeof(ChainDesc) == 24, "ChainDesc must stay 24 bytes");
 
-constexpr int kMaxLaneRadius = 8;      // lane-per-job kernel is instantiated for R in [0, 8]
-// lane kernel LDS tiles, by the longer side of the job (a window of L floats needs L+3 floats of its
-// CAP because it is copied in 16-byte aligned chunks):
-//   tier 0 "narrow": 256 jobs x  36 floats, longer side <= 13
-//   tier 1 "medium": 128 jobs x  76 floats, longer side <= 33
-//   tier 2 "wide"  :  64 jobs x 156 floats, longer side <= 73
-constexpr int kLaneTiers = 3;
-constexpr int kLaneJobs[kLaneTiers] = {256, 128, 64};
-constexpr int kLaneCap[kLaneTiers] = {16, 36, 76};
-constexpr int kLaneStride[kLaneTiers] = {36, 76, 156};
-constexpr int kLaneMaxN[kLaneTiers] = {13, 33, 73};
+constexpr int kMaxLaneRadius = 6;      // lane-per-job DP is instantiated for R in [0, 6]
+constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is at most this
+// tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
+constexpr uint32_t kTileLdsFloats = 10240; // 40 KiB -> 3-4 workgroups per CU
+constexpr uint32_t kTileMaxJobs = 1024;
+constexpr uint32_t kTileMaxSpans = 96;
 constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
 
 struct Launch {
     uint32_t kind;
-    int32_t param;      // band lane: R | tier<<7 ; wreg: registers per lane ; full: rows per lane ; band wave: LDS floats
+    int32_t param;      // band tile: LDS floats ; wreg: registers per lane ; full: rows per lane ; band wave: LDS floats
     uint64_t first;     // first plan-order job
     uint64_t count;     // jobs in this launch
 };
@@ -72,8 +82,8 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-hipError_t launch_band_lane(int R, int tier, const DevJob *jobs, uint64_t count, const float *ev,
-                            const float *ref, float *out, hipStream_t s);
+hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+                            uint32_t lds_floats, const float *ev, const float *ref, float *out, hipStream_t s);
 hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev,
                             const float *ref, float *out, hipStream_t s);
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats,

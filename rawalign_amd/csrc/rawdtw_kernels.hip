@@ -1,7 +1,7 @@
 // rawdtw_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for RawAlign's DTW hot path.
 //
 // What they replace (reference file:line):
-//   k_band_lane / k_band_wave : DTW_global_slantedbanded_antidiagonalwise  src/dtw.cpp:273-520
+//   k_band_tile / k_band_wreg / k_band_wave : DTW_global_slantedbanded_antidiagonalwise  src/dtw.cpp:273-520
 //   k_full_wave<.,false>      : DTW_global                                 src/dtw.cpp:37-66
 //   k_full_wave<.,true> + k_tb_walk : DTW_global_tb                        src/dtw.cpp:595-667
 //
@@ -46,22 +46,33 @@ __device__ __forceinline__ float wave_shl1(float v, float fill)
 // ---------------------------------------------------------------------------------------------
 // Lane-per-job banded kernel.  Sparse-mode segments are tiny (2..~70 events, radius 1..6):
 // intra-job parallelism is a handful of cells per antidiagonal, so each lane owns one job and
-// the three rotating antidiagonal buffers of dtw.cpp:305-314 live in registers (radius is a
-// template parameter, every buffer index is a compile-time constant).
+// the antidiagonal buffers live in registers (radius is a template parameter, every buffer index
+// is a compile-time constant).
 //
-// Operands: the workgroup first stages the windows of its JOBS jobs from HBM into LDS with
+// Buffers.  The reference rotates three buffers (dtw.cpp:305-314, 410-413, 487-490); slots an
+// antidiagonal does not overwrite keep stale values, but no in-matrix cell ever reads such a slot
+// (every neighbour read is either a cell of the band's cell set or a guarded/never-written slot
+// holding 1e10 -- the oracle's orc_dtw_banded_cellset states exactly this and is bit-identical to
+// the reference).  So clipped cells are written as 1e10 and two buffers suffice: p1 = latest
+// antidiagonal, p2 = the one before.  A column whose centre row advances computes its secondary
+// antidiagonal in place over p2 and its primary in place over p1 (each cell reads only its own
+// slot of the buffer it overwrites); a column that stays on the row computes its primary over p2
+// and swaps.  No rotation copies.
+//
+// Control.  Jobs are sorted by (longer side, shorter side), so the 64 jobs of a wave almost always
+// share one shape; then the whole band geometry (row advance, clipping) is wave-uniform and the
+// loop runs with scalar control flow (`lane_dp` instantiated on readfirstlane'd lengths).
+//
+// Operands.  The workgroup first stages the windows of its JOBS jobs from HBM into LDS with
 // coalesced 16-byte loads (a lane reading its own window 4 bytes at a time would pull a whole
 // 128-byte line per element through L2).  Each job owns STRIDE floats of LDS: the 16-byte
 // aligned chunks covering its longer window at [0, CAP) and its shorter one at [CAP, 2*CAP);
-// STRIDE/4 is odd so that lanes spread over the banks.  The DP then slides both windows through
+// STRIDE/4 is odd so that lanes spread over the banks.  The DP slides both windows through
 // registers -- one new a-value per column, one new b-value when the centre row moves -- fetched
 // from LDS one step ahead of their use.
 // ---------------------------------------------------------------------------------------------
-template <int R, int JOBS, int CAP, int STRIDE>
-__global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ jobs, uint32_t count,
-                                                    const float *__restrict__ ev,
-                                                    const float *__restrict__ ref,
-                                                    float *__restrict__ out)
+template <int R>
+__device__ __forceinline__ float lane_dp(const float *LA, const float *LB, const uint32_t N, const uint32_t M)
 {
     constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
     constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
@@ -69,53 +80,14 @@ __global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ j
     constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
     constexpr int HP = P / 2, HS = S / 2;
     constexpr bool EVEN = (R % 2 == 0);
-    constexpr int CW = CAP / 4;         // 16-byte chunks per window
-    static_assert(CAP % 4 == 0 && STRIDE % 4 == 0 && (STRIDE / 4) % 2 == 1 && STRIDE >= 2 * CAP, "LDS layout");
-
-    __shared__ __attribute__((aligned(16))) float win[JOBS * STRIDE];
-    __shared__ unsigned long long win_src[JOBS * 2]; // 16-byte aligned global address of each window
-    __shared__ int win_chunks[JOBS * 2];             // chunks to copy for each window
-
-    const int tid = threadIdx.x;
-    const uint32_t g = blockIdx.x * (uint32_t)JOBS + tid;
-    const bool active = g < count;
-    DevJob jb = jobs[active ? g : count - 1];
-    const float *A = ev + jb.read_off;
-    const float *B = ref + jb.ref_off;
-    uint32_t N = jb.n, M = jb.m;
-    if (N < M) { // dtw.cpp:284-292
-        const float *tp = A; A = B; B = tp;
-        uint32_t tn = N; N = M; M = tn;
-    }
-    const uint32_t misA = (uint32_t)(((uintptr_t)A >> 2) & 3u), misB = (uint32_t)(((uintptr_t)B >> 2) & 3u);
-    win_src[2 * tid] = (unsigned long long)((uintptr_t)A & ~(uintptr_t)15);
-    win_src[2 * tid + 1] = (unsigned long long)((uintptr_t)B & ~(uintptr_t)15);
-    win_chunks[2 * tid] = active ? (int)((misA + N + 3) >> 2) : 0;
-    win_chunks[2 * tid + 1] = active ? (int)((misB + M + 3) >> 2) : 0;
-    __syncthreads();
-    // cooperative copy: consecutive threads take consecutive chunks of the same window
-#pragma unroll 2
-    for (int cidx = tid; cidx < JOBS * 2 * CW; cidx += JOBS) {
-        const int w = cidx / CW;          // window index = job*2 + which
-        const int k = cidx - w * CW;      // chunk inside the window
-        if (k < win_chunks[w]) {
-            const float4 v = *reinterpret_cast<const float4 *>(win_src[w] + 16ull * (unsigned)k);
-            const int job = w >> 1;
-            *reinterpret_cast<float4 *>(&win[job * STRIDE + (w & 1) * CAP + 4 * k]) = v;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    const float *LA = &win[tid * STRIDE + misA];
-    const float *LB = &win[tid * STRIDE + CAP + misB];
     const int iN = (int)N, iM = (int)M;
 
-    float d0[K], d1[K], d2[K];
+    float p1[K], p2[K];
     float aw[K];     // aw[x] = A[col + HP - x]
     float bw[K + 1]; // bw[x] = B[row - HP - 1 + x]
 #pragma unroll
     for (int x = 0; x < K; x++) {
-        d0[x] = kInf; d1[x] = kInf; d2[x] = kInf;
+        p1[x] = kInf; p2[x] = kInf;
         const int ia = HP - x;
         aw[x] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
     }
@@ -124,10 +96,8 @@ __global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ j
         const int ib = x - HP - 1;
         bw[x] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
     }
-    const float a_first = LA[0], b_first = LB[0], a_last = LA[iN - 1], b_last = LB[iM - 1];
-
-    // column 0: only the corner (dtw.cpp:317-347), already rotated into place
-    d1[HP + SH] = dist(a_first, b_first);
+    // column 0: only the corner (dtw.cpp:317-347)
+    p1[HP + SH] = dist(LA[0], LB[0]);
 
     int row = 0;
     uint32_t rem = 0; // M*col - row*N, so "row advances" <=> rem + M >= N  (dtw.cpp:352-359)
@@ -143,9 +113,6 @@ __global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ j
     for (uint32_t col = 1; col < N; col++) {
         rem += M;
         const bool adv = rem >= N;
-        if (adv) { rem -= N; row++; }
-
-        // slide the operand windows, then issue the next fetches
 #pragma unroll
         for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
         aw[0] = a_next;
@@ -154,14 +121,16 @@ __global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ j
             a_next = LA[ia >= iN ? iN - 1 : ia];
         }
         if (adv) {
+            rem -= N;
+            row++;
 #pragma unroll
             for (int x = 0; x < K; x++) bw[x] = bw[x + 1];
             bw[K] = b_next;
-            const int ib = row + 1 - HP - 1 + K;
-            b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-        }
-
-        if (adv) { // secondary antidiagonal (dtw.cpp:361-414)
+            {
+                const int ib = row + 1 - HP - 1 + K;
+                b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+            }
+            // secondary antidiagonal (dtw.cpp:361-414), in place over p2
 #pragma unroll
             for (int o = 0; o < S; o++) {
                 const int i = (int)col + HS - 1 - o;
@@ -171,52 +140,139 @@ __global__ __launch_bounds__(JOBS) void k_band_lane(const DevJob *__restrict__ j
                 const float bv = EVEN ? bw[o + 1] : bw[o];
                 float top, tl, left;
                 if (SH == 0) {
-                    top = d1[o]; tl = d0[o]; left = d1[o + 1 < K ? o + 1 : K - 1];
+                    top = p1[o]; tl = p2[o]; left = p1[o + 1 < K ? o + 1 : K - 1];
                 } else {
-                    top = (o == 0) ? kInf : d1[o];
-                    tl = (o == 0 && !prev_adv) ? kInf : d0[o];
-                    left = (o == S - 1) ? kInf : d1[o + 1 < K ? o + 1 : K - 1];
+                    top = (o == 0) ? kInf : p1[o];
+                    tl = (o == 0 && !prev_adv) ? kInf : p2[o];
+                    left = (o == S - 1) ? kInf : p1[o + 1 < K ? o + 1 : K - 1];
                 }
                 const float v = min3f(top, left, tl) + dist(av, bv);
-                if (valid) d2[o] = v;
+                p2[o] = valid ? v : kInf;
+            }
+            // primary, centre row advanced (dtw.cpp:430-436, 459-463): dp1 = the secondary (now p2),
+            // dp0 = the previous primary (p1), in place over p1
+#pragma unroll
+            for (int o = 0; o < P; o++) {
+                const int i = (int)col + HP - o;
+                const int j = row - HP + o;
+                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+                const float av = aw[o];
+                const float bv = bw[o + 1];
+                if (SH == 0) {
+                    const float top = (o == 0) ? kInf : p2[o > 0 ? o - 1 : 0];
+                    const float tl = p1[o];
+                    const float left = (o == P - 1) ? kInf : p2[o];
+                    const float v = min3f(top, left, tl) + dist(av, bv);
+                    p1[o] = valid ? v : kInf;
+                } else {
+                    constexpr int kmax = K - 1;
+                    const float top = p2[o];
+                    const float tl = p1[o + 1 < K ? o + 1 : kmax];
+                    const float left = p2[o + 1 < K ? o + 1 : kmax];
+                    const float v = min3f(top, left, tl) + dist(av, bv);
+                    p1[o + 1 < K ? o + 1 : kmax] = valid ? v : kInf;
+                }
+            }
+        } else {
+            // primary, same centre row (dtw.cpp:437-444, 464-473): dp1 = p1, dp0 = p2; computed in place
+            // over p2 from the highest offset down, then the two buffers trade places
+#pragma unroll
+            for (int o = P - 1; o >= 0; o--) {
+                const int i = (int)col + HP - o;
+                const int j = row - HP + o;
+                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+                const float av = aw[o];
+                const float bv = bw[o + 1];
+                if (SH == 0) {
+                    const float top = (o == 0) ? kInf : p1[o > 0 ? o - 1 : 0];
+                    const float tl = (o == 0) ? kInf : p2[o > 0 ? o - 1 : 0];
+                    const float left = p1[o];
+                    const float v = min3f(top, left, tl) + dist(av, bv);
+                    p2[o] = valid ? v : kInf;
+                } else {
+                    constexpr int kmax = K - 1;
+                    const float top = (o == 0) ? kInf : p1[o];
+                    const float tl = (o == 0 && !prev_adv) ? kInf : p2[o];
+                    const float left = p1[o + 1 < K ? o + 1 : kmax];
+                    const float v = min3f(top, left, tl) + dist(av, bv);
+                    p2[o + 1 < K ? o + 1 : kmax] = valid ? v : kInf;
+                }
             }
 #pragma unroll
-            for (int x = 0; x < K; x++) { float t = d0[x]; d0[x] = d1[x]; d1[x] = d2[x]; d2[x] = t; }
+            for (int x = 0; x < K; x++) { const float t = p1[x]; p1[x] = p2[x]; p2[x] = t; }
         }
-
-        // primary antidiagonal (dtw.cpp:416-485)
-#pragma unroll
-        for (int o = 0; o < P; o++) {
-            const int i = (int)col + HP - o;
-            const int j = row - HP + o;
-            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-            const float av = aw[o];
-            const float bv = bw[o + 1];
-            float top, tl, left;
-            if (SH == 0) {
-                top = (o == 0) ? kInf : d1[o > 0 ? o - 1 : 0];
-                const float tl_flat = (o == 0) ? kInf : d0[o > 0 ? o - 1 : 0];
-                tl = adv ? d0[o] : tl_flat;
-                left = (o == P - 1 && adv) ? kInf : d1[o];
-                const float v = min3f(top, left, tl) + dist(av, bv);
-                if (valid) d2[o] = v;
-            } else {
-                top = (o == 0 && !adv) ? kInf : d1[o];
-                const float tl_flat = (o == 0 && !prev_adv) ? kInf : d0[o];
-                tl = adv ? d0[o + 1 < K ? o + 1 : K - 1] : tl_flat;
-                left = d1[o + 1 < K ? o + 1 : K - 1];
-                const float v = min3f(top, left, tl) + dist(av, bv);
-                if (valid) d2[o + 1 < K ? o + 1 : K - 1] = v;
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < K; x++) { float t = d0[x]; d0[x] = d1[x]; d1[x] = d2[x]; d2[x] = t; }
         prev_adv = adv;
     }
+    return p1[HP + SH]; // dtw.cpp:506-512
+}
 
-    float res = d1[HP + SH]; // dtw.cpp:506-512
-    if (jb.flags & kFlagExcludeLast) res = res - dist(a_last, b_last);
-    out[jb.aux] = res; // job order (aux = the job's index in the caller's batch)
+// Tile kernel.  A tile is a run of CONSECUTIVE jobs of the batch (consecutive parts of the same
+// chains), so the windows it needs form a few contiguous spans of the event and reference arenas:
+// the workgroup copies each span HBM -> LDS once with coalesced 16-byte loads (adjacent parts share
+// their anchor element and their cache lines; an earlier version that sorted jobs globally by shape
+// fetched a whole 128-byte line per ~24-byte window: L2 miss rate 94 %, 3x the algorithmic bytes).
+// The planner stores the tile's job records already ordered by (radius, longer side, shorter side),
+// so that the 64 lanes of a wave get jobs of (nearly) one shape; records carry LDS offsets, the
+// swap (dtw.cpp:284-292) and the slant-corrected radius (dtw.cpp:298-300) are resolved on the host.
+template <int R>
+__device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
+{
+    const float *LA = win + tj.offA;
+    const float *LB = win + tj.offB;
+    const uint32_t N = tj.N, M = tj.M;
+    // wave-uniform shape?
+    const uint32_t N0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);
+    const uint32_t M0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);
+    float res;
+    if (__all(N == N0 && M == M0)) res = lane_dp<R>(LA, LB, N0, M0);
+    else res = lane_dp<R>(LA, LB, N, M);
+    if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
+    return res;
+}
+
+template <int R>
+__device__ __forceinline__ void tile_dispatch(const float *win, const TileJob &tj, int myR, float &res)
+{
+    if (__any(myR == R)) {
+        if (myR == R) res = tile_job<R>(win, tj);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_band_tile(const TileDesc *__restrict__ tiles,
+                                                   const TileSpan *__restrict__ spans,
+                                                   const TileJob *__restrict__ tjobs,
+                                                   const float *__restrict__ ev,
+                                                   const float *__restrict__ ref,
+                                                   float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    const int tid = threadIdx.x;
+    const TileDesc td = tiles[blockIdx.x];
+    // stage the spans
+    for (uint32_t sidx = 0; sidx < td.n_spans; sidx++) {
+        const TileSpan sp = spans[td.span_first + sidx];
+        const uint32_t chunks = sp.chunks_arena & 0x7fffffffu;
+        const float4 *src = reinterpret_cast<const float4 *>(((sp.chunks_arena >> 31) ? ref : ev) + sp.src);
+        float4 *dst = reinterpret_cast<float4 *>(win + sp.lds_off);
+        for (uint32_t k = tid; k < chunks; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+    const uint32_t rounds = (td.n_jobs + 255u) / 256u;
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+        const uint32_t r = rd * 256u + tid;
+        const bool act = r < td.n_jobs;
+        const TileJob tj = tjobs[td.job_first + (act ? r : td.n_jobs - 1)];
+        const int myR = act ? (int)tj.R : -1;
+        float res = 0.0f;
+        tile_dispatch<0>(win, tj, myR, res);
+        tile_dispatch<1>(win, tj, myR, res);
+        tile_dispatch<2>(win, tj, myR, res);
+        tile_dispatch<3>(win, tj, myR, res);
+        tile_dispatch<4>(win, tj, myR, res);
+        tile_dispatch<5>(win, tj, myR, res);
+        tile_dispatch<6>(win, tj, myR, res);
+        if (act) out[tj.aux] = res; // job order (aux = the job's index in the caller's batch)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -690,44 +746,18 @@ hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const
     return hipGetLastError();
 }
 
-template <int R, int T>
-static hipError_t launch_lane_rt(const DevJob *jobs, uint64_t count, const float *ev, const float *ref, float *out,
-                                 hipStream_t s)
+hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+                            uint32_t lds_floats, const float *ev, const float *ref, float *out, hipStream_t s)
 {
-    const uint32_t blocks = (uint32_t)((count + kLaneJobs[T] - 1) / kLaneJobs[T]);
-    hipLaunchKernelGGL((k_band_lane<R, kLaneJobs[T], kLaneCap[T], kLaneStride[T]>), dim3(blocks), dim3(kLaneJobs[T]), 0,
-                       s, jobs, (uint32_t)count, ev, ref, out);
+    if (n_tiles == 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_tile),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_band_tile, dim3((uint32_t)n_tiles), dim3(256), lds_bytes, s, tiles, spans, tjobs, ev, ref, out);
     return hipGetLastError();
-}
-
-template <int R>
-static hipError_t launch_lane_r(int tier, const DevJob *jobs, uint64_t count, const float *ev, const float *ref,
-                                float *out, hipStream_t s)
-{
-    switch (tier) {
-    case 0: return launch_lane_rt<R, 0>(jobs, count, ev, ref, out, s);
-    case 1: return launch_lane_rt<R, 1>(jobs, count, ev, ref, out, s);
-    case 2: return launch_lane_rt<R, 2>(jobs, count, ev, ref, out, s);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_band_lane(int R, int tier, const DevJob *jobs, uint64_t count, const float *ev,
-                            const float *ref, float *out, hipStream_t s)
-{
-    if (count == 0) return hipSuccess;
-    switch (R) {
-    case 0: return launch_lane_r<0>(tier, jobs, count, ev, ref, out, s);
-    case 1: return launch_lane_r<1>(tier, jobs, count, ev, ref, out, s);
-    case 2: return launch_lane_r<2>(tier, jobs, count, ev, ref, out, s);
-    case 3: return launch_lane_r<3>(tier, jobs, count, ev, ref, out, s);
-    case 4: return launch_lane_r<4>(tier, jobs, count, ev, ref, out, s);
-    case 5: return launch_lane_r<5>(tier, jobs, count, ev, ref, out, s);
-    case 6: return launch_lane_r<6>(tier, jobs, count, ev, ref, out, s);
-    case 7: return launch_lane_r<7>(tier, jobs, count, ev, ref, out, s);
-    case 8: return launch_lane_r<8>(tier, jobs, count, ev, ref, out, s);
-    default: return hipErrorInvalidValue;
-    }
 }
 
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats, const float *ev,
