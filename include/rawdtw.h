@@ -216,6 +216,14 @@ int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_m
  * receives launch i's MEAN duration over the reps. */
 int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, float *launch_ms,
                           uint32_t *launch_kind, uint32_t cap, uint32_t *n_launches);
+/* Pipelined form of the above: enqueue one run without any host synchronisation (with a HIP
+ * event pair per launch when timed != 0), call it as often as wanted, also alternating between
+ * batches of different contexts so that several mini-batches are in flight (the reference keeps two,
+ * rmap.cpp:1033); then, after rawdtw_sync(), collect the mean per-launch durations of all runs
+ * enqueued since the last collect. */
+int rawdtw_batch_enqueue(rawdtw_ctx *ctx, rawdtw_batch *batch, int timed);
+int rawdtw_batch_collect(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms, uint32_t *launch_kind,
+                         uint32_t cap, uint32_t *n_launches, uint32_t *n_runs);
 /* static facts about launch i of the batch (same indexing as launch_ms): kind, parameter
  * (band radius / rows per lane / LDS floats), jobs, their algorithmic bytes and DP cells */
 int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *kind, int32_t *param,

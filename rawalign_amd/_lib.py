@@ -86,6 +86,8 @@ SYMBOLS = {
     "rawdtw_batch_run": (I32, [VP, VP]),
     "rawdtw_batch_run_timed": (I32, [VP, VP, VP, VP, U32, C.POINTER(U32)]),
     "rawdtw_batch_run_reps": (I32, [VP, VP, U32, VP, VP, U32, C.POINTER(U32)]),
+    "rawdtw_batch_enqueue": (I32, [VP, VP, I32]),
+    "rawdtw_batch_collect": (I32, [VP, VP, VP, VP, U32, C.POINTER(U32), C.POINTER(U32)]),
     "rawdtw_batch_launch_stats": (I32, [VP, U32, C.POINTER(U32), C.POINTER(I32), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)]),
     "rawdtw_batch_fetch": (I32, [VP, VP, VP, VP, VP]),
     "rawdtw_batch_destroy": (I32, [VP]),

@@ -280,6 +280,20 @@ class Batch:
             return []
         return [(int(kind[k] & 0xFF), int(kind[k] >> 8), float(ms[k])) for k in range(min(n.value, cap))]
 
+    def enqueue(self, timed: bool = False):
+        """One run, no host synchronisation (pipelined submission)."""
+        self.engine._check(self.engine.lib.rawdtw_batch_enqueue(self.engine._ctx, self._h, int(timed)))
+
+    def collect(self):
+        """Wait for the engine's stream and return [(kind, param, mean_ms)] over the timed runs enqueued."""
+        cap = 64
+        ms = np.zeros(cap, np.float32)
+        kind = np.zeros(cap, np.uint32)
+        n, runs = C.c_uint32(), C.c_uint32()
+        self.engine._check(self.engine.lib.rawdtw_batch_collect(self.engine._ctx, self._h, _ptr(ms), _ptr(kind), cap,
+                                                                C.byref(n), C.byref(runs)))
+        return [(int(kind[k] & 0xFF), int(kind[k] >> 8), float(ms[k])) for k in range(min(n.value, cap))], runs.value
+
     def launch_stats(self, with_cells=True):
         out = []
         i = 0

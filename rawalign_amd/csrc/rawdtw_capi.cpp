@@ -49,6 +49,7 @@ struct rawdtw_plan {
     TileDesc *d_tiles = nullptr;
     TileSpan *d_spans = nullptr;
     TileJob *d_tjobs = nullptr;
+    unsigned long long *d_masks = nullptr; // band bitmasks of the micro-path shapes
     uint64_t n_tiles = 0;
     uint32_t tile_lds_floats = 0;
     FullAux *d_aux = nullptr;      // indexed like d_jobs (only meaningful for full-matrix jobs)
@@ -71,6 +72,8 @@ struct rawdtw_batch {
     uint64_t *d_chain_off = nullptr;
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
+    std::vector<hipEvent_t> ev; // event pairs of the runs enqueued since the last collect
+    uint32_t ev_runs = 0;
 };
 
 namespace {
@@ -126,6 +129,33 @@ uint64_t banded_cells(uint32_t n, uint32_t m, int R)
         }
     }
     return cells;
+}
+
+// bitmask of the band's cell set for a shape whose longer side is <= 8: bit 8*j + i  <=>  cell
+// (i over the longer sequence, j over the shorter) is evaluated (same walk as banded_cells)
+uint64_t band_mask8(uint32_t N, uint32_t M, int R)
+{
+    const int P = R + ((R % 2 == 0) ? 1 : 0), S = R + ((R % 2 == 1) ? 1 : 0);
+    uint64_t mask = 1; // (0,0)
+    int row = 0;
+    uint32_t rem = 0;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        if (adv) { rem -= N; row++; }
+        for (int pass = adv ? 0 : 1; pass < 2; pass++) {
+            const int len = pass == 0 ? S : P;
+            const int si = pass == 0 ? (int)col + S / 2 - 1 : (int)col + P / 2;
+            const int sj = pass == 0 ? row - S / 2 : row - P / 2;
+            int lo = 0, hi = len;
+            lo = std::max(lo, si - (int)N + 1);
+            lo = std::max(lo, -sj);
+            hi = std::min(hi, si + 1);
+            hi = std::min(hi, (int)M - sj);
+            for (int o = lo; o < hi; o++) mask |= 1ull << (8 * (sj + o) + (si - o));
+        }
+    }
+    return mask;
 }
 
 inline int full_rpl(uint32_t ny)
@@ -276,6 +306,8 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     std::vector<TileDesc> tiles;
     std::vector<TileSpan> spans;
     std::vector<TileJob> tjobs;
+    std::vector<unsigned long long> masks;
+    std::vector<int32_t> mask_index(8 * 8 * (kMaxLaneRadius + 1), -1); // (N-1, M-1, R) -> index into masks
     uint32_t tile_lds_max = 0;
     if (!pl->launches.empty() && pl->launches[0].kind == kKindBandLane) {
         const uint64_t nt = pl->launches[0].count;
@@ -307,7 +339,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             }
             // order the tile's records by (radius, longer side, shorter side): waves get one shape
             std::sort(tjobs.begin() + t_first, tjobs.begin() + t_end, [](const TileJob &x, const TileJob &y) {
-                if (x.R != y.R) return x.R < y.R;
+                if (x.R != y.R) return x.R < y.R; // dispatch kind
                 if (x.N != y.N) return x.N > y.N;
                 if (x.M != y.M) return x.M > y.M;
                 return x.aux < y.aux;
@@ -354,8 +386,16 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 lds_used += ea + eb;
                 pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
                 TileJob &tj = tjobs[p];
-                tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.R = (uint8_t)d.R; tj.flags = (uint8_t)d.flags;
+                tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
                 tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
+                if (NA <= 8) { // micro path: band membership from a per-shape bitmask
+                    int32_t &mi = mask_index[((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + d.R];
+                    if (mi < 0) { mi = (int32_t)masks.size(); masks.push_back(band_mask8(NA, NB, d.R)); }
+                    tj.pad = (uint32_t)mi;
+                    tj.R = NA <= 4 ? 0 : 1;
+                } else {
+                    tj.R = (uint8_t)(2 + d.R);
+                }
                 break;
             }
         }
@@ -409,6 +449,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         (st = dev_alloc(ctx, &pl->d_tiles, (uint64_t)tiles.size())) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_spans, (uint64_t)spans.size())) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_tjobs, (uint64_t)tjobs.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)masks.size())) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_aux, n_dev_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_bnd, bnd)) != RAWDTW_OK ||
@@ -430,6 +471,8 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             e = hipMemcpyAsync(pl->d_spans, spans.data(), spans.size() * sizeof(TileSpan), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && !tjobs.empty())
             e = hipMemcpyAsync(pl->d_tjobs, tjobs.data(), tjobs.size() * sizeof(TileJob), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && !masks.empty())
+            e = hipMemcpyAsync(pl->d_masks, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             rawdtw_plan_destroy(pl);
@@ -449,7 +492,7 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
     hipError_t e = hipSuccess;
     switch (L.kind) {
     case kKindBandLane:
-        e = launch_band_tile(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->tile_lds_floats, ctx->d_ev,
+        e = launch_band_tile(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats, ctx->d_ev,
                              ctx->d_ref, out, stream);
         break;
     case kKindBandWreg:
@@ -754,6 +797,7 @@ int rawdtw_plan_destroy(rawdtw_plan *plan)
     if (plan->d_tiles) (void)hipFree(plan->d_tiles);
     if (plan->d_spans) (void)hipFree(plan->d_spans);
     if (plan->d_tjobs) (void)hipFree(plan->d_tjobs);
+    if (plan->d_masks) (void)hipFree(plan->d_masks);
     if (plan->d_cost) (void)hipFree(plan->d_cost);
     if (plan->d_bnd) (void)hipFree(plan->d_bnd);
     if (plan->d_dir) (void)hipFree(plan->d_dir);
@@ -1019,47 +1063,76 @@ int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_m
     return st;
 }
 
-int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, float *launch_ms, uint32_t *launch_kind,
-                          uint32_t cap, uint32_t *n_launches)
+static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e)
+{
+    rawdtw_plan *pl = batch->plan;
+    const uint32_t np = (uint32_t)pl->launches.size();
+    int st = run_all_launches(ctx, pl, e);
+    for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
+        if (e && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK) st = batch_tail(ctx, batch, k);
+        if (st == RAWDTW_OK && e && hipEventRecord(e[2 * (np + k) + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    }
+    return st;
+}
+
+int rawdtw_batch_enqueue(rawdtw_ctx *ctx, rawdtw_batch *batch, int timed)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t nl = (uint32_t)batch->plan->launches.size() + 2;
+    hipEvent_t *e = nullptr;
+    if (timed) {
+        const size_t base = batch->ev.size();
+        batch->ev.resize(base + 2 * nl, nullptr);
+        for (size_t k = base; k < batch->ev.size(); k++) HIP_TRY(ctx, hipEventCreate(&batch->ev[k]));
+        e = &batch->ev[base];
+        batch->ev_runs++;
+    }
+    return batch_enqueue_one(ctx, batch, e);
+}
+
+int rawdtw_batch_collect(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms, uint32_t *launch_kind, uint32_t cap,
+                         uint32_t *n_launches, uint32_t *n_runs)
 {
     if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
     rawdtw_plan *pl = batch->plan;
     const uint32_t np = (uint32_t)pl->launches.size(), nl = np + 2;
     if (n_launches) *n_launches = nl;
-    const bool timed = launch_ms != nullptr;
-    std::vector<hipEvent_t> ev;
-    if (timed) {
-        ev.assign((size_t)reps * 2 * nl, nullptr);
-        for (auto &e : ev) HIP_TRY(ctx, hipEventCreate(&e));
-    }
+    if (n_runs) *n_runs = batch->ev_runs;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int st = RAWDTW_OK;
-    for (uint32_t r = 0; r < reps && st == RAWDTW_OK; r++) {
-        hipEvent_t *e = timed ? &ev[(size_t)r * 2 * nl] : nullptr;
-        st = run_all_launches(ctx, pl, e);
-        for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
-            if (timed && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-            if (st == RAWDTW_OK) st = batch_tail(ctx, batch, k);
-            if (st == RAWDTW_OK && timed && hipEventRecord(e[2 * (np + k) + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    for (uint32_t i = 0; i < nl && i < cap; i++) {
+        double acc = 0;
+        for (uint32_t r = 0; r < batch->ev_runs; r++) {
+            float ms = 0.f;
+            const size_t b = (size_t)r * 2 * nl + 2 * i;
+            if (hipEventElapsedTime(&ms, batch->ev[b], batch->ev[b + 1]) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+            acc += ms;
         }
+        if (launch_ms) launch_ms[i] = batch->ev_runs ? (float)(acc / batch->ev_runs) : 0.f;
+        if (launch_kind)
+            launch_kind[i] = i < np ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
+                                    : (i == np ? kKindChainFold : kKindReadSelect);
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
-    if (timed && st == RAWDTW_OK) {
-        for (uint32_t i = 0; i < nl && i < cap; i++) {
-            double acc = 0;
-            for (uint32_t r = 0; r < reps; r++) {
-                float ms = 0.f;
-                const size_t b = (size_t)r * 2 * nl + 2 * i;
-                if (hipEventElapsedTime(&ms, ev[b], ev[b + 1]) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-                acc += ms;
-            }
-            launch_ms[i] = reps ? (float)(acc / reps) : 0.f;
-            if (launch_kind)
-                launch_kind[i] = i < np ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
-                                        : (i == np ? kKindChainFold : kKindReadSelect);
-        }
-    }
-    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
-    if (st != RAWDTW_OK && ctx->err.empty()) ctx->err = "run_reps failed";
+    for (auto &e : batch->ev) if (e) (void)hipEventDestroy(e);
+    batch->ev.clear();
+    batch->ev_runs = 0;
+    if (st != RAWDTW_OK && ctx->err.empty()) ctx->err = "collect failed";
+    return st;
+}
+
+int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, float *launch_ms, uint32_t *launch_kind,
+                          uint32_t cap, uint32_t *n_launches)
+{
+    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    if (n_launches) *n_launches = (uint32_t)batch->plan->launches.size() + 2;
+    int st = RAWDTW_OK;
+    for (uint32_t r = 0; r < reps && st == RAWDTW_OK; r++) st = rawdtw_batch_enqueue(ctx, batch, launch_ms != nullptr);
+    if (launch_ms) {
+        int st2 = rawdtw_batch_collect(ctx, batch, launch_ms, launch_kind, cap, nullptr, nullptr);
+        if (st == RAWDTW_OK) st = st2;
+    } else if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
     return st;
 }
 
@@ -1113,6 +1186,7 @@ int rawdtw_batch_destroy(rawdtw_batch *b)
 {
     if (!b) return RAWDTW_OK;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     rawdtw_plan_destroy(b->plan);
     if (b->d_chains) (void)hipFree(b->d_chains);
     if (b->d_chain_off) (void)hipFree(b->d_chain_off);

@@ -44,9 +44,9 @@ struct TileSpan {
 };
 struct TileJob {
     uint16_t offA, offB;   // LDS float offsets of the longer / shorter window
-    uint8_t N, M, R, flags; // longer side, shorter side, slant-corrected radius, kFlagExcludeLast
+    uint8_t N, M, R, flags; // longer side, shorter side, dispatch kind (0 micro4, 1 micro8, 2+radius lane DP), kFlagExcludeLast
     uint32_t aux;          // job index in the caller's batch
-    uint32_t pad;
+    uint32_t pad;          // micro kinds: index of the shape's band mask
 };
 static_assert(sizeof(TileDesc) == 16 && sizeof(TileSpan) == 16 && sizeof(TileJob) == 16, "tile records are 16 bytes");
 
@@ -83,7 +83,8 @@ struct FullAux {
 };
 
 hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
-                            uint32_t lds_floats, const float *ev, const float *ref, float *out, hipStream_t s);
+                            const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
+                            float *out, hipStream_t s);
 hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev,
                             const float *ref, float *out, hipStream_t s);
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats,

@@ -230,17 +230,61 @@ __device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
     return res;
 }
 
-template <int R>
-__device__ __forceinline__ void tile_dispatch(const float *win, const TileJob &tj, int myR, float &res)
+// Micro path for the shapes that dominate sparse mode (longer side <= W, W = 4 or 8): the whole
+// band fits a W x W grid, so the DP runs row by row over W statically indexed registers and band
+// membership comes from a per-shape bitmask the planner computed by walking the reference's
+// antidiagonals once (bit 8*j + i <=> cell (i over the longer sequence, j over the shorter) is in the
+// band's cell set).  Same values as the antidiagonal order: a cell is min3 of its in-band neighbours
+// (absent = 1e10) plus its distance, whatever the evaluation order.
+template <int W>
+__device__ __forceinline__ float micro_job(const float *win, const TileJob &tj, const unsigned long long *masks)
 {
-    if (__any(myR == R)) {
-        if (myR == R) res = tile_job<R>(win, tj);
+    const float *LA = win + tj.offA;
+    const float *LB = win + tj.offB;
+    const uint32_t N = tj.N, M = tj.M;
+    const unsigned long long mask = masks[tj.pad];
+    float a[W], v[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) { a[i] = LA[i]; v[i] = kInf; } // columns >= N are never in the mask
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        if (__any((uint32_t)j < M)) {       // wave-uniform: skip rows no lane needs
+            if ((uint32_t)j < M) {          // per lane
+                const float bj = LB[j];
+                const uint32_t rowmask = (uint32_t)(mask >> (8 * j)) & 0xffu;
+                float diag = (j == 0) ? 0.0f : kInf; // virtual corner: D[0][0] = 0 + dist
+                float left = kInf;
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+                    const float up = v[i];
+                    const float val = min3f(up, left, diag) + dist(a[i], bj);
+                    const float keep = (rowmask & (1u << i)) ? val : kInf;
+                    diag = up; left = keep; v[i] = keep;
+                }
+            }
+        }
+    }
+    float res = v[0];
+#pragma unroll
+    for (int i = 1; i < W; i++) res = (N - 1 == (uint32_t)i) ? v[i] : res;
+    if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
+    return res;
+}
+
+enum : int { kTileKindMicro4 = 0, kTileKindMicro8 = 1, kTileKindLane0 = 2 }; // lane kinds: 2 + radius
+
+template <int R>
+__device__ __forceinline__ void tile_dispatch(const float *win, const TileJob &tj, int kind, float &res)
+{
+    if (__any(kind == kTileKindLane0 + R)) {
+        if (kind == kTileKindLane0 + R) res = tile_job<R>(win, tj);
     }
 }
 
 __global__ __launch_bounds__(256) void k_band_tile(const TileDesc *__restrict__ tiles,
                                                    const TileSpan *__restrict__ spans,
                                                    const TileJob *__restrict__ tjobs,
+                                                   const unsigned long long *__restrict__ masks,
                                                    const float *__restrict__ ev,
                                                    const float *__restrict__ ref,
                                                    float *__restrict__ out)
@@ -262,15 +306,17 @@ __global__ __launch_bounds__(256) void k_band_tile(const TileDesc *__restrict__ 
         const uint32_t r = rd * 256u + tid;
         const bool act = r < td.n_jobs;
         const TileJob tj = tjobs[td.job_first + (act ? r : td.n_jobs - 1)];
-        const int myR = act ? (int)tj.R : -1;
+        const int kind = act ? (int)tj.R : -1; // the planner stores the dispatch kind in the R byte
         float res = 0.0f;
-        tile_dispatch<0>(win, tj, myR, res);
-        tile_dispatch<1>(win, tj, myR, res);
-        tile_dispatch<2>(win, tj, myR, res);
-        tile_dispatch<3>(win, tj, myR, res);
-        tile_dispatch<4>(win, tj, myR, res);
-        tile_dispatch<5>(win, tj, myR, res);
-        tile_dispatch<6>(win, tj, myR, res);
+        if (__any(kind == kTileKindMicro4)) { if (kind == kTileKindMicro4) res = micro_job<4>(win, tj, masks); }
+        if (__any(kind == kTileKindMicro8)) { if (kind == kTileKindMicro8) res = micro_job<8>(win, tj, masks); }
+        tile_dispatch<0>(win, tj, kind, res);
+        tile_dispatch<1>(win, tj, kind, res);
+        tile_dispatch<2>(win, tj, kind, res);
+        tile_dispatch<3>(win, tj, kind, res);
+        tile_dispatch<4>(win, tj, kind, res);
+        tile_dispatch<5>(win, tj, kind, res);
+        tile_dispatch<6>(win, tj, kind, res);
         if (act) out[tj.aux] = res; // job order (aux = the job's index in the caller's batch)
     }
 }
@@ -747,7 +793,8 @@ hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const
 }
 
 hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
-                            uint32_t lds_floats, const float *ev, const float *ref, float *out, hipStream_t s)
+                            const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
+                            float *out, hipStream_t s)
 {
     if (n_tiles == 0) return hipSuccess;
     const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
@@ -756,7 +803,8 @@ hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileS
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_band_tile, dim3((uint32_t)n_tiles), dim3(256), lds_bytes, s, tiles, spans, tjobs, ev, ref, out);
+    hipLaunchKernelGGL(k_band_tile, dim3((uint32_t)n_tiles), dim3(256), lds_bytes, s, tiles, spans, tjobs, masks, ev, ref,
+                       out);
     return hipGetLastError();
 }
 
