@@ -177,6 +177,37 @@ uint32_t rawdtw_read_replay(const rawdtw_align_opt_t *opt, uint32_t n_chains,
                             uint8_t *keep);
 
 
+/* ---- consumers of alignment_score downstream of the DTW block (pure host code) ---- */
+typedef struct {
+    float chaining_score;
+    float alignment_score;
+    uint32_t reference_sequence_index;
+    uint32_t start_position;
+    uint32_t end_position;
+    uint32_t n_anchors;
+    int32_t strand;
+    uint32_t mapq; /* out: comp_mapq's value for the first kept chain */
+    uint32_t tag;  /* caller's handle; travels with the record through the sort */
+} rawdtw_chain_t; /* the scalar fields of ri_chain_t (src/rmap.h:29-46) */
+
+typedef struct {
+    int evaluate_chains;      /* opt->flag & RI_M_DTW_EVALUATE_CHAINS */
+    float min_bestmap_ratio;  /* roptions.c:28 (1.2) */
+    float min_meanmap_ratio;  /* roptions.c:31 (5)   */
+    uint32_t min_chain_anchor; /* roptions.c:25 (2)  */
+} rawdtw_select_opt_t;
+
+/* gen_primary_chains + comp_mapq (src/rmap.cpp:90-128, 65-88): sorts `chains` in place exactly as
+ * std::sort(..., std::greater<ri_chain_t>()) does, writes the indices (into the SORTED array) of
+ * the primary chains to kept[] and sets chains[kept[0]].mapq.  Returns the number kept. */
+uint32_t rawdtw_gen_primary_chains(rawdtw_chain_t *chains, uint32_t n_chains,
+                                   const rawdtw_select_opt_t *opt, uint32_t *kept);
+/* is_mapped_with_high_confidence (src/rmap.cpp:594-665) over the primary chains, best first. */
+int rawdtw_is_mapped_with_high_confidence(const rawdtw_chain_t *primary, uint32_t n_chains,
+                                          const rawdtw_select_opt_t *opt);
+/* find_outlier (src/sequence_until.c:4-18): x[point][dim], n dims, m points. */
+float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m);
+
 /* The evaluation order of one read's chains: the permutation std::sort (libstdc++, unstable)
  * produces for the comparator a.chaining_score > b.chaining_score (rmap.cpp:512). */
 int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out);

@@ -33,6 +33,31 @@ class AlignOpt(C.Structure):
     ]
 
 
+class ChainRec(C.Structure):
+    """rawdtw_chain_t"""
+    _fields_ = [
+        ("chaining_score", C.c_float),
+        ("alignment_score", C.c_float),
+        ("reference_sequence_index", C.c_uint32),
+        ("start_position", C.c_uint32),
+        ("end_position", C.c_uint32),
+        ("n_anchors", C.c_uint32),
+        ("strand", C.c_int32),
+        ("mapq", C.c_uint32),
+        ("tag", C.c_uint32),
+    ]
+
+
+class SelectOpt(C.Structure):
+    """rawdtw_select_opt_t"""
+    _fields_ = [
+        ("evaluate_chains", C.c_int),
+        ("min_bestmap_ratio", C.c_float),
+        ("min_meanmap_ratio", C.c_float),
+        ("min_chain_anchor", C.c_uint32),
+    ]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [
         ("n_jobs", C.c_uint64),
@@ -79,6 +104,9 @@ SYMBOLS = {
     "rawdtw_chain_build_jobs": (I32, [C.POINTER(AlignOpt), VP, U32, U64, U32, I32, VP]),
     "rawdtw_chain_replay": (F32, [C.POINTER(AlignOpt), VP, U32, VP, F32]),
     "rawdtw_read_replay": (U32, [C.POINTER(AlignOpt), U32, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_gen_primary_chains": (U32, [VP, U32, C.POINTER(SelectOpt), VP]),
+    "rawdtw_is_mapped_with_high_confidence": (I32, [VP, U32, C.POINTER(SelectOpt)]),
+    "rawdtw_find_outlier": (F32, [VP, U32, U32]),
     "rawdtw_sort_by_chaining_score": (I32, [VP, U32, VP]),
     "rawdtw_batch_build_jobs": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, U64, C.POINTER(U64)]),
     "rawdtw_batch_create": (I32, [VP, C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, C.POINTER(VP)]),

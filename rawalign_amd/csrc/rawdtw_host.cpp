@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rawdtw.h"
@@ -140,6 +141,84 @@ uint32_t rawdtw_read_replay(const rawdtw_align_opt_t *opt, uint32_t n_chains, co
         }
     }
     return kept;
+}
+
+uint32_t rawdtw_gen_primary_chains(rawdtw_chain_t *chains, uint32_t n_chains, const rawdtw_select_opt_t *opt,
+                                   uint32_t *kept)
+{
+    if (!chains || !opt || !kept || n_chains == 0) return 0;
+    // rmap.h:41-45: operator> compares the tuple (alignment_score, chaining_score, n_anchors, strand,
+    // reference_sequence_index, start_position, end_position); rmap.cpp:91 sorts descending with it
+    std::sort(chains, chains + n_chains, [](const rawdtw_chain_t &a, const rawdtw_chain_t &b) {
+        return std::tie(a.alignment_score, a.chaining_score, a.n_anchors, a.strand, a.reference_sequence_index,
+                        a.start_position, a.end_position) >
+               std::tie(b.alignment_score, b.chaining_score, b.n_anchors, b.strand, b.reference_sequence_index,
+                        b.start_position, b.end_position);
+    });
+    uint32_t nk = 0;
+    kept[nk++] = 0; // rmap.cpp:94
+    for (uint32_t ci = 1; ci < n_chains; ++ci) {
+        const rawdtw_chain_t &back = chains[kept[nk - 1]];
+        if (opt->evaluate_chains) { // rmap.cpp:100-104: below a third of the last primary's score: stop
+            if (chains[ci].alignment_score < back.alignment_score / 3) break;
+        } else {
+            if (chains[ci].chaining_score < back.chaining_score / 3) break;
+        }
+        bool is_primary = true; // rmap.cpp:113-120: overlap with an earlier primary on the same sequence
+        for (uint32_t pi = 0; pi < nk; ++pi) {
+            const rawdtw_chain_t &p = chains[kept[pi]];
+            if (chains[ci].reference_sequence_index == p.reference_sequence_index &&
+                std::max(chains[ci].start_position, p.start_position) <= std::min(chains[ci].end_position, p.end_position)) {
+                is_primary = false;
+                break;
+            }
+        }
+        if (is_primary) kept[nk++] = ci;
+    }
+    // comp_mapq, rmap.cpp:65-88
+    if (nk == 1) chains[kept[0]].mapq = 60;
+    else {
+        const rawdtw_chain_t &c0 = chains[kept[0]], &c1 = chains[kept[1]];
+        int mapq;
+        if (opt->evaluate_chains) mapq = (int)(40 * (1 - c1.alignment_score / c0.alignment_score));
+        else mapq = (int)(40 * (1 - c1.chaining_score / c0.chaining_score));
+        if (mapq > 60) mapq = 60;
+        if (mapq < 0) mapq = 0;
+        chains[kept[0]].mapq = (uint32_t)(uint8_t)mapq;
+    }
+    return nk;
+}
+
+int rawdtw_is_mapped_with_high_confidence(const rawdtw_chain_t *c, uint32_t n_chains, const rawdtw_select_opt_t *opt)
+{
+    const uint32_t n_anchors0 = n_chains ? c[0].n_anchors : 0; // rmap.cpp:597-598
+    if (n_anchors0 == 0) return 0;
+    auto score = [&](uint32_t k) { return opt->evaluate_chains ? c[k].alignment_score : c[k].chaining_score; };
+    if (n_chains >= 2) {
+        if (score(0) / score(1) >= opt->min_bestmap_ratio) return 1; // rmap.cpp:604, 651
+        float mean = 0;
+        for (uint32_t k = 0; k < n_chains; ++k) mean += score(k);
+        mean /= n_chains;
+        if (score(0) >= opt->min_meanmap_ratio * mean) return 1; // rmap.cpp:615, 658
+        return 0;
+    }
+    return (n_chains == 1 && c[0].n_anchors >= opt->min_chain_anchor) ? 1 : 0; // rmap.cpp:620, 659
+}
+
+float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m)
+{
+    uint32_t outlier = 0;
+    float max_dist = 0.0f;
+    for (uint32_t i = 0; i < m; i++) {
+        float dist = 0.0f;
+        for (uint32_t j = 0; j < n; j++) {
+            const float d = x[i][j] - x[outlier][j];
+            volatile float sq = d * d; // product rounded, then added: the reference build vectorises this loop
+            dist += sq;                // (mul + add) and fuses only its scalar tail; compared within 1e-6 in tests
+        }
+        if (dist > max_dist) { max_dist = dist; outlier = i; }
+    }
+    return max_dist;
 }
 
 int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out)
