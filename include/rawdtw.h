@@ -79,6 +79,21 @@ int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uin
 /* Adopt a device-resident arena instead (caller keeps ownership; 16-byte aligned). */
 int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats);
 
+/* ---- index file reader: the part of ri_idx_load (src/rawindex.cpp:317-377) the DTW path needs --
+ * header, sequence table and the per-sequence forward/reverse signal arrays of a RawAlign `.ind`
+ * file (format written by ri_idx_dump, src/rawindex.cpp:275-315: magic "RI" (2 bytes, rawindex.h:7-8), 8 x u32 parameters
+ * {w,e,n,q,lq,k,n_seq,flag}, then per sequence {u8 name_len, name, u32 len, len fwd floats, len rev
+ * floats}; the hash buckets that follow are not read).  rawdtw_index_upload streams the signal
+ * arrays straight into the ctx's reference arena, so a human-size index never sits in host memory. */
+typedef struct rawdtw_index rawdtw_index;
+int rawdtw_index_open(const char *path, rawdtw_index **out);
+int rawdtw_index_info(const rawdtw_index *idx, uint32_t *n_seq, uint32_t pars[8]);
+int rawdtw_index_seq(const rawdtw_index *idx, uint32_t i, const char **name, uint32_t *len);
+int rawdtw_index_upload(rawdtw_ctx *ctx, const rawdtw_index *idx);
+/* host copy of one strand's array (tests / CPU baseline); out must hold len floats */
+int rawdtw_index_read_signal(const rawdtw_index *idx, uint32_t i, int strand, float *out);
+int rawdtw_index_close(rawdtw_index *idx);
+
 /* ---- read events: the `a` operand (p->events[read].values, rmap.cpp:517) of all
  * reads of a batch, concatenated by the caller. ---- */
 int rawdtw_upload_events(rawdtw_ctx *ctx, const float *h_events, uint64_t n_floats);

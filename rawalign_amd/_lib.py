@@ -86,6 +86,12 @@ SYMBOLS = {
     "rawdtw_upload_reference": (I32, [VP, U32, VP, VP, VP]),
     "rawdtw_reference_offset": (I32, [VP, U32, I32, C.POINTER(U64)]),
     "rawdtw_set_reference_device": (I32, [VP, VP, U64]),
+    "rawdtw_index_open": (I32, [C.c_char_p, C.POINTER(VP)]),
+    "rawdtw_index_info": (I32, [VP, C.POINTER(U32), VP]),
+    "rawdtw_index_seq": (I32, [VP, U32, C.POINTER(C.c_char_p), C.POINTER(U32)]),
+    "rawdtw_index_upload": (I32, [VP, VP]),
+    "rawdtw_index_read_signal": (I32, [VP, U32, I32, VP]),
+    "rawdtw_index_close": (I32, [VP]),
     "rawdtw_upload_events": (I32, [VP, VP, U64]),
     "rawdtw_set_events_device": (I32, [VP, VP, U64]),
     "rawdtw_score_batch": (I32, [VP, VP, U64, VP, U64, VP]),
