@@ -276,3 +276,82 @@ def test_align_chain_cigar_quirks(engine, oracle):
         opt = ra.MapOpt()
         ch = ra.align_chain(engine, ra.Chain(50.0, 0, 1, anchors), events, opt, cigar=False, min_score=ms)
         assert bits(ch.alignment_score) == bits(oracle.align_chain(anchors, refsig, events, OrcOpt(1, 1, 0.10, 0.4, 20.0, 1), ms))
+
+
+def test_human_scale_reference_offsets(engine, oracle):
+    """configs[3] (human CHM13: 2 x 3.1e9 floats = 24.8 GB of reference signal): window offsets beyond
+    2^32 elements.  A 4.4e9-float arena (17.6 GB) is adopted from torch; jobs sit on both sides of 2^32."""
+    import torch
+
+    n_big = (1 << 32) + (1 << 27)
+    try:
+        arena = torch.empty(n_big, dtype=torch.float32, device="cuda:0")
+    except RuntimeError:
+        pytest.skip("not enough device memory for a 17.6 GB arena")
+    rng = np.random.default_rng(12)
+    seg = rng.normal(size=200000).astype(np.float32)
+    places = [0, (1 << 32) - 100000, (1 << 32) + 300007, n_big - len(seg)]  # the second one straddles 2^32
+    for p in places:
+        arena[p:p + len(seg)] = torch.from_numpy(seg).cuda()
+    torch.cuda.synchronize()
+    engine.set_reference_device(arena.data_ptr(), n_big, keepalive=arena)
+    events = (seg[:50000] + rng.normal(scale=0.2, size=50000)).astype(np.float32)
+    cases, jobs = [], []
+    for k in range(400):
+        n = int(rng.integers(2, 70)) if k % 8 else int(rng.integers(200, 1500))
+        m = max(2, int(n * rng.uniform(0.6, 1.3)))
+        eo = int(rng.integers(0, len(events) - n))
+        so = int(rng.integers(0, len(seg) - m))
+        base = places[k % 4]
+        R0 = -1 if k % 5 == 0 else max(1, int(np.float32(n) * np.float32(0.1)))
+        jobs.append((base + so, eo, n, m, R0, k & 1, 0))
+        cases.append((events[eo:eo + n], seg[so:so + m], R0, k & 1))
+    jobs = np.array(jobs, dtype=JOB_DTYPE)
+    got = engine.score_batch(jobs, events)
+    want = np.array([oracle.dtw_global(a, b, ex) if R0 < 0 else oracle.dtw_banded(a, b, R0, ex)
+                     for a, b, R0, ex in cases], np.float32)
+    assert_bits_equal(got, want, "offsets beyond 2^32")
+    del arena
+
+
+def test_yeast_like_global_full_cigar(engine, oracle):
+    """configs[2]: multi-sequence reference, border=global, fill=full, --dtw-output-cigar on the best
+    chain: scores through the batch path, traceback through align_chain(cigar=True), both strands."""
+    from oracle.loader import OrcOpt
+    from rawalign_amd import synth
+
+    ref = synth.make_reference([30000, 80000, 12000, 55000], seed=41)
+    engine.upload_reference(ref.forward, ref.reverse)
+    offs = {(s, st): engine.reference_offset(s, st) for s in range(ref.n_seq) for st in (0, 1)}
+    cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=40, max_chunks=3), seed=5)
+    engine.upload_events(cb.events)
+    opt = ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0, flag=0x2 | 0x4)
+    batch = ra.Batch(engine, opt, cb)
+    batch.run()
+    score, keep = batch.fetch()
+    oopt = OrcOpt(0, 0, 0.10, 0.4, 20.0, 1)
+    inv = {v: k for k, v in offs.items()}
+    checked_tb = 0
+    for r in range(cb.n_reads):
+        best = np.float32(0.0)
+        first = True
+        for c in range(int(cb.chain_off[r]), int(cb.chain_off[r + 1])):
+            a = cb.anchors[int(cb.anchor_off[c]):int(cb.anchor_off[c + 1])]
+            seq, st = inv[int(cb.ref_base[c])]
+            arr = ref.forward[seq] if st == 1 else ref.reverse[seq]
+            ev = cb.events[int(cb.read_base[c]):]
+            want = oracle.align_chain(a, arr, ev, oopt, float(best))
+            assert bits(score[c]) == bits(want)
+            if want >= np.float32(20.0) and want > best:
+                best = want
+            if first and keep[c] and checked_tb < 6:
+                # rmap.cpp:715-717 on chains[0]: traceback with the global-mode offset quirk
+                ch = ra.Chain(1.0, seq, st, a)
+                ra.align_chain(engine, ch, ev, opt, cigar=True)
+                sc, cost, pi, pj, pd = oracle.align_chain_cigar(a, arr, ev, oopt)
+                assert bits(ch.alignment_score) == bits(sc) and bits(ch.dtw_result.cost) == bits(cost)
+                assert np.array_equal(ch.dtw_result.i, pi) and np.array_equal(ch.dtw_result.j, pj)
+                assert np.array_equal(ch.dtw_result.difference.view(np.uint32), pd.view(np.uint32))
+                checked_tb += 1
+            first = False
+    assert checked_tb > 0
