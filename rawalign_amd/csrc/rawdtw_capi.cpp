@@ -23,7 +23,10 @@ struct rawdtw_ctx {
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
     bool serial_launches = false;
-    int lane_max_radius = 6; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
+    bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
+    uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
+    uint32_t lane_max_n = kLaneMaxN;
+    int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
     // reference arena
     float *d_ref = nullptr;
     uint64_t n_ref = 0;
@@ -50,8 +53,8 @@ struct rawdtw_plan {
     TileSpan *d_spans = nullptr;
     TileJob *d_tjobs = nullptr;
     unsigned long long *d_masks = nullptr; // band bitmasks of the micro-path shapes
-    uint64_t n_tiles = 0;
-    uint32_t tile_lds_floats = 0;
+    uint64_t n_tiles = 0, n_tiles_hi = 0;   // d_tiles = [bulk tiles][wide-band tiles]
+    uint32_t tile_lds_floats = 0, tile_hi_lds_floats = 0;
     FullAux *d_aux = nullptr;      // indexed like d_jobs (only meaningful for full-matrix jobs)
     float *d_cost = nullptr;
     float *d_bnd = nullptr;
@@ -78,6 +81,7 @@ struct rawdtw_batch {
     uint64_t n_reads = 0, n_chains = 0;
     ChainDesc *d_chains = nullptr;
     uint64_t *d_chain_off = nullptr;
+    uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
     std::vector<hipEvent_t> ev; // event pairs of the runs enqueued since the last collect
@@ -254,16 +258,17 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
             }
             const uint32_t K = (uint32_t)R + 1;
-            if (R <= ctx->lane_max_radius && N <= (uint32_t)kLaneMaxN) cls = 0;
+            if (R <= ctx->lane_max_radius && N <= ctx->lane_max_n) cls = 0;
+            else if (R <= kMaxLaneRadiusHi && ctx->lane_hi && N <= 200) cls = 1; // any radius 0..8 (the instance covers all)
             else if (K <= 64u * kMaxWregChunks) {
                 uint32_t chunks = 1, lg = 0;
                 while (64u * chunks < K) { chunks <<= 1; lg++; }
-                cls = 40 + lg;
+                cls = chunks <= 4 ? 40 : 40 + lg; // one merged launch for radius+1 <= 256 (param 0)
             } else {
                 cls = 48 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
             }
         }
-        if (cls == 0) keyed[k].key = k; // tile jobs stay in job order: consecutive parts share their spans
+        if (cls <= 1) keyed[k].key = (cls << 56) | k; // tile jobs stay in job order: consecutive parts share their spans
         else {
             const uint64_t lim = (1ull << 28) - 1;
             keyed[k].key = (cls << 56) | ((lim - std::min<uint64_t>(N, lim)) << 28) | (lim - std::min<uint64_t>(NY, lim));
@@ -303,7 +308,8 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             Launch L{};
             L.first = p; L.count = 0;
             if (cls == 0) { L.kind = kKindBandLane; L.param = 0; }
-            else if (cls < 48) { L.kind = kKindBandWreg; L.param = 1 << (cls - 40); }
+            else if (cls == 1) { L.kind = kKindBandLaneHi; L.param = 0; }
+            else if (cls < 48) { L.kind = kKindBandWreg; L.param = cls == 40 ? 0 : 1 << (cls - 40); }
             else if (cls < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
             else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 56); }
             pl->launches.push_back(L);
@@ -317,15 +323,21 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     std::vector<unsigned long long> masks;
     std::vector<int32_t> mask_index(8 * 8 * (kMaxLaneRadius + 1), -1); // (N-1, M-1, R) -> index into masks
     uint32_t tile_lds_max = 0;
-    if (!pl->launches.empty() && pl->launches[0].kind == kKindBandLane) {
-        const uint64_t nt = pl->launches[0].count;
-        pl->n_tile_jobs = nt;
-        tjobs.resize(nt);
+    for (const Launch &TL : pl->launches) if (TL.kind == kKindBandLane || TL.kind == kKindBandLaneHi) pl->n_tile_jobs += TL.count;
+    tjobs.resize(pl->n_tile_jobs);
+    for (Launch &TL : pl->launches) {
+        if (TL.kind != kKindBandLane && TL.kind != kKindBandLaneHi) continue;
+        const bool hi = TL.kind == kKindBandLaneHi;
+        const uint64_t p0 = TL.first, nt = TL.first + TL.count;
+        const uint32_t lds_budget = hi ? kTileHiLdsFloats : ctx->tile_lds_floats;
+        const uint32_t max_jobs = hi ? kTileHiMaxJobs : ctx->tile_max_jobs;
+        const size_t tiles_before = tiles.size();
+        tile_lds_max = 0;
         struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
         std::vector<Sp> cur;
         struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
         std::vector<Pend> pend;
-        uint64_t t_first = 0;
+        uint64_t t_first = p0;
         uint32_t lds_used = 0;
         auto span_cost = [](const Sp &s) { return (uint32_t)(((s.end - s.start) + 3) & ~3ull); };
         auto close_tile = [&](uint64_t t_end) {
@@ -370,7 +382,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             extra = (uint32_t)((((w0 & 3ull) + len) + 3) & ~3ull);
             return -1;
         };
-        for (uint64_t p = 0; p < nt; p++) {
+        for (uint64_t p = p0; p < nt; p++) {
             const DevJob &d = pl->h_jobs[p];
             const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
             const uint64_t a0 = swap ? d.ref_off : d.read_off, b0 = swap ? d.read_off : d.ref_off;
@@ -382,8 +394,8 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 // place B after tentatively accounting for A (a fresh span for A cannot serve B: other arena)
                 int qb = place(b0, NB, b_ref, eb);
                 const uint32_t new_spans = (qa < 0) + (qb < 0);
-                if (attempt == 0 && (lds_used + ea + eb > kTileLdsFloats || cur.size() + new_spans > kTileMaxSpans ||
-                                     p - t_first >= kTileMaxJobs)) {
+                if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > kTileMaxSpans ||
+                                     p - t_first >= max_jobs)) {
                     close_tile(p);
                     continue; // retry in the fresh tile
                 }
@@ -396,7 +408,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 TileJob &tj = tjobs[p];
                 tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
                 tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
-                if (NA <= 8) { // micro path: band membership from a per-shape bitmask
+                if (!hi && NA <= 8) { // micro path: band membership from a per-shape bitmask
                     int32_t &mi = mask_index[((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + d.R];
                     if (mi < 0) { mi = (int32_t)masks.size(); masks.push_back(band_mask8(NA, NB, d.R)); }
                     tj.pad = (uint32_t)mi;
@@ -408,9 +420,9 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             }
         }
         close_tile(nt);
-        pl->n_tiles = tiles.size();
-        pl->tile_lds_floats = tile_lds_max;
-        pl->launches[0].param = (int32_t)tile_lds_max;
+        if (hi) { pl->n_tiles_hi = tiles.size() - tiles_before; pl->tile_hi_lds_floats = tile_lds_max; }
+        else { pl->n_tiles = tiles.size() - tiles_before; pl->tile_lds_floats = tile_lds_max; }
+        TL.param = (int32_t)tile_lds_max;
     }
     // a banded-wave launch only needs LDS for its own largest K (jobs are sorted by N, not K)
     for (Launch &L : pl->launches)
@@ -430,7 +442,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 const double N = std::max(d.n, d.m), M = std::min(d.n, d.m);
                 const double w = d.R < 0 ? M : std::min<double>(2.0 * d.R + 1.0, M);
                 // wave-per-job kernels spend a whole wave on one job
-                work[i] += N * (L.kind == kKindBandLane ? w : std::max(w, 64.0));
+                work[i] += N * ((L.kind == kKindBandLane || L.kind == kKindBandLaneHi) ? w : std::max(w, 64.0));
             }
         }
         pl->run_order.resize(pl->launches.size());
@@ -444,7 +456,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     I.algorithmic_bytes = alg_bytes;
     I.n_launches = (uint32_t)pl->launches.size();
     for (const Launch &L : pl->launches) {
-        if (L.kind == kKindBandLane) I.n_lane_jobs += L.count;
+        if (L.kind == kKindBandLane || L.kind == kKindBandLaneHi) I.n_lane_jobs += L.count;
         else if (L.kind == kKindBandWave || L.kind == kKindBandWreg) I.n_wave_band_jobs += L.count;
         else I.n_full_jobs += L.count;
     }
@@ -500,8 +512,12 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
     hipError_t e = hipSuccess;
     switch (L.kind) {
     case kKindBandLane:
-        e = launch_band_tile(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats, ctx->d_ev,
-                             ctx->d_ref, out, stream);
+        e = launch_band_tile(false, pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats,
+                             ctx->d_ev, ctx->d_ref, out, stream);
+        break;
+    case kKindBandLaneHi:
+        e = launch_band_tile(true, pl->d_tiles + pl->n_tiles, pl->n_tiles_hi, pl->d_spans, pl->d_tjobs, pl->d_masks,
+                             pl->tile_hi_lds_floats, ctx->d_ev, ctx->d_ref, out, stream);
         break;
     case kKindBandWreg:
         e = launch_band_wreg(L.param, jobs, L.count, ctx->d_ev, ctx->d_ref, out, stream);
@@ -637,6 +653,10 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return RAWDTW_ERR_INVALID;
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
+    if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "lane_max_n")) { ctx->lane_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), kLaneMaxN); return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_radius")) {
         ctx->lane_max_radius = value < 0 ? 0 : (value > kMaxLaneRadius ? kMaxLaneRadius : (int)value);
         return RAWDTW_OK;
@@ -1016,13 +1036,20 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     st = build_plan(ctx, jobs.data(), n_jobs, false, &b->plan);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chains, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chain_off, n_reads + 1);
+    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_fold_order, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_full, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_gate, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_score, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_keep, n_chains);
     if (st == RAWDTW_OK) {
         hipError_t e = hipSuccess;
+        std::vector<uint32_t> fold_order(n_chains);
+        for (uint64_t c = 0; c < n_chains; c++) fold_order[c] = (uint32_t)c;
+        std::stable_sort(fold_order.begin(), fold_order.end(),
+                         [&](uint32_t x, uint32_t y) { return desc[x].n_jobs > desc[y].n_jobs; });
         if (n_chains) e = hipMemcpyAsync(b->d_chains, desc.data(), n_chains * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && n_chains)
+            e = hipMemcpyAsync(b->d_fold_order, fold_order.data(), n_chains * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(b->d_chain_off, chain_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = hip_fail(ctx, e, "uploading chain descriptors");
@@ -1044,7 +1071,7 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
 {
     hipError_t e;
     if (which == 0)
-        e = launch_chain_fold(b->d_chains, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
+        e = launch_chain_fold(b->d_chains, b->d_fold_order, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
                               b->d_full, b->d_gate, ctx->stream);
     else
         e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
@@ -1198,6 +1225,7 @@ int rawdtw_batch_destroy(rawdtw_batch *b)
     rawdtw_plan_destroy(b->plan);
     if (b->d_chains) (void)hipFree(b->d_chains);
     if (b->d_chain_off) (void)hipFree(b->d_chain_off);
+    if (b->d_fold_order) (void)hipFree(b->d_fold_order);
     if (b->d_full) (void)hipFree(b->d_full);
     if (b->d_gate) (void)hipFree(b->d_gate);
     if (b->d_score) (void)hipFree(b->d_score);

@@ -32,7 +32,8 @@ enum LaunchKind : uint32_t {
     kKindTbWalk = 5,    // traceback walk
     kKindChainFold = 6, // per-chain fold of the part costs (align_chain)
     kKindReadSelect = 7, // per-read accept/cut loop (gen_chains DTW block)
-    kKindBandWreg = 8    // wave-per-job banded kernel, band in registers (param = registers per lane per buffer)
+    kKindBandWreg = 8,   // wave-per-job banded kernel, band in registers (param = registers per lane per buffer)
+    kKindBandLaneHi = 9  // tile kernel instance for the wider bands (radius 4..8)
 };
 
 // Tile kernel records (planner output)
@@ -60,11 +61,15 @@ struct ChainDesc {
 };
 static_assert(sizeof(ChainDesc) == 24, "ChainDesc must stay 24 bytes");
 
-constexpr int kMaxLaneRadius = 6;      // lane-per-job DP is instantiated for R in [0, 6]
+constexpr int kMaxLaneRadius = 3;      // lane-per-job DP is instantiated for R in [0, 3]: a sweep showed that the rare
+                                       // jobs with larger radii (0.4 % of a sparse batch) cost half of the tile kernel's
+                                       // time through divergence and register pressure; they go to k_band_wreg<1>
+constexpr int kMaxLaneRadiusHi = 8;    // second tile-kernel instance: radii kMaxLaneRadius+1 .. 8
 constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is at most this
 // tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
-constexpr uint32_t kTileLdsFloats = 10240; // 40 KiB -> 3-4 workgroups per CU
+constexpr uint32_t kTileLdsFloats = 5120;  // 20 KiB -> 8 workgroups per CU (swept: 4096..32768)
 constexpr uint32_t kTileMaxJobs = 1024;
+constexpr uint32_t kTileHiLdsFloats = 10240, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;
 constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
@@ -82,7 +87,7 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+hipError_t launch_band_tile(bool hi, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                             const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
                             float *out, hipStream_t s);
 hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev,
@@ -97,8 +102,8 @@ hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux
                           const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                           uint32_t *path_j, float *path_d, hipStream_t s);
 
-hipError_t launch_chain_fold(const ChainDesc *chains, uint64_t n_chains, const float *job_cost, float bonus,
-                             int fused, float *full_score, float *att_last, hipStream_t s);
+hipError_t launch_chain_fold(const ChainDesc *chains, const uint32_t *order, uint64_t n_chains, const float *job_cost,
+                             float bonus, int fused, float *full_score, float *att_last, hipStream_t s);
 hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const float *full_score,
                               const float *att_last, float min_score, float *score, uint8_t *keep,
                               hipStream_t s);

@@ -281,13 +281,24 @@ __device__ __forceinline__ void tile_dispatch(const float *win, const TileJob &t
     }
 }
 
-__global__ __launch_bounds__(256) void k_band_tile(const TileDesc *__restrict__ tiles,
-                                                   const TileSpan *__restrict__ spans,
-                                                   const TileJob *__restrict__ tjobs,
-                                                   const unsigned long long *__restrict__ masks,
-                                                   const float *__restrict__ ev,
-                                                   const float *__restrict__ ref,
-                                                   float *__restrict__ out)
+template <int R, int RHI>
+__device__ __forceinline__ void tile_dispatch_range(const float *win, const TileJob &tj, int kind, float &res)
+{
+    tile_dispatch<R>(win, tj, kind, res);
+    if constexpr (R < RHI) tile_dispatch_range<R + 1, RHI>(win, tj, kind, res);
+}
+
+// Two instances: <0, 3, true, 256> for the bulk (radius <= 3, micro paths for the tiniest shapes) and
+// <0, 8, false, 64> (optional, "lane_hi") for the rare wider bands -- kept apart so that their registers and their long
+// columns do not tax the waves of the bulk (0.4 % of the jobs cost half the time when mixed in).
+template <int RLO, int RHI, bool MICRO, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restrict__ tiles,
+                                                       const TileSpan *__restrict__ spans,
+                                                       const TileJob *__restrict__ tjobs,
+                                                       const unsigned long long *__restrict__ masks,
+                                                       const float *__restrict__ ev,
+                                                       const float *__restrict__ ref,
+                                                       float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     const int tid = threadIdx.x;
@@ -298,25 +309,21 @@ __global__ __launch_bounds__(256) void k_band_tile(const TileDesc *__restrict__ 
         const uint32_t chunks = sp.chunks_arena & 0x7fffffffu;
         const float4 *src = reinterpret_cast<const float4 *>(((sp.chunks_arena >> 31) ? ref : ev) + sp.src);
         float4 *dst = reinterpret_cast<float4 *>(win + sp.lds_off);
-        for (uint32_t k = tid; k < chunks; k += 256) dst[k] = src[k];
+        for (uint32_t k = tid; k < chunks; k += THREADS) dst[k] = src[k];
     }
     __syncthreads();
-    const uint32_t rounds = (td.n_jobs + 255u) / 256u;
+    const uint32_t rounds = (td.n_jobs + THREADS - 1) / THREADS;
     for (uint32_t rd = 0; rd < rounds; rd++) {
-        const uint32_t r = rd * 256u + tid;
+        const uint32_t r = rd * THREADS + tid;
         const bool act = r < td.n_jobs;
         const TileJob tj = tjobs[td.job_first + (act ? r : td.n_jobs - 1)];
         const int kind = act ? (int)tj.R : -1; // the planner stores the dispatch kind in the R byte
         float res = 0.0f;
-        if (__any(kind == kTileKindMicro4)) { if (kind == kTileKindMicro4) res = micro_job<4>(win, tj, masks); }
-        if (__any(kind == kTileKindMicro8)) { if (kind == kTileKindMicro8) res = micro_job<8>(win, tj, masks); }
-        tile_dispatch<0>(win, tj, kind, res);
-        tile_dispatch<1>(win, tj, kind, res);
-        tile_dispatch<2>(win, tj, kind, res);
-        tile_dispatch<3>(win, tj, kind, res);
-        tile_dispatch<4>(win, tj, kind, res);
-        tile_dispatch<5>(win, tj, kind, res);
-        tile_dispatch<6>(win, tj, kind, res);
+        if constexpr (MICRO) {
+            if (__any(kind == kTileKindMicro4)) { if (kind == kTileKindMicro4) res = micro_job<4>(win, tj, masks); }
+            if (__any(kind == kTileKindMicro8)) { if (kind == kTileKindMicro8) res = micro_job<8>(win, tj, masks); }
+        }
+        tile_dispatch_range<RLO, RHI>(win, tj, kind, res);
         if (act) out[tj.aux] = res; // job order (aux = the job's index in the caller's batch)
     }
 }
@@ -421,13 +428,9 @@ __global__ __launch_bounds__(64) void k_band_wave(const DevJob *__restrict__ job
 // Same physical indexing, guards and stale-slot behaviour as dtw.cpp:305-491.
 // ---------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ jobs,
-                                                  const float *__restrict__ ev,
-                                                  const float *__restrict__ ref,
-                                                  float *__restrict__ out)
+__device__ __forceinline__ void wreg_body(const DevJob &jb, const int lane, const float *__restrict__ ev,
+                                          const float *__restrict__ ref, float *__restrict__ out)
 {
-    const DevJob jb = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
     const float *A = ev + jb.read_off;
     const float *B = ref + jb.ref_off;
     uint32_t N = jb.n, M = jb.m;
@@ -541,6 +544,31 @@ __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ job
         if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
         out[jb.aux] = res;
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ jobs,
+                                                  const float *__restrict__ ev,
+                                                  const float *__restrict__ ref,
+                                                  float *__restrict__ out)
+{
+    wreg_body<C>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
+}
+
+// One launch for every job whose band fits 256 lanes-slots (radius + 1 <= 256): the registers-per-lane
+// variant is picked per job (wave-uniform).  Jobs are sorted longest first, so the few long jobs
+// that bound the launch's duration start first and the many short ones fill in around them --
+// as separate launches they were separate long poles on separate streams.
+__global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict__ jobs,
+                                                        const float *__restrict__ ev,
+                                                        const float *__restrict__ ref,
+                                                        float *__restrict__ out)
+{
+    const DevJob jb = jobs[blockIdx.x];
+    const int K = jb.R + 1;
+    if (K <= 64) wreg_body<1>(jb, (int)threadIdx.x, ev, ref, out);
+    else if (K <= 128) wreg_body<2>(jb, (int)threadIdx.x, ev, ref, out);
+    else wreg_body<4>(jb, (int)threadIdx.x, ev, ref, out);
 }
 
 template <int RPL> struct DirWord { using type = uint8_t; };
@@ -707,16 +735,20 @@ __global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs,
 // read.  All arithmetic is fp32 in the reference's order; the final score is a single fma when the
 // reference build contracts it.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict__ chains, uint64_t n_chains,
+__global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict__ chains,
+                                                    const uint32_t *__restrict__ order, uint64_t n_chains,
                                                     const float *__restrict__ job_cost, float bonus,
                                                     int fused, float *__restrict__ full_score,
                                                     float *__restrict__ att_last)
 {
-    // one wave per chain: the part costs are fetched 64 at a time (coalesced), the fp32 fold itself
-    // is inherently sequential and runs on wave-uniform values taken out of the chunk with readlane
-    const uint64_t c = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    // One wave per chain (`order`: longest chains first, so the long folds start first).  The part
+    // costs are fetched 64 at a time (coalesced, next chunk in flight while the current one is folded);
+    // the fp32 fold itself is inherently sequential and runs on wave-uniform values taken out of the
+    // chunk with v_readlane.  (A lane-per-chain variant was slower: ~40 k chains are too few lanes.)
+    const uint64_t t = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (c >= n_chains) return;
+    if (t >= n_chains) return;
+    const uint32_t c = order[t];
     const ChainDesc d = chains[c];
     float attainable = (float)d.span * bonus; // rmap.cpp:205,246
     float cost = 0.0f;
@@ -724,8 +756,10 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
     // all parts but the last: cost += sub; attainable -= sub (two independent fp32 chains)
     const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0;
     uint32_t base = 0;
+    float nxt = ((uint32_t)lane < d.n_jobs) ? jc[lane] : 0.0f;
     for (; base + 64 <= body; base += 64) {
-        const float chunk = jc[base + lane];
+        const float chunk = nxt;
+        nxt = (base + 64 + (uint32_t)lane < d.n_jobs) ? jc[base + 64 + lane] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 64; k++) {
             const float sub = read_lane(chunk, k);
@@ -735,7 +769,7 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
     }
     {
         const uint32_t cnt = d.n_jobs - base; // 0..64 parts left, the last one included
-        const float chunk = ((uint32_t)lane < cnt) ? jc[base + lane] : 0.0f;
+        const float chunk = nxt;
         for (uint32_t k = 0; k + 1 < cnt; k++) {
             const float sub = read_lane(chunk, (int)k);
             cost += sub;
@@ -774,11 +808,11 @@ __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_chain_fold(const ChainDesc *chains, uint64_t n_chains, const float *job_cost, float bonus,
-                             int fused, float *full_score, float *att_last, hipStream_t s)
+hipError_t launch_chain_fold(const ChainDesc *chains, const uint32_t *order, uint64_t n_chains, const float *job_cost,
+                             float bonus, int fused, float *full_score, float *att_last, hipStream_t s)
 {
     if (n_chains == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 3) / 4)), dim3(256), 0, s, chains, n_chains,
+    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 3) / 4)), dim3(256), 0, s, chains, order, n_chains,
                        job_cost, bonus, fused, full_score, att_last);
     return hipGetLastError();
 }
@@ -792,20 +826,29 @@ hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const
     return hipGetLastError();
 }
 
-hipError_t launch_band_tile(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+template <int RLO, int RHI, bool MICRO, int THREADS>
+static hipError_t launch_tile_t(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+                                const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
+                                float *out, hipStream_t s)
+{
+    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    auto kern = k_band_tile<RLO, RHI, MICRO, THREADS>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((uint32_t)n_tiles), dim3(THREADS), lds_bytes, s, tiles, spans, tjobs, masks, ev, ref, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_band_tile(bool hi, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                             const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
                             float *out, hipStream_t s)
 {
     if (n_tiles == 0) return hipSuccess;
-    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_tile),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k_band_tile, dim3((uint32_t)n_tiles), dim3(256), lds_bytes, s, tiles, spans, tjobs, masks, ev, ref,
-                       out);
-    return hipGetLastError();
+    if (hi) return launch_tile_t<0, kMaxLaneRadiusHi, false, 64>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
+    return launch_tile_t<0, kMaxLaneRadius, true, 256>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
 }
 
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats, const float *ev,
@@ -835,6 +878,9 @@ hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, cons
 {
     if (count == 0) return hipSuccess;
     switch (chunks) {
+    case 0: // merged launch: radius + 1 <= 256, variant chosen per job
+        hipLaunchKernelGGL(k_band_wreg_small, dim3((uint32_t)count), dim3(64), 0, s, jobs, ev, ref, out);
+        return hipGetLastError();
     case 1: return launch_wreg_c<1>(jobs, count, ev, ref, out, s);
     case 2: return launch_wreg_c<2>(jobs, count, ev, ref, out, s);
     case 4: return launch_wreg_c<4>(jobs, count, ev, ref, out, s);
