@@ -23,6 +23,8 @@ struct rawdtw_ctx {
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
     bool serial_launches = false;
+    int n_side = 1; // side streams actually used (RAWDTW_SIDE_STREAMS, 0..kSide); swept: 1 is best with 2 batches in flight
+    uint32_t lane_hi_max_n = 96;
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
@@ -259,7 +261,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             }
             const uint32_t K = (uint32_t)R + 1;
             if (R <= ctx->lane_max_radius && N <= ctx->lane_max_n) cls = 0;
-            else if (R <= kMaxLaneRadiusHi && ctx->lane_hi && N <= 200) cls = 1; // any radius 0..8 (the instance covers all)
+            else if (R <= kMaxLaneRadiusHi && ctx->lane_hi && N <= ctx->lane_hi_max_n) cls = 1; // any radius 0..8 (the instance covers all)
             else if (K <= 64u * kMaxWregChunks) {
                 uint32_t chunks = 1, lg = 0;
                 while (64u * chunks < K) { chunks <<= 1; lg++; }
@@ -544,22 +546,22 @@ int run_all_launches(rawdtw_ctx *ctx, rawdtw_plan *pl, hipEvent_t *ev)
 {
     const size_t nl = pl->launches.size();
     if (nl == 0) return RAWDTW_OK;
-    const bool fork = nl > 1 && !ctx->serial_launches;
+    const bool fork = nl > 1 && !ctx->serial_launches && ctx->n_side > 0;
     if (fork) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        for (int k = 0; k < rawdtw_ctx::kSide; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+        for (int k = 0; k < ctx->n_side; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
     int st = RAWDTW_OK;
     for (size_t q = 0; q < nl && st == RAWDTW_OK; q++) {
         const size_t i = pl->run_order[q];
-        const int sl = fork ? (int)(q % (rawdtw_ctx::kSide + 1)) : 0;
+        const int sl = fork ? (int)(q % (ctx->n_side + 1)) : 0;
         hipStream_t s = sl == 0 ? ctx->stream : ctx->side[sl - 1];
         if (ev && hipEventRecord(ev[2 * i], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) st = run_launch(ctx, pl, pl->launches[i], s);
         if (st == RAWDTW_OK && ev && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
     }
     if (fork)
-        for (int k = 0; k < rawdtw_ctx::kSide; k++) {
+        for (int k = 0; k < ctx->n_side; k++) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join[k], ctx->side[k]));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
         }
@@ -615,6 +617,9 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
         ok = hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { rawdtw_destroy(ctx); return RAWDTW_ERR_DEVICE; }
+    if (const char *e = getenv("RAWDTW_SIDE_STREAMS")) ctx->n_side = std::min(std::max(atoi(e), 0), (int)rawdtw_ctx::kSide);
+    if (const char *e = getenv("RAWDTW_LANE_HI")) ctx->lane_hi = atoi(e) != 0;
+    if (const char *e = getenv("RAWDTW_LANE_HI_MAX_N")) ctx->lane_hi_max_n = (uint32_t)std::min(std::max(atoi(e), 8), 200);
     if (const char *e = getenv("RAWDTW_LANE_MAX_R")) {
         int v = atoi(e);
         ctx->lane_max_radius = v < 0 ? 0 : (v > kMaxLaneRadius ? kMaxLaneRadius : v);
@@ -655,6 +660,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_n")) { ctx->lane_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), kLaneMaxN); return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_radius")) {

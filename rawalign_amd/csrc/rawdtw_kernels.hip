@@ -22,6 +22,8 @@ __device__ __forceinline__ float min3f(float top, float left, float tl)
 
 __device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float wave_shr1(float v, float fill)
 {
     // lane l receives lane l-1's value; lane 0 keeps `fill`  (DPP wave_shr:1 = 0x138)
@@ -760,12 +762,13 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
     for (; base + 64 <= body; base += 64) {
         const float chunk = nxt;
         nxt = (base + 64 + (uint32_t)lane < d.n_jobs) ? jc[base + 64 + lane] : 0.0f;
+        v2f acc = {cost, attainable};
 #pragma unroll
         for (int k = 0; k < 64; k++) {
             const float sub = read_lane(chunk, k);
-            cost += sub;       // rmap.cpp:279
-            attainable -= sub; // rmap.cpp:280
+            acc += v2f{sub, -sub}; // one packed add: cost += sub (rmap.cpp:279), attainable -= sub (rmap.cpp:280)
         }
+        cost = acc.x; attainable = acc.y;
     }
     {
         const uint32_t cnt = d.n_jobs - base; // 0..64 parts left, the last one included

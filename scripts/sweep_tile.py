@@ -14,15 +14,14 @@ offs = {(0, st): eng.reference_offset(0, st) for st in (0, 1)}
 cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=16384), seed=20231007 + 7919)
 eng.upload_events(cb.events)
 eng.set_option("serial_launches", 1)
-import itertools
-combos = [(lds, mj, lmr, ln) for lmr in (2, 3) for lds in (5120, 6144) for mj in (1024,) for ln in (20, 28, 40, 73)]
-for lds, mj, lmr, ln in combos:
-    eng.set_option("lane_max_n", ln)
+combos = [(5120, 1024, 3, 73, hi, hn) for hi, hn in ((0, 96), (1, 48), (1, 96), (1, 200))]
+for lds, mj, lmr, ln, hi, hn in combos:
+    eng.set_option("lane_max_n", ln); eng.set_option("lane_hi", hi); eng.set_option("lane_hi_max_n", hn)
     eng.set_option("tile_lds_floats", lds); eng.set_option("tile_max_jobs", mj); eng.set_option("lane_max_radius", lmr)
     b = ra.Batch(eng, ra.MapOpt(), cb)
     b.run_reps(2, timed=False)
     L = b.run_reps(8, timed=True)
     st = b.launch_stats(with_cells=False)
-    print(json.dumps({"lds_floats": lds, "max_jobs": mj, "lane_max_r": lmr, "lane_max_n": ln,
+    print(json.dumps({"lds_floats": lds, "max_jobs": mj, "lane_max_r": lmr, "lane_max_n": ln, "hi": hi, "hi_max_n": hn,
                       "launches": [(ra.Engine.KIND_NAMES.get(k), p, round(ms, 4), st[i]["n_jobs"]) for i, (k, p, ms) in enumerate(L)]}))
     b.close()
