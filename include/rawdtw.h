@@ -223,6 +223,33 @@ int rawdtw_is_mapped_with_high_confidence(const rawdtw_chain_t *primary, uint32_
 /* find_outlier (src/sequence_until.c:4-18): x[point][dim], n dims, m points. */
 float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m);
 
+/* ---- chaining DP of gen_chains (src/rmap.cpp:430-507) and traceback_chains (src/rmap.cpp:130-173) for
+ * one (reference sequence, strand): anchors must be sorted by (target_position, query_position) as
+ * rmap.cpp:396-401 does.  Emits up to num_best_chains chains; chain k owns
+ * out_anchors[out_off[k]..out_off[k+1]) (end-first).  max_chaining_score is the running maximum over
+ * all (sequence, strand) pairs of the read and is updated in place (rmap.cpp:431,485-487).
+ * Returns the number of chains written, or a negative value when an output array is too small. */
+typedef struct {
+    int max_gap_length;        /* roptions.c:13 (2000) */
+    int max_target_gap_length; /* roptions.c:14 (5000) */
+    int chaining_band_length;  /* roptions.c:15 (5000) */
+    int max_num_skips;         /* roptions.c:16 (25)   */
+    int min_num_anchors;       /* roptions.c:17 (2)    */
+    int num_best_chains;       /* roptions.c:18 (3)    */
+    float min_chaining_score;  /* roptions.c:19 (10)   */
+    int e;                     /* ri->e: events per seed */
+    int disable_score_filtering; /* RI_M_DISABLE_CHAININGSCORE_FILTERING */
+} rawdtw_chain_opt_t;
+
+typedef struct {
+    float chaining_score;
+    uint32_t start_position, end_position, n_anchors;
+} rawdtw_chain_out_t;
+
+int rawdtw_chain_anchors(const rawdtw_chain_opt_t *opt, const rawdtw_anchor_t *anchors, uint32_t n_anchors,
+                         float *max_chaining_score, rawdtw_chain_out_t *out_chains, uint64_t *out_off,
+                         rawdtw_anchor_t *out_anchors, uint32_t chains_cap, uint64_t anchors_cap);
+
 /* The evaluation order of one read's chains: the permutation std::sort (libstdc++, unstable)
  * produces for the comparator a.chaining_score > b.chaining_score (rmap.cpp:512). */
 int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out);

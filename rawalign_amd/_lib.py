@@ -58,6 +58,26 @@ class SelectOpt(C.Structure):
     ]
 
 
+class ChainOpt(C.Structure):
+    """rawdtw_chain_opt_t, defaults of src/roptions.c:13-19"""
+    _fields_ = [
+        ("max_gap_length", C.c_int),
+        ("max_target_gap_length", C.c_int),
+        ("chaining_band_length", C.c_int),
+        ("max_num_skips", C.c_int),
+        ("min_num_anchors", C.c_int),
+        ("num_best_chains", C.c_int),
+        ("min_chaining_score", C.c_float),
+        ("e", C.c_int),
+        ("disable_score_filtering", C.c_int),
+    ]
+
+
+class ChainOut(C.Structure):
+    _fields_ = [("chaining_score", C.c_float), ("start_position", C.c_uint32), ("end_position", C.c_uint32),
+                ("n_anchors", C.c_uint32)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [
         ("n_jobs", C.c_uint64),
@@ -113,6 +133,7 @@ SYMBOLS = {
     "rawdtw_gen_primary_chains": (U32, [VP, U32, C.POINTER(SelectOpt), VP]),
     "rawdtw_is_mapped_with_high_confidence": (I32, [VP, U32, C.POINTER(SelectOpt)]),
     "rawdtw_find_outlier": (F32, [VP, U32, U32]),
+    "rawdtw_chain_anchors": (I32, [C.POINTER(ChainOpt), VP, U32, C.POINTER(F32), VP, VP, VP, U32, U64]),
     "rawdtw_sort_by_chaining_score": (I32, [VP, U32, VP]),
     "rawdtw_batch_build_jobs": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, U64, C.POINTER(U64)]),
     "rawdtw_batch_create": (I32, [VP, C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, C.POINTER(VP)]),

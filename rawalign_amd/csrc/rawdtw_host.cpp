@@ -13,7 +13,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/rawdtw.h"
@@ -219,6 +221,83 @@ float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m)
         if (dist > max_dist) { max_dist = dist; outlier = i; }
     }
     return max_dist;
+}
+
+int rawdtw_chain_anchors(const rawdtw_chain_opt_t *opt, const rawdtw_anchor_t *anchors, uint32_t n_anchors,
+                         float *max_chaining_score, rawdtw_chain_out_t *out_chains, uint64_t *out_off,
+                         rawdtw_anchor_t *out_anchors, uint32_t chains_cap, uint64_t anchors_cap)
+{
+    if (!opt || (!anchors && n_anchors) || !max_chaining_score || !out_chains || !out_off || !out_anchors) return -1;
+    std::vector<float> score(n_anchors);
+    std::vector<size_t> pred(n_anchors);
+    std::vector<char> used(n_anchors, 0);
+    std::vector<std::pair<float, size_t>> ends;
+    float maxs = *max_chaining_score;
+    for (size_t ai = 0; ai < n_anchors; ++ai) {
+        score[ai] = (float)opt->e; // rmap.cpp:444-445 (distance coefficient 1)
+        pred[ai] = ai;
+        const int32_t ct = (int32_t)anchors[ai].target_position, cq = (int32_t)anchors[ai].query_position;
+        int32_t start = 0;
+        if (ai > (size_t)opt->chaining_band_length) start = (int32_t)ai - opt->chaining_band_length;
+        int32_t skips = 0;
+        for (int32_t pi = (int32_t)ai - 1; pi >= start; --pi) {
+            const int32_t pt = (int32_t)anchors[pi].target_position, pq = (int32_t)anchors[pi].query_position;
+            if (pq == cq) continue;                                   // rmap.cpp:458
+            if (pt == ct) continue;                                   // rmap.cpp:459
+            if (pt + opt->max_target_gap_length < ct) break;          // rmap.cpp:460
+            const int32_t td = ct - pt, qd = cq - pq;
+            float cur = 0;
+            if (qd < 0) continue;                                     // rmap.cpp:467
+            const float matching = (float)std::min(std::min(td, qd), opt->e); // rmap.cpp:469
+            const int gap = std::abs(td - qd);
+            const float scale = td > 0 ? (float)qd / td : 1;
+            if (gap < opt->max_gap_length && scale < 5 && scale > 0.75) cur = score[pi] + matching; // rmap.cpp:474-476
+            if (cur > score[ai]) { score[ai] = cur; pred[ai] = (size_t)pi; --skips; }
+            else { ++skips; if (skips > opt->max_num_skips) break; }  // rmap.cpp:478-484
+        }
+        if (score[ai] > maxs) maxs = score[ai];                      // rmap.cpp:486-488
+        if (opt->disable_score_filtering || (score[ai] >= opt->min_chaining_score && score[ai] > maxs / 2))
+            ends.emplace_back(score[ai], ai);                        // rmap.cpp:489-493
+    }
+    *max_chaining_score = maxs;
+    // rmap.cpp:175-179 `compare`: score descending, then anchor index descending
+    std::sort(ends.begin(), ends.end(), [](const std::pair<float, size_t> &l, const std::pair<float, size_t> &r) {
+        if (l.first > r.first) return true;
+        if (l.first == r.first) return l.second > r.second;
+        return false;
+    });
+    uint32_t nc = 0;
+    uint64_t na = 0;
+    out_off[0] = 0;
+    for (size_t k = 0; k < ends.size() && k < (size_t)opt->num_best_chains; ++k) {
+        const size_t end_idx = ends[k].second;
+        if (!used[end_idx]) { // traceback_chains, rmap.cpp:130-173
+            std::vector<rawdtw_anchor_t> chain;
+            bool stop_at_used = false;
+            size_t cur = end_idx;
+            chain.push_back(anchors[cur]);
+            if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
+            used[cur] = 1;
+            while (pred[cur] != cur && !used[pred[cur]]) {
+                cur = pred[cur];
+                chain.push_back(anchors[cur]);
+                if (pred[cur] != cur && used[pred[cur]]) stop_at_used = true;
+                used[cur] = 1;
+            }
+            if (chain.size() >= (size_t)opt->min_num_anchors) {
+                float adj = score[end_idx];
+                if (stop_at_used) adj -= score[pred[cur]];
+                if (nc >= chains_cap || na + chain.size() > anchors_cap) return -2;
+                out_chains[nc] = rawdtw_chain_out_t{adj, anchors[cur].target_position, anchors[end_idx].target_position,
+                                                    (uint32_t)chain.size()};
+                for (size_t q = 0; q < chain.size(); ++q) out_anchors[na + q] = chain[q]; // end-first, as pushed
+                na += chain.size();
+                out_off[++nc] = na;
+            }
+        }
+        if (!opt->disable_score_filtering && score[end_idx] < maxs / 2) break; // rmap.cpp:502-504
+    }
+    return (int)nc;
 }
 
 int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out)

@@ -14,7 +14,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from ._lib import ChainRec, SelectOpt, load_library
+from ._lib import ChainOpt, ChainOut, ChainRec, SelectOpt, load_library
+from .dtw import ANCHOR_DTYPE
 from .align import RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_OUTPUT_CIGAR, Chain, MapOpt, dtwresult_to_string
 
 f32 = np.float32
@@ -79,6 +80,36 @@ def find_outlier(x) -> np.float32:
     m, n = x.shape
     rows = (C.c_void_p * m)(*[x[i].ctypes.data for i in range(m)])
     return np.float32(lib.rawdtw_find_outlier(rows, n, m))
+
+
+def default_chain_opt(e: int = 6) -> ChainOpt:
+    """src/roptions.c:13-19; e = events per seed (6 for the `sensitive` preset, main.cpp:138)."""
+    return ChainOpt(2000, 5000, 5000, 25, 2, 3, 10.0, e, 0)
+
+
+def chain_anchors(anchors, copt: ChainOpt, max_chaining_score: float, ref_index: int, strand: int):
+    """The chaining DP + traceback of gen_chains for one (sequence, strand) (rmap.cpp:430-507, 130-173).
+    `anchors` (ANCHOR_DTYPE) must be sorted by (target, query) (rmap.cpp:396-401).
+    Returns (list of Chain, updated running max chaining score)."""
+    lib = load_library()
+    a = np.ascontiguousarray(anchors, dtype=ANCHOR_DTYPE)
+    n = len(a)
+    cap_c = max(1, copt.num_best_chains)
+    outc = (ChainOut * cap_c)()
+    off = (C.c_uint64 * (cap_c + 1))()
+    outa = np.zeros(max(n, 1), ANCHOR_DTYPE)
+    ms = C.c_float(max_chaining_score)
+    nc = lib.rawdtw_chain_anchors(C.byref(copt), a.ctypes.data_as(C.c_void_p), n, C.byref(ms), outc, off,
+                                  outa.ctypes.data_as(C.c_void_p), cap_c, len(outa))
+    if nc < 0:
+        raise RuntimeError("chain output buffers too small")
+    chains = []
+    for k in range(nc):
+        ch = Chain(float(outc[k].chaining_score), ref_index, strand, outa[off[k]:off[k + 1]].copy())
+        ch.start_position = int(outc[k].start_position)
+        ch.end_position = int(outc[k].end_position)
+        chains.append(ch)
+    return chains, float(ms.value)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -160,3 +160,90 @@ def test_sequence_until_state_machine():
     # estimates are fractions in [0,1]: distances are far below 1.5, so it fires at the first eligible test:
     # tests happen at nreads = 15, 20, 25, ... and the outlier check starts once tn_samples estimates exist
     assert fired_at == 29 and su.stop == 30
+
+
+def py_chain(anchors, e=6, max_gap=2000, max_tgap=5000, band=5000, max_skips=25, min_anchors=2, nbest=3,
+             min_score=10.0, maxs=0.0):
+    """Plain-Python restatement of the chaining DP + traceback (rmap.cpp:430-507, 130-173), fp32 scores."""
+    n = len(anchors)
+    score = [f32(e)] * n
+    pred = list(range(n))
+    used = [False] * n
+    ends = []
+    maxs = f32(maxs)
+    T = [int(x) for x in anchors["target_position"]]
+    Q = [int(x) for x in anchors["query_position"]]
+    for ai in range(n):
+        start = ai - band if ai > band else 0
+        skips = 0
+        for pi in range(ai - 1, start - 1, -1):
+            if Q[pi] == Q[ai] or T[pi] == T[ai]:
+                continue
+            if T[pi] + max_tgap < T[ai]:
+                break
+            td, qd = T[ai] - T[pi], Q[ai] - Q[pi]
+            if qd < 0:
+                continue
+            cur = f32(0)
+            scale = f32(f32(qd) / f32(td)) if td > 0 else f32(1)
+            if abs(td - qd) < max_gap and scale < f32(5) and float(scale) > 0.75:
+                cur = f32(score[pi] + f32(min(td, qd, e)))
+            if cur > score[ai]:
+                score[ai], pred[ai] = cur, pi
+                skips -= 1
+            else:
+                skips += 1
+                if skips > max_skips:
+                    break
+        if score[ai] > maxs:
+            maxs = score[ai]
+        if score[ai] >= f32(min_score) and score[ai] > f32(maxs / f32(2)):
+            ends.append((score[ai], ai))
+    ends.sort(key=lambda x: (-float(x[0]), -x[1]))
+    chains = []
+    for k, (_, end) in enumerate(ends[:nbest]):
+        if not used[end]:
+            idx = [end]
+            stop = pred[end] != end and used[pred[end]]
+            used[end] = True
+            cur = end
+            while pred[cur] != cur and not used[pred[cur]]:
+                cur = pred[cur]
+                idx.append(cur)
+                if pred[cur] != cur and used[pred[cur]]:
+                    stop = True
+                used[cur] = True
+            if len(idx) >= min_anchors:
+                adj = score[end]
+                if stop:
+                    adj = f32(adj - score[pred[cur]])
+                chains.append((float(adj), idx))
+        if score[end] < f32(maxs / f32(2)):
+            break
+    return chains, float(maxs)
+
+
+def test_chaining_dp_matches_restatement():
+    rng = np.random.default_rng(17)
+    copt = M.default_chain_opt(6)
+    for trial in range(120):
+        # seed hits on a true diagonal with local stretch + random false hits
+        n_true = int(rng.integers(0, 60))
+        q = np.sort(rng.choice(800, size=n_true, replace=False)) if n_true else np.zeros(0, int)
+        t = 3000 + (q * rng.uniform(0.7, 1.0)).astype(int) + rng.integers(0, 3, n_true)
+        nf = int(rng.integers(0, 80))
+        qf, tf = rng.integers(0, 800, nf), rng.integers(0, 20000, nf)
+        a = np.zeros(n_true + nf, ra.ANCHOR_DTYPE)
+        a["query_position"] = np.concatenate([q, qf])
+        a["target_position"] = np.concatenate([t, tf])
+        a = np.sort(a, order=["target_position", "query_position"])  # rmap.h:24-26 operator<
+        start_max = float(rng.choice([0.0, 30.0]))
+        got, gmax = M.chain_anchors(a, copt, start_max, ref_index=0, strand=1)
+        want, wmax = py_chain(a, maxs=start_max)
+        assert gmax == wmax
+        assert len(got) == len(want)
+        for g, (ws, widx) in zip(got, want):
+            assert f32(g.chaining_score) == f32(ws)
+            assert [int(x) for x in g.anchors["target_position"]] == [int(a[i]["target_position"]) for i in widx]
+            assert [int(x) for x in g.anchors["query_position"]] == [int(a[i]["query_position"]) for i in widx]
+            assert g.start_position == int(a[widx[-1]]["target_position"]) and g.end_position == int(a[widx[0]]["target_position"])
