@@ -1,0 +1,236 @@
+"""Chunk-round mapper: the control flow of map_worker_for / ri_map_frag / gen_chains
+(src/rmap.cpp:667-699, 545-578, 315-541) turned inside out so that every chunk round makes ONE
+device submission for all active reads (option A).
+
+Per round, for every active read (host): take the chunk's events, re-seed with the previous
+chains' anchors plus the chunk's new seed hits (rmap.cpp:344-391), sort (396-401), run the chaining
+DP per (sequence, strand) (430-507), order the chains by chaining score (512).  Then one
+`Batch` scores every chain of every read on the device (DTW + fold + accept/cut), and the host
+finishes the round: gen_primary_chains, comp_mapq, the stop rule (532-541, 692).
+
+Event detection and seeding are NOT implemented here (they stay in RawAlign: revent.c, rsketch.c,
+rawindex.cpp); a `SeedSource` supplies each chunk's events and seed hits.  `SyntheticSeeds`
+imitates them for tests and demos.  The scorer is pluggable so that tests can run the same control
+flow with the CPU oracle and compare PAF lines."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import mapping as M
+from .align import Batch, CandidateBatch, Chain, MapOpt
+from .dtw import ANCHOR_DTYPE
+
+
+@dataclass
+class ReadJob:
+    name: str
+    qlen: int                      # samples in the read
+    n_chunks_available: int        # chunks the read has signal for
+    events: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))  # p->events[read].values
+    chains: list = field(default_factory=list)     # reg0->chains (primary chains, best first)
+    chunks_done: int = 0
+    finished: bool = False
+    broke_early: bool = False
+
+
+class SyntheticSeeds:
+    """Stands in for detect_events + ri_sketch + ri_idx_get: per read and chunk, the chunk's events and
+    the (sequence, strand, target, query-in-chunk) seed hits."""
+
+    def __init__(self, ref, n_reads, seed, events_per_chunk=520, hit_prob=0.2, false_hits=25, noise_sd=0.25,
+                 max_chunks=6, unmappable_frac=0.1):
+        self.ref = ref
+        rng = np.random.default_rng(seed)
+        self.rng = rng
+        self.reads = []
+        lens = np.array([len(x) for x in ref.forward])
+        for r in range(n_reads):
+            seq = int(rng.choice(len(lens), p=lens / lens.sum()))
+            strand = int(rng.integers(0, 2))
+            chunks = int(rng.integers(1, max_chunks + 1))
+            n_k = min(chunks * int(events_per_chunk / 1.28), lens[seq] - 1)
+            start = int(rng.integers(0, lens[seq] - n_k))
+            mult = rng.choice(4, size=n_k, p=(0.06, 0.66, 0.22, 0.06))
+            mult[0] = max(mult[0], 1)
+            t_of_ev = np.repeat(start + np.arange(n_k), mult)
+            arr = ref.forward[seq] if strand == 1 else ref.reverse[seq]
+            mappable = rng.random() >= unmappable_frac
+            vals = arr[t_of_ev] + rng.normal(0, noise_sd, len(t_of_ev)) if mappable else rng.normal(0, 1, len(t_of_ev))
+            self.reads.append(dict(seq=seq, strand=strand, t_of_ev=t_of_ev, vals=vals.astype(np.float32),
+                                   mappable=mappable, n_ev=len(t_of_ev)))
+        self.events_per_chunk = events_per_chunk
+        self.hit_prob = hit_prob
+        self.false_hits = false_hits
+        self.lens = lens
+
+    def read_job(self, r) -> ReadJob:
+        rd = self.reads[r]
+        n_chunks = (rd["n_ev"] + self.events_per_chunk - 1) // self.events_per_chunk
+        return ReadJob(f"read_{r}", qlen=n_chunks * 4000, n_chunks_available=n_chunks)
+
+    def chunk(self, r, c):
+        """events of chunk c (z-normalised per chunk, revent.c:178-184) and its seed hits."""
+        rd = self.reads[r]
+        lo, hi = c * self.events_per_chunk, min(rd["n_ev"], (c + 1) * self.events_per_chunk)
+        ev = rd["vals"][lo:hi].astype(np.float64)
+        ev = ((ev - ev.mean()) / max(ev.std(), 1e-9)).astype(np.float32)
+        rng = np.random.default_rng(hash((r, c)) & 0xFFFFFFFF)
+        hits = []
+        if rd["mappable"]:
+            sel = np.nonzero(rng.random(hi - lo) < self.hit_prob)[0]
+            for q in sel:
+                hits.append((rd["seq"], rd["strand"], int(rd["t_of_ev"][lo + q]), int(q)))
+        for _ in range(self.false_hits):
+            s = int(rng.integers(0, len(self.lens)))
+            hits.append((s, int(rng.integers(0, 2)), int(rng.integers(0, self.lens[s])), int(rng.integers(0, hi - lo))))
+        return ev, hits
+
+
+class OracleScorer:
+    """CPU scorer with the oracle (tests only): same interface as the GPU scorer."""
+
+    def __init__(self, oracle, ref):
+        self.oracle = oracle
+        self.ref = ref
+
+    def score(self, reads, opt: MapOpt):
+        from oracle.loader import OrcOpt
+
+        oopt = OrcOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                      opt.dtw_min_score, int(opt.fused_score))
+        out = []
+        for events, chains in reads:
+            best = np.float32(0.0)
+            kept = []
+            for ch in chains:
+                arr = self.ref.forward[ch.reference_sequence_index] if ch.strand == 1 else self.ref.reverse[ch.reference_sequence_index]
+                s = self.oracle.align_chain(ch.anchors, arr, events, oopt, float(best))
+                ch.alignment_score = float(s)
+                if s >= np.float32(opt.dtw_min_score):
+                    if s > best:
+                        best = s
+                    kept.append(ch)
+            out.append(kept)
+        return out
+
+
+class DeviceScorer:
+    def __init__(self, engine):
+        self.engine = engine
+        self.offs = {}
+
+    def score(self, reads, opt: MapOpt):
+        eng = self.engine
+        ev_parts, read_base, acc = [], [], 0
+        for events, _ in reads:
+            ev_parts.append(events)
+            read_base.append(acc)
+            acc += len(events)
+        chain_off, anchor_off, anchors, ref_base, rbase, flat = [0], [0], [], [], [], []
+        for ri, (_, chains) in enumerate(reads):
+            for ch in chains:
+                key = (ch.reference_sequence_index, ch.strand)
+                if key not in self.offs:
+                    self.offs[key] = eng.reference_offset(*key)
+                anchors.append(np.ascontiguousarray(ch.anchors, ANCHOR_DTYPE))
+                anchor_off.append(anchor_off[-1] + len(ch.anchors))
+                ref_base.append(self.offs[key])
+                rbase.append(read_base[ri])
+                flat.append(ch)
+            chain_off.append(len(flat))
+        if not flat:
+            return [[] for _ in reads]
+        cb = CandidateBatch(np.concatenate(ev_parts), np.array(chain_off, np.uint64), np.array(anchor_off, np.uint64),
+                            np.concatenate(anchors), np.array(ref_base, np.uint64), np.array(rbase, np.uint32))
+        eng.upload_events(cb.events)
+        b = Batch(eng, opt, cb)
+        b.run()
+        score, keep = b.fetch()
+        b.close()
+        out = []
+        for ri in range(len(reads)):
+            kept = []
+            for c in range(chain_off[ri], chain_off[ri + 1]):
+                flat[c].alignment_score = float(score[c])
+                if keep[c]:
+                    kept.append(flat[c])
+            out.append(kept)
+        return out
+
+
+def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(), e: int = 6):
+    """Runs chunk rounds until every read stopped; returns the PAF lines in read order."""
+    copt = M.default_chain_opt(e)
+    jobs = {r: seeds.read_job(r) for r in read_ids}
+    names = [f"seq{s}" for s in range(len(seeds.lens))]
+    rounds = 0
+    while True:
+        active = [r for r in read_ids if not jobs[r].finished]
+        if not active:
+            break
+        rounds += 1
+        submission = []
+        for r in active:
+            rj = jobs[r]
+            ev, hits = seeds.chunk(r, rj.chunks_done)
+            chunk_start = len(rj.events)                       # reg->offset (rmap.cpp:574)
+            rj.events = np.concatenate([rj.events, ev])        # rmap.cpp:554-567
+            per = {}
+            for ch in rj.chains:                               # rmap.cpp:344-357: re-seed with previous anchors
+                per.setdefault((ch.reference_sequence_index, ch.strand), []).extend(
+                    (int(a["target_position"]), int(a["query_position"])) for a in ch.anchors)
+            for s, st, t, q in hits:                           # rmap.cpp:371-391
+                per.setdefault((s, st), []).append((t, q + chunk_start))
+            chains, maxs = [], 0.0
+            for s in range(len(seeds.lens)):                   # rmap.cpp:432-433: sequence-major, strand 0 then 1
+                for st in (0, 1):
+                    lst = per.get((s, st))
+                    if not lst:
+                        continue
+                    a = np.array(sorted(lst), dtype=[("target_position", "<u4"), ("query_position", "<u4")])
+                    cs, maxs = M.chain_anchors(a.astype(ANCHOR_DTYPE), copt, maxs, s, st)
+                    chains.extend(cs)
+            from .align import evaluation_order
+
+            if chains:
+                order = evaluation_order(scorer.engine if hasattr(scorer, "engine") else _SortHelper.get(),
+                                         [c.chaining_score for c in chains])
+                chains = [chains[int(k)] for k in order]
+            submission.append((rj.events, chains))
+        kept = scorer.score(submission, opt)
+        for r, post in zip(active, kept):
+            rj = jobs[r]
+            rj.chains = M.gen_primary_chains(post, opt, stop) if post else []
+            rj.chunks_done += 1
+            if M.is_mapped_with_high_confidence(rj.chains, opt, stop):   # rmap.cpp:692
+                rj.finished, rj.broke_early = True, True
+            elif rj.chunks_done >= min(rj.n_chunks_available, stop.max_num_chunk):
+                rj.finished = True
+    lines = []
+    for r in read_ids:
+        rj = jobs[r]
+        rs = M.ReadState(rj.name, rj.qlen, len(rj.events), rj.chunks_done if not rj.broke_early else rj.chunks_done - 1,
+                         rj.broke_early, 0.0, rj.chains)
+        lines.append(M.paf_line(rs, names, [int(x) for x in seeds.lens], opt, stop))
+    return lines, rounds
+
+
+class _SortHelper:
+    """evaluation_order needs only the library handle."""
+    _inst = None
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            from ._lib import load_library
+
+            class _E:
+                lib = load_library()
+
+                @staticmethod
+                def _check(st):
+                    assert st == 0
+            cls._inst = _E()
+        return cls._inst
