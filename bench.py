@@ -230,8 +230,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": f"{kname}(param={dparam})", "launch_ms": dms,
-                         "launch_ms_isolated": isolated[dom][2],
-                         "achieved_isolated": dbytes / (isolated[dom][2] * 1e-3) / 1e9 if isolated[dom][2] > 0 else 0.0,
+                         "note": "launch_ms is the HIP-event bracket inside the timed region, where this launch shares "
+                                 "the chip with the other launches of its batch and with the other batch in flight; "
+                                 "`isolated` is the same launch alone on the chip (second pass, launches serialised)",
+                         "isolated": {"launch_ms": isolated[dom][2],
+                                      "achieved": dbytes / (isolated[dom][2] * 1e-3) / 1e9 if isolated[dom][2] > 0 else 0.0,
+                                      "frac": (dbytes / (isolated[dom][2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated[dom][2] > 0 else 0.0},
                          "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": stats[dom]["n_jobs"]},
             "launches": [{"kernel": ra.Engine.KIND_NAMES.get(k, str(k)),
                           "param": p, "ms": round(ms, 5), "ms_isolated": round(isolated[i][2], 5),
