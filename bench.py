@@ -94,8 +94,15 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        # rehearsal knobs (several ranks on a one-GPU box): RAWDTW_BENCH_BACKEND=gloo, RAWDTW_BENCH_DEVICE=0
+        backend = os.environ.get("RAWDTW_BENCH_BACKEND", "nccl")
+        if "RAWDTW_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["RAWDTW_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     import rawalign_amd as ra
     from rawalign_amd import synth
     from rawalign_amd.shard import rank_seed
@@ -173,7 +180,8 @@ def main():
     (reads_t, chains_t, jobs_t, cells_t, mapped_t, bytes_t), T = reduce_counters(
         dist, [args.reads * args.steps, total("n_chains"), total("n_jobs"), total("cells"), total(mapped_slots),
                total("algorithmic_bytes")],
-        elapsed, device=torch.device("cuda", local_rank) if dist is not None else None)
+        elapsed, device=torch.device("cuda", local_rank)
+        if (dist is not None and os.environ.get("RAWDTW_BENCH_BACKEND", "nccl") == "nccl") else None)
 
     if rank == 0:
         stats = batch.launch_stats(with_cells=False)
