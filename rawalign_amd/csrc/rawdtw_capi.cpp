@@ -25,6 +25,7 @@ struct rawdtw_ctx {
     bool serial_launches = false;
     int n_side = 1; // side streams actually used (RAWDTW_SIDE_STREAMS, 0..kSide); swept: 1 is best with 2 batches in flight
     uint32_t lane_hi_max_n = 96;
+    int micro_max_n = 8; // shapes with longer side <= this use the micro paths (0: none, 4: micro4 only)
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
@@ -410,7 +411,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
                 TileJob &tj = tjobs[p];
                 tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
                 tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
-                if (!hi && NA <= 8) { // micro path: band membership from a per-shape bitmask
+                if (!hi && NA <= (uint32_t)ctx->micro_max_n) { // micro path: band membership from a per-shape bitmask
                     int32_t &mi = mask_index[((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + d.R];
                     if (mi < 0) { mi = (int32_t)masks.size(); masks.push_back(band_mask8(NA, NB, d.R)); }
                     tj.pad = (uint32_t)mi;
@@ -660,6 +661,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_n")) { ctx->lane_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), kLaneMaxN); return RAWDTW_OK; }

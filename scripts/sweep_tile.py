@@ -14,14 +14,14 @@ offs = {(0, st): eng.reference_offset(0, st) for st in (0, 1)}
 cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=16384), seed=20231007 + 7919)
 eng.upload_events(cb.events)
 eng.set_option("serial_launches", 1)
-combos = [(5120, 1024, 3, 73, hi, hn) for hi, hn in ((0, 96), (1, 48), (1, 96), (1, 200))]
-for lds, mj, lmr, ln, hi, hn in combos:
-    eng.set_option("lane_max_n", ln); eng.set_option("lane_hi", hi); eng.set_option("lane_hi_max_n", hn)
+combos = [(5120, 1024, 3, 73, mm) for mm in (8, 4, 0)] + [(4096, 768, 3, 73, 8), (5120, 1536, 3, 73, 8), (7168, 1536, 3, 73, 8)]
+for lds, mj, lmr, ln, mm in combos:
+    eng.set_option("lane_max_n", ln); eng.set_option("micro_max_n", mm)
     eng.set_option("tile_lds_floats", lds); eng.set_option("tile_max_jobs", mj); eng.set_option("lane_max_radius", lmr)
     b = ra.Batch(eng, ra.MapOpt(), cb)
     b.run_reps(2, timed=False)
     L = b.run_reps(8, timed=True)
     st = b.launch_stats(with_cells=False)
-    print(json.dumps({"lds_floats": lds, "max_jobs": mj, "lane_max_r": lmr, "lane_max_n": ln, "hi": hi, "hi_max_n": hn,
+    print(json.dumps({"lds_floats": lds, "max_jobs": mj, "lane_max_r": lmr, "lane_max_n": ln, "micro": mm,
                       "launches": [(ra.Engine.KIND_NAMES.get(k), p, round(ms, 4), st[i]["n_jobs"]) for i, (k, p, ms) in enumerate(L)]}))
     b.close()

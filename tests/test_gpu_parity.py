@@ -355,3 +355,35 @@ def test_yeast_like_global_full_cigar(engine, oracle):
                 checked_tb += 1
             first = False
     assert checked_tb > 0
+
+
+def test_planner_options_do_not_change_results(oracle):
+    """Every tuning knob (kernel class boundaries, tile sizes, micro paths, stream layout) must leave
+    the costs bit-identical: they only move jobs between kernels."""
+    rng = np.random.default_rng(21)
+    cases = []
+    for t in range(3000):
+        n = int(rng.integers(1, 110))
+        m = max(1, int(round(n * rng.uniform(0.4, 1.5))))
+        R0 = default_radius(n) if t % 4 else int(rng.integers(0, 12))
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), R0, t & 1))
+    jobs, ev, rf = make_arena_jobs(cases)
+    want = oracle_costs(oracle, jobs, ev, rf)
+    settings = [
+        {},
+        {"lane_hi": 1, "lane_hi_max_n": 200},
+        {"micro_max_n": 0},
+        {"micro_max_n": 4, "tile_lds_floats": 2048, "tile_max_jobs": 64},
+        {"lane_max_radius": 0, "lane_max_n": 12},
+        {"lane_max_radius": 1, "lane_hi": 1, "lane_hi_max_n": 40, "serial_launches": 1},
+        {"tile_lds_floats": 30000, "tile_max_jobs": 4096},
+    ]
+    for st in settings:
+        eng = ra.Engine(0)
+        for k, v in st.items():
+            eng.set_option(k, v)
+        assert_bits_equal(run(eng, jobs, ev, rf), want, f"options {st}")
+        eng.close()
+    eng = ra.Engine(0)
+    with pytest.raises(ra.RawDTWError):
+        eng.set_option("no_such_option", 1)
