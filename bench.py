@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="mini-batches in flight per GPU (the reference's kt_pipeline keeps 2, rmap.cpp:1033); "
                          "step k runs batch k %% inflight, each on its own context/streams")
     ap.add_argument("--cpu-threads", type=int, default=16)

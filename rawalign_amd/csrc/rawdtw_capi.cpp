@@ -23,9 +23,12 @@ struct rawdtw_ctx {
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
     bool serial_launches = false;
-    int n_side = 1; // side streams actually used (RAWDTW_SIDE_STREAMS, 0..kSide); swept: 1 is best with 2 batches in flight
+    int n_side = 0; // side streams used to fork the launches of one batch (RAWDTW_SIDE_STREAMS, 0..kSide). 0: the
+                    // launches of a batch run in sequence on its one stream and overlap comes from several batches in
+                    // flight on several contexts (swept: best throughput and cleaner per-kernel timings)
     uint32_t lane_hi_max_n = 96;
     int micro_max_n = 8; // shapes with longer side <= this use the micro paths (0: none, 4: micro4 only)
+    bool grp16 = true; // bands of at most 16 offsets: four jobs per wave (else one job per wave)
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
@@ -263,6 +266,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             const uint32_t K = (uint32_t)R + 1;
             if (R <= ctx->lane_max_radius && N <= ctx->lane_max_n) cls = 0;
             else if (R <= kMaxLaneRadiusHi && ctx->lane_hi && N <= ctx->lane_hi_max_n) cls = 1; // any radius 0..8 (the instance covers all)
+            else if (K <= 16 && ctx->grp16) cls = 39; // four jobs per wave (16-lane rows)
             else if (K <= 64u * kMaxWregChunks) {
                 uint32_t chunks = 1, lg = 0;
                 while (64u * chunks < K) { chunks <<= 1; lg++; }
@@ -312,6 +316,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             L.first = p; L.count = 0;
             if (cls == 0) { L.kind = kKindBandLane; L.param = 0; }
             else if (cls == 1) { L.kind = kKindBandLaneHi; L.param = 0; }
+            else if (cls == 39) { L.kind = kKindBandWreg; L.param = -16; }
             else if (cls < 48) { L.kind = kKindBandWreg; L.param = cls == 40 ? 0 : 1 << (cls - 40); }
             else if (cls < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
             else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 56); }
@@ -613,12 +618,14 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
         delete ctx;
         return RAWDTW_ERR_DEVICE;
     }
+    if (const char *e = getenv("RAWDTW_SIDE_STREAMS")) ctx->n_side = std::min(std::max(atoi(e), 0), (int)rawdtw_ctx::kSide);
+    // only the side streams that will be used: HIP maps streams onto a handful of hardware queues, and an
+    // idle stream still takes a slot in that rotation
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < rawdtw_ctx::kSide && ok; k++)
+    for (int k = 0; k < ctx->n_side && ok; k++)
         ok = hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { rawdtw_destroy(ctx); return RAWDTW_ERR_DEVICE; }
-    if (const char *e = getenv("RAWDTW_SIDE_STREAMS")) ctx->n_side = std::min(std::max(atoi(e), 0), (int)rawdtw_ctx::kSide);
     if (const char *e = getenv("RAWDTW_LANE_HI")) ctx->lane_hi = atoi(e) != 0;
     if (const char *e = getenv("RAWDTW_LANE_HI_MAX_N")) ctx->lane_hi_max_n = (uint32_t)std::min(std::max(atoi(e), 8), 200);
     if (const char *e = getenv("RAWDTW_LANE_MAX_R")) {
@@ -661,6 +668,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "grp16")) { ctx->grp16 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }

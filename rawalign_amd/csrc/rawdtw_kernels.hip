@@ -226,8 +226,12 @@ __device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
     const uint32_t N0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);
     const uint32_t M0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);
     float res;
-    if (__all(N == N0 && M == M0)) res = lane_dp<R>(LA, LB, N0, M0);
-    else res = lane_dp<R>(LA, LB, N, M);
+    // records are sorted by (longer side, shorter side): a wave usually shares the longer side (then the
+    // column loop and half of the clipping are scalar) and often the whole shape (then everything is)
+    if (__all(N == N0)) {
+        if (__all(M == M0)) res = lane_dp<R>(LA, LB, N0, M0);
+        else res = lane_dp<R>(LA, LB, N0, M);
+    } else res = lane_dp<R>(LA, LB, N, M);
     if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
     return res;
 }
@@ -305,6 +309,9 @@ __global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restric
     extern __shared__ __attribute__((aligned(16))) float win[];
     const int tid = threadIdx.x;
     const TileDesc td = tiles[blockIdx.x];
+    auto load_job = [&](uint32_t r) { return tjobs[td.job_first + (r < td.n_jobs ? r : td.n_jobs - 1)]; };
+    // the first round's records travel while the spans are staged
+    TileJob tj_next = load_job((uint32_t)tid);
     // stage the spans
     for (uint32_t sidx = 0; sidx < td.n_spans; sidx++) {
         const TileSpan sp = spans[td.span_first + sidx];
@@ -318,7 +325,8 @@ __global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restric
     for (uint32_t rd = 0; rd < rounds; rd++) {
         const uint32_t r = rd * THREADS + tid;
         const bool act = r < td.n_jobs;
-        const TileJob tj = tjobs[td.job_first + (act ? r : td.n_jobs - 1)];
+        const TileJob tj = tj_next;
+        tj_next = load_job(r + THREADS); // next round's records in flight behind this round's DP
         const int kind = act ? (int)tj.R : -1; // the planner stores the dispatch kind in the R byte
         float res = 0.0f;
         if constexpr (MICRO) {
@@ -543,6 +551,129 @@ __device__ __forceinline__ void wreg_body(const DevJob &jb, const int lane, cons
     for (int c = 0; c < C; c++)
         if ((pstar >> 6) == c) res = read_lane(d1[c], pstar & 63);
     if (lane == 0) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Four jobs per wave: the same register-resident scheme as wreg_body<1>, but for bands that fit 16
+// lanes (radius + 1 <= 16) each job takes one 16-lane DPP row, so a wave advances four jobs per
+// instruction instead of one.  Control values (lengths, centre row, remainder) are per-row vector
+// registers; neighbours move with row_shr/row_shl, the fresh operand of each row comes out of a
+// 16-wide per-row chunk through ds_bpermute.  Two buffers, clipped cells written as 1e10 (lane_dp).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_shr1(float v, float fill)
+{
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float row_shl1(float v, float fill)
+{
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+__global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jobs, uint32_t count,
+                                                   const float *__restrict__ ev,
+                                                   const float *__restrict__ ref,
+                                                   float *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int p = lane & 15, rowbase = lane & 48;
+    const uint32_t idx = blockIdx.x * 4u + (uint32_t)(lane >> 4);
+    const bool have = idx < count;
+    const DevJob jb = jobs[have ? idx : count - 1];
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        const uint32_t tn = N; N = M; M = tn;
+    }
+    if (!have) N = 1; // an empty row never enters the column loop
+    const int R = jb.R;
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int SH = P > S ? 0 : 1;
+    const int HP = P / 2;
+    const int iN = (int)N, iM = (int)M;
+    auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
+    auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
+
+    float p1 = (p == HP + SH) ? dist(A[0], B[0]) : kInf, p2 = kInf;
+    float ap = ldA(HP + SH - p), bp = ldB(p - HP - SH);
+    const bool in_sec = p < S, in_prim = (p - SH) >= 0 && (p - SH) < P;
+    const int a0 = HP + SH + 1, b0 = 16 - HP - SH;
+    float acur = ldA(a0 + p), anxt = ldA(a0 + 16 + p);
+    float bcur = ldB(b0 + p), bnxt = ldB(b0 + 16 + p);
+
+    int row = 0;
+    uint32_t rem = 0;
+    bool prev_adv = false;
+    // the wave runs as long as its longest row
+    uint32_t Nmax = (uint32_t)__builtin_amdgcn_readlane((int)N, 0);
+    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 16));
+    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 32));
+    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 48));
+    for (uint32_t col = 1; col < Nmax; col++) {
+        const bool live = col < N;
+        const uint32_t ca = (col - 1) & 15u;
+        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 16 + p); }
+        const float fresh_a = lane_gather(acur, rowbase + (int)ca);
+        bool adv = false;
+        if (live) {
+            rem += M;
+            adv = rem >= N;
+            if (adv) { rem -= N; row++; }
+        }
+        const int cb = (row - 1) & 15;
+        if (adv && cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 16 + p); }
+        const float fresh_b = lane_gather(bcur, rowbase + cb);
+        // shifted views of the two buffers (taken before anything is overwritten)
+        const float p1_up = row_shl1(p1, kInf);   // dp1[p+1]
+        if (adv) {
+            // b-window: every lane takes its right neighbour's value
+            bp = row_shl1(bp, fresh_b);
+            // secondary antidiagonal (dtw.cpp:361-414), in place over p2: cell of lane p is (si - p, sj + p)
+            const int si = (int)col - 1 + HP + SH, sj = row - HP - SH;
+            float left = p1_up, top = p1, tl = p2;
+            if (SH) {
+                if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
+                if (p == S - 1) left = kInf;
+            }
+            const float v = min3f(top, left, tl) + dist(ap, bp);
+            const bool valid = in_sec && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
+            p2 = valid ? v : kInf;
+        }
+        if (live) {
+            // a-window: every lane takes its left neighbour's value
+            ap = row_shr1(ap, fresh_a);
+            // primary antidiagonal (dtw.cpp:416-485): offset o = p - SH, cell (si - p, sj + p)
+            const int si = (int)col + HP + SH, sj = row - HP - SH;
+            const bool valid = in_prim && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
+            const float p2_dn = row_shr1(p2, kInf); // after a secondary: dp1[p-1]; otherwise dp0[p-1]
+            if (adv) {
+                float left = p2;
+                if (!SH && p == P - 1) left = kInf;
+                const float v = min3f(p2_dn, left, p1) + dist(ap, bp);
+                p1 = valid ? v : kInf;
+            } else {
+                float top = row_shr1(p1, kInf), tl = p2_dn;
+                if (p - SH == 0) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
+                const float v = min3f(top, p1, tl) + dist(ap, bp);
+                p2 = p1;
+                p1 = valid ? v : kInf;
+            }
+            prev_adv = adv;
+        }
+    }
+    if (have && p == P / 2 + SH) { // dtw.cpp:506-512
+        float res = p1;
         if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
         out[jb.aux] = res;
     }
@@ -881,6 +1012,9 @@ hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, cons
 {
     if (count == 0) return hipSuccess;
     switch (chunks) {
+    case -16: // four jobs per wave, radius + 1 <= 16
+        hipLaunchKernelGGL(k_band_grp16, dim3((uint32_t)((count + 3) / 4)), dim3(64), 0, s, jobs, (uint32_t)count, ev, ref, out);
+        return hipGetLastError();
     case 0: // merged launch: radius + 1 <= 256, variant chosen per job
         hipLaunchKernelGGL(k_band_wreg_small, dim3((uint32_t)count), dim3(64), 0, s, jobs, ev, ref, out);
         return hipGetLastError();
