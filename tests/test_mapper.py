@@ -39,3 +39,46 @@ def test_device_path_paf_identical_to_oracle_path(oracle):
         a, ra_ = mapper.map_reads(seeds, list(range(40)), mapper.OracleScorer(oracle, ref), opt)
         b, rb_ = mapper.map_reads(seeds, list(range(40)), mapper.DeviceScorer(eng), opt)
         assert ra_ == rb_ and a == b
+
+
+def _abundance_stop(lines, n_seq):
+    """configs[4]-style consumer: feed the mapped reads, in output order, to sequence-until."""
+    from rawalign_amd.mapping import SequenceUntil
+
+    su = SequenceUntil(n_seq=n_seq, tmin_reads=8, ttest_freq=4, tn_samples=3, t_threshold=1.5)
+    for k, l in enumerate(lines):
+        f = l.split("\t")
+        if f[4] in "+-":
+            ref_id = int(f[5][3:])              # "seq<N>"
+            if su.add_mapped_read(ref_id, int(f[10]), k):
+                break
+    return su.stop, su.c_estimations.copy()
+
+
+def test_multi_genome_sequence_until_oracle_path(oracle):
+    """Metagenomic multi-genome index + real-time sequence-until on the CPU leg (plumbing of configs[4])."""
+    ref = synth.make_reference([20000, 35000, 12000], seed=20231005 + 5)
+    seeds = mapper.SyntheticSeeds(ref, 40, seed=11, max_chunks=3)
+    lines, _ = mapper.map_reads(seeds, list(range(40)), mapper.OracleScorer(oracle, ref), ra.MapOpt())
+    stop, est = _abundance_stop(lines, 3)
+    assert stop > 0 and est.sum() > 0
+    # every mapped read landed on the genome and strand it was drawn from
+    for l in lines:
+        f = l.split("\t")
+        if f[4] in "+-":
+            rd = seeds.reads[int(f[0].split("_")[1])]
+            assert int(f[5][3:]) == rd["seq"] and f[4] == ("-" if rd["strand"] else "+")
+
+
+@pytest.mark.gpu
+def test_multi_genome_sequence_until_device_equals_oracle(oracle):
+    ref = synth.make_reference([20000, 35000, 12000], seed=20231005 + 5)
+    seeds = mapper.SyntheticSeeds(ref, 60, seed=12, max_chunks=3)
+    eng = ra.Engine(0)
+    eng.upload_reference(ref.forward, ref.reverse)
+    a, _ = mapper.map_reads(seeds, list(range(60)), mapper.OracleScorer(oracle, ref), ra.MapOpt())
+    b, _ = mapper.map_reads(seeds, list(range(60)), mapper.DeviceScorer(eng), ra.MapOpt())
+    assert a == b
+    sa, ea = _abundance_stop(a, 3)
+    sb, eb = _abundance_stop(b, 3)
+    assert sa == sb and np.array_equal(ea, eb)
