@@ -117,11 +117,32 @@ class OracleScorer:
 
 
 class DeviceScorer:
-    def __init__(self, engine):
+    """Scores a round's chains on the device.
+
+    memoise=True adds the cross-chunk cache of SURVEY.md 8(f-4): the reference re-aligns every surviving
+    chain from scratch in every chunk round (rmap.cpp:516-517), but a sparse part between two anchors that
+    already existed in an earlier round has the same operands (events are append-only, rmap.cpp:554-567) and
+    therefore the same cost.  Only unseen parts are sent to the device (always without exclude_last); the
+    excluded variant is the cached cost minus the last cell's distance, which is exactly what the DTW
+    functions return (dtw.cpp:514-516), so results are bit-identical to scoring everything again."""
+
+    def __init__(self, engine, memoise: bool = False):
         self.engine = engine
         self.offs = {}
+        self.memoise = memoise
+        self.cache = {}       # (read key, seq, strand, t0, q0, t1, q1) -> np.float32 cost without exclusion
+        self.jobs_scored = 0
+        self.jobs_reused = 0
 
-    def score(self, reads, opt: MapOpt):
+    def _offset(self, ch):
+        key = (ch.reference_sequence_index, ch.strand)
+        if key not in self.offs:
+            self.offs[key] = self.engine.reference_offset(*key)
+        return self.offs[key]
+
+    def score(self, reads, opt: MapOpt, read_keys=None):
+        if self.memoise and opt.dtw_border_constraint == 1:
+            return self._score_memoised(reads, opt, read_keys)
         eng = self.engine
         ev_parts, read_base, acc = [], [], 0
         for events, _ in reads:
@@ -131,12 +152,9 @@ class DeviceScorer:
         chain_off, anchor_off, anchors, ref_base, rbase, flat = [0], [0], [], [], [], []
         for ri, (_, chains) in enumerate(reads):
             for ch in chains:
-                key = (ch.reference_sequence_index, ch.strand)
-                if key not in self.offs:
-                    self.offs[key] = eng.reference_offset(*key)
                 anchors.append(np.ascontiguousarray(ch.anchors, ANCHOR_DTYPE))
                 anchor_off.append(anchor_off[-1] + len(ch.anchors))
-                ref_base.append(self.offs[key])
+                ref_base.append(self._offset(ch))
                 rbase.append(read_base[ri])
                 flat.append(ch)
             chain_off.append(len(flat))
@@ -146,6 +164,7 @@ class DeviceScorer:
                             np.concatenate(anchors), np.array(ref_base, np.uint64), np.array(rbase, np.uint32))
         eng.upload_events(cb.events)
         b = Batch(eng, opt, cb)
+        self.jobs_scored += b.info()["n_jobs"]
         b.run()
         score, keep = b.fetch()
         b.close()
@@ -158,6 +177,89 @@ class DeviceScorer:
                     kept.append(flat[c])
             out.append(kept)
         return out
+
+    def _score_memoised(self, reads, opt: MapOpt, read_keys):
+        import ctypes as C
+
+        from .dtw import JOB_DTYPE
+
+        eng, lib = self.engine, self.engine.lib
+        copt = opt.c_struct()
+        banded = opt.dtw_fill_method != 0
+        ev_parts, read_base, acc = [], [], 0
+        for events, _ in reads:
+            ev_parts.append(events)
+            read_base.append(acc)
+            acc += len(events)
+        events_cat = np.concatenate(ev_parts) if ev_parts else np.zeros(0, np.float32)
+        new_jobs, new_keys = [], []
+        plans = []   # per read: list of (chain, [part keys in align order], [exclude flags], [(a_last index, b arrays)])
+        for ri, (events, chains) in enumerate(reads):
+            rk = read_keys[ri] if read_keys is not None else ri
+            per_read = []
+            for ch in chains:
+                a = ch.anchors
+                parts = len(a) - 1
+                keys = []
+                for p in range(parts):
+                    s, e = a[parts - p], a[parts - p - 1]
+                    key = (rk, ch.reference_sequence_index, ch.strand, int(s["target_position"]), int(s["query_position"]),
+                           int(e["target_position"]), int(e["query_position"]))
+                    keys.append(key)
+                    if key not in self.cache:
+                        self.cache[key] = None  # pending
+                        n = int(e["query_position"]) - int(s["query_position"]) + 1
+                        m = int(e["target_position"]) - int(s["target_position"]) + 1
+                        R0 = max(1, int(np.float32(n) * np.float32(opt.dtw_band_radius_frac))) if banded else -1
+                        new_jobs.append((self._offset(ch) + int(s["target_position"]), read_base[ri] + int(s["query_position"]),
+                                         n, m, R0, 0, 0))
+                        new_keys.append(key)
+                    else:
+                        self.jobs_reused += 1
+                per_read.append((ch, keys))
+            plans.append(per_read)
+        if new_jobs:
+            jobs = np.array(new_jobs, dtype=JOB_DTYPE)
+            costs = eng.score_batch(jobs, events_cat)
+            self.jobs_scored += len(jobs)
+            for k, c in zip(new_keys, costs):
+                self.cache[k] = np.float32(c)
+        # compose the per-part costs the reference would have computed and fold them on the host
+        out = []
+        arena_cache = {}
+        for ri, (events, chains) in enumerate(reads):
+            best = np.float32(0.0)
+            kept = []
+            for ch, keys in plans[ri]:
+                a = np.ascontiguousarray(ch.anchors, ANCHOR_DTYPE)
+                parts = len(a) - 1
+                costs = np.zeros(max(parts, 1), np.float32)
+                for p, key in enumerate(keys):
+                    c = self.cache[key]
+                    if p != parts - 1:  # exclude_last_element (rmap.cpp:270): minus the last cell's distance
+                        q1, t1 = key[6], key[5]
+                        akey = (ch.reference_sequence_index, ch.strand)
+                        if akey not in arena_cache:
+                            arena_cache[akey] = self._ref_array(ch)
+                        d = np.float32(abs(np.float32(events[q1]) - np.float32(arena_cache[akey][t1])))
+                        c = np.float32(c - d)
+                    costs[p] = c
+                s = np.float32(lib.rawdtw_chain_replay(C.byref(copt), a.ctypes.data_as(C.c_void_p), len(a),
+                                                        costs.ctypes.data_as(C.c_void_p), C.c_float(float(best))))
+                ch.alignment_score = float(s)
+                if s >= np.float32(opt.dtw_min_score):
+                    if s > best:
+                        best = s
+                    kept.append(ch)
+            out.append(kept)
+        return out
+
+    def _ref_array(self, ch):
+        """Host copy of a strand's signal array (for the one subtraction per excluded part)."""
+        if not hasattr(self, "ref_host"):
+            raise RuntimeError("memoised scoring needs DeviceScorer.ref_host = synth.Reference / index signals")
+        r = self.ref_host
+        return r.forward[ch.reference_sequence_index] if ch.strand == 1 else r.reverse[ch.reference_sequence_index]
 
 
 def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(), e: int = 6):
@@ -199,7 +301,7 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
                                          [c.chaining_score for c in chains])
                 chains = [chains[int(k)] for k in order]
             submission.append((rj.events, chains))
-        kept = scorer.score(submission, opt)
+        kept = scorer.score(submission, opt, read_keys=active) if getattr(scorer, "memoise", False) else scorer.score(submission, opt)
         for r, post in zip(active, kept):
             rj = jobs[r]
             rj.chains = M.gen_primary_chains(post, opt, stop) if post else []

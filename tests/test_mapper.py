@@ -82,3 +82,23 @@ def test_multi_genome_sequence_until_device_equals_oracle(oracle):
     sa, ea = _abundance_stop(a, 3)
     sb, eb = _abundance_stop(b, 3)
     assert sa == sb and np.array_equal(ea, eb)
+
+
+@pytest.mark.gpu
+def test_cross_chunk_memoisation_is_exact_and_saves_work(oracle):
+    """parts already scored in an earlier chunk round are reused; PAF lines unchanged."""
+    ref, seeds = setup(40)
+    eng = ra.Engine(0)
+    eng.upload_reference(ref.forward, ref.reverse)
+    for opt in (ra.MapOpt(), ra.MapOpt(dtw_fill_method=0)):
+        plain = mapper.DeviceScorer(eng)
+        memo = mapper.DeviceScorer(eng, memoise=True)
+        memo.ref_host = ref
+        # a stop rule that never fires: every read goes through all of its chunks, chains grow round by round
+        from rawalign_amd.mapping import StopOpt
+
+        never = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
+        a, ra_ = mapper.map_reads(seeds, list(range(40)), plain, opt, never)
+        b, rb_ = mapper.map_reads(seeds, list(range(40)), memo, opt, never)
+        assert a == b and ra_ == rb_ and ra_ > 1
+        assert memo.jobs_reused > 0 and memo.jobs_scored < plain.jobs_scored
