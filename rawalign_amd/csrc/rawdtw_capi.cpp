@@ -185,8 +185,8 @@ inline uint64_t dir_bytes_for(uint32_t n, uint32_t m, int rpl)
 {
     const uint32_t NX = n > m ? n : m, NY = n > m ? m : n;
     const uint64_t strips = (NY + 64ull * rpl - 1) / (64ull * rpl);
-    const uint64_t word = rpl == 8 ? 2 : 1;
-    return strips * ((uint64_t)NX + 63) * 64 * word;
+    const uint64_t spb = rpl == 8 ? 8 : 16; // steps per 16-byte block (k_full_wave)
+    return strips * (((uint64_t)NX + 63 + spb - 1) / spb) * 64 * 16;
 }
 
 template <typename T> int dev_alloc(rawdtw_ctx *ctx, T **p, uint64_t count)

@@ -728,9 +728,14 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
     const uint32_t NY = swapped ? jb.m : jb.n;
     constexpr uint32_t STRIP = 64u * RPL;
     const uint32_t nstrips = (NY + STRIP - 1) / STRIP;
-    const uint32_t TX = NX + 63; // step stride of one strip in the direction buffer
+    // Direction words are written in blocks of SPB steps: a lane's SPB consecutive words are 16 contiguous
+    // bytes, so a block leaves the wave as one 1-KiB dwordx4 store ([strip][block][lane][step in block]).
+    // Per step the word goes to LDS (2 KiB transposition buffer), per block each lane reads back its 16 bytes.
+    constexpr uint32_t SPB = 16u / sizeof(word_t);
+    const uint32_t TXB = (NX + 63 + SPB - 1) / SPB; // blocks per strip
     float *bnd = bnd_ws + ax.bnd_off;
-    word_t *dirs = reinterpret_cast<word_t *>(dir_ws + ax.dir_off);
+    uint4 *dirs = reinterpret_cast<uint4 *>(dir_ws + ax.dir_off);
+    __shared__ __attribute__((aligned(16))) word_t tbuf[TB ? 64 * SPB : 1];
 
     float result = 0.0f;
     for (uint32_t s = 0; s < nstrips; s++) {
@@ -774,16 +779,24 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
                         // Y rows are a-indices unless swapped.
                         const float rl = swapped ? left : ab; // D[i-1][j]
                         const float rt = swapped ? ab : left; // D[i][j-1]
-                        uint32_t c = 0;
-                        if (rl < __builtin_fminf(rt, d)) c = 1u;
-                        else if (rt < __builtin_fminf(rl, d)) c = 2u;
+                        // dtw.cpp:633-646, branch-free: 1 = i-1 strictly best, 2 = j-1 strictly best, else diagonal
+                        const uint32_t c1 = rl < __builtin_fminf(rt, d) ? 1u : 0u;
+                        const uint32_t c2 = rt < __builtin_fminf(rl, d) ? 2u : 0u;
+                        const uint32_t c = c1 ? 1u : c2;
                         code |= c << (2 * k);
                     }
                     d = left; ab = nv; v[k] = nv;
                 }
                 diag_in = up_in;
                 last_out = v[RPL - 1];
-                if (TB && has_rows) dirs[((uint64_t)s * TX + t) * 64u + lane] = (word_t)code;
+                if (TB) tbuf[lane * SPB + (t % SPB)] = (word_t)code;
+            }
+            if (TB && ((t % SPB) == SPB - 1 || t + 1 == steps)) {
+                // same wave wrote and reads the buffer; LDS operations of a wave complete in order, the
+                // barrier (a single-wave workgroup: no wait) keeps the compiler from reordering across types
+                __syncthreads();
+                const uint4 blk = *reinterpret_cast<const uint4 *>(&tbuf[lane * SPB]);
+                if (has_rows) dirs[((uint64_t)s * TXB + t / SPB) * 64u + lane] = blk;
             }
             if (hands_down && t >= 63u) {
                 // lane 63 finished column c = t-63 in this step; gather 64 of them, store coalesced
@@ -833,7 +846,8 @@ __global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs,
     const float *b = ref + jb.ref_off;
     const bool swapped = jb.n > jb.m;
     const uint32_t NX = swapped ? jb.n : jb.m;
-    const uint64_t TX = (uint64_t)NX + 63u;
+    const uint32_t SPB = rpl == 8 ? 8u : 16u;                 // steps per 16-byte block (k_full_wave)
+    const uint64_t TXB = ((uint64_t)NX + 63u + SPB - 1) / SPB; // blocks per strip
     const uint8_t *d8 = dir_ws + ax.dir_off;
     const uint16_t *d16 = reinterpret_cast<const uint16_t *>(d8);
     const uint64_t po = path_off[g];
@@ -846,7 +860,8 @@ __global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs,
         else {
             const uint32_t y = swapped ? j : i, x = swapped ? i : j;
             const uint32_t s = y / (64u * rpl), l = (y / rpl) & 63u, kk = y % rpl;
-            const uint64_t at = ((uint64_t)s * TX + x + l) * 64u + l;
+            const uint32_t t = x + l;
+            const uint64_t at = (((uint64_t)s * TXB + t / SPB) * 64u + l) * SPB + (t % SPB); // word index
             const uint32_t word = (rpl == 8) ? d16[at] : d8[at];
             const uint32_t code = (word >> (2 * kk)) & 3u;
             if (code == 1u) i--;

@@ -389,3 +389,40 @@ def test_planner_options_do_not_change_results(oracle):
     eng = ra.Engine(0)
     with pytest.raises(ra.RawDTWError):
         eng.set_option("no_such_option", 1)
+
+
+def test_batch_edge_cases(engine, oracle):
+    """Reads without chains, a batch without any chain, and single-anchor chains (no DTW call at all:
+    align_chain returns 0*bonus - 0, which fails dtw_min_score)."""
+    from rawalign_amd.align import CandidateBatch
+
+    rng = np.random.default_rng(2)
+    refsig = rng.normal(size=3000).astype(np.float32)
+    engine.upload_reference([refsig], [refsig[::-1].copy()])
+    events = rng.normal(size=500).astype(np.float32)
+    engine.upload_events(events)
+    base = engine.reference_offset(0, 1)
+    # no chains at all
+    cb0 = CandidateBatch(events, np.zeros(4, np.uint64), np.zeros(1, np.uint64), np.zeros(0, ra.ANCHOR_DTYPE),
+                         np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    b0 = ra.Batch(engine, ra.MapOpt(), cb0)
+    b0.run()
+    s0, k0 = b0.fetch()
+    assert len(s0) == 0 and len(k0) == 0
+    # read 0: nothing; read 1: a single-anchor chain and a real chain; read 2: nothing
+    a1 = np.zeros(1, ra.ANCHOR_DTYPE); a1[0] = (100, 7)
+    q = np.array([5, 12, 30, 31, 60]); t = np.array([200, 206, 221, 223, 250])
+    a2 = np.zeros(5, ra.ANCHOR_DTYPE); a2["query_position"] = q[::-1]; a2["target_position"] = t[::-1]
+    ev2 = events.copy()
+    ev2[5:61] = refsig[200:256]
+    engine.upload_events(ev2)
+    cb = CandidateBatch(ev2, np.array([0, 0, 2, 2], np.uint64), np.array([0, 1, 6], np.uint64),
+                        np.concatenate([a1, a2]), np.array([base, base], np.uint64), np.zeros(2, np.uint32))
+    b = ra.Batch(engine, ra.MapOpt(dtw_min_score=5.0), cb)
+    b.run()
+    score, keep = b.fetch()
+    assert score[0] == 0.0 and keep[0] == 0
+    from oracle.loader import OrcOpt
+
+    want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
+    assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
