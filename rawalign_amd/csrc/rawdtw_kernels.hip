@@ -755,6 +755,7 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
         // virtual row above row 0 is +inf, its corner D[-1][-1] is 0 so that D[0][0] = dist
         float diag_in = (s == 0 && lane == 0) ? 0.0f : kInf;
         float last_out = kInf, xval = 0.0f, xchunk = 0.0f, bchunk = kInf, wchunk = 0.0f;
+        const int sh_up = swapped ? 1 : 0, sh_lf = swapped ? 0 : 1; // bit of the 2-bit code each plane sets
 
         for (uint32_t t = 0; t < steps; t++) {
             if ((t & 63u) == 0) {
@@ -775,15 +776,14 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
                     const float left = v[k];
                     const float nv = min3f(ab, left, d) + dist(xval, yv[k]);
                     if (TB) {
-                        // reference names: left = D[i-1][j], top = D[i][j-1] with i over a, j over b.
-                        // Y rows are a-indices unless swapped.
-                        const float rl = swapped ? left : ab; // D[i-1][j]
-                        const float rt = swapped ? ab : left; // D[i][j-1]
-                        // dtw.cpp:633-646, branch-free: 1 = i-1 strictly best, 2 = j-1 strictly best, else diagonal
-                        const uint32_t c1 = rl < __builtin_fminf(rt, d) ? 1u : 0u;
-                        const uint32_t c2 = rt < __builtin_fminf(rl, d) ? 2u : 0u;
-                        const uint32_t c = c1 ? 1u : c2;
-                        code |= c << (2 * k);
+                        // dtw.cpp:633-646 with left = D[i-1][j], top = D[i][j-1] (i over a, j over b):
+                        //   left < min(top, tl) -> 1 (i-1) ; else top < min(left, tl) -> 2 (j-1) ; else 0.
+                        // In kernel coordinates: up = ab (row-1), lf = left (column-1).  "up strictly best"
+                        // and "lf strictly best" exclude each other, so the code is two bit planes; Y rows
+                        // are a-indices unless swapped, which only decides which plane is bit 0.
+                        const uint32_t c_up = ab < __builtin_fminf(left, d) ? 1u : 0u;
+                        const uint32_t c_lf = left < __builtin_fminf(ab, d) ? 1u : 0u;
+                        code |= (c_up << (2 * k + sh_up)) | (c_lf << (2 * k + sh_lf));
                     }
                     d = left; ab = nv; v[k] = nv;
                 }
