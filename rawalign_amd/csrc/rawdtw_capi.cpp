@@ -29,6 +29,7 @@ struct rawdtw_ctx {
     uint32_t lane_hi_max_n = 96;
     int micro_max_n = 8; // shapes with longer side <= this use the micro paths (0: none, 4: micro4 only)
     bool grp16 = true; // bands of at most 16 offsets: four jobs per wave (else one job per wave)
+    bool full_wg = true; // full-matrix jobs with >= 3 strips: four waves per job, pipelined strips
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
@@ -252,6 +253,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         if (j.band_radius == RAWDTW_FULL) {
             const int rpl = full_rpl(NY);
             cls = 56 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
+            if (rpl == 8 && NY > 2 * 512u && ctx->full_wg) cls = 60; // >= 3 strips: four waves per job
         } else {
             if (traceback) {
                 delete pl;
@@ -299,11 +301,12 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = keyed[p].idx;
         const uint64_t cls = keyed[p].key >> 56;
         if (cls >= 56) {
-            const int rpl = 1 << (cls - 56);
+            const int rpl = cls == 60 ? 8 : 1 << (cls - 56);
+            const uint64_t rows = cls == 60 ? kFullWgWaves : 1; // boundary rows: a ring for the pipelined variant
             const uint32_t NX = std::max(j.n, j.m), NY = std::min(j.n, j.m);
             if (NY > 64u * rpl) { // multi-strip: needs a boundary row
                 pl->h_aux[p].bnd_off = bnd;
-                bnd += ((uint64_t)NX + 63) & ~63ull;
+                bnd += rows * (((uint64_t)NX + 63) & ~63ull);
             }
             if (traceback) {
                 pl->h_aux[p].dir_off = dirb;
@@ -319,7 +322,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
             else if (cls == 39) { L.kind = kKindBandWreg; L.param = -16; }
             else if (cls < 48) { L.kind = kKindBandWreg; L.param = cls == 40 ? 0 : 1 << (cls - 40); }
             else if (cls < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
-            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = 1 << (cls - 56); }
+            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = cls == 60 ? 8 + 256 : 1 << (cls - 56); }
             pl->launches.push_back(L);
         }
         pl->launches.back().count++;
@@ -668,6 +671,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "full_wg")) { ctx->full_wg = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "grp16")) { ctx->grp16 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
@@ -921,7 +925,7 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         st = rawdtw_plan_run(ctx, pl);
         if (st != RAWDTW_OK) { cleanup(); return st; }
         for (const Launch &L : pl->launches) {
-            e = launch_tb_walk(pl->d_jobs + L.first, L.count, pl->d_aux + L.first, L.param, ctx->d_ev, ctx->d_ref,
+            e = launch_tb_walk(pl->d_jobs + L.first, L.count, pl->d_aux + L.first, L.param & 255, ctx->d_ev, ctx->d_ref,
                                pl->d_dir, d_poff + L.first, d_plen + L.first, d_pi, d_pj, d_pd, ctx->stream);
             if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback walk launch"); }
         }

@@ -71,6 +71,7 @@ constexpr uint32_t kTileLdsFloats = 5120;  // 20 KiB -> 8 workgroups per CU (swe
 constexpr uint32_t kTileMaxJobs = 1024;
 constexpr uint32_t kTileHiLdsFloats = 10240, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;
+constexpr int kFullWgWaves = 4;        // waves per job in the pipelined-strip variant of the full-matrix kernel
 constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB
 

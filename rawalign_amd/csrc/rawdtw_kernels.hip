@@ -707,8 +707,14 @@ __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict
 template <int RPL> struct DirWord { using type = uint8_t; };
 template <> struct DirWord<8> { using type = uint16_t; };
 
-template <int RPL, bool TB>
-__global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ jobs,
+// WAVES = 1: one wave per job, strips in sequence.  WAVES = 4 (jobs with several strips): the four waves
+// of a workgroup take strips w, w+4, ... and run them as a pipeline -- strip s+1 trails strip s by at
+// least one 64-column chunk -- so a long job finishes up to four times sooner (a launch of long jobs is
+// bounded by its longest job, not by throughput).  Boundary rows then form a ring of WAVES rows in HBM;
+// a strip publishes how many of its columns are flushed through an LDS progress word (strip index in the
+// high bits, so the word only ever grows) and its successor spins on that word before each chunk load.
+template <int RPL, bool TB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_full_wave(const DevJob *__restrict__ jobs,
                                                   const FullAux *__restrict__ aux,
                                                   const float *__restrict__ ev,
                                                   const float *__restrict__ ref,
@@ -718,7 +724,8 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
     using word_t = typename DirWord<RPL>::type;
     const DevJob jb = jobs[blockIdx.x];
     const FullAux ax = aux[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = threadIdx.x >> 6;
     const float *a = ev + jb.read_off;
     const float *b = ref + jb.ref_off;
     const bool swapped = jb.n > jb.m; // the longer sequence is swept
@@ -733,12 +740,21 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
     // Per step the word goes to LDS (2 KiB transposition buffer), per block each lane reads back its 16 bytes.
     constexpr uint32_t SPB = 16u / sizeof(word_t);
     const uint32_t TXB = (NX + 63 + SPB - 1) / SPB; // blocks per strip
-    float *bnd = bnd_ws + ax.bnd_off;
+    const uint32_t row_stride = (NX + 63u) & ~63u; // floats per boundary row (matches the planner)
+    float *bnd_base = bnd_ws + ax.bnd_off;
     uint4 *dirs = reinterpret_cast<uint4 *>(dir_ws + ax.dir_off);
-    __shared__ __attribute__((aligned(16))) word_t tbuf[TB ? 64 * SPB : 1];
+    __shared__ __attribute__((aligned(16))) word_t tbuf_all[TB ? WAVES * 64 * SPB : 1];
+    word_t *tbuf = tbuf_all + (TB ? wv * 64 * SPB : 0);
+    __shared__ uint32_t progress[WAVES]; // progress[s % WAVES] = (s << 21) | columns of strip s flushed
+    if (WAVES > 1) {
+        if (threadIdx.x < WAVES) progress[threadIdx.x] = 0;
+        __syncthreads();
+    }
 
     float result = 0.0f;
-    for (uint32_t s = 0; s < nstrips; s++) {
+    for (uint32_t s = wv; s < nstrips; s += WAVES) {
+        const float *bnd_in = bnd_base + (uint64_t)((s + WAVES - 1) % WAVES) * row_stride; // written by strip s-1
+        float *bnd = bnd_base + (uint64_t)(s % WAVES) * row_stride;                          // read by strip s+1
         const uint32_t y0 = (s * 64u + lane) * RPL;
         float yv[RPL], v[RPL];
 #pragma unroll
@@ -761,7 +777,16 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
             if ((t & 63u) == 0) {
                 const uint32_t idx = t + lane;
                 xchunk = X[idx < NX ? idx : NX - 1];
-                if (s > 0) bchunk = idx < NX ? bnd[idx] : kInf;
+                if (s > 0) {
+                    if (WAVES > 1) {
+                        // wait until strip s-1 has flushed the columns of this chunk
+                        const uint32_t need = ((s - 1) << 21) | ((t + 64u < NX) ? t + 64u : NX);
+                        while (__hip_atomic_load(&progress[(s - 1) % WAVES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                            __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    bchunk = idx < NX ? bnd_in[idx] : kInf;
+                }
             }
             const float x0 = read_lane(xchunk, (int)(t & 63u));
             const float b0 = read_lane(bchunk, (int)(t & 63u));
@@ -793,8 +818,8 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
             }
             if (TB && ((t % SPB) == SPB - 1 || t + 1 == steps)) {
                 // same wave wrote and reads the buffer; LDS operations of a wave complete in order, the
-                // barrier (a single-wave workgroup: no wait) keeps the compiler from reordering across types
-                __syncthreads();
+                // fence keeps the compiler from reordering the differently typed accesses
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 const uint4 blk = *reinterpret_cast<const uint4 *>(&tbuf[lane * SPB]);
                 if (has_rows) dirs[((uint64_t)s * TXB + t / SPB) * 64u + lane] = blk;
             }
@@ -806,6 +831,12 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
                 if ((c & 63u) == 63u || c == NX - 1) {
                     const uint32_t base = c & ~63u;
                     if (base + lane <= c) bnd[base + lane] = wchunk;
+                    if (WAVES > 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0)
+                            __hip_atomic_store(&progress[s % WAVES], (s << 21) | (c + 1u), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
@@ -820,7 +851,8 @@ __global__ __launch_bounds__(64) void k_full_wave(const DevJob *__restrict__ job
         }
         __threadfence_block();
     }
-    if (lane == 0) {
+    // the wave that ran the last strip owns the result
+    if (lane == 0 && nstrips > 0 && ((nstrips - 1) % WAVES) == wv) {
         if (jb.flags & kFlagExcludeLast) result = result - dist(a[jb.n - 1], b[jb.m - 1]);
         out[jb.aux] = result;
     }
@@ -1048,7 +1080,7 @@ static hipError_t launch_full_t(const DevJob *jobs, uint64_t count, const FullAu
                                 const float *ref, float *out, float *bnd_ws, uint8_t *dir_ws,
                                 hipStream_t s)
 {
-    hipLaunchKernelGGL((k_full_wave<RPL, TB>), dim3((uint32_t)count), dim3(64), 0, s, jobs, aux, ev, ref,
+    hipLaunchKernelGGL((k_full_wave<RPL, TB, 1>), dim3((uint32_t)count), dim3(64), 0, s, jobs, aux, ev, ref,
                        out, bnd_ws, dir_ws);
     return hipGetLastError();
 }
@@ -1067,6 +1099,12 @@ hipError_t launch_full_wave(int rpl, bool tb, const DevJob *jobs, uint64_t count
         RAWDTW_FULL_CASE(2)
         RAWDTW_FULL_CASE(4)
         RAWDTW_FULL_CASE(8)
+    case 8 + 256: // multi-strip jobs: four waves per job (kFullWgWaves)
+        if (tb) hipLaunchKernelGGL((k_full_wave<8, true, kFullWgWaves>), dim3((uint32_t)count), dim3(64 * kFullWgWaves), 0, s,
+                                   jobs, aux, ev, ref, out, bnd_ws, dir_ws);
+        else hipLaunchKernelGGL((k_full_wave<8, false, kFullWgWaves>), dim3((uint32_t)count), dim3(64 * kFullWgWaves), 0, s,
+                                jobs, aux, ev, ref, out, bnd_ws, dir_ws);
+        return hipGetLastError();
     default: return hipErrorInvalidValue;
     }
 #undef RAWDTW_FULL_CASE

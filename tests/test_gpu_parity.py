@@ -100,7 +100,8 @@ def test_random_full(engine, oracle):
     """DTW_global through every rows-per-lane class and across strip boundaries."""
     rng = np.random.default_rng(5)
     shapes = [(1, 1), (2, 2), (1, 50), (50, 1), (63, 64), (64, 65), (65, 64), (128, 200), (129, 300), (256, 256),
-              (257, 256), (511, 700), (512, 512), (513, 514), (700, 520), (1025, 1100), (1600, 1030), (40, 3000)]
+              (257, 256), (511, 700), (512, 512), (513, 514), (700, 520), (1025, 1100), (1600, 1030), (40, 3000),
+              (2100, 2300), (1537, 1536), (3000, 2049), (1025, 5000)]  # the last four: >= 3 strips, four waves per job
     cases = []
     for n, m in shapes:
         for ex in (0, 1):
@@ -115,7 +116,7 @@ def test_random_full(engine, oracle):
 def test_random_traceback(engine, oracle):
     rng = np.random.default_rng(6)
     shapes = [(1, 1), (1, 7), (7, 1), (2, 2), (30, 20), (64, 64), (65, 100), (130, 129), (260, 300), (513, 600),
-              (600, 513), (900, 1100)]
+              (600, 513), (900, 1100), (1500, 1300), (1100, 2600)]
     cases = [(rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), -1, k & 1)
              for k, (n, m) in enumerate(shapes)]
     jobs, ev, rf = make_arena_jobs(cases)
@@ -378,6 +379,7 @@ def test_planner_options_do_not_change_results(oracle):
         {"lane_max_radius": 1, "lane_hi": 1, "lane_hi_max_n": 40, "serial_launches": 1},
         {"tile_lds_floats": 30000, "tile_max_jobs": 4096},
         {"grp16": 0},
+        {"full_wg": 0},
         {"lane_max_radius": 0, "lane_max_n": 8, "grp16": 1},
     ]
     for st in settings:
