@@ -62,9 +62,12 @@ int rawdtw_destroy(rawdtw_ctx *ctx);
 const char *rawdtw_last_error(const rawdtw_ctx *ctx);
 const char *rawdtw_status_string(int status);
 int rawdtw_sync(rawdtw_ctx *ctx);
-/* tuning knobs: "serial_launches" (0/1: run a batch's launches one after another on the main
- * stream instead of concurrently -- for per-kernel timing), "lane_max_radius" (0..8: largest
- * post-slant band radius handled by the lane-per-job kernel) */
+/* tuning knobs (results never depend on them; tests/test_gpu_parity.py checks that):
+ *   "plan_threads"    host threads of the batch planner (0 = from the job count and the machine, <= 16)
+ *   "serial_launches" 0/1: with side streams, run a batch's launches in sequence anyway
+ *   "lane_max_radius" 0..3: largest post-slant radius on the tile kernel; "lane_max_n": longest side there
+ *   "lane_hi", "lane_hi_max_n": optional second tile instance for radii up to 8
+ *   "micro_max_n" 0/4/8, "grp16" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs": kernel selection */
 int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);
 /* the ctx's hipStream_t, as void* (for event timing on the stream kernels run on) */
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream);
@@ -122,6 +125,19 @@ typedef struct {
 int rawdtw_plan_create(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs,
                        rawdtw_plan **out);
 int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info);
+/* Host half of rawdtw_plan_create only -- no device is touched and nothing is scored.  Bins the
+ * jobs against arenas of n_events / n_reference floats with `threads` planner threads and the
+ * given planner options (names as for rawdtw_set_option), then checks every invariant the
+ * kernels rely on (each job planned exactly once, launches partition the plan, every tile's
+ * windows staged inside its LDS budget at the right place).  Returns the status plan_create
+ * would return; `message` (optional) receives the reason of a failure.  The extra option
+ * "verify" = 0 skips the self-check and the cell count (to time the planner alone).  For
+ * host-side tests and for sizing a batch before a device is attached. */
+int rawdtw_plan_dry_run(uint64_t n_events, uint64_t n_reference, const rawdtw_job_t *jobs,
+                        uint64_t n_jobs, int threads, const char *const *option_names,
+                        const int64_t *option_values, uint32_t n_options,
+                        rawdtw_plan_info_t *info, uint64_t *n_tiles, char *message,
+                        uint32_t message_cap);
 int rawdtw_plan_run(rawdtw_ctx *ctx, rawdtw_plan *plan);
 int rawdtw_plan_fetch(rawdtw_ctx *ctx, rawdtw_plan *plan, float *out_cost);
 /* device pointer to the costs (job order) and the host array mapping launch order -> job index */

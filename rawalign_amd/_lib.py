@@ -117,6 +117,7 @@ SYMBOLS = {
     "rawdtw_score_batch": (I32, [VP, VP, U64, VP, U64, VP]),
     "rawdtw_plan_create": (I32, [VP, VP, U64, C.POINTER(VP)]),
     "rawdtw_plan_info": (I32, [VP, C.POINTER(PlanInfo)]),
+    "rawdtw_plan_dry_run": (I32, [U64, U64, VP, U64, C.c_int, VP, VP, U32, C.POINTER(PlanInfo), C.POINTER(U64), VP, U32]),
     "rawdtw_plan_run": (I32, [VP, VP]),
     "rawdtw_plan_fetch": (I32, [VP, VP, VP]),
     "rawdtw_plan_device_costs": (I32, [VP, C.POINTER(VP), C.POINTER(VP)]),

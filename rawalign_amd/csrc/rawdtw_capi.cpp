@@ -4,16 +4,44 @@
 // There is NO CPU fallback in here: every scoring entry point runs the HIP kernels or
 // returns an error status.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rawdtw_internal.h"
 
 using namespace rawdtw;
+
+// Array of trivially-copyable records whose resize leaves the elements uninitialised: the planner's
+// large outputs are written once, in parallel, and a value-initialising resize would first sweep them
+// on one thread (page faults included).
+template <typename T> struct RawVec {
+    T *p = nullptr;
+    size_t n = 0;
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    void resize(size_t count)
+    {
+        free(p);
+        p = count ? static_cast<T *>(malloc(count * sizeof(T))) : nullptr;
+        if (count && !p) { n = 0; throw std::bad_alloc(); }
+        n = count;
+    }
+    size_t size() const { return n; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+};
 
 struct rawdtw_ctx {
     int device = 0;
@@ -33,6 +61,7 @@ struct rawdtw_ctx {
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
+    int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
     int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
     // reference arena
     float *d_ref = nullptr;
@@ -50,7 +79,7 @@ struct rawdtw_ctx {
 struct rawdtw_plan {
     rawdtw_ctx *ctx = nullptr;
     uint64_t n_jobs = 0;
-    std::vector<uint32_t> order;   // plan position -> job index
+    RawVec<uint32_t> order;        // plan position -> job index
     std::vector<Launch> launches;
     std::vector<uint32_t> run_order; // launch indices, heaviest first
     std::vector<int32_t> launch_rpl;
@@ -67,10 +96,11 @@ struct rawdtw_plan {
     float *d_bnd = nullptr;
     uint8_t *d_dir = nullptr;
     uint64_t bnd_floats = 0, dir_bytes = 0;
-    std::vector<DevJob> h_jobs;    // plan order (kept for traceback + info)
-    std::vector<FullAux> h_aux;
+    RawVec<DevJob> h_jobs;         // plan order (kept for traceback + info)
+    std::vector<FullAux> h_aux;    // of the non-tile jobs: index = plan position - n_tile_jobs
     rawdtw_plan_info_t info{};
     bool cells_counted = false;
+    int plan_threads_used = 1;
 };
 
 struct rawdtw_index {
@@ -212,229 +242,374 @@ int ensure_events_capacity(rawdtw_ctx *ctx, uint64_t n)
     return RAWDTW_OK;
 }
 
-// Build a plan. traceback=true: every job must be a full-matrix job and gets a direction buffer.
-int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool traceback,
-               rawdtw_plan **out)
-{
-    *out = nullptr;
-    if (!ctx) return RAWDTW_ERR_INVALID;
-    if (n_jobs > 0 && !jobs) return fail(ctx, RAWDTW_ERR_INVALID, "jobs is NULL");
-    if (n_jobs >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "more than 2^32-1 jobs in one batch");
-    rawdtw_plan *pl = new (std::nothrow) rawdtw_plan;
-    if (!pl) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
-    pl->ctx = ctx;
-    pl->n_jobs = n_jobs;
+// ---- planner ---------------------------------------------------------------------------------
+// Everything up to the device upload is host work on plain arrays (plan_host), so that it can be
+// checked without a GPU (rawdtw_plan_dry_run) and spread over threads: at the bench's 5 M jobs per
+// mini-batch a one-thread planner costs a thousand times the kernels it feeds.
 
-    // sort key: class in the top bits, then descending length so long jobs start first
-    //   banded tile (lane DP): class = 0, kept in JOB order (R in 0..lane_max_radius, longer side <= 73)
-    //   banded wave, register: class = 40 + log2(chunks)      (radius+1 <= 64*chunks, chunks <= 32)
-    //   banded wave, LDS     : class = 48 + lds bucket
-    //   full                 : class = 56 + log2(rpl)
-    // inside a class: longer side descending, then shorter side descending (waves share one shape)
-    struct Keyed { uint64_t key; uint32_t idx; int32_t R; };
-    std::vector<Keyed> keyed(n_jobs);
-    uint64_t alg_bytes = 0;
-    for (uint64_t k = 0; k < n_jobs; k++) {
-        const rawdtw_job_t &j = jobs[k];
-        if (j.n == 0 || j.m == 0 || j.band_radius < RAWDTW_FULL ||
-            j.n >= 0x7fffffffu || j.m >= 0x7fffffffu) {
-            delete pl;
-            return fail(ctx, RAWDTW_ERR_INVALID,
-                        "job " + std::to_string(k) + ": zero length or negative band radius (dtw.cpp:274-277 asserts)");
+struct PlanCfg {
+    uint64_t n_ev = 0, n_ref = 0;
+    int lane_max_radius = kMaxLaneRadius;
+    uint32_t lane_max_n = kLaneMaxN, lane_hi_max_n = 96;
+    bool lane_hi = false, grp16 = true, full_wg = true;
+    int micro_max_n = 8;
+    uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
+    int threads = 0; // 0: pick from the job count and the machine
+};
+
+// tile records built on the host (uploaded by build_plan)
+struct HostTiles {
+    std::vector<TileDesc> tiles;
+    std::vector<TileSpan> spans;
+    RawVec<TileJob> tjobs;
+    std::vector<unsigned long long> masks;
+};
+
+PlanCfg cfg_of(const rawdtw_ctx *ctx)
+{
+    PlanCfg c;
+    c.n_ev = ctx->n_ev; c.n_ref = ctx->n_ref;
+    c.lane_max_radius = ctx->lane_max_radius; c.lane_max_n = ctx->lane_max_n; c.lane_hi_max_n = ctx->lane_hi_max_n;
+    c.lane_hi = ctx->lane_hi; c.grp16 = ctx->grp16; c.full_wg = ctx->full_wg; c.micro_max_n = ctx->micro_max_n;
+    c.tile_lds_floats = ctx->tile_lds_floats; c.tile_max_jobs = ctx->tile_max_jobs; c.threads = ctx->plan_threads;
+    return c;
+}
+
+// run fn(t) for t in [0, T) on T threads (the caller's thread takes t = 0)
+template <typename F> void parallel_for(int T, F fn)
+{
+    if (T <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto &x : th) x.join();
+}
+
+// band masks of every micro shape: index ((N-1)*8 + (M-1)) * (kMaxLaneRadius+1) + R, N >= M
+const std::vector<unsigned long long> &micro_masks()
+{
+    static const std::vector<unsigned long long> table = [] {
+        std::vector<unsigned long long> t(8 * 8 * (kMaxLaneRadius + 1), 0ull);
+        for (uint32_t N = 1; N <= 8; N++)
+            for (uint32_t M = 1; M <= N; M++)
+                for (int R = 0; R <= kMaxLaneRadius; R++)
+                    t[((N - 1) * 8 + (M - 1)) * (kMaxLaneRadius + 1) + R] = band_mask8(N, M, R);
+        return t;
+    }();
+    return table;
+}
+
+// Tiles for plan positions [p0, p1) of the tile class `hi` (consecutive jobs in job order).  Appends
+// to tiles/spans (span_first relative to `spans`), fills tjobs[p] in place; returns the largest LDS image.
+uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, uint64_t p0, uint64_t p1,
+                     std::vector<TileDesc> &tiles, std::vector<TileSpan> &spans, TileJob *tjobs)
+{
+    const uint32_t lds_budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
+    const uint32_t max_jobs = hi ? kTileHiMaxJobs : cfg.tile_max_jobs;
+    uint32_t tile_lds_max = 0;
+    struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
+    std::vector<Sp> cur;
+    struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
+    std::vector<Pend> pend;
+    std::vector<uint32_t> ia, ib;
+    std::vector<TileJob> tmp;
+    uint64_t t_first = p0;
+    uint32_t lds_used = 0;
+    auto span_cost = [](const Sp &s) { return (uint32_t)(((s.end - s.start) + 3) & ~3ull); };
+    auto close_tile = [&](uint64_t t_end) {
+        if (t_end == t_first) return;
+        uint32_t off = 0;
+        const uint32_t span_first = (uint32_t)spans.size();
+        for (Sp &s : cur) {
+            s.lds = off;
+            const uint32_t len4 = span_cost(s);
+            spans.push_back(TileSpan{s.start, off, (len4 / 4) | (s.is_ref ? 0x80000000u : 0u)});
+            off += len4;
         }
-        if ((uint64_t)j.read_off + j.n > ctx->n_ev || j.ref_off + j.m > ctx->n_ref) {
-            delete pl;
-            return fail(ctx, RAWDTW_ERR_RANGE, "job " + std::to_string(k) + ": window outside the uploaded arenas");
+        tile_lds_max = std::max(tile_lds_max, off);
+        for (uint64_t p = t_first; p < t_end; p++) {
+            const Pend &pe = pend[p - t_first];
+            TileJob &tj = tjobs[p];
+            tj.offA = (uint16_t)(cur[pe.spA].lds + (pe.a0 - cur[pe.spA].start));
+            tj.offB = (uint16_t)(cur[pe.spB].lds + (pe.b0 - cur[pe.spB].start));
         }
-        alg_bytes += 4ull * ((uint64_t)j.n + j.m) + 4 + 32;
-        const uint32_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m);
-        uint64_t cls;
-        int32_t R = -1;
-        if (j.band_radius == RAWDTW_FULL) {
-            const int rpl = full_rpl(NY);
-            cls = 56 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
-            if (rpl == 8 && NY > 2 * 512u && ctx->full_wg) cls = 60; // >= 3 strips: four waves per job
-        } else {
-            if (traceback) {
-                delete pl;
-                return fail(ctx, RAWDTW_ERR_UNSUPPORTED,
-                            "traceback of a banded job is not implemented (rmap.cpp:223-225 assert(false))");
+        // order the tile's records by (dispatch kind, longer side desc, shorter side desc, job): waves get one
+        // shape.  Stable LSD radix sort over the three bytes (the records start in job order).
+        const uint32_t cnt = (uint32_t)(t_end - t_first);
+        tmp.assign(tjobs + t_first, tjobs + t_end);
+        ia.resize(cnt); ib.resize(cnt);
+        for (uint32_t q = 0; q < cnt; q++) ia[q] = q;
+        for (int pass = 0; pass < 3; pass++) {
+            uint32_t count[257] = {0};
+            auto digit = [&](uint32_t q) -> uint32_t {
+                const TileJob &x = tmp[q];
+                return pass == 0 ? 255u - x.M : pass == 1 ? 255u - x.N : x.R;
+            };
+            for (uint32_t q = 0; q < cnt; q++) count[digit(ia[q]) + 1]++;
+            for (int b = 0; b < 256; b++) count[b + 1] += count[b];
+            for (uint32_t q = 0; q < cnt; q++) ib[count[digit(ia[q])]++] = ia[q];
+            ia.swap(ib);
+        }
+        for (uint32_t q = 0; q < cnt; q++) tjobs[t_first + q] = tmp[ia[q]];
+        tiles.push_back(TileDesc{(uint32_t)t_first, (uint32_t)(t_end - t_first), span_first, (uint32_t)cur.size()});
+        cur.clear(); pend.clear(); lds_used = 0; t_first = t_end;
+    };
+    // find the span that holds (or can be grown to hold) window [w0, w0+len) of the given arena; -1: a new one
+    auto place = [&](uint64_t w0, uint32_t len, bool is_ref, uint32_t &extra) -> int {
+        extra = 0;
+        for (int q = (int)cur.size() - 1; q >= 0 && q >= (int)cur.size() - 8; q--) {
+            Sp &s = cur[q];
+            if (s.is_ref != is_ref || w0 < s.start || w0 > s.end) continue;
+            if (w0 + len <= s.end) return q; // already covered
+            const uint32_t before = span_cost(s);
+            Sp grown = s; grown.end = w0 + len;
+            extra = span_cost(grown) - before;
+            return q; // caller extends after the budget check
+        }
+        extra = (uint32_t)((((w0 & 3ull) + len) + 3) & ~3ull);
+        return -1;
+    };
+    for (uint64_t p = p0; p < p1; p++) {
+        const DevJob &d = h_jobs[p];
+        const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
+        const uint64_t a0 = swap ? d.ref_off : d.read_off, b0 = swap ? d.read_off : d.ref_off;
+        const uint32_t NA = swap ? d.m : d.n, NB = swap ? d.n : d.m;
+        const bool a_ref = swap, b_ref = !swap;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            uint32_t ea = 0, eb = 0;
+            int qa = place(a0, NA, a_ref, ea);
+            int qb = place(b0, NB, b_ref, eb); // a fresh span for A cannot serve B: other arena
+            const uint32_t new_spans = (qa < 0) + (qb < 0);
+            if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > kTileMaxSpans ||
+                                 p - t_first >= max_jobs)) {
+                close_tile(p);
+                continue; // retry in the fresh tile
             }
-            R = slanted_radius(j.n, j.m, j.band_radius);
-            if (R < 0 || R + 1 > kMaxWaveBandK) {
-                delete pl;
-                return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
-            }
-            const uint32_t K = (uint32_t)R + 1;
-            if (R <= ctx->lane_max_radius && N <= ctx->lane_max_n) cls = 0;
-            else if (R <= kMaxLaneRadiusHi && ctx->lane_hi && N <= ctx->lane_hi_max_n) cls = 1; // any radius 0..8 (the instance covers all)
-            else if (K <= 16 && ctx->grp16) cls = 39; // four jobs per wave (16-lane rows)
-            else if (K <= 64u * kMaxWregChunks) {
-                uint32_t chunks = 1, lg = 0;
-                while (64u * chunks < K) { chunks <<= 1; lg++; }
-                cls = chunks <= 4 ? 40 : 40 + lg; // one merged launch for radius+1 <= 256 (param 0)
+            if (qa < 0) { cur.push_back(Sp{a0 & ~3ull, a0 + NA, a_ref, 0}); qa = (int)cur.size() - 1; }
+            else cur[qa].end = std::max(cur[qa].end, a0 + NA);
+            if (qb < 0) { cur.push_back(Sp{b0 & ~3ull, b0 + NB, b_ref, 0}); qb = (int)cur.size() - 1; }
+            else cur[qb].end = std::max(cur[qb].end, b0 + NB);
+            lds_used += ea + eb;
+            pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
+            TileJob &tj = tjobs[p];
+            tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
+            tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
+            if (!hi && NA <= (uint32_t)cfg.micro_max_n) { // micro path: band membership from a per-shape bitmask
+                tj.pad = ((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + (uint32_t)d.R;
+                tj.R = NA <= 4 ? 0 : 1;
             } else {
-                cls = 48 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
+                tj.R = (uint8_t)(2 + d.R);
+            }
+            break;
+        }
+    }
+    close_tile(p1);
+    return tile_lds_max;
+}
+
+// Host half of plan creation.  traceback=true: every job must be a full-matrix job and gets a direction buffer.
+// Sort key of the jobs outside the tile kernel: class in the top bits, then descending length so long jobs start first
+//   banded tile (lane DP): class 0 (and 1 for the optional wide instance), kept in JOB order
+//   banded 16-lane rows  : class 39
+//   banded wave, register: class 40 (<= 4 chunks, merged) / 40 + log2(chunks)      (radius+1 <= 64*chunks, chunks <= 32)
+//   banded wave, LDS     : class 48 + lds bucket
+//   full                 : class 56 + log2(rpl), 60 = four waves per job
+int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, bool traceback, rawdtw_plan *pl,
+              HostTiles &ht, std::string &err)
+{
+    pl->n_jobs = n_jobs;
+    int T = cfg.threads;
+    if (T <= 0) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        T = (int)std::min<uint64_t>(std::min<unsigned>(hc ? hc : 1, 16), n_jobs / 32768 + 1);
+    }
+    T = std::max(1, std::min(T, 64));
+    auto seg = [&](int t, uint64_t n) { return n * (uint64_t)t / (uint64_t)T; };
+    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = now();
+        fprintf(stderr, "[plan] %-10s %8.2f ms (T=%d)\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count(), T);
+        t_prev = t;
+    };
+
+    // ---- pass A: validate + classify -----------------------------------------------------------
+    RawVec<uint8_t> cls;
+    RawVec<int32_t> Rv;
+    cls.resize(n_jobs);
+    Rv.resize(n_jobs);
+    struct PerThread {
+        uint64_t n0 = 0, n1 = 0, nother = 0, alg_bytes = 0;
+        uint64_t bad = ~0ull; int bad_status = RAWDTW_OK; const char *bad_msg = nullptr;
+        double work0 = 0, work1 = 0;
+        char pad[64];
+    };
+    std::vector<PerThread> pt(T);
+    parallel_for(T, [&](int t) {
+        PerThread &P = pt[t];
+        for (uint64_t k = seg(t, n_jobs); k < seg(t + 1, n_jobs); k++) {
+            const rawdtw_job_t &j = jobs[k];
+            auto bad = [&](int status, const char *msg) { if (P.bad == ~0ull) { P.bad = k; P.bad_status = status; P.bad_msg = msg; } };
+            if (j.n == 0 || j.m == 0 || j.band_radius < RAWDTW_FULL || j.n >= 0x7fffffffu || j.m >= 0x7fffffffu) {
+                bad(RAWDTW_ERR_INVALID, "zero length or negative band radius (dtw.cpp:274-277 asserts)");
+                continue;
+            }
+            if ((uint64_t)j.read_off + j.n > cfg.n_ev || j.ref_off + j.m > cfg.n_ref) {
+                bad(RAWDTW_ERR_RANGE, "window outside the uploaded arenas");
+                continue;
+            }
+            P.alg_bytes += 4ull * ((uint64_t)j.n + j.m) + 4 + 32;
+            const uint32_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m);
+            uint32_t c;
+            int32_t R = -1;
+            if (j.band_radius == RAWDTW_FULL) {
+                const int rpl = full_rpl(NY);
+                c = 56 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
+                if (rpl == 8 && NY > 2 * 512u && cfg.full_wg) c = 60; // >= 3 strips: four waves per job
+            } else {
+                if (traceback) {
+                    bad(RAWDTW_ERR_UNSUPPORTED, "traceback of a banded job is not implemented (rmap.cpp:223-225 assert(false))");
+                    continue;
+                }
+                R = slanted_radius(j.n, j.m, j.band_radius);
+                if (R < 0 || R + 1 > kMaxWaveBandK) {
+                    bad(RAWDTW_ERR_UNSUPPORTED, "band radius too large for the LDS-resident band kernel");
+                    continue;
+                }
+                const uint32_t K = (uint32_t)R + 1;
+                if (R <= cfg.lane_max_radius && N <= cfg.lane_max_n) c = 0;
+                else if (R <= kMaxLaneRadiusHi && cfg.lane_hi && N <= cfg.lane_hi_max_n) c = 1; // the wide instance covers radii 0..8
+                else if (K <= 16 && cfg.grp16) c = 39; // four jobs per wave (16-lane rows)
+                else if (K <= 64u * kMaxWregChunks) {
+                    uint32_t chunks = 1, lg = 0;
+                    while (64u * chunks < K) { chunks <<= 1; lg++; }
+                    c = chunks <= 4 ? 40 : 40 + lg; // one merged launch for radius+1 <= 256 (param 0)
+                } else {
+                    c = 48 + (K <= 8192 ? 0 : 1); // LDS buckets: 3K floats
+                }
+            }
+            cls[k] = (uint8_t)c;
+            Rv[k] = R;
+            if (c == 0) { P.n0++; P.work0 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
+            else if (c == 1) { P.n1++; P.work1 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
+            else P.nother++;
+        }
+    });
+    lap("classify");
+    {   // first offending job, as the one-thread planner would report it
+        uint64_t bad = ~0ull; int t_bad = -1;
+        for (int t = 0; t < T; t++) if (pt[t].bad < bad) { bad = pt[t].bad; t_bad = t; }
+        if (t_bad >= 0) {
+            err = "job " + std::to_string(bad) + ": " + pt[t_bad].bad_msg;
+            return pt[t_bad].bad_status;
+        }
+    }
+    uint64_t n0 = 0, n1 = 0, nother = 0, alg_bytes = 0;
+    double work0 = 0, work1 = 0;
+    std::vector<uint64_t> base0(T), base1(T), baseo(T);
+    for (int t = 0; t < T; t++) {
+        base0[t] = n0; base1[t] = n1; baseo[t] = nother;
+        n0 += pt[t].n0; n1 += pt[t].n1; nother += pt[t].nother; alg_bytes += pt[t].alg_bytes;
+        work0 += pt[t].work0; work1 += pt[t].work1;
+    }
+    pl->n_tile_jobs = n0 + n1;
+
+    // ---- pass B: plan positions.  Tile classes keep job order; the rest is sorted by (class, shape) ----
+    struct Keyed { uint64_t key; uint32_t idx; };
+    std::vector<Keyed> keyed(nother);
+    pl->order.resize(n_jobs);
+    pl->h_jobs.resize(n_jobs);
+    auto put = [&](uint64_t p, uint64_t k) {
+        const rawdtw_job_t &j = jobs[k];
+        pl->order[p] = (uint32_t)k;
+        DevJob &d = pl->h_jobs[p];
+        d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
+        d.R = Rv[k]; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = (uint32_t)k;
+    };
+    parallel_for(T, [&](int t) {
+        uint64_t q0 = base0[t], q1 = n0 + base1[t], qo = baseo[t];
+        for (uint64_t k = seg(t, n_jobs); k < seg(t + 1, n_jobs); k++) {
+            const uint32_t c = cls[k];
+            if (c == 0) put(q0++, k);
+            else if (c == 1) put(q1++, k);
+            else {
+                const rawdtw_job_t &j = jobs[k];
+                const uint64_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m), lim = (1ull << 28) - 1;
+                keyed[qo++] = Keyed{((uint64_t)c << 56) | ((lim - std::min(N, lim)) << 28) | (lim - std::min(NY, lim)), (uint32_t)k};
             }
         }
-        if (cls <= 1) keyed[k].key = (cls << 56) | k; // tile jobs stay in job order: consecutive parts share their spans
-        else {
-            const uint64_t lim = (1ull << 28) - 1;
-            keyed[k].key = (cls << 56) | ((lim - std::min<uint64_t>(N, lim)) << 28) | (lim - std::min<uint64_t>(NY, lim));
-        }
-        keyed[k].idx = (uint32_t)k;
-        keyed[k].R = R;
-    }
+    });
+    lap("scatter");
     std::sort(keyed.begin(), keyed.end(), [](const Keyed &x, const Keyed &y) {
         return x.key != y.key ? x.key < y.key : x.idx < y.idx;
     });
+    for (uint64_t q = 0; q < nother; q++) put(pl->n_tile_jobs + q, keyed[q].idx);
+    lap("sort-rest");
 
-    pl->order.resize(n_jobs);
-    pl->h_jobs.resize(n_jobs);
-    pl->h_aux.assign(n_jobs, FullAux{0, 0});
+    // ---- launches: the two tile classes, then maximal runs of equal class; workspace of the full-matrix jobs ----
+    pl->h_aux.assign(nother, FullAux{0, 0}); // indexed like d_jobs: plan position - n_tile_jobs
+    if (n0) pl->launches.push_back(Launch{kKindBandLane, 0, 0, n0});
+    if (n1) pl->launches.push_back(Launch{kKindBandLaneHi, 0, n0, n1});
     uint64_t bnd = 0, dirb = 0;
-    for (uint64_t p = 0; p < n_jobs; p++) {
-        const rawdtw_job_t &j = jobs[keyed[p].idx];
-        pl->order[p] = keyed[p].idx;
-        DevJob &d = pl->h_jobs[p];
-        d.ref_off = j.ref_off; d.read_off = j.read_off; d.n = j.n; d.m = j.m;
-        d.R = keyed[p].R; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = keyed[p].idx;
-        const uint64_t cls = keyed[p].key >> 56;
-        if (cls >= 56) {
-            const int rpl = cls == 60 ? 8 : 1 << (cls - 56);
-            const uint64_t rows = cls == 60 ? kFullWgWaves : 1; // boundary rows: a ring for the pipelined variant
+    for (uint64_t q = 0; q < nother; q++) {
+        const uint64_t p = pl->n_tile_jobs + q;
+        const uint64_t c = keyed[q].key >> 56;
+        const DevJob &j = pl->h_jobs[p];
+        if (c >= 56) {
+            const int rpl = c == 60 ? 8 : 1 << (c - 56);
+            const uint64_t rows = c == 60 ? kFullWgWaves : 1; // boundary rows: a ring for the pipelined variant
             const uint32_t NX = std::max(j.n, j.m), NY = std::min(j.n, j.m);
             if (NY > 64u * rpl) { // multi-strip: needs a boundary row
-                pl->h_aux[p].bnd_off = bnd;
+                pl->h_aux[q].bnd_off = bnd;
                 bnd += rows * (((uint64_t)NX + 63) & ~63ull);
             }
             if (traceback) {
-                pl->h_aux[p].dir_off = dirb;
+                pl->h_aux[q].dir_off = dirb;
                 dirb += (dir_bytes_for(j.n, j.m, rpl) + 255) & ~255ull;
             }
         }
-        // launches: maximal runs of equal class
-        if (pl->launches.empty() || (keyed[p - 1].key >> 56) != cls) {
+        if (q == 0 || (keyed[q - 1].key >> 56) != c) {
             Launch L{};
             L.first = p; L.count = 0;
-            if (cls == 0) { L.kind = kKindBandLane; L.param = 0; }
-            else if (cls == 1) { L.kind = kKindBandLaneHi; L.param = 0; }
-            else if (cls == 39) { L.kind = kKindBandWreg; L.param = -16; }
-            else if (cls < 48) { L.kind = kKindBandWreg; L.param = cls == 40 ? 0 : 1 << (cls - 40); }
-            else if (cls < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
-            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = cls == 60 ? 8 + 256 : 1 << (cls - 56); }
+            if (c == 39) { L.kind = kKindBandWreg; L.param = -16; }
+            else if (c < 48) { L.kind = kKindBandWreg; L.param = c == 40 ? 0 : 1 << (c - 40); }
+            else if (c < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
+            else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = c == 60 ? 8 + 256 : 1 << (c - 56); }
             pl->launches.push_back(L);
         }
         pl->launches.back().count++;
     }
-    // ---- tiles for the lane-eligible jobs (plan positions [0, n_tile_jobs), job order) ----
-    std::vector<TileDesc> tiles;
-    std::vector<TileSpan> spans;
-    std::vector<TileJob> tjobs;
-    std::vector<unsigned long long> masks;
-    std::vector<int32_t> mask_index(8 * 8 * (kMaxLaneRadius + 1), -1); // (N-1, M-1, R) -> index into masks
-    uint32_t tile_lds_max = 0;
-    for (const Launch &TL : pl->launches) if (TL.kind == kKindBandLane || TL.kind == kKindBandLaneHi) pl->n_tile_jobs += TL.count;
-    tjobs.resize(pl->n_tile_jobs);
+
+    // ---- tiles: each thread tiles a contiguous run of the job-ordered positions (a tile never spans two runs) ----
+    ht.tjobs.resize(pl->n_tile_jobs);
+    if (n0 && cfg.micro_max_n > 0) ht.masks = micro_masks();
     for (Launch &TL : pl->launches) {
         if (TL.kind != kKindBandLane && TL.kind != kKindBandLaneHi) continue;
         const bool hi = TL.kind == kKindBandLaneHi;
-        const uint64_t p0 = TL.first, nt = TL.first + TL.count;
-        const uint32_t lds_budget = hi ? kTileHiLdsFloats : ctx->tile_lds_floats;
-        const uint32_t max_jobs = hi ? kTileHiMaxJobs : ctx->tile_max_jobs;
-        const size_t tiles_before = tiles.size();
-        tile_lds_max = 0;
-        struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
-        std::vector<Sp> cur;
-        struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
-        std::vector<Pend> pend;
-        uint64_t t_first = p0;
-        uint32_t lds_used = 0;
-        auto span_cost = [](const Sp &s) { return (uint32_t)(((s.end - s.start) + 3) & ~3ull); };
-        auto close_tile = [&](uint64_t t_end) {
-            if (t_end == t_first) return;
-            uint32_t off = 0;
-            const uint32_t span_first = (uint32_t)spans.size();
-            for (Sp &s : cur) {
-                s.lds = off;
-                const uint32_t len4 = span_cost(s);
-                spans.push_back(TileSpan{s.start, off, (len4 / 4) | (s.is_ref ? 0x80000000u : 0u)});
-                off += len4;
-            }
-            tile_lds_max = std::max(tile_lds_max, off);
-            for (uint64_t p = t_first; p < t_end; p++) {
-                const Pend &pe = pend[p - t_first];
-                TileJob &tj = tjobs[p];
-                tj.offA = (uint16_t)(cur[pe.spA].lds + (pe.a0 - cur[pe.spA].start));
-                tj.offB = (uint16_t)(cur[pe.spB].lds + (pe.b0 - cur[pe.spB].start));
-            }
-            // order the tile's records by (radius, longer side, shorter side): waves get one shape
-            std::sort(tjobs.begin() + t_first, tjobs.begin() + t_end, [](const TileJob &x, const TileJob &y) {
-                if (x.R != y.R) return x.R < y.R; // dispatch kind
-                if (x.N != y.N) return x.N > y.N;
-                if (x.M != y.M) return x.M > y.M;
-                return x.aux < y.aux;
-            });
-            tiles.push_back(TileDesc{(uint32_t)t_first, (uint32_t)(t_end - t_first), span_first, (uint32_t)cur.size()});
-            cur.clear(); pend.clear(); lds_used = 0; t_first = t_end;
-        };
-        // find (or make) the span that holds window [w0, w0+len) of the given arena; returns its index or -1
-        auto place = [&](uint64_t w0, uint32_t len, bool is_ref, uint32_t &extra) -> int {
-            extra = 0;
-            for (int q = (int)cur.size() - 1; q >= 0 && q >= (int)cur.size() - 8; q--) {
-                Sp &s = cur[q];
-                if (s.is_ref != is_ref || w0 < s.start || w0 > s.end) continue;
-                if (w0 + len <= s.end) return q; // already covered
-                const uint32_t before = span_cost(s);
-                Sp grown = s; grown.end = w0 + len;
-                extra = span_cost(grown) - before;
-                return q; // caller extends after the budget check
-            }
-            extra = (uint32_t)((((w0 & 3ull) + len) + 3) & ~3ull);
-            return -1;
-        };
-        for (uint64_t p = p0; p < nt; p++) {
-            const DevJob &d = pl->h_jobs[p];
-            const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
-            const uint64_t a0 = swap ? d.ref_off : d.read_off, b0 = swap ? d.read_off : d.ref_off;
-            const uint32_t NA = swap ? d.m : d.n, NB = swap ? d.n : d.m;
-            const bool a_ref = swap, b_ref = !swap;
-            for (int attempt = 0; attempt < 2; attempt++) {
-                uint32_t ea = 0, eb = 0;
-                int qa = place(a0, NA, a_ref, ea);
-                // place B after tentatively accounting for A (a fresh span for A cannot serve B: other arena)
-                int qb = place(b0, NB, b_ref, eb);
-                const uint32_t new_spans = (qa < 0) + (qb < 0);
-                if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > kTileMaxSpans ||
-                                     p - t_first >= max_jobs)) {
-                    close_tile(p);
-                    continue; // retry in the fresh tile
-                }
-                if (qa < 0) { cur.push_back(Sp{a0 & ~3ull, a0 + NA, a_ref, 0}); qa = (int)cur.size() - 1; }
-                else cur[qa].end = std::max(cur[qa].end, a0 + NA);
-                if (qb < 0) { cur.push_back(Sp{b0 & ~3ull, b0 + NB, b_ref, 0}); qb = (int)cur.size() - 1; }
-                else cur[qb].end = std::max(cur[qb].end, b0 + NB);
-                lds_used += ea + eb;
-                pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
-                TileJob &tj = tjobs[p];
-                tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
-                tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
-                if (!hi && NA <= (uint32_t)ctx->micro_max_n) { // micro path: band membership from a per-shape bitmask
-                    int32_t &mi = mask_index[((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + d.R];
-                    if (mi < 0) { mi = (int32_t)masks.size(); masks.push_back(band_mask8(NA, NB, d.R)); }
-                    tj.pad = (uint32_t)mi;
-                    tj.R = NA <= 4 ? 0 : 1;
-                } else {
-                    tj.R = (uint8_t)(2 + d.R);
-                }
-                break;
-            }
+        const int TT = (int)std::min<uint64_t>(T, TL.count / 8192 + 1);
+        std::vector<std::vector<TileDesc>> tl(TT);
+        std::vector<std::vector<TileSpan>> sp(TT);
+        std::vector<uint32_t> lmax(TT, 0);
+        parallel_for(TT, [&](int t) {
+            const uint64_t a = TL.first + TL.count * (uint64_t)t / TT, b = TL.first + TL.count * (uint64_t)(t + 1) / TT;
+            lmax[t] = build_tiles(cfg, hi, pl->h_jobs, a, b, tl[t], sp[t], ht.tjobs.data());
+        });
+        const size_t tiles_before = ht.tiles.size();
+        uint32_t tile_lds_max = 0;
+        for (int t = 0; t < TT; t++) {
+            const uint32_t span_base = (uint32_t)ht.spans.size();
+            for (TileDesc d : tl[t]) { d.span_first += span_base; ht.tiles.push_back(d); }
+            ht.spans.insert(ht.spans.end(), sp[t].begin(), sp[t].end());
+            tile_lds_max = std::max(tile_lds_max, lmax[t]);
         }
-        close_tile(nt);
-        if (hi) { pl->n_tiles_hi = tiles.size() - tiles_before; pl->tile_hi_lds_floats = tile_lds_max; }
-        else { pl->n_tiles = tiles.size() - tiles_before; pl->tile_lds_floats = tile_lds_max; }
+        if (hi) { pl->n_tiles_hi = ht.tiles.size() - tiles_before; pl->tile_hi_lds_floats = tile_lds_max; }
+        else { pl->n_tiles = ht.tiles.size() - tiles_before; pl->tile_lds_floats = tile_lds_max; }
         TL.param = (int32_t)tile_lds_max;
     }
+    lap("tiles");
     // a banded-wave launch only needs LDS for its own largest K (jobs are sorted by N, not K)
     for (Launch &L : pl->launches)
         if (L.kind == kKindBandWave) {
@@ -448,12 +623,13 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         std::vector<double> work(pl->launches.size(), 0.0);
         for (size_t i = 0; i < pl->launches.size(); i++) {
             const Launch &L = pl->launches[i];
+            if (L.kind == kKindBandLane) { work[i] = work0; continue; }
+            if (L.kind == kKindBandLaneHi) { work[i] = work1; continue; }
             for (uint64_t p = L.first; p < L.first + L.count; p++) {
                 const DevJob &d = pl->h_jobs[p];
                 const double N = std::max(d.n, d.m), M = std::min(d.n, d.m);
                 const double w = d.R < 0 ? M : std::min<double>(2.0 * d.R + 1.0, M);
-                // wave-per-job kernels spend a whole wave on one job
-                work[i] += N * ((L.kind == kKindBandLane || L.kind == kKindBandLaneHi) ? w : std::max(w, 64.0));
+                work[i] += N * std::max(w, 64.0); // wave-per-job kernels spend a whole wave on one job
             }
         }
         pl->run_order.resize(pl->launches.size());
@@ -471,39 +647,145 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         else if (L.kind == kKindBandWave || L.kind == kKindBandWreg) I.n_wave_band_jobs += L.count;
         else I.n_full_jobs += L.count;
     }
-    I.workspace_bytes = bnd * 4 + dirb + (n_jobs - pl->n_tile_jobs) * (sizeof(DevJob) + sizeof(FullAux)) + n_jobs * 4 +
-                        tiles.size() * sizeof(TileDesc) + spans.size() * sizeof(TileSpan) + tjobs.size() * sizeof(TileJob);
+    I.workspace_bytes = bnd * 4 + dirb + nother * (sizeof(DevJob) + sizeof(FullAux)) + n_jobs * 4 +
+                        ht.tiles.size() * sizeof(TileDesc) + ht.spans.size() * sizeof(TileSpan) +
+                        ht.tjobs.size() * sizeof(TileJob) + ht.masks.size() * 8;
+    pl->plan_threads_used = T;
+    lap("finish");
+    return RAWDTW_OK;
+}
 
+// Self-check of a host plan against the jobs it was built from (rawdtw_plan_dry_run; tests).  Returns an
+// empty string when every invariant the kernels rely on holds.
+std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, const rawdtw_plan *pl,
+                             const HostTiles &ht)
+{
+    auto S = [](uint64_t v) { return std::to_string(v); };
+    if (pl->order.size() != n_jobs || pl->h_jobs.size() != n_jobs) return "order/h_jobs size";
+    std::vector<uint8_t> seen(n_jobs, 0);
+    for (uint64_t p = 0; p < n_jobs; p++) {
+        const uint32_t k = pl->order[p];
+        if (k >= n_jobs || seen[k]) return "job " + S(k) + " missing or planned twice";
+        seen[k] = 1;
+        const DevJob &d = pl->h_jobs[p];
+        if (d.aux != k || d.n != jobs[k].n || d.m != jobs[k].m || d.ref_off != jobs[k].ref_off || d.read_off != jobs[k].read_off)
+            return "record of job " + S(k) + " differs from the job";
+    }
+    uint64_t covered = 0;
+    for (const Launch &L : pl->launches) {
+        if (L.first != covered || L.count == 0) return "launches do not partition the plan";
+        covered += L.count;
+    }
+    if (covered != n_jobs) return "launches cover " + S(covered) + " of " + S(n_jobs) + " jobs";
+    if (ht.tiles.size() != pl->n_tiles + pl->n_tiles_hi || ht.tjobs.size() != pl->n_tile_jobs) return "tile counts";
+    std::vector<uint8_t> tseen(n_jobs, 0);
+    uint64_t next_job = 0;
+    for (size_t ti = 0; ti < ht.tiles.size(); ti++) {
+        const TileDesc &t = ht.tiles[ti];
+        const bool hi = ti >= pl->n_tiles;
+        const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
+        if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
+        next_job += t.n_jobs;
+        if (t.n_jobs > (hi ? kTileHiMaxJobs : cfg.tile_max_jobs) || t.n_spans > kTileMaxSpans || t.n_spans == 0)
+            return "tile " + S(ti) + ": too many jobs or spans";
+        if ((uint64_t)t.span_first + t.n_spans > ht.spans.size()) return "tile " + S(ti) + ": spans out of range";
+        uint32_t off = 0;
+        for (uint32_t s = 0; s < t.n_spans; s++) {
+            const TileSpan &sp = ht.spans[t.span_first + s];
+            const uint32_t len = 4 * (sp.chunks_arena & 0x7fffffffu);
+            const bool is_ref = sp.chunks_arena >> 31;
+            if (sp.lds_off != off || (sp.src & 3) || len == 0) return "tile " + S(ti) + ": span layout";
+            // the copy reads whole 16-byte chunks: the arenas are allocated with that slack (see upload_*), the
+            // span itself must start inside the arena
+            if (sp.src >= (is_ref ? cfg.n_ref : cfg.n_ev)) return "tile " + S(ti) + ": span outside its arena";
+            off += len;
+        }
+        if (off > budget || off > (hi ? pl->tile_hi_lds_floats : pl->tile_lds_floats)) return "tile " + S(ti) + ": LDS image over budget";
+        for (uint32_t q = 0; q < t.n_jobs; q++) {
+            const TileJob &tj = ht.tjobs[t.job_first + q];
+            const uint32_t k = tj.aux;
+            if (k >= n_jobs || tseen[k]) return "tile job " + S(k) + " duplicated";
+            tseen[k] = 1;
+            const rawdtw_job_t &j = jobs[k];
+            const bool swap = j.n < j.m;
+            const uint64_t a0 = swap ? j.ref_off : j.read_off, b0 = swap ? j.read_off : j.ref_off;
+            const uint32_t NA = swap ? j.m : j.n, NB = swap ? j.n : j.m;
+            if (tj.N != NA || tj.M != NB || ((tj.flags & kFlagExcludeLast) != 0) != (j.exclude_last != 0))
+                return "tile job " + S(k) + ": shape or flags";
+            const int R = slanted_radius(j.n, j.m, j.band_radius);
+            if (tj.R >= 2) { if ((int)tj.R - 2 != R) return "tile job " + S(k) + ": radius"; }
+            else {
+                if (NA > (tj.R == 0 ? 4u : 8u) || tj.pad >= ht.masks.size() || ht.masks[tj.pad] != band_mask8(NA, NB, R))
+                    return "tile job " + S(k) + ": micro mask";
+            }
+            // both windows must lie inside one staged span of the right arena, at the right place
+            for (int w = 0; w < 2; w++) {
+                const uint32_t o = w ? tj.offB : tj.offA, len = w ? NB : NA;
+                const uint64_t g0 = w ? b0 : a0;
+                const bool want_ref = w ? !swap : swap;
+                bool ok = false;
+                for (uint32_t s = 0; s < t.n_spans && !ok; s++) {
+                    const TileSpan &sp = ht.spans[t.span_first + s];
+                    const uint32_t slen = 4 * (sp.chunks_arena & 0x7fffffffu);
+                    if ((bool)(sp.chunks_arena >> 31) != want_ref) continue;
+                    if (o >= sp.lds_off && o + len <= sp.lds_off + slen && sp.src + (o - sp.lds_off) == g0) ok = true;
+                }
+                if (!ok) return "tile job " + S(k) + ": window " + (w ? "B" : "A") + " not staged";
+            }
+        }
+        for (uint32_t q = 1; q < t.n_jobs; q++) { // dispatch order inside the tile
+            const TileJob &x = ht.tjobs[t.job_first + q - 1], &y = ht.tjobs[t.job_first + q];
+            if (x.R > y.R || (x.R == y.R && x.N < y.N)) return "tile " + S(ti) + ": records not sorted";
+        }
+    }
+    if (next_job != pl->n_tile_jobs) return "tiles cover " + S(next_job) + " of " + S(pl->n_tile_jobs) + " tile jobs";
+    for (uint64_t p = 0; p < pl->n_tile_jobs; p++) if (!tseen[pl->order[p]]) return "tile-class job without a tile";
+    return "";
+}
+
+int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool traceback, rawdtw_plan **out)
+{
+    *out = nullptr;
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (n_jobs > 0 && !jobs) return fail(ctx, RAWDTW_ERR_INVALID, "jobs is NULL");
+    if (n_jobs >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "more than 2^32-1 jobs in one batch");
+    rawdtw_plan *pl = new (std::nothrow) rawdtw_plan;
+    if (!pl) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    pl->ctx = ctx;
+    HostTiles ht;
+    std::string err;
     int st;
+    try {
+        st = plan_host(cfg_of(ctx), jobs, n_jobs, traceback, pl, ht, err);
+    } catch (const std::bad_alloc &) {
+        st = RAWDTW_ERR_OOM; err = "host allocation failed";
+    }
+    if (st != RAWDTW_OK) { delete pl; return fail(ctx, st, err); }
+
     const uint64_t n_dev_jobs = n_jobs - pl->n_tile_jobs;
     if ((st = dev_alloc(ctx, &pl->d_jobs, n_dev_jobs)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_tiles, (uint64_t)tiles.size())) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_spans, (uint64_t)spans.size())) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_tjobs, (uint64_t)tjobs.size())) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)masks.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_tiles, (uint64_t)ht.tiles.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_spans, (uint64_t)ht.spans.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_tjobs, (uint64_t)ht.tjobs.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)ht.masks.size())) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_aux, n_dev_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_bnd, bnd)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_dir, dirb)) != RAWDTW_OK) {
+        (st = dev_alloc(ctx, &pl->d_bnd, pl->bnd_floats)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_dir, pl->dir_bytes)) != RAWDTW_OK) {
         rawdtw_plan_destroy(pl);
         return st;
     }
     if (n_jobs) {
         hipError_t e = hipSuccess;
-        if (n_dev_jobs)
-            e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data() + pl->n_tile_jobs, n_dev_jobs * sizeof(DevJob),
-                               hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && n_dev_jobs)
-            e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data() + pl->n_tile_jobs, n_dev_jobs * sizeof(FullAux),
-                               hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && !tiles.empty())
-            e = hipMemcpyAsync(pl->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && !spans.empty())
-            e = hipMemcpyAsync(pl->d_spans, spans.data(), spans.size() * sizeof(TileSpan), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && !tjobs.empty())
-            e = hipMemcpyAsync(pl->d_tjobs, tjobs.data(), tjobs.size() * sizeof(TileJob), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && !masks.empty())
-            e = hipMemcpyAsync(pl->d_masks, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+        auto up = [&](void *dst, const void *src, size_t bytes) {
+            if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        };
+        up(pl->d_jobs, pl->h_jobs.data() + pl->n_tile_jobs, n_dev_jobs * sizeof(DevJob));
+        up(pl->d_aux, pl->h_aux.data(), n_dev_jobs * sizeof(FullAux));
+        up(pl->d_tiles, ht.tiles.data(), ht.tiles.size() * sizeof(TileDesc));
+        up(pl->d_spans, ht.spans.data(), ht.spans.size() * sizeof(TileSpan));
+        up(pl->d_tjobs, ht.tjobs.data(), ht.tjobs.size() * sizeof(TileJob));
+        up(pl->d_masks, ht.masks.data(), ht.masks.size() * 8);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             rawdtw_plan_destroy(pl);
@@ -512,6 +794,24 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
     }
     *out = pl;
     return RAWDTW_OK;
+}
+
+// cells evaluated by plan positions [p0, p1) (exact band cell sets; reporting only)
+uint64_t count_cells(const rawdtw_plan *pl, uint64_t p0, uint64_t p1)
+{
+    const int T = (int)std::min<uint64_t>(std::max(pl->plan_threads_used, 1), (p1 - p0) / 32768 + 1);
+    std::vector<uint64_t> part(T, 0);
+    parallel_for(T, [&](int t) {
+        uint64_t c = 0;
+        for (uint64_t p = p0 + (p1 - p0) * (uint64_t)t / T; p < p0 + (p1 - p0) * (uint64_t)(t + 1) / T; p++) {
+            const DevJob &d = pl->h_jobs[p];
+            c += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
+        }
+        part[t] = c;
+    });
+    uint64_t cells = 0;
+    for (uint64_t c : part) cells += c;
+    return cells;
 }
 
 int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t stream)
@@ -671,6 +971,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
+    if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "full_wg")) { ctx->full_wg = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "grp16")) { ctx->grp16 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
@@ -775,15 +1076,59 @@ int rawdtw_plan_create(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_job
     return build_plan(ctx, jobs, n_jobs, false, out);
 }
 
+int rawdtw_plan_dry_run(uint64_t n_events, uint64_t n_reference, const rawdtw_job_t *jobs, uint64_t n_jobs, int threads,
+                        const char *const *option_names, const int64_t *option_values, uint32_t n_options,
+                        rawdtw_plan_info_t *info, uint64_t *n_tiles, char *message, uint32_t message_cap)
+{
+    auto say = [&](const std::string &s) {
+        if (message && message_cap) { snprintf(message, message_cap, "%s", s.c_str()); }
+    };
+    say("");
+    if ((n_jobs && !jobs) || n_jobs >= (1ull << 32) || (n_options && (!option_names || !option_values))) return RAWDTW_ERR_INVALID;
+    PlanCfg cfg;
+    cfg.n_ev = n_events; cfg.n_ref = n_reference; cfg.threads = threads;
+    bool verify = true;
+    for (uint32_t i = 0; i < n_options; i++) {
+        const char *nm = option_names[i];
+        const int64_t v = option_values[i];
+        if (!strcmp(nm, "verify")) verify = v != 0; // dry run only: skip the self-check (to time the planner alone)
+        else if (!strcmp(nm, "tile_lds_floats")) cfg.tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 1024), 40000);
+        else if (!strcmp(nm, "tile_max_jobs")) cfg.tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 64), 65535);
+        else if (!strcmp(nm, "full_wg")) cfg.full_wg = v != 0;
+        else if (!strcmp(nm, "grp16")) cfg.grp16 = v != 0;
+        else if (!strcmp(nm, "micro_max_n")) cfg.micro_max_n = v >= 8 ? 8 : (v >= 4 ? 4 : 0);
+        else if (!strcmp(nm, "lane_hi")) cfg.lane_hi = v != 0;
+        else if (!strcmp(nm, "lane_hi_max_n")) cfg.lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 8), 200);
+        else if (!strcmp(nm, "lane_max_n")) cfg.lane_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 8), kLaneMaxN);
+        else if (!strcmp(nm, "lane_max_radius")) cfg.lane_max_radius = v < 0 ? 0 : (v > kMaxLaneRadius ? kMaxLaneRadius : (int)v);
+        else { say(std::string("unknown option ") + nm); return RAWDTW_ERR_INVALID; }
+    }
+    rawdtw_plan pl;
+    HostTiles ht;
+    std::string err;
+    int st;
+    try {
+        st = plan_host(cfg, jobs, n_jobs, false, &pl, ht, err);
+        if (st == RAWDTW_OK && verify) {
+            err = verify_host_plan(cfg, jobs, n_jobs, &pl, ht);
+            if (!err.empty()) st = RAWDTW_ERR_DEVICE + 100; // never returned for a correct planner
+        }
+    } catch (const std::bad_alloc &) {
+        st = RAWDTW_ERR_OOM; err = "host allocation failed";
+    }
+    say(err);
+    if (st != RAWDTW_OK) return st;
+    if (info) { pl.info.cells = verify ? count_cells(&pl, 0, n_jobs) : 0; *info = pl.info; }
+    if (n_tiles) *n_tiles = ht.tiles.size();
+    return RAWDTW_OK;
+}
+
 int rawdtw_plan_info(const rawdtw_plan *plan, rawdtw_plan_info_t *info)
 {
     if (!plan || !info) return RAWDTW_ERR_INVALID;
     rawdtw_plan *pl = const_cast<rawdtw_plan *>(plan);
     if (!pl->cells_counted) {
-        uint64_t cells = 0;
-        for (const DevJob &d : pl->h_jobs)
-            cells += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
-        pl->info.cells = cells;
+        pl->info.cells = count_cells(pl, 0, pl->n_jobs);
         pl->cells_counted = true;
     }
     *info = pl->info;
@@ -1032,23 +1377,45 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
                                      0, &n_jobs);
     if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
-    std::vector<rawdtw_job_t> jobs(n_jobs);
-    st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), jobs.data(),
-                                 n_jobs, &n_jobs);
-    if (st != RAWDTW_OK) return fail(ctx, st, "job building failed");
+    // jobs and chain descriptors, chain ranges spread over the planner's threads
+    RawVec<rawdtw_job_t> jobs;
     std::vector<ChainDesc> desc(n_chains);
-    for (uint64_t c = 0; c < n_chains; c++) {
-        const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
-        ChainDesc &d = desc[c];
-        d.job_first = job_off[c];
-        d.n_jobs = (uint32_t)(job_off[c + 1] - job_off[c]);
-        d.reserved = 0;
-        if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
-        const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
-        d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
-        uint32_t na = 0;
-        for (uint64_t k = job_off[c]; k < job_off[c + 1]; k++) na += jobs[k].n; // rmap.cpp:236,292
-        d.num_aligned = na;
+    try { jobs.resize(n_jobs); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    {
+        int T = ctx->plan_threads;
+        if (T <= 0) {
+            const unsigned hc = std::thread::hardware_concurrency();
+            T = (int)std::min<uint64_t>(std::min<unsigned>(hc ? hc : 1, 16), n_jobs / 32768 + 1);
+        }
+        T = std::max(1, std::min(T, 64));
+        std::vector<int> status(T, RAWDTW_OK);
+        parallel_for(T, [&](int t) {
+            // split by jobs, not chains: chain lengths are skewed
+            const uint64_t j_lo = n_jobs * (uint64_t)t / T, j_hi = n_jobs * (uint64_t)(t + 1) / T;
+            const uint64_t c_lo = std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_lo) - job_off.begin();
+            const uint64_t c_hi = t + 1 == T ? n_chains
+                                             : std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_hi) - job_off.begin();
+            for (uint64_t c = c_lo; c < c_hi; c++) {
+                const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+                const uint32_t nj = (uint32_t)(job_off[c + 1] - job_off[c]);
+                if (nj) {
+                    int s2 = rawdtw_chain_build_jobs(opt, anchors + a0, (uint32_t)(a1 - a0), ref_base[c], read_base[c], 0,
+                                                     jobs.data() + job_off[c]);
+                    if (s2 != RAWDTW_OK) { status[t] = s2; return; }
+                }
+                ChainDesc &d = desc[c];
+                d.job_first = job_off[c];
+                d.n_jobs = nj;
+                d.reserved = 0;
+                if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
+                const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
+                d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
+                uint32_t na = 0;
+                for (uint64_t k = job_off[c]; k < job_off[c + 1]; k++) na += jobs[k].n; // rmap.cpp:236,292
+                d.num_aligned = na;
+            }
+        });
+        for (int t = 0; t < T; t++) if (status[t] != RAWDTW_OK) return fail(ctx, status[t], "job building failed");
     }
     rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
     if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
@@ -1063,10 +1430,16 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_keep, n_chains);
     if (st == RAWDTW_OK) {
         hipError_t e = hipSuccess;
+        // fold order: longest chain first (stable counting sort on the part count)
         std::vector<uint32_t> fold_order(n_chains);
-        for (uint64_t c = 0; c < n_chains; c++) fold_order[c] = (uint32_t)c;
-        std::stable_sort(fold_order.begin(), fold_order.end(),
-                         [&](uint32_t x, uint32_t y) { return desc[x].n_jobs > desc[y].n_jobs; });
+        {
+            constexpr uint32_t kB = 65536;
+            std::vector<uint64_t> start(kB + 1, 0);
+            auto bucket = [&](uint64_t c) { return kB - 1 - std::min<uint32_t>(desc[c].n_jobs, kB - 1); };
+            for (uint64_t c = 0; c < n_chains; c++) start[bucket(c) + 1]++;
+            for (uint32_t q = 0; q < kB; q++) start[q + 1] += start[q];
+            for (uint64_t c = 0; c < n_chains; c++) fold_order[start[bucket(c)]++] = (uint32_t)c;
+        }
         if (n_chains) e = hipMemcpyAsync(b->d_chains, desc.data(), n_chains * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && n_chains)
             e = hipMemcpyAsync(b->d_fold_order, fold_order.data(), n_chains * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -1210,12 +1583,12 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
         return RAWDTW_OK;
     }
     const Launch &L = pl->launches[i];
-    uint64_t bytes = 0, cl = 0;
+    uint64_t bytes = 0;
     for (uint64_t p = L.first; p < L.first + L.count; p++) {
         const DevJob &d = pl->h_jobs[p];
         bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
-        if (cells) cl += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
     }
+    const uint64_t cl = cells ? count_cells(pl, L.first, L.first + L.count) : 0;
     if (kind) *kind = L.kind;
     if (param) *param = L.param;
     if (n_jobs) *n_jobs = L.count;

@@ -49,6 +49,25 @@ def _f32(x) -> np.ndarray:
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def plan_dry_run(jobs: np.ndarray, n_events: int, n_reference: int, threads: int = 0, options=None):
+    """Host half of plan creation only (include/rawdtw.h: rawdtw_plan_dry_run): bins `jobs`, checks the plan's
+    invariants and returns (info dict, n_tiles).  Touches no device and scores nothing."""
+    lib = load_library()
+    jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
+    options = dict(options or {})
+    names = (C.c_char_p * max(len(options), 1))(*[k.encode() for k in options])
+    vals = (C.c_int64 * max(len(options), 1))(*[int(v) for v in options.values()])
+    info = PlanInfo()
+    n_tiles = C.c_uint64()
+    msg = C.create_string_buffer(512)
+    st = lib.rawdtw_plan_dry_run(int(n_events), int(n_reference), _ptr(jobs), len(jobs), int(threads),
+                                 C.cast(names, C.c_void_p), C.cast(vals, C.c_void_p), len(options), C.byref(info),
+                                 C.byref(n_tiles), C.cast(msg, C.c_void_p), 512)
+    if st != 0:
+        raise RawDTWError(st, msg.value.decode())
+    return {f: getattr(info, f) for f, _ in PlanInfo._fields_}, int(n_tiles.value)
+
+
 class Plan:
     """A size-binned batch resident on the device (rawdtw_plan)."""
 

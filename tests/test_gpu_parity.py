@@ -381,6 +381,8 @@ def test_planner_options_do_not_change_results(oracle):
         {"grp16": 0},
         {"full_wg": 0},
         {"lane_max_radius": 0, "lane_max_n": 8, "grp16": 1},
+        {"plan_threads": 1},
+        {"plan_threads": 7, "tile_max_jobs": 64},
     ]
     for st in settings:
         eng = ra.Engine(0)
