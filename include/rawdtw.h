@@ -67,7 +67,12 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "serial_launches" 0/1: with side streams, run a batch's launches in sequence anyway
  *   "lane_max_radius" 0..3: largest post-slant radius on the tile kernel; "lane_max_n": longest side there
  *   "lane_hi", "lane_hi_max_n": optional second tile instance for radii up to 8
- *   "micro_max_n" 0/4/8, "grp16" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs": kernel selection */
+ *   "micro_max_n" 0/4/8, "grp16" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs", "tile_max_spans",
+ *   "tile_threads" 256/512/1024: kernel selection
+ *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
+ *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
+ *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)
+ * The environment variable RAWDTW_OPTS="name=value,..." applies options at rawdtw_create. */
 int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);
 /* the ctx's hipStream_t, as void* (for event timing on the stream kernels run on) */
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream);

@@ -28,3 +28,5 @@ __all__ = [
     "MapOpt", "Chain", "Batch", "CandidateBatch", "ReadCandidates", "align_chain", "evaluate_reads",
     "load_library", "library_path", "LibraryMissing", "RawDTWError",
 ]
+
+DEFAULT_FOLD_MODE = 2  # rawdtw_set_option("fold_mode"): the library's default chain-fold kernel

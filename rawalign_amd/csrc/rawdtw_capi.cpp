@@ -61,6 +61,11 @@ struct rawdtw_ctx {
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
+    uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
+    bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
+    int fold_mode = 2; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work)
+    int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
+    uint32_t tile_max_spans = kTileMaxSpans;
     int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
     int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
     // reference arena
@@ -253,7 +258,7 @@ struct PlanCfg {
     uint32_t lane_max_n = kLaneMaxN, lane_hi_max_n = 96;
     bool lane_hi = false, grp16 = true, full_wg = true;
     int micro_max_n = 8;
-    uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
+    uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs, tile_max_spans = kTileMaxSpans;
     int threads = 0; // 0: pick from the job count and the machine
 };
 
@@ -272,6 +277,7 @@ PlanCfg cfg_of(const rawdtw_ctx *ctx)
     c.lane_max_radius = ctx->lane_max_radius; c.lane_max_n = ctx->lane_max_n; c.lane_hi_max_n = ctx->lane_hi_max_n;
     c.lane_hi = ctx->lane_hi; c.grp16 = ctx->grp16; c.full_wg = ctx->full_wg; c.micro_max_n = ctx->micro_max_n;
     c.tile_lds_floats = ctx->tile_lds_floats; c.tile_max_jobs = ctx->tile_max_jobs; c.threads = ctx->plan_threads;
+    c.tile_max_spans = ctx->tile_max_spans;
     return c;
 }
 
@@ -308,6 +314,11 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
     const uint32_t lds_budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
     const uint32_t max_jobs = hi ? kTileHiMaxJobs : cfg.tile_max_jobs;
     uint32_t tile_lds_max = 0;
+    // profiling aid (scripts/valu_by_class.py), never set in production: RAWDTW_DEBUG_SKIP="lo,hi,r" leaves the jobs with
+    // lo <= longer side <= hi (and radius r, -1 = any) staged but unscored (their cost reads 0), to attribute kernel time
+    int dbg_lo = 0, dbg_hi = -1, dbg_r = -1;
+    const char *dbg_env = getenv("RAWDTW_DEBUG_SKIP");
+    const bool dbg_skip = dbg_env && sscanf(dbg_env, "%d,%d,%d", &dbg_lo, &dbg_hi, &dbg_r) == 3;
     struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
     std::vector<Sp> cur;
     struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
@@ -381,7 +392,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
             int qa = place(a0, NA, a_ref, ea);
             int qb = place(b0, NB, b_ref, eb); // a fresh span for A cannot serve B: other arena
             const uint32_t new_spans = (qa < 0) + (qb < 0);
-            if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > kTileMaxSpans ||
+            if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > (hi ? kTileMaxSpans : cfg.tile_max_spans) ||
                                  p - t_first >= max_jobs)) {
                 close_tile(p);
                 continue; // retry in the fresh tile
@@ -401,6 +412,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
             } else {
                 tj.R = (uint8_t)(2 + d.R);
             }
+            if (dbg_skip && (int)NA >= dbg_lo && (int)NA <= dbg_hi && (dbg_r < 0 || dbg_r == d.R)) tj.R = 255; // no kernel path: cost 0
             break;
         }
     }
@@ -494,8 +506,10 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
             cls[k] = (uint8_t)c;
             Rv[k] = R;
             if (c == 0) { P.n0++; P.work0 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
-            else if (c == 1) { P.n1++; P.work1 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
-            else P.nother++;
+            else {
+                if (c == 1) { P.n1++; P.work1 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
+                P.nother++; // class 1 is sorted with the rest (by shape), it only shares the tile kernel with class 0
+            }
         }
     });
     lap("classify");
@@ -509,15 +523,18 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
     }
     uint64_t n0 = 0, n1 = 0, nother = 0, alg_bytes = 0;
     double work0 = 0, work1 = 0;
-    std::vector<uint64_t> base0(T), base1(T), baseo(T);
+    std::vector<uint64_t> base0(T), baseo(T);
     for (int t = 0; t < T; t++) {
-        base0[t] = n0; base1[t] = n1; baseo[t] = nother;
+        base0[t] = n0; baseo[t] = nother;
         n0 += pt[t].n0; n1 += pt[t].n1; nother += pt[t].nother; alg_bytes += pt[t].alg_bytes;
         work0 += pt[t].work0; work1 += pt[t].work1;
     }
     pl->n_tile_jobs = n0 + n1;
 
-    // ---- pass B: plan positions.  Tile classes keep job order; the rest is sorted by (class, shape) ----
+    // ---- pass B: plan positions.  The bulk tile class keeps job order (consecutive parts share their spans); the
+    // rest is sorted by (class, shape).  Class 1 (wide-band tile instance) sorts first, by (radius, longer side,
+    // shorter side): its jobs are rare and far apart, so nothing is shared anyway, and a wave of one radius and
+    // similar lengths runs one pass of the lane DP instead of one per radius present ----
     struct Keyed { uint64_t key; uint32_t idx; };
     std::vector<Keyed> keyed(nother);
     pl->order.resize(n_jobs);
@@ -530,15 +547,16 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
         d.R = Rv[k]; d.flags = j.exclude_last ? kFlagExcludeLast : 0u; d.aux = (uint32_t)k;
     };
     parallel_for(T, [&](int t) {
-        uint64_t q0 = base0[t], q1 = n0 + base1[t], qo = baseo[t];
+        uint64_t q0 = base0[t], qo = baseo[t];
         for (uint64_t k = seg(t, n_jobs); k < seg(t + 1, n_jobs); k++) {
             const uint32_t c = cls[k];
             if (c == 0) put(q0++, k);
-            else if (c == 1) put(q1++, k);
             else {
                 const rawdtw_job_t &j = jobs[k];
                 const uint64_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m), lim = (1ull << 28) - 1;
-                keyed[qo++] = Keyed{((uint64_t)c << 56) | ((lim - std::min(N, lim)) << 28) | (lim - std::min(NY, lim)), (uint32_t)k};
+                uint64_t key = ((uint64_t)c << 56) | ((lim - std::min(N, lim)) << 28) | (lim - std::min(NY, lim));
+                if (c == 1) key = (1ull << 56) | ((uint64_t)Rv[k] << 40) | ((255 - std::min<uint64_t>(N, 255)) << 20) | (255 - std::min<uint64_t>(NY, 255));
+                keyed[qo++] = Keyed{key, (uint32_t)k};
             }
         }
     });
@@ -546,17 +564,18 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
     std::sort(keyed.begin(), keyed.end(), [](const Keyed &x, const Keyed &y) {
         return x.key != y.key ? x.key < y.key : x.idx < y.idx;
     });
-    for (uint64_t q = 0; q < nother; q++) put(pl->n_tile_jobs + q, keyed[q].idx);
+    for (uint64_t q = 0; q < nother; q++) put(n0 + q, keyed[q].idx); // class 1 first: positions [n0, n0 + n1)
     lap("sort-rest");
 
     // ---- launches: the two tile classes, then maximal runs of equal class; workspace of the full-matrix jobs ----
-    pl->h_aux.assign(nother, FullAux{0, 0}); // indexed like d_jobs: plan position - n_tile_jobs
+    const uint64_t n_dev = nother - n1; // jobs with a device record (all but the tile classes)
+    pl->h_aux.assign(n_dev, FullAux{0, 0}); // indexed like d_jobs: plan position - n_tile_jobs
     if (n0) pl->launches.push_back(Launch{kKindBandLane, 0, 0, n0});
     if (n1) pl->launches.push_back(Launch{kKindBandLaneHi, 0, n0, n1});
     uint64_t bnd = 0, dirb = 0;
-    for (uint64_t q = 0; q < nother; q++) {
+    for (uint64_t q = 0; q < n_dev; q++) {
         const uint64_t p = pl->n_tile_jobs + q;
-        const uint64_t c = keyed[q].key >> 56;
+        const uint64_t c = keyed[n1 + q].key >> 56;
         const DevJob &j = pl->h_jobs[p];
         if (c >= 56) {
             const int rpl = c == 60 ? 8 : 1 << (c - 56);
@@ -571,7 +590,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
                 dirb += (dir_bytes_for(j.n, j.m, rpl) + 255) & ~255ull;
             }
         }
-        if (q == 0 || (keyed[q - 1].key >> 56) != c) {
+        if (q == 0 || (keyed[n1 + q - 1].key >> 56) != c) {
             Launch L{};
             L.first = p; L.count = 0;
             if (c == 39) { L.kind = kKindBandWreg; L.param = -16; }
@@ -647,7 +666,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
         else if (L.kind == kKindBandWave || L.kind == kKindBandWreg) I.n_wave_band_jobs += L.count;
         else I.n_full_jobs += L.count;
     }
-    I.workspace_bytes = bnd * 4 + dirb + nother * (sizeof(DevJob) + sizeof(FullAux)) + n_jobs * 4 +
+    I.workspace_bytes = bnd * 4 + dirb + n_dev * (sizeof(DevJob) + sizeof(FullAux)) + n_jobs * 4 +
                         ht.tiles.size() * sizeof(TileDesc) + ht.spans.size() * sizeof(TileSpan) +
                         ht.tjobs.size() * sizeof(TileJob) + ht.masks.size() * 8;
     pl->plan_threads_used = T;
@@ -686,7 +705,7 @@ std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint6
         const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
         if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
         next_job += t.n_jobs;
-        if (t.n_jobs > (hi ? kTileHiMaxJobs : cfg.tile_max_jobs) || t.n_spans > kTileMaxSpans || t.n_spans == 0)
+        if (t.n_jobs > (hi ? kTileHiMaxJobs : cfg.tile_max_jobs) || t.n_spans > (hi ? kTileMaxSpans : cfg.tile_max_spans) || t.n_spans == 0)
             return "tile " + S(ti) + ": too many jobs or spans";
         if ((uint64_t)t.span_first + t.n_spans > ht.spans.size()) return "tile " + S(ti) + ": spans out of range";
         uint32_t off = 0;
@@ -821,13 +840,17 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
     const FullAux *aux = pl->d_aux + (L.first >= pl->n_tile_jobs ? L.first - pl->n_tile_jobs : 0);
     float *out = pl->d_cost; // job order: every kernel stores at out[job.aux]
     hipError_t e = hipSuccess;
+    {   // timing experiments only (RAWDTW_OPTS=debug_skip_kinds=mask, bit = launch kind, the 16-lane-row kernel = bit 15)
+        const bool grp16 = L.kind == kKindBandWreg && L.param == -16;
+        if (ctx->debug_skip_kinds & (1u << (grp16 ? 15 : L.kind))) return RAWDTW_OK;
+    }
     switch (L.kind) {
     case kKindBandLane:
-        e = launch_band_tile(false, pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats,
+        e = launch_band_tile(false, ctx->tile_threads, pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats,
                              ctx->d_ev, ctx->d_ref, out, stream);
         break;
     case kKindBandLaneHi:
-        e = launch_band_tile(true, pl->d_tiles + pl->n_tiles, pl->n_tiles_hi, pl->d_spans, pl->d_tjobs, pl->d_masks,
+        e = launch_band_tile(true, 64, pl->d_tiles + pl->n_tiles, pl->n_tiles_hi, pl->d_spans, pl->d_tjobs, pl->d_masks,
                              pl->tile_hi_lds_floats, ctx->d_ev, ctx->d_ref, out, stream);
         break;
     case kKindBandWreg:
@@ -848,6 +871,42 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
     return RAWDTW_OK;
 }
 
+// Which launches of a plan travel as one k_band_merged launch (indices into pl->launches, -1 = none).
+struct MergeSel { int tile = -1, grp16 = -1, wreg = -1; bool on() const { return tile >= 0; } };
+
+MergeSel merge_of(const rawdtw_ctx *ctx, const rawdtw_plan *pl)
+{
+    MergeSel m;
+    if (!ctx->merge_small || ctx->tile_threads != 256 || (ctx->n_side > 0 && !ctx->serial_launches)) return m;
+    int tile = -1;
+    for (size_t i = 0; i < pl->launches.size(); i++) {
+        const Launch &L = pl->launches[i];
+        if (L.kind == kKindBandLane) tile = (int)i;
+        else if (L.kind == kKindBandWreg && L.param == -16) m.grp16 = (int)i;
+        else if (L.kind == kKindBandWreg && L.param == 0) m.wreg = (int)i;
+    }
+    if (tile >= 0 && (m.grp16 >= 0 || m.wreg >= 0)) m.tile = tile;
+    else m = MergeSel{};
+    return m;
+}
+
+int run_merged(rawdtw_ctx *ctx, rawdtw_plan *pl, const MergeSel &m, hipStream_t stream)
+{
+    auto recs = [&](int i, uint64_t &n) -> const DevJob * {
+        n = 0;
+        if (i < 0) return nullptr;
+        const Launch &L = pl->launches[i];
+        n = L.count;
+        return pl->d_jobs + (L.first - pl->n_tile_jobs);
+    };
+    uint64_t n_w = 0, n_g = 0;
+    const DevJob *wj = recs(m.wreg, n_w), *gj = recs(m.grp16, n_g);
+    hipError_t e = launch_band_merged(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats,
+                                      wj, n_w, gj, n_g, ctx->d_ev, ctx->d_ref, pl->d_cost, stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "kernel launch");
+    return RAWDTW_OK;
+}
+
 // All launches of a plan are independent: fork them over the main and side streams (heaviest
 // first), join back on the main stream.  `ev`, when given, receives a start/stop event pair per
 // launch (2*n entries), recorded on the stream that launch runs on.
@@ -861,12 +920,15 @@ int run_all_launches(rawdtw_ctx *ctx, rawdtw_plan *pl, hipEvent_t *ev)
         for (int k = 0; k < ctx->n_side; k++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
     int st = RAWDTW_OK;
+    const MergeSel mg = merge_of(ctx, pl);
     for (size_t q = 0; q < nl && st == RAWDTW_OK; q++) {
         const size_t i = pl->run_order[q];
         const int sl = fork ? (int)(q % (ctx->n_side + 1)) : 0;
         hipStream_t s = sl == 0 ? ctx->stream : ctx->side[sl - 1];
         if (ev && hipEventRecord(ev[2 * i], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        if (st == RAWDTW_OK) st = run_launch(ctx, pl, pl->launches[i], s);
+        if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.wreg)) { /* travels inside the tile launch */ }
+        else if (mg.on() && (int)i == mg.tile) { if (st == RAWDTW_OK) st = run_merged(ctx, pl, mg, s); }
+        else if (st == RAWDTW_OK) st = run_launch(ctx, pl, pl->launches[i], s);
         if (st == RAWDTW_OK && ev && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
     }
     if (fork)
@@ -935,6 +997,18 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
         int v = atoi(e);
         ctx->lane_max_radius = v < 0 ? 0 : (v > kMaxLaneRadius ? kMaxLaneRadius : v);
     }
+    if (const char *e = getenv("RAWDTW_OPTS")) { // "name=value,name=value": rawdtw_set_option for each (tuning runs)
+        std::string all(e);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos) (void)rawdtw_set_option(ctx, item.substr(0, eq).c_str(), atoll(item.c_str() + eq + 1));
+            pos = end + 1;
+        }
+    }
     *out = ctx;
     return RAWDTW_OK;
 }
@@ -972,6 +1046,11 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
+    if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
+    if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
+    if (!strcmp(name, "tile_max_spans")) { ctx->tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 4096); return RAWDTW_OK; }
     if (!strcmp(name, "full_wg")) { ctx->full_wg = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "grp16")) { ctx->grp16 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
@@ -1094,6 +1173,7 @@ int rawdtw_plan_dry_run(uint64_t n_events, uint64_t n_reference, const rawdtw_jo
         if (!strcmp(nm, "verify")) verify = v != 0; // dry run only: skip the self-check (to time the planner alone)
         else if (!strcmp(nm, "tile_lds_floats")) cfg.tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 1024), 40000);
         else if (!strcmp(nm, "tile_max_jobs")) cfg.tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 64), 65535);
+        else if (!strcmp(nm, "tile_max_spans")) cfg.tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 8), 4096);
         else if (!strcmp(nm, "full_wg")) cfg.full_wg = v != 0;
         else if (!strcmp(nm, "grp16")) cfg.grp16 = v != 0;
         else if (!strcmp(nm, "micro_max_n")) cfg.micro_max_n = v >= 8 ? 8 : (v >= 4 ? 4 : 0);
@@ -1463,8 +1543,9 @@ int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint6
 static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
 {
     hipError_t e;
+    if (ctx->debug_skip_kinds & (1u << (which == 0 ? kKindChainFold : kKindReadSelect))) return RAWDTW_OK;
     if (which == 0)
-        e = launch_chain_fold(b->d_chains, b->d_fold_order, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
+        e = launch_chain_fold(ctx->fold_mode, b->d_chains, b->d_fold_order, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
                               b->d_full, b->d_gate, ctx->stream);
     else
         e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
@@ -1583,15 +1664,28 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
         return RAWDTW_OK;
     }
     const Launch &L = pl->launches[i];
-    uint64_t bytes = 0;
-    for (uint64_t p = L.first; p < L.first + L.count; p++) {
-        const DevJob &d = pl->h_jobs[p];
-        bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
-    }
-    const uint64_t cl = cells ? count_cells(pl, L.first, L.first + L.count) : 0;
-    if (kind) *kind = L.kind;
+    const MergeSel mg = merge_of(batch->ctx, pl);
+    uint64_t bytes = 0, cl = 0, nj = 0;
+    auto add = [&](const Launch &X) {
+        for (uint64_t p = X.first; p < X.first + X.count; p++) {
+            const DevJob &d = pl->h_jobs[p];
+            bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
+        }
+        if (cells) cl += count_cells(pl, X.first, X.first + X.count);
+        nj += X.count;
+    };
+    uint32_t k = L.kind;
+    if (mg.on() && (int)i == mg.tile) { // the merged launch reports the three classes it carries
+        k = kKindBandMerged;
+        add(L);
+        if (mg.grp16 >= 0) add(pl->launches[mg.grp16]);
+        if (mg.wreg >= 0) add(pl->launches[mg.wreg]);
+    } else if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.wreg)) {
+        /* folded into the merged launch: nothing of its own */
+    } else add(L);
+    if (kind) *kind = k;
     if (param) *param = L.param;
-    if (n_jobs) *n_jobs = L.count;
+    if (n_jobs) *n_jobs = nj;
     if (algorithmic_bytes) *algorithmic_bytes = bytes;
     if (cells) *cells = cl;
     return RAWDTW_OK;

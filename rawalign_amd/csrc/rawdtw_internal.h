@@ -33,7 +33,8 @@ enum LaunchKind : uint32_t {
     kKindChainFold = 6, // per-chain fold of the part costs (align_chain)
     kKindReadSelect = 7, // per-read accept/cut loop (gen_chains DTW block)
     kKindBandWreg = 8,   // wave-per-job banded kernel, band in registers (param = registers per lane per buffer)
-    kKindBandLaneHi = 9  // tile kernel instance for the wider bands (radius 4..8)
+    kKindBandLaneHi = 9, // tile kernel instance for the wider bands (radius 4..8)
+    kKindBandMerged = 10 // reporting only: the tile launch when it also carries the two small banded classes (k_band_merged)
 };
 
 // Tile kernel records (planner output)
@@ -69,7 +70,7 @@ constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is 
 // tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
 constexpr uint32_t kTileLdsFloats = 5120;  // 20 KiB -> 8 workgroups per CU (swept: 4096..32768)
 constexpr uint32_t kTileMaxJobs = 1024;
-constexpr uint32_t kTileHiLdsFloats = 10240, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
+constexpr uint32_t kTileHiLdsFloats = 14336, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;
 constexpr int kFullWgWaves = 4;        // waves per job in the pipelined-strip variant of the full-matrix kernel
 constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
@@ -88,7 +89,11 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-hipError_t launch_band_tile(bool hi, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+                              const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,
+                              const DevJob *gjobs, uint64_t n_g, const float *ev, const float *ref, float *out,
+                              hipStream_t s);
+hipError_t launch_band_tile(bool hi, int threads, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                             const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
                             float *out, hipStream_t s);
 hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, const float *ev,
@@ -103,8 +108,8 @@ hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux
                           const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                           uint32_t *path_j, float *path_d, hipStream_t s);
 
-hipError_t launch_chain_fold(const ChainDesc *chains, const uint32_t *order, uint64_t n_chains, const float *job_cost,
-                             float bonus, int fused, float *full_score, float *att_last, hipStream_t s);
+hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
+                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, hipStream_t s);
 hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const float *full_score,
                               const float *att_last, float min_score, float *score, uint8_t *keep,
                               hipStream_t s);

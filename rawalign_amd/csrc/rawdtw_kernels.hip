@@ -16,8 +16,12 @@ namespace rawdtw {
 
 __device__ __forceinline__ float min3f(float top, float left, float tl)
 {
-    // std::min(std::min(top,left),topleft); identical for non-NaN operands, one v_min3_f32
-    return __builtin_fminf(__builtin_fminf(top, left), tl);
+    // std::min(std::min(top,left),topleft); identical for non-NaN operands.  Written as the instruction: through
+    // fminf the compiler must quiet signalling NaNs first (a v_max_f32 x,x per operand it cannot prove canonical,
+    // and two v_min_f32 instead of one v_min3_f32) -- a quarter of the lane DP's VALU work.
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(top), "v"(left), "v"(tl));
+    return r;
 }
 
 __device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
@@ -298,17 +302,16 @@ __device__ __forceinline__ void tile_dispatch_range(const float *win, const Tile
 // <0, 8, false, 64> (optional, "lane_hi") for the rare wider bands -- kept apart so that their registers and their long
 // columns do not tax the waves of the bulk (0.4 % of the jobs cost half the time when mixed in).
 template <int RLO, int RHI, bool MICRO, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restrict__ tiles,
-                                                       const TileSpan *__restrict__ spans,
-                                                       const TileJob *__restrict__ tjobs,
-                                                       const unsigned long long *__restrict__ masks,
-                                                       const float *__restrict__ ev,
-                                                       const float *__restrict__ ref,
-                                                       float *__restrict__ out)
+__device__ __forceinline__ void tile_block(float *win, const TileDesc td, const TileSpan *__restrict__ spans,
+                                           const TileJob *__restrict__ tjobs,
+                                           const unsigned long long *__restrict__ masks,
+                                           const float *__restrict__ ev, const float *__restrict__ ref,
+                                           float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float win[];
     const int tid = threadIdx.x;
-    const TileDesc td = tiles[blockIdx.x];
+    // staging waves go first: a fresh workgroup's loads must not queue behind the VALU work of the older
+    // workgroups on its SIMDs (the scheduler favours older waves)
+    __builtin_amdgcn_s_setprio(3);
     auto load_job = [&](uint32_t r) { return tjobs[td.job_first + (r < td.n_jobs ? r : td.n_jobs - 1)]; };
     // the first round's records travel while the spans are staged
     TileJob tj_next = load_job((uint32_t)tid);
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restric
         for (uint32_t k = tid; k < chunks; k += THREADS) dst[k] = src[k];
     }
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     const uint32_t rounds = (td.n_jobs + THREADS - 1) / THREADS;
     for (uint32_t rd = 0; rd < rounds; rd++) {
         const uint32_t r = rd * THREADS + tid;
@@ -336,6 +340,19 @@ __global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restric
         tile_dispatch_range<RLO, RHI>(win, tj, kind, res);
         if (act) out[tj.aux] = res; // job order (aux = the job's index in the caller's batch)
     }
+}
+
+template <int RLO, int RHI, bool MICRO, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_band_tile(const TileDesc *__restrict__ tiles,
+                                                       const TileSpan *__restrict__ spans,
+                                                       const TileJob *__restrict__ tjobs,
+                                                       const unsigned long long *__restrict__ masks,
+                                                       const float *__restrict__ ev,
+                                                       const float *__restrict__ ref,
+                                                       float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    tile_block<RLO, RHI, MICRO, THREADS>(win, tiles[blockIdx.x], spans, tjobs, masks, ev, ref, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,14 +595,12 @@ __device__ __forceinline__ float lane_gather(float v, int src_lane)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }
 
-__global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jobs, uint32_t count,
-                                                   const float *__restrict__ ev,
-                                                   const float *__restrict__ ref,
-                                                   float *__restrict__ out)
+__device__ __forceinline__ void grp16_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
+                                           const float *__restrict__ ev, const float *__restrict__ ref,
+                                           float *__restrict__ out)
 {
-    const int lane = threadIdx.x;
     const int p = lane & 15, rowbase = lane & 48;
-    const uint32_t idx = blockIdx.x * 4u + (uint32_t)(lane >> 4);
+    const uint32_t idx = wave * 4u + (uint32_t)(lane >> 4);
     const bool have = idx < count;
     const DevJob jb = jobs[have ? idx : count - 1];
     const float *A = ev + jb.read_off;
@@ -679,6 +694,14 @@ __global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jo
     }
 }
 
+__global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jobs, uint32_t count,
+                                                   const float *__restrict__ ev,
+                                                   const float *__restrict__ ref,
+                                                   float *__restrict__ out)
+{
+    grp16_wave(jobs, count, blockIdx.x, (int)threadIdx.x, ev, ref, out);
+}
+
 template <int C>
 __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ jobs,
                                                   const float *__restrict__ ev,
@@ -692,16 +715,55 @@ __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ job
 // variant is picked per job (wave-uniform).  Jobs are sorted longest first, so the few long jobs
 // that bound the launch's duration start first and the many short ones fill in around them --
 // as separate launches they were separate long poles on separate streams.
+__device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const float *__restrict__ ev,
+                                               const float *__restrict__ ref, float *__restrict__ out)
+{
+    const int K = jb.R + 1;
+    if (K <= 64) wreg_body<1>(jb, lane, ev, ref, out);
+    else if (K <= 128) wreg_body<2>(jb, lane, ev, ref, out);
+    else wreg_body<4>(jb, lane, ev, ref, out);
+}
+
 __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict__ jobs,
                                                         const float *__restrict__ ev,
                                                         const float *__restrict__ ref,
                                                         float *__restrict__ out)
 {
-    const DevJob jb = jobs[blockIdx.x];
-    const int K = jb.R + 1;
-    if (K <= 64) wreg_body<1>(jb, (int)threadIdx.x, ev, ref, out);
-    else if (K <= 128) wreg_body<2>(jb, (int)threadIdx.x, ev, ref, out);
-    else wreg_body<4>(jb, (int)threadIdx.x, ev, ref, out);
+    wreg_small_job(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
+}
+
+// One launch for the three kernels every sparse batch needs -- the tile kernel (bulk), the 16-lane-row kernel
+// (radius 4..15) and the register-resident wave kernel (radius + 1 <= 256, a few hundred long jobs).  A stream
+// runs its kernels one after another and gfx950 ignores hipExtAnyOrderLaunch (scripts/experiments/anyorder.hip), so
+// as separate launches the ~0.3 ms of the longest wide-band job sat in the batch's critical path while using a few
+// percent of the chip.  Here it is the first workgroups of the launch and runs next to the tiles.  Workgroups are
+// 256 threads: [0, nbw) take four wave jobs each, [nbw, nbw+nbg) sixteen 16-lane-row jobs each, the rest one tile each.
+__global__ __launch_bounds__(256) void k_band_merged(const TileDesc *__restrict__ tiles,
+                                                     const TileSpan *__restrict__ spans,
+                                                     const TileJob *__restrict__ tjobs,
+                                                     const unsigned long long *__restrict__ masks,
+                                                     const DevJob *__restrict__ wjobs, uint32_t n_w,
+                                                     const DevJob *__restrict__ gjobs, uint32_t n_g,
+                                                     const float *__restrict__ ev, const float *__restrict__ ref,
+                                                     float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    const uint32_t nbw = (n_w + 3u) / 4u, nbg = (n_g + 15u) / 16u;
+    uint32_t b = blockIdx.x;
+    const uint32_t wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    if (b < nbw) {
+        const uint32_t j = b * 4u + wv;
+        if (j < n_w) wreg_small_job(wjobs[j], lane, ev, ref, out);
+        return;
+    }
+    b -= nbw;
+    if (b < nbg) {
+        grp16_wave(gjobs, n_g, b * 4u + wv, lane, ev, ref, out);
+        return;
+    }
+    b -= nbg;
+    tile_block<0, kMaxLaneRadius, true, 256>(win, tiles[b], spans, tjobs, masks, ev, ref, out);
 }
 
 template <int RPL> struct DirWord { using type = uint8_t; };
@@ -969,6 +1031,49 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
     }
 }
 
+// Lane-per-chain fold: 64 chains per wave (`order`: longest first, so a wave's chains have similar lengths), each
+// lane adds its own chain's part costs in order.  One packed add per 64 parts instead of a v_readlane + add per
+// part: ~30x less VALU work than k_chain_fold, which matters once several batches share the chip (the DTW kernels
+// are VALU-bound).  Each lane streams 4 bytes at a time through its own cache lines; U parts are fetched one
+// round ahead so that a round costs one memory round trip.
+template <int U>
+__global__ __launch_bounds__(64) void k_chain_fold_lane(const ChainDesc *__restrict__ chains,
+                                                        const uint32_t *__restrict__ order, uint64_t n_chains,
+                                                        const float *__restrict__ job_cost, float bonus, int fused,
+                                                        float *__restrict__ full_score, float *__restrict__ att_last)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const bool act = t < n_chains;
+    const uint32_t c = act ? order[t] : 0u;
+    ChainDesc d = chains[act ? c : order[0]];
+    if (!act) d.n_jobs = 0;
+    const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0; // all parts but the last: cost += sub; attainable -= sub
+    const float *jc = job_cost + d.job_first;
+    v2f acc = {0.0f, (float)d.span * bonus}; // {cost, attainable}  (rmap.cpp:205,246)
+    float nx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) nx[u] = ((uint32_t)u < body) ? jc[u] : 0.0f;
+    for (uint32_t k = 0; __any(k < body); k += U) {
+        float cur[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[u] = nx[u];
+#pragma unroll
+        for (int u = 0; u < U; u++) nx[u] = (k + U + (uint32_t)u < body) ? jc[k + U + u] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v2f{cur[u], -cur[u]}; // x + 0 and x - 0 are exact: finished chains idle
+    }
+    float cost = acc.x;
+    const float gate = d.n_jobs ? acc.y : __builtin_inff(); // tested before the last (or only) DTW call; none: no check
+    if (d.n_jobs) cost += jc[d.n_jobs - 1];                 // the last part only adds to the cost (rmap.cpp:279-280)
+    float score;
+    if (fused) score = __builtin_fmaf((float)d.num_aligned, bonus, -cost);
+    else { const float prod = (float)d.num_aligned * bonus; score = prod - cost; }
+    if (act) {
+        full_score[c] = score;
+        att_last[c] = gate;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict__ chain_off, uint64_t n_reads,
                                                      const float *__restrict__ full_score,
                                                      const float *__restrict__ att_last, float min_score,
@@ -989,12 +1094,19 @@ __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_chain_fold(const ChainDesc *chains, const uint32_t *order, uint64_t n_chains, const float *job_cost,
-                             float bonus, int fused, float *full_score, float *att_last, hipStream_t s)
+hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
+                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, hipStream_t s)
 {
     if (n_chains == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 3) / 4)), dim3(256), 0, s, chains, order, n_chains,
-                       job_cost, bonus, fused, full_score, att_last);
+    if (mode == 1)
+        hipLaunchKernelGGL(k_chain_fold_lane<16>, dim3((uint32_t)((n_chains + 63) / 64)), dim3(64), 0, s, chains, order,
+                           n_chains, job_cost, bonus, fused, full_score, att_last);
+    else if (mode == 2)
+        hipLaunchKernelGGL(k_chain_fold_lane<32>, dim3((uint32_t)((n_chains + 63) / 64)), dim3(64), 0, s, chains, order,
+                           n_chains, job_cost, bonus, fused, full_score, att_last);
+    else
+        hipLaunchKernelGGL(k_chain_fold, dim3((uint32_t)((n_chains + 3) / 4)), dim3(256), 0, s, chains, order, n_chains,
+                           job_cost, bonus, fused, full_score, att_last);
     return hipGetLastError();
 }
 
@@ -1023,13 +1135,33 @@ static hipError_t launch_tile_t(const TileDesc *tiles, uint64_t n_tiles, const T
     return hipGetLastError();
 }
 
-hipError_t launch_band_tile(bool hi, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
-                            const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
-                            float *out, hipStream_t s)
+hipError_t launch_band_tile(bool hi, int threads, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans,
+                            const TileJob *tjobs, const unsigned long long *masks, uint32_t lds_floats, const float *ev,
+                            const float *ref, float *out, hipStream_t s)
 {
     if (n_tiles == 0) return hipSuccess;
     if (hi) return launch_tile_t<0, kMaxLaneRadiusHi, false, 64>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
+    if (threads >= 1024) return launch_tile_t<0, kMaxLaneRadius, true, 1024>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
+    if (threads >= 512) return launch_tile_t<0, kMaxLaneRadius, true, 512>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
     return launch_tile_t<0, kMaxLaneRadius, true, 256>(tiles, n_tiles, spans, tjobs, masks, lds_floats, ev, ref, out, s);
+}
+
+hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
+                              const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,
+                              const DevJob *gjobs, uint64_t n_g, const float *ev, const float *ref, float *out,
+                              hipStream_t s)
+{
+    const uint64_t blocks = (n_w + 3) / 4 + (n_g + 15) / 16 + n_tiles;
+    if (blocks == 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_merged),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_band_merged, dim3((uint32_t)blocks), dim3(256), lds_bytes, s, tiles, spans, tjobs, masks, wjobs,
+                       (uint32_t)n_w, gjobs, (uint32_t)n_g, ev, ref, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_floats, const float *ev,

@@ -116,7 +116,7 @@ class Engine:
     """One rawdtw_ctx (one HIP device, one stream)."""
 
     KIND_NAMES = {1: "band_lane", 2: "band_wave_lds", 3: "full_wave", 4: "full_tb", 5: "tb_walk", 6: "chain_fold",
-                  7: "read_select", 8: "band_wreg", 9: "band_lane_hi"}
+                  7: "read_select", 8: "band_wreg", 9: "band_lane_hi", 10: "band_merged"}
 
     def __init__(self, device: int = 0):
         self.lib = load_library()

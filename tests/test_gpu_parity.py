@@ -223,6 +223,12 @@ def test_batch_matches_oracle_loop(engine, oracle, border, fill):
     batch = ra.Batch(engine, opt, cb)
     batch.run()
     score, keep = batch.fetch()
+    for mode in (0, 1, 2):  # every fold kernel (wave per chain, lane per chain with 16 / 32 parts per round)
+        engine.set_option("fold_mode", mode)
+        batch.run()
+        s2, k2 = batch.fetch()
+        assert np.array_equal(s2.view(np.uint32), score.view(np.uint32)) and np.array_equal(k2, keep), mode
+    engine.set_option("fold_mode", ra.DEFAULT_FOLD_MODE)
     oopt = OrcOpt(border, fill, 0.10, 0.4, 20.0, 1)
     arrays = {1: ref.forward[0], 0: ref.reverse[0]}
     strand_of = {offs[(0, 1)]: 1, offs[(0, 0)]: 0}
@@ -381,6 +387,8 @@ def test_planner_options_do_not_change_results(oracle):
         {"grp16": 0},
         {"full_wg": 0},
         {"lane_max_radius": 0, "lane_max_n": 8, "grp16": 1},
+        {"merge_small": 0},
+        {"merge_small": 0, "grp16": 0},
         {"plan_threads": 1},
         {"plan_threads": 7, "tile_max_jobs": 64},
     ]
