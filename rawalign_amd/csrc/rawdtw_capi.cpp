@@ -62,6 +62,7 @@ struct rawdtw_ctx {
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
     uint32_t lane_max_n = kLaneMaxN;
     uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
+    uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
     int fold_mode = 2; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work)
     int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
@@ -260,6 +261,12 @@ struct PlanCfg {
     int micro_max_n = 8;
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs, tile_max_spans = kTileMaxSpans;
     int threads = 0; // 0: pick from the job count and the machine
+    // Optional: tile-eligible jobs that are rare inside a tile (long, or of a radius few neighbours share) leave the job
+    // order and are tiled by shape instead: longer side >= sort_n, radius 1 with longer side >= sort_r1_n, radius 3
+    // (0 = never).  Measured on the bench workload with sort_n = 17: the tile kernel's VALU work drops 40 % (full waves of
+    // one shape), but every such job then fetches its own cache lines (+130 MB of scattered reads per batch); alone the
+    // kernel breaks even, with several batches in flight throughput falls 5-15 %.  Off by default.
+    uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64;
 };
 
 // tile records built on the host (uploaded by build_plan)
@@ -278,6 +285,7 @@ PlanCfg cfg_of(const rawdtw_ctx *ctx)
     c.lane_hi = ctx->lane_hi; c.grp16 = ctx->grp16; c.full_wg = ctx->full_wg; c.micro_max_n = ctx->micro_max_n;
     c.tile_lds_floats = ctx->tile_lds_floats; c.tile_max_jobs = ctx->tile_max_jobs; c.threads = ctx->plan_threads;
     c.tile_max_spans = ctx->tile_max_spans;
+    c.sort_n = ctx->sort_n; c.sort_r1_n = ctx->sort_r1_n; c.sort_r3 = ctx->sort_r3; c.sorted_tile_jobs = ctx->sorted_tile_jobs;
     return c;
 }
 
@@ -308,17 +316,17 @@ const std::vector<unsigned long long> &micro_masks()
 
 // Tiles for plan positions [p0, p1) of the tile class `hi` (consecutive jobs in job order).  Appends
 // to tiles/spans (span_first relative to `spans`), fills tjobs[p] in place; returns the largest LDS image.
-uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, uint64_t p0, uint64_t p1,
+uint32_t build_tiles(const PlanCfg &cfg, bool hi, bool by_shape, uint32_t max_jobs, uint32_t max_spans, const RawVec<DevJob> &h_jobs, uint64_t p0, uint64_t p1,
                      std::vector<TileDesc> &tiles, std::vector<TileSpan> &spans, TileJob *tjobs)
 {
     const uint32_t lds_budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
-    const uint32_t max_jobs = hi ? kTileHiMaxJobs : cfg.tile_max_jobs;
     uint32_t tile_lds_max = 0;
     // profiling aid (scripts/valu_by_class.py), never set in production: RAWDTW_DEBUG_SKIP="lo,hi,r" leaves the jobs with
     // lo <= longer side <= hi (and radius r, -1 = any) staged but unscored (their cost reads 0), to attribute kernel time
     int dbg_lo = 0, dbg_hi = -1, dbg_r = -1;
     const char *dbg_env = getenv("RAWDTW_DEBUG_SKIP");
     const bool dbg_skip = dbg_env && sscanf(dbg_env, "%d,%d,%d", &dbg_lo, &dbg_hi, &dbg_r) == 3;
+    const bool dbg_noload = getenv("RAWDTW_DEBUG_SORT_NOLOAD") != nullptr, dbg_aux = getenv("RAWDTW_DEBUG_SORT_AUX") != nullptr;
     struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
     std::vector<Sp> cur;
     struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
@@ -335,7 +343,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
         for (Sp &s : cur) {
             s.lds = off;
             const uint32_t len4 = span_cost(s);
-            spans.push_back(TileSpan{s.start, off, (len4 / 4) | (s.is_ref ? 0x80000000u : 0u)});
+            spans.push_back(TileSpan{s.start, off, ((dbg_noload && by_shape) ? 0u : (len4 / 4)) | (s.is_ref ? 0x80000000u : 0u)});
             off += len4;
         }
         tile_lds_max = std::max(tile_lds_max, off);
@@ -363,7 +371,8 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
             ia.swap(ib);
         }
         for (uint32_t q = 0; q < cnt; q++) tjobs[t_first + q] = tmp[ia[q]];
-        tiles.push_back(TileDesc{(uint32_t)t_first, (uint32_t)(t_end - t_first), span_first, (uint32_t)cur.size()});
+        tiles.push_back(TileDesc{(uint32_t)t_first, (uint32_t)(t_end - t_first), span_first,
+                                 (uint32_t)cur.size() | (by_shape && !hi ? 0x80000000u : 0u)});
         cur.clear(); pend.clear(); lds_used = 0; t_first = t_end;
     };
     // find the span that holds (or can be grown to hold) window [w0, w0+len) of the given arena; -1: a new one
@@ -371,7 +380,9 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
         extra = 0;
         for (int q = (int)cur.size() - 1; q >= 0 && q >= (int)cur.size() - 8; q--) {
             Sp &s = cur[q];
-            if (s.is_ref != is_ref || w0 < s.start || w0 > s.end) continue;
+            // a window that starts a little past the span still extends it (a part that left for another class leaves
+            // a hole in its chain's windows; staging the hole is cheaper than another span)
+            if (s.is_ref != is_ref || w0 < s.start || w0 > s.end + kSpanGapFloats) continue;
             if (w0 + len <= s.end) return q; // already covered
             const uint32_t before = span_cost(s);
             Sp grown = s; grown.end = w0 + len;
@@ -392,7 +403,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
             int qa = place(a0, NA, a_ref, ea);
             int qb = place(b0, NB, b_ref, eb); // a fresh span for A cannot serve B: other arena
             const uint32_t new_spans = (qa < 0) + (qb < 0);
-            if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > (hi ? kTileMaxSpans : cfg.tile_max_spans) ||
+            if (attempt == 0 && (lds_used + ea + eb > lds_budget || cur.size() + new_spans > max_spans ||
                                  p - t_first >= max_jobs)) {
                 close_tile(p);
                 continue; // retry in the fresh tile
@@ -405,7 +416,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, const RawVec<DevJob> &h_jobs, 
             pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
             TileJob &tj = tjobs[p];
             tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
-            tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
+            tj.aux = (dbg_aux && by_shape) ? (uint32_t)p : d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
             if (!hi && NA <= (uint32_t)cfg.micro_max_n) { // micro path: band membership from a per-shape bitmask
                 tj.pad = ((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + (uint32_t)d.R;
                 tj.R = NA <= 4 ? 0 : 1;
@@ -454,7 +465,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
     cls.resize(n_jobs);
     Rv.resize(n_jobs);
     struct PerThread {
-        uint64_t n0 = 0, n1 = 0, nother = 0, alg_bytes = 0;
+        uint64_t n0 = 0, n1 = 0, n2 = 0, nother = 0, alg_bytes = 0;
         uint64_t bad = ~0ull; int bad_status = RAWDTW_OK; const char *bad_msg = nullptr;
         double work0 = 0, work1 = 0;
         char pad[64];
@@ -492,7 +503,11 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
                     continue;
                 }
                 const uint32_t K = (uint32_t)R + 1;
-                if (R <= cfg.lane_max_radius && N <= cfg.lane_max_n) c = 0;
+                if (R <= cfg.lane_max_radius && N <= cfg.lane_max_n) {
+                    c = 0;
+                    if ((cfg.sort_n && N >= cfg.sort_n) || (cfg.sort_r1_n && R == 1 && N >= cfg.sort_r1_n) || (cfg.sort_r3 && R == 3))
+                        c = 2; // rare inside a tile: tiled by shape, full waves of one shape
+                }
                 else if (R <= kMaxLaneRadiusHi && cfg.lane_hi && N <= cfg.lane_hi_max_n) c = 1; // the wide instance covers radii 0..8
                 else if (K <= 16 && cfg.grp16) c = 39; // four jobs per wave (16-lane rows)
                 else if (K <= 64u * kMaxWregChunks) {
@@ -508,7 +523,8 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
             if (c == 0) { P.n0++; P.work0 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
             else {
                 if (c == 1) { P.n1++; P.work1 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
-                P.nother++; // class 1 is sorted with the rest (by shape), it only shares the tile kernel with class 0
+                if (c == 2) { P.n2++; P.work0 += (double)N * std::min<double>(2.0 * R + 1.0, NY); }
+                P.nother++; // classes 1 and 2 are sorted with the rest (by shape); they only share the tile kernels
             }
         }
     });
@@ -521,15 +537,15 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
             return pt[t_bad].bad_status;
         }
     }
-    uint64_t n0 = 0, n1 = 0, nother = 0, alg_bytes = 0;
+    uint64_t n0 = 0, n1 = 0, n2 = 0, nother = 0, alg_bytes = 0;
     double work0 = 0, work1 = 0;
     std::vector<uint64_t> base0(T), baseo(T);
     for (int t = 0; t < T; t++) {
         base0[t] = n0; baseo[t] = nother;
-        n0 += pt[t].n0; n1 += pt[t].n1; nother += pt[t].nother; alg_bytes += pt[t].alg_bytes;
+        n0 += pt[t].n0; n1 += pt[t].n1; n2 += pt[t].n2; nother += pt[t].nother; alg_bytes += pt[t].alg_bytes;
         work0 += pt[t].work0; work1 += pt[t].work1;
     }
-    pl->n_tile_jobs = n0 + n1;
+    pl->n_tile_jobs = n0 + n1 + n2; // plan order: [class 0, job order][class 2, by shape][class 1, by shape][the rest]
 
     // ---- pass B: plan positions.  The bulk tile class keeps job order (consecutive parts share their spans); the
     // rest is sorted by (class, shape).  Class 1 (wide-band tile instance) sorts first, by (radius, longer side,
@@ -555,7 +571,8 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
                 const rawdtw_job_t &j = jobs[k];
                 const uint64_t N = std::max(j.n, j.m), NY = std::min(j.n, j.m), lim = (1ull << 28) - 1;
                 uint64_t key = ((uint64_t)c << 56) | ((lim - std::min(N, lim)) << 28) | (lim - std::min(NY, lim));
-                if (c == 1) key = (1ull << 56) | ((uint64_t)Rv[k] << 40) | ((255 - std::min<uint64_t>(N, 255)) << 20) | (255 - std::min<uint64_t>(NY, 255));
+                if (c == 1 || c == 2) // top byte: class 2 sorts before class 1
+                    key = ((uint64_t)(c == 2 ? 1 : 2) << 56) | ((uint64_t)Rv[k] << 40) | ((255 - std::min<uint64_t>(N, 255)) << 20) | (255 - std::min<uint64_t>(NY, 255));
                 keyed[qo++] = Keyed{key, (uint32_t)k};
             }
         }
@@ -564,18 +581,19 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
     std::sort(keyed.begin(), keyed.end(), [](const Keyed &x, const Keyed &y) {
         return x.key != y.key ? x.key < y.key : x.idx < y.idx;
     });
-    for (uint64_t q = 0; q < nother; q++) put(n0 + q, keyed[q].idx); // class 1 first: positions [n0, n0 + n1)
+    for (uint64_t q = 0; q < nother; q++) put(n0 + q, keyed[q].idx); // classes 2 and 1 first: positions [n0, n0 + n2 + n1)
     lap("sort-rest");
 
     // ---- launches: the two tile classes, then maximal runs of equal class; workspace of the full-matrix jobs ----
-    const uint64_t n_dev = nother - n1; // jobs with a device record (all but the tile classes)
+    const uint64_t n_dev = nother - n1 - n2; // jobs with a device record (all but the tile classes)
+    const uint64_t n12 = n1 + n2;
     pl->h_aux.assign(n_dev, FullAux{0, 0}); // indexed like d_jobs: plan position - n_tile_jobs
-    if (n0) pl->launches.push_back(Launch{kKindBandLane, 0, 0, n0});
-    if (n1) pl->launches.push_back(Launch{kKindBandLaneHi, 0, n0, n1});
+    if (n0 + n2) pl->launches.push_back(Launch{kKindBandLane, 0, 0, n0 + n2});
+    if (n1) pl->launches.push_back(Launch{kKindBandLaneHi, 0, n0 + n2, n1});
     uint64_t bnd = 0, dirb = 0;
     for (uint64_t q = 0; q < n_dev; q++) {
         const uint64_t p = pl->n_tile_jobs + q;
-        const uint64_t c = keyed[n1 + q].key >> 56;
+        const uint64_t c = keyed[n12 + q].key >> 56;
         const DevJob &j = pl->h_jobs[p];
         if (c >= 56) {
             const int rpl = c == 60 ? 8 : 1 << (c - 56);
@@ -590,7 +608,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
                 dirb += (dir_bytes_for(j.n, j.m, rpl) + 255) & ~255ull;
             }
         }
-        if (q == 0 || (keyed[n1 + q - 1].key >> 56) != c) {
+        if (q == 0 || (keyed[n12 + q - 1].key >> 56) != c) {
             Launch L{};
             L.first = p; L.count = 0;
             if (c == 39) { L.kind = kKindBandWreg; L.param = -16; }
@@ -604,25 +622,38 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
 
     // ---- tiles: each thread tiles a contiguous run of the job-ordered positions (a tile never spans two runs) ----
     ht.tjobs.resize(pl->n_tile_jobs);
-    if (n0 && cfg.micro_max_n > 0) ht.masks = micro_masks();
+    if ((n0 || n2) && cfg.micro_max_n > 0) ht.masks = micro_masks();
     for (Launch &TL : pl->launches) {
         if (TL.kind != kKindBandLane && TL.kind != kKindBandLaneHi) continue;
         const bool hi = TL.kind == kKindBandLaneHi;
-        const int TT = (int)std::min<uint64_t>(T, TL.count / 8192 + 1);
-        std::vector<std::vector<TileDesc>> tl(TT);
-        std::vector<std::vector<TileSpan>> sp(TT);
-        std::vector<uint32_t> lmax(TT, 0);
-        parallel_for(TT, [&](int t) {
-            const uint64_t a = TL.first + TL.count * (uint64_t)t / TT, b = TL.first + TL.count * (uint64_t)(t + 1) / TT;
-            lmax[t] = build_tiles(cfg, hi, pl->h_jobs, a, b, tl[t], sp[t], ht.tjobs.data());
-        });
         const size_t tiles_before = ht.tiles.size();
         uint32_t tile_lds_max = 0;
-        for (int t = 0; t < TT; t++) {
-            const uint32_t span_base = (uint32_t)ht.spans.size();
-            for (TileDesc d : tl[t]) { d.span_first += span_base; ht.tiles.push_back(d); }
-            ht.spans.insert(ht.spans.end(), sp[t].begin(), sp[t].end());
-            tile_lds_max = std::max(tile_lds_max, lmax[t]);
+        // the bulk launch has two runs: class 0 in job order, then class 2 by shape (small tiles of whole waves)
+        // (a by-shape tile holds two spans per job: nothing is shared)
+        struct Run { uint64_t first, count; uint32_t max_jobs, max_spans; bool by_shape; };
+        std::vector<Run> runs;
+        if (hi) runs.push_back(Run{TL.first, TL.count, kTileHiMaxJobs, 2 * kTileHiMaxJobs, true});
+        else {
+            if (n0) runs.push_back(Run{0, n0, cfg.tile_max_jobs, cfg.tile_max_spans, false});
+            if (n2) runs.push_back(Run{n0, n2, cfg.sorted_tile_jobs, std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs), true});
+        }
+        for (const Run &run : runs) {
+            const int TT = (int)std::min<uint64_t>(T, run.count / 8192 + 1);
+            std::vector<std::vector<TileDesc>> tl(TT);
+            std::vector<std::vector<TileSpan>> sp(TT);
+            std::vector<uint32_t> lmax(TT, 0);
+            // thread boundaries at multiples of 64 jobs: a sorted run is cut into whole waves
+            auto cut = [&](int t) { return t >= TT ? run.count : (run.count * (uint64_t)t / TT) & ~63ull; };
+            parallel_for(TT, [&](int t) {
+                lmax[t] = build_tiles(cfg, hi, run.by_shape, run.max_jobs, run.max_spans, pl->h_jobs, run.first + cut(t), run.first + cut(t + 1), tl[t], sp[t],
+                                      ht.tjobs.data());
+            });
+            for (int t = 0; t < TT; t++) {
+                const uint32_t span_base = (uint32_t)ht.spans.size();
+                for (TileDesc d : tl[t]) { d.span_first += span_base; ht.tiles.push_back(d); }
+                ht.spans.insert(ht.spans.end(), sp[t].begin(), sp[t].end());
+                tile_lds_max = std::max(tile_lds_max, lmax[t]);
+            }
         }
         if (hi) { pl->n_tiles_hi = ht.tiles.size() - tiles_before; pl->tile_hi_lds_floats = tile_lds_max; }
         else { pl->n_tiles = ht.tiles.size() - tiles_before; pl->tile_lds_floats = tile_lds_max; }
@@ -700,12 +731,14 @@ std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint6
     std::vector<uint8_t> tseen(n_jobs, 0);
     uint64_t next_job = 0;
     for (size_t ti = 0; ti < ht.tiles.size(); ti++) {
-        const TileDesc &t = ht.tiles[ti];
+        TileDesc t = ht.tiles[ti];
+        t.n_spans &= 0x7fffffffu;
         const bool hi = ti >= pl->n_tiles;
         const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
         if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
         next_job += t.n_jobs;
-        if (t.n_jobs > (hi ? kTileHiMaxJobs : cfg.tile_max_jobs) || t.n_spans > (hi ? kTileMaxSpans : cfg.tile_max_spans) || t.n_spans == 0)
+        if (t.n_jobs > (hi ? kTileHiMaxJobs : std::max(cfg.tile_max_jobs, cfg.sorted_tile_jobs)) || t.n_spans == 0 ||
+            t.n_spans > (hi ? 2 * kTileHiMaxJobs : std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs)))
             return "tile " + S(ti) + ": too many jobs or spans";
         if ((uint64_t)t.span_first + t.n_spans > ht.spans.size()) return "tile " + S(ti) + ": spans out of range";
         uint32_t off = 0;
@@ -1047,6 +1080,10 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "sort_n")) { ctx->sort_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
+    if (!strcmp(name, "sort_r1_n")) { ctx->sort_r1_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
+    if (!strcmp(name, "sort_r3")) { ctx->sort_r3 = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
@@ -1174,6 +1211,10 @@ int rawdtw_plan_dry_run(uint64_t n_events, uint64_t n_reference, const rawdtw_jo
         else if (!strcmp(nm, "tile_lds_floats")) cfg.tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 1024), 40000);
         else if (!strcmp(nm, "tile_max_jobs")) cfg.tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 64), 65535);
         else if (!strcmp(nm, "tile_max_spans")) cfg.tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 8), 4096);
+        else if (!strcmp(nm, "sort_n")) cfg.sort_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 0), 255);
+        else if (!strcmp(nm, "sort_r1_n")) cfg.sort_r1_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 0), 255);
+        else if (!strcmp(nm, "sort_r3")) cfg.sort_r3 = v != 0;
+        else if (!strcmp(nm, "sorted_tile_jobs")) cfg.sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 16), 1024);
         else if (!strcmp(nm, "full_wg")) cfg.full_wg = v != 0;
         else if (!strcmp(nm, "grp16")) cfg.grp16 = v != 0;
         else if (!strcmp(nm, "micro_max_n")) cfg.micro_max_n = v >= 8 ? 8 : (v >= 4 ? 4 : 0);

@@ -38,7 +38,7 @@ enum LaunchKind : uint32_t {
 };
 
 // Tile kernel records (planner output)
-struct TileDesc { uint32_t job_first, n_jobs, span_first, n_spans; };
+struct TileDesc { uint32_t job_first, n_jobs, span_first, n_spans; }; // n_spans bit 31: many short spans (a by-shape tile)
 struct TileSpan {
     uint64_t src;          // float index of the span's first (16-byte aligned) element in its arena
     uint32_t lds_off;      // float offset in the tile's LDS image (multiple of 4)
@@ -72,6 +72,7 @@ constexpr uint32_t kTileLdsFloats = 5120;  // 20 KiB -> 8 workgroups per CU (swe
 constexpr uint32_t kTileMaxJobs = 1024;
 constexpr uint32_t kTileHiLdsFloats = 14336, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;
+constexpr uint32_t kSpanGapFloats = 48; // a window starting this close behind a span extends it instead of opening a new one
 constexpr int kFullWgWaves = 4;        // waves per job in the pipelined-strip variant of the full-matrix kernel
 constexpr int kMaxWregChunks = 32;     // register-resident wave kernel: radius + 1 <= 64 * 32
 constexpr int kMaxWaveBandK = 13000;   // 3*K floats of LDS must fit 160 KiB

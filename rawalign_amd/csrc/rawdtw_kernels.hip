@@ -315,13 +315,51 @@ __device__ __forceinline__ void tile_block(float *win, const TileDesc td, const 
     auto load_job = [&](uint32_t r) { return tjobs[td.job_first + (r < td.n_jobs ? r : td.n_jobs - 1)]; };
     // the first round's records travel while the spans are staged
     TileJob tj_next = load_job((uint32_t)tid);
-    // stage the spans
-    for (uint32_t sidx = 0; sidx < td.n_spans; sidx++) {
-        const TileSpan sp = spans[td.span_first + sidx];
-        const uint32_t chunks = sp.chunks_arena & 0x7fffffffu;
-        const float4 *src = reinterpret_cast<const float4 *>(((sp.chunks_arena >> 31) ? ref : ev) + sp.src);
-        float4 *dst = reinterpret_cast<float4 *>(win + sp.lds_off);
-        for (uint32_t k = tid; k < chunks; k += THREADS) dst[k] = src[k];
+    // stage the spans: a few long ones (consecutive parts of a chain) with the whole workgroup on each, or -- tiles of
+    // shape-sorted jobs: two short spans per job -- eight lanes per span, THREADS/8 spans at a time
+    if (td.n_spans >> 31) {
+        // four spans per lane group and pass: all descriptors first, then every chunk of the four spans (up to 24
+        // chunks = 96 floats each, more than the longest tile-eligible window), then the LDS writes -- two memory
+        // round trips per pass.  The staging registers are dead before the DP's become live.
+        constexpr uint32_t G = THREADS / 8, U = 4, CH = 3;
+        const uint32_t g = (uint32_t)tid >> 3, l = (uint32_t)tid & 7u;
+        const uint32_t n_spans = td.n_spans & 0x7fffffffu;
+        for (uint32_t s0 = g; s0 < n_spans; s0 += G * U) {
+            TileSpan sp[U];
+            float4 v[U][CH];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t sidx = s0 + u * G;
+                sp[u] = spans[td.span_first + (sidx < n_spans ? sidx : s0)];
+                if (sidx >= n_spans) sp[u].chunks_arena = 0;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t chunks = sp[u].chunks_arena & 0x7fffffffu;
+                const float4 *src = reinterpret_cast<const float4 *>(((sp[u].chunks_arena >> 31) ? ref : ev) + sp[u].src);
+#pragma unroll
+                for (uint32_t c = 0; c < CH; c++)
+                    if (l + 8 * c < chunks) v[u][c] = src[l + 8 * c];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t chunks = sp[u].chunks_arena & 0x7fffffffu;
+                const float4 *src = reinterpret_cast<const float4 *>(((sp[u].chunks_arena >> 31) ? ref : ev) + sp[u].src);
+                float4 *dst = reinterpret_cast<float4 *>(win + sp[u].lds_off);
+#pragma unroll
+                for (uint32_t c = 0; c < CH; c++)
+                    if (l + 8 * c < chunks) dst[l + 8 * c] = v[u][c];
+                for (uint32_t k = l + 8 * CH; k < chunks; k += 8) dst[k] = src[k]; // (merged spans can be longer)
+            }
+        }
+    } else {
+        for (uint32_t sidx = 0; sidx < td.n_spans; sidx++) {
+            const TileSpan sp = spans[td.span_first + sidx];
+            const uint32_t chunks = sp.chunks_arena & 0x7fffffffu;
+            const float4 *src = reinterpret_cast<const float4 *>(((sp.chunks_arena >> 31) ? ref : ev) + sp.src);
+            float4 *dst = reinterpret_cast<float4 *>(win + sp.lds_off);
+            for (uint32_t k = tid; k < chunks; k += THREADS) dst[k] = src[k];
+        }
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);

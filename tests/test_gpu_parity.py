@@ -388,6 +388,8 @@ def test_planner_options_do_not_change_results(oracle):
         {"full_wg": 0},
         {"lane_max_radius": 0, "lane_max_n": 8, "grp16": 1},
         {"merge_small": 0},
+        {"sort_n": 17, "sort_r1_n": 9, "sort_r3": 1},
+        {"sort_n": 5, "sorted_tile_jobs": 128},
         {"merge_small": 0, "grp16": 0},
         {"plan_threads": 1},
         {"plan_threads": 7, "tile_max_jobs": 64},
