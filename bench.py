@@ -33,8 +33,8 @@ SEED = 20231005 + 2  # seed = 20231005 + config id
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
     ap.add_argument("--inflight", type=int, default=4,
@@ -210,8 +210,8 @@ def main():
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
 
         def kernel_name(kind, param):
-            if kind == 8 and param == -16:
-                return "band_grp16"
+            if kind == 8 and param in (-16, -8):
+                return "band_grp16" if param == -16 else "band_grp8"
             return ra.Engine.KIND_NAMES.get(kind, str(kind))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")

@@ -67,7 +67,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "serial_launches" 0/1: with side streams, run a batch's launches in sequence anyway
  *   "lane_max_radius" 0..3: largest post-slant radius on the tile kernel; "lane_max_n": longest side there
  *   "lane_hi", "lane_hi_max_n": optional second tile instance for radii up to 8
- *   "micro_max_n" 0/4/8, "grp16" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs", "tile_max_spans",
+ *   "micro_max_n" 0/4/8, "grp16" 0/1, "grp8" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs", "tile_max_spans",
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)

@@ -57,6 +57,7 @@ struct rawdtw_ctx {
     uint32_t lane_hi_max_n = 96;
     int micro_max_n = 8; // shapes with longer side <= this use the micro paths (0: none, 4: micro4 only)
     bool grp16 = true; // bands of at most 16 offsets: four jobs per wave (else one job per wave)
+    bool grp8 = true;  // ... and of at most 8 offsets: eight jobs per wave
     bool full_wg = true; // full-matrix jobs with >= 3 strips: four waves per job, pipelined strips
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
@@ -257,7 +258,7 @@ struct PlanCfg {
     uint64_t n_ev = 0, n_ref = 0;
     int lane_max_radius = kMaxLaneRadius;
     uint32_t lane_max_n = kLaneMaxN, lane_hi_max_n = 96;
-    bool lane_hi = false, grp16 = true, full_wg = true;
+    bool lane_hi = false, grp16 = true, grp8 = true, full_wg = true;
     int micro_max_n = 8;
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs, tile_max_spans = kTileMaxSpans;
     int threads = 0; // 0: pick from the job count and the machine
@@ -282,7 +283,7 @@ PlanCfg cfg_of(const rawdtw_ctx *ctx)
     PlanCfg c;
     c.n_ev = ctx->n_ev; c.n_ref = ctx->n_ref;
     c.lane_max_radius = ctx->lane_max_radius; c.lane_max_n = ctx->lane_max_n; c.lane_hi_max_n = ctx->lane_hi_max_n;
-    c.lane_hi = ctx->lane_hi; c.grp16 = ctx->grp16; c.full_wg = ctx->full_wg; c.micro_max_n = ctx->micro_max_n;
+    c.lane_hi = ctx->lane_hi; c.grp16 = ctx->grp16; c.grp8 = ctx->grp8; c.full_wg = ctx->full_wg; c.micro_max_n = ctx->micro_max_n;
     c.tile_lds_floats = ctx->tile_lds_floats; c.tile_max_jobs = ctx->tile_max_jobs; c.threads = ctx->plan_threads;
     c.tile_max_spans = ctx->tile_max_spans;
     c.sort_n = ctx->sort_n; c.sort_r1_n = ctx->sort_r1_n; c.sort_r3 = ctx->sort_r3; c.sorted_tile_jobs = ctx->sorted_tile_jobs;
@@ -509,6 +510,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
                         c = 2; // rare inside a tile: tiled by shape, full waves of one shape
                 }
                 else if (R <= kMaxLaneRadiusHi && cfg.lane_hi && N <= cfg.lane_hi_max_n) c = 1; // the wide instance covers radii 0..8
+                else if (K <= 8 && cfg.grp16 && cfg.grp8) c = 38; // eight jobs per wave (8-lane groups)
                 else if (K <= 16 && cfg.grp16) c = 39; // four jobs per wave (16-lane rows)
                 else if (K <= 64u * kMaxWregChunks) {
                     uint32_t chunks = 1, lg = 0;
@@ -611,7 +613,8 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
         if (q == 0 || (keyed[n12 + q - 1].key >> 56) != c) {
             Launch L{};
             L.first = p; L.count = 0;
-            if (c == 39) { L.kind = kKindBandWreg; L.param = -16; }
+            if (c == 38) { L.kind = kKindBandWreg; L.param = -8; }
+            else if (c == 39) { L.kind = kKindBandWreg; L.param = -16; }
             else if (c < 48) { L.kind = kKindBandWreg; L.param = c == 40 ? 0 : 1 << (c - 40); }
             else if (c < 56) { L.kind = kKindBandWave; L.param = 3 * kMaxWaveBandK; }
             else { L.kind = traceback ? kKindFullTb : kKindFullWave; L.param = c == 60 ? 8 + 256 : 1 << (c - 56); }
@@ -874,8 +877,8 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
     float *out = pl->d_cost; // job order: every kernel stores at out[job.aux]
     hipError_t e = hipSuccess;
     {   // timing experiments only (RAWDTW_OPTS=debug_skip_kinds=mask, bit = launch kind, the 16-lane-row kernel = bit 15)
-        const bool grp16 = L.kind == kKindBandWreg && L.param == -16;
-        if (ctx->debug_skip_kinds & (1u << (grp16 ? 15 : L.kind))) return RAWDTW_OK;
+        const bool grp = L.kind == kKindBandWreg && (L.param == -16 || L.param == -8);
+        if (ctx->debug_skip_kinds & (1u << (grp ? 15 : L.kind))) return RAWDTW_OK;
     }
     switch (L.kind) {
     case kKindBandLane:
@@ -905,7 +908,7 @@ int run_launch(rawdtw_ctx *ctx, rawdtw_plan *pl, const Launch &L, hipStream_t st
 }
 
 // Which launches of a plan travel as one k_band_merged launch (indices into pl->launches, -1 = none).
-struct MergeSel { int tile = -1, grp16 = -1, wreg = -1; bool on() const { return tile >= 0; } };
+struct MergeSel { int tile = -1, grp16 = -1, grp8 = -1, wreg = -1; bool on() const { return tile >= 0; } };
 
 MergeSel merge_of(const rawdtw_ctx *ctx, const rawdtw_plan *pl)
 {
@@ -916,9 +919,10 @@ MergeSel merge_of(const rawdtw_ctx *ctx, const rawdtw_plan *pl)
         const Launch &L = pl->launches[i];
         if (L.kind == kKindBandLane) tile = (int)i;
         else if (L.kind == kKindBandWreg && L.param == -16) m.grp16 = (int)i;
+        else if (L.kind == kKindBandWreg && L.param == -8) m.grp8 = (int)i;
         else if (L.kind == kKindBandWreg && L.param == 0) m.wreg = (int)i;
     }
-    if (tile >= 0 && (m.grp16 >= 0 || m.wreg >= 0)) m.tile = tile;
+    if (tile >= 0 && (m.grp16 >= 0 || m.grp8 >= 0 || m.wreg >= 0)) m.tile = tile;
     else m = MergeSel{};
     return m;
 }
@@ -932,10 +936,10 @@ int run_merged(rawdtw_ctx *ctx, rawdtw_plan *pl, const MergeSel &m, hipStream_t 
         n = L.count;
         return pl->d_jobs + (L.first - pl->n_tile_jobs);
     };
-    uint64_t n_w = 0, n_g = 0;
-    const DevJob *wj = recs(m.wreg, n_w), *gj = recs(m.grp16, n_g);
+    uint64_t n_w = 0, n_g = 0, n_h = 0;
+    const DevJob *wj = recs(m.wreg, n_w), *gj = recs(m.grp16, n_g), *hj = recs(m.grp8, n_h);
     hipError_t e = launch_band_merged(pl->d_tiles, pl->n_tiles, pl->d_spans, pl->d_tjobs, pl->d_masks, pl->tile_lds_floats,
-                                      wj, n_w, gj, n_g, ctx->d_ev, ctx->d_ref, pl->d_cost, stream);
+                                      wj, n_w, gj, n_g, hj, n_h, ctx->d_ev, ctx->d_ref, pl->d_cost, stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "kernel launch");
     return RAWDTW_OK;
 }
@@ -959,7 +963,7 @@ int run_all_launches(rawdtw_ctx *ctx, rawdtw_plan *pl, hipEvent_t *ev)
         const int sl = fork ? (int)(q % (ctx->n_side + 1)) : 0;
         hipStream_t s = sl == 0 ? ctx->stream : ctx->side[sl - 1];
         if (ev && hipEventRecord(ev[2 * i], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.wreg)) { /* travels inside the tile launch */ }
+        if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.grp8 || (int)i == mg.wreg)) { /* travels inside the tile launch */ }
         else if (mg.on() && (int)i == mg.tile) { if (st == RAWDTW_OK) st = run_merged(ctx, pl, mg, s); }
         else if (st == RAWDTW_OK) st = run_launch(ctx, pl, pl->launches[i], s);
         if (st == RAWDTW_OK && ev && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) st = RAWDTW_ERR_DEVICE;
@@ -1090,6 +1094,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_spans")) { ctx->tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 4096); return RAWDTW_OK; }
     if (!strcmp(name, "full_wg")) { ctx->full_wg = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "grp16")) { ctx->grp16 = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "grp8")) { ctx->grp8 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "micro_max_n")) { ctx->micro_max_n = value >= 8 ? 8 : (value >= 4 ? 4 : 0); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }
@@ -1217,6 +1222,7 @@ int rawdtw_plan_dry_run(uint64_t n_events, uint64_t n_reference, const rawdtw_jo
         else if (!strcmp(nm, "sorted_tile_jobs")) cfg.sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 16), 1024);
         else if (!strcmp(nm, "full_wg")) cfg.full_wg = v != 0;
         else if (!strcmp(nm, "grp16")) cfg.grp16 = v != 0;
+        else if (!strcmp(nm, "grp8")) cfg.grp8 = v != 0;
         else if (!strcmp(nm, "micro_max_n")) cfg.micro_max_n = v >= 8 ? 8 : (v >= 4 ? 4 : 0);
         else if (!strcmp(nm, "lane_hi")) cfg.lane_hi = v != 0;
         else if (!strcmp(nm, "lane_hi_max_n")) cfg.lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(v, 8), 200);
@@ -1720,8 +1726,9 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
         k = kKindBandMerged;
         add(L);
         if (mg.grp16 >= 0) add(pl->launches[mg.grp16]);
+        if (mg.grp8 >= 0) add(pl->launches[mg.grp8]);
         if (mg.wreg >= 0) add(pl->launches[mg.wreg]);
-    } else if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.wreg)) {
+    } else if (mg.on() && ((int)i == mg.grp16 || (int)i == mg.grp8 || (int)i == mg.wreg)) {
         /* folded into the merged launch: nothing of its own */
     } else add(L);
     if (kind) *kind = k;

@@ -92,8 +92,8 @@ struct FullAux {
 
 hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                               const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,
-                              const DevJob *gjobs, uint64_t n_g, const float *ev, const float *ref, float *out,
-                              hipStream_t s);
+                              const DevJob *gjobs, uint64_t n_g, const DevJob *hjobs, uint64_t n_h, const float *ev,
+                              const float *ref, float *out, hipStream_t s);
 hipError_t launch_band_tile(bool hi, int threads, const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                             const unsigned long long *masks, uint32_t lds_floats, const float *ev, const float *ref,
                             float *out, hipStream_t s);

@@ -633,12 +633,17 @@ __device__ __forceinline__ float lane_gather(float v, int src_lane)
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }
 
-__device__ __forceinline__ void grp16_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
+template <int W>
+__device__ __forceinline__ void grp_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
                                            const float *__restrict__ ev, const float *__restrict__ ref,
                                            float *__restrict__ out)
 {
-    const int p = lane & 15, rowbase = lane & 48;
-    const uint32_t idx = wave * 4u + (uint32_t)(lane >> 4);
+    static_assert(W == 16 || W == 8, "group width");
+    const int p = lane & (W - 1), rowbase = lane & (64 - W);
+    const uint32_t idx = wave * (64u / W) + (uint32_t)(lane / W);
+    // neighbour shifts inside a group: a DPP row shift; 8-lane groups patch the lane at the group's edge
+    auto shl1 = [&](float v, float fill) { const float t = row_shl1(v, fill); return (W == 8 && p == 7) ? fill : t; };
+    auto shr1 = [&](float v, float fill) { const float t = row_shr1(v, fill); return (W == 8 && p == 0) ? fill : t; };
     const bool have = idx < count;
     const DevJob jb = jobs[have ? idx : count - 1];
     const float *A = ev + jb.read_off;
@@ -661,22 +666,21 @@ __device__ __forceinline__ void grp16_wave(const DevJob *__restrict__ jobs, uint
     float p1 = (p == HP + SH) ? dist(A[0], B[0]) : kInf, p2 = kInf;
     float ap = ldA(HP + SH - p), bp = ldB(p - HP - SH);
     const bool in_sec = p < S, in_prim = (p - SH) >= 0 && (p - SH) < P;
-    const int a0 = HP + SH + 1, b0 = 16 - HP - SH;
-    float acur = ldA(a0 + p), anxt = ldA(a0 + 16 + p);
-    float bcur = ldB(b0 + p), bnxt = ldB(b0 + 16 + p);
+    const int a0 = HP + SH + 1, b0 = W - HP - SH;
+    float acur = ldA(a0 + p), anxt = ldA(a0 + W + p);
+    float bcur = ldB(b0 + p), bnxt = ldB(b0 + W + p);
 
     int row = 0;
     uint32_t rem = 0;
     bool prev_adv = false;
     // the wave runs as long as its longest row
-    uint32_t Nmax = (uint32_t)__builtin_amdgcn_readlane((int)N, 0);
-    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 16));
-    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 32));
-    Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, 48));
+    uint32_t Nmax = 1;
+#pragma unroll
+    for (int g = 0; g < 64; g += W) Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, g));
     for (uint32_t col = 1; col < Nmax; col++) {
         const bool live = col < N;
-        const uint32_t ca = (col - 1) & 15u;
-        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 16 + p); }
+        const uint32_t ca = (col - 1) & (uint32_t)(W - 1);
+        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + W + p); }
         const float fresh_a = lane_gather(acur, rowbase + (int)ca);
         bool adv = false;
         if (live) {
@@ -684,14 +688,14 @@ __device__ __forceinline__ void grp16_wave(const DevJob *__restrict__ jobs, uint
             adv = rem >= N;
             if (adv) { rem -= N; row++; }
         }
-        const int cb = (row - 1) & 15;
-        if (adv && cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 16 + p); }
+        const int cb = (row - 1) & (W - 1);
+        if (adv && cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + W + p); }
         const float fresh_b = lane_gather(bcur, rowbase + cb);
         // shifted views of the two buffers (taken before anything is overwritten)
-        const float p1_up = row_shl1(p1, kInf);   // dp1[p+1]
+        const float p1_up = shl1(p1, kInf);   // dp1[p+1]
         if (adv) {
             // b-window: every lane takes its right neighbour's value
-            bp = row_shl1(bp, fresh_b);
+            bp = shl1(bp, fresh_b);
             // secondary antidiagonal (dtw.cpp:361-414), in place over p2: cell of lane p is (si - p, sj + p)
             const int si = (int)col - 1 + HP + SH, sj = row - HP - SH;
             float left = p1_up, top = p1, tl = p2;
@@ -705,18 +709,18 @@ __device__ __forceinline__ void grp16_wave(const DevJob *__restrict__ jobs, uint
         }
         if (live) {
             // a-window: every lane takes its left neighbour's value
-            ap = row_shr1(ap, fresh_a);
+            ap = shr1(ap, fresh_a);
             // primary antidiagonal (dtw.cpp:416-485): offset o = p - SH, cell (si - p, sj + p)
             const int si = (int)col + HP + SH, sj = row - HP - SH;
             const bool valid = in_prim && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
-            const float p2_dn = row_shr1(p2, kInf); // after a secondary: dp1[p-1]; otherwise dp0[p-1]
+            const float p2_dn = shr1(p2, kInf); // after a secondary: dp1[p-1]; otherwise dp0[p-1]
             if (adv) {
                 float left = p2;
                 if (!SH && p == P - 1) left = kInf;
                 const float v = min3f(p2_dn, left, p1) + dist(ap, bp);
                 p1 = valid ? v : kInf;
             } else {
-                float top = row_shr1(p1, kInf), tl = p2_dn;
+                float top = shr1(p1, kInf), tl = p2_dn;
                 if (p - SH == 0) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
                 const float v = min3f(top, p1, tl) + dist(ap, bp);
                 p2 = p1;
@@ -737,7 +741,16 @@ __global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jo
                                                    const float *__restrict__ ref,
                                                    float *__restrict__ out)
 {
-    grp16_wave(jobs, count, blockIdx.x, (int)threadIdx.x, ev, ref, out);
+    grp_wave<16>(jobs, count, blockIdx.x, (int)threadIdx.x, ev, ref, out);
+}
+
+// ... and eight jobs per wave for bands of at most 8 offsets (radius <= 7)
+__global__ __launch_bounds__(64) void k_band_grp8(const DevJob *__restrict__ jobs, uint32_t count,
+                                                  const float *__restrict__ ev,
+                                                  const float *__restrict__ ref,
+                                                  float *__restrict__ out)
+{
+    grp_wave<8>(jobs, count, blockIdx.x, (int)threadIdx.x, ev, ref, out);
 }
 
 template <int C>
@@ -782,11 +795,12 @@ __global__ __launch_bounds__(256) void k_band_merged(const TileDesc *__restrict_
                                                      const unsigned long long *__restrict__ masks,
                                                      const DevJob *__restrict__ wjobs, uint32_t n_w,
                                                      const DevJob *__restrict__ gjobs, uint32_t n_g,
+                                                     const DevJob *__restrict__ hjobs, uint32_t n_h,
                                                      const float *__restrict__ ev, const float *__restrict__ ref,
                                                      float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
-    const uint32_t nbw = (n_w + 3u) / 4u, nbg = (n_g + 15u) / 16u;
+    const uint32_t nbw = (n_w + 3u) / 4u, nbg = (n_g + 15u) / 16u, nbh = (n_h + 31u) / 32u;
     uint32_t b = blockIdx.x;
     const uint32_t wv = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -797,10 +811,15 @@ __global__ __launch_bounds__(256) void k_band_merged(const TileDesc *__restrict_
     }
     b -= nbw;
     if (b < nbg) {
-        grp16_wave(gjobs, n_g, b * 4u + wv, lane, ev, ref, out);
+        grp_wave<16>(gjobs, n_g, b * 4u + wv, lane, ev, ref, out);
         return;
     }
     b -= nbg;
+    if (b < nbh) {
+        grp_wave<8>(hjobs, n_h, b * 4u + wv, lane, ev, ref, out);
+        return;
+    }
+    b -= nbh;
     tile_block<0, kMaxLaneRadius, true, 256>(win, tiles[b], spans, tjobs, masks, ev, ref, out);
 }
 
@@ -1186,10 +1205,10 @@ hipError_t launch_band_tile(bool hi, int threads, const TileDesc *tiles, uint64_
 
 hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                               const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,
-                              const DevJob *gjobs, uint64_t n_g, const float *ev, const float *ref, float *out,
-                              hipStream_t s)
+                              const DevJob *gjobs, uint64_t n_g, const DevJob *hjobs, uint64_t n_h, const float *ev,
+                              const float *ref, float *out, hipStream_t s)
 {
-    const uint64_t blocks = (n_w + 3) / 4 + (n_g + 15) / 16 + n_tiles;
+    const uint64_t blocks = (n_w + 3) / 4 + (n_g + 15) / 16 + (n_h + 31) / 32 + n_tiles;
     if (blocks == 0) return hipSuccess;
     const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
     if (lds_bytes > 64 * 1024) {
@@ -1198,7 +1217,7 @@ hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const Til
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_band_merged, dim3((uint32_t)blocks), dim3(256), lds_bytes, s, tiles, spans, tjobs, masks, wjobs,
-                       (uint32_t)n_w, gjobs, (uint32_t)n_g, ev, ref, out);
+                       (uint32_t)n_w, gjobs, (uint32_t)n_g, hjobs, (uint32_t)n_h, ev, ref, out);
     return hipGetLastError();
 }
 
@@ -1229,6 +1248,9 @@ hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, cons
 {
     if (count == 0) return hipSuccess;
     switch (chunks) {
+    case -8: // eight jobs per wave, radius + 1 <= 8
+        hipLaunchKernelGGL(k_band_grp8, dim3((uint32_t)((count + 7) / 8)), dim3(64), 0, s, jobs, (uint32_t)count, ev, ref, out);
+        return hipGetLastError();
     case -16: // four jobs per wave, radius + 1 <= 16
         hipLaunchKernelGGL(k_band_grp16, dim3((uint32_t)((count + 3) / 4)), dim3(64), 0, s, jobs, (uint32_t)count, ev, ref, out);
         return hipGetLastError();

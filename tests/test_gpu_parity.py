@@ -385,6 +385,8 @@ def test_planner_options_do_not_change_results(oracle):
         {"lane_max_radius": 1, "lane_hi": 1, "lane_hi_max_n": 40, "serial_launches": 1},
         {"tile_lds_floats": 30000, "tile_max_jobs": 4096},
         {"grp16": 0},
+        {"grp8": 0},
+        {"grp8": 0, "merge_small": 0},
         {"full_wg": 0},
         {"lane_max_radius": 0, "lane_max_n": 8, "grp16": 1},
         {"merge_small": 0},

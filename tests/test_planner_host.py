@@ -70,7 +70,7 @@ def test_dry_run_sparse_batch_threads_agree():
         assert tiles1 <= tiles <= tiles1 + threads           # a tile never spans two threads' runs
 
 
-@pytest.mark.parametrize("options", [{}, {"micro_max_n": 0}, {"grp16": 0}, {"full_wg": 0}, {"lane_hi": 1},
+@pytest.mark.parametrize("options", [{}, {"micro_max_n": 0}, {"grp16": 0}, {"grp8": 0}, {"full_wg": 0}, {"lane_hi": 1},
                                      {"tile_lds_floats": 2048, "tile_max_jobs": 64}, {"lane_max_radius": 1, "lane_max_n": 32},
                                      {"sort_n": 17, "sort_r1_n": 9, "sort_r3": 1}, {"sort_n": 9, "sorted_tile_jobs": 128}])
 def test_dry_run_every_class(options):
