@@ -327,7 +327,6 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, bool by_shape, uint32_t max_jo
     int dbg_lo = 0, dbg_hi = -1, dbg_r = -1;
     const char *dbg_env = getenv("RAWDTW_DEBUG_SKIP");
     const bool dbg_skip = dbg_env && sscanf(dbg_env, "%d,%d,%d", &dbg_lo, &dbg_hi, &dbg_r) == 3;
-    const bool dbg_noload = getenv("RAWDTW_DEBUG_SORT_NOLOAD") != nullptr, dbg_aux = getenv("RAWDTW_DEBUG_SORT_AUX") != nullptr;
     struct Sp { uint64_t start, end; bool is_ref; uint32_t lds; }; // [start,end) in floats, start 4-aligned
     std::vector<Sp> cur;
     struct Pend { uint32_t spA, spB; uint64_t a0, b0; };
@@ -344,7 +343,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, bool by_shape, uint32_t max_jo
         for (Sp &s : cur) {
             s.lds = off;
             const uint32_t len4 = span_cost(s);
-            spans.push_back(TileSpan{s.start, off, ((dbg_noload && by_shape) ? 0u : (len4 / 4)) | (s.is_ref ? 0x80000000u : 0u)});
+            spans.push_back(TileSpan{s.start, off, (len4 / 4) | (s.is_ref ? 0x80000000u : 0u)});
             off += len4;
         }
         tile_lds_max = std::max(tile_lds_max, off);
@@ -417,7 +416,7 @@ uint32_t build_tiles(const PlanCfg &cfg, bool hi, bool by_shape, uint32_t max_jo
             pend.push_back(Pend{(uint32_t)qa, (uint32_t)qb, a0, b0});
             TileJob &tj = tjobs[p];
             tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
-            tj.aux = (dbg_aux && by_shape) ? (uint32_t)p : d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
+            tj.aux = d.aux; tj.pad = 0; tj.offA = tj.offB = 0;
             if (!hi && NA <= (uint32_t)cfg.micro_max_n) { // micro path: band membership from a per-shape bitmask
                 tj.pad = ((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + (uint32_t)d.R;
                 tj.R = NA <= 4 ? 0 : 1;

@@ -23,12 +23,8 @@ N = np.maximum(jobs["n"], jobs["m"]).astype(np.int64); M = np.minimum(jobs["n"],
 R0 = jobs["band_radius"].astype(np.int64); R = R0 + ((N - M) * R0 + N - 1) // N
 sub = np.ascontiguousarray(jobs[(R <= 3) & (N <= 73)])
 eng.set_option("merge_small", 0)
-for dbg in ((), ("RAWDTW_DEBUG_SORT_NOLOAD",), ("RAWDTW_DEBUG_SORT_AUX",), ("RAWDTW_DEBUG_SORT_NOLOAD", "RAWDTW_DEBUG_SORT_AUX")):
-  for k in ("RAWDTW_DEBUG_SORT_NOLOAD", "RAWDTW_DEBUG_SORT_AUX"): os.environ.pop(k, None)
-  for k in dbg: os.environ[k] = "1"
-  print("debug:", dbg)
-  for skip in ("0,255,-1",):
-    for sort in ({"sort_n": 0, "sort_r1_n": 0, "sort_r3": 0}, {"sort_n": 17, "sort_r1_n": 0, "sort_r3": 0}):
+for skip in (None, "0,16,-1", "0,255,-1"):
+    for sort in ({"sort_n": 0, "sort_r1_n": 0, "sort_r3": 0}, {"sort_n": 17, "sort_r1_n": 0, "sort_r3": 0}, {"sort_n": 17, "sort_r1_n": 9, "sort_r3": 1}):
         if skip is None: os.environ.pop("RAWDTW_DEBUG_SKIP", None)
         else: os.environ["RAWDTW_DEBUG_SKIP"] = skip
         for k, v in sort.items(): eng.set_option(k, v)
