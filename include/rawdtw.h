@@ -70,6 +70,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "micro_max_n" 0/4/8, "grp16" 0/1, "grp8" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs", "tile_max_spans",
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
+ *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create bins/tiles the bulk class on the device
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
  *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
  *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)
@@ -301,6 +302,12 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
                         const uint64_t *chain_off, const uint64_t *anchor_off,
                         const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
                         const uint32_t *read_base, rawdtw_batch **out);
+/* Self-check of a batch's plan (tests, bring-up): downloads the tile records the kernels will read and
+ * checks them against `jobs` (the batch's job list as rawdtw_batch_build_jobs gives it): every job in
+ * exactly one launch, every window staged inside its tile's LDS image at the right place.
+ * *device_planned tells whether the tile class was planned on the device. */
+int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const rawdtw_job_t *jobs,
+                             uint64_t n_jobs, int *device_planned, char *message, uint32_t message_cap);
 int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint64_t *n_chains);
 int rawdtw_batch_run(rawdtw_ctx *ctx, rawdtw_batch *batch);
 /* as rawdtw_plan_run_timed, with two more launches (kinds 6, 7) for fold and select */

@@ -138,6 +138,7 @@ SYMBOLS = {
     "rawdtw_sort_by_chaining_score": (I32, [VP, U32, VP]),
     "rawdtw_batch_build_jobs": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, U64, C.POINTER(U64)]),
     "rawdtw_batch_create": (I32, [VP, C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, C.POINTER(VP)]),
+    "rawdtw_batch_verify_plan": (I32, [VP, VP, VP, U64, C.POINTER(C.c_int), VP, U32]),
     "rawdtw_batch_info": (I32, [VP, C.POINTER(PlanInfo), C.POINTER(U64)]),
     "rawdtw_batch_run": (I32, [VP, VP]),
     "rawdtw_batch_run_timed": (I32, [VP, VP, VP, VP, U32, C.POINTER(U32)]),

@@ -256,6 +256,33 @@ class Batch:
         d["n_reads"] = self.cb.n_reads
         return d
 
+    def build_jobs(self):
+        """The batch's job list as the library builds it (rawdtw_batch_build_jobs): (jobs, job_off)."""
+        from .dtw import JOB_DTYPE
+
+        cb, lib, a = self.cb, self.engine.lib, self._arrays
+        job_off = np.zeros(cb.n_chains + 1, np.uint64)
+        nj = C.c_uint64()
+        args = (C.byref(self._copt), cb.n_chains, _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), _ptr(job_off))
+        self.engine._check(lib.rawdtw_batch_build_jobs(*args, None, 0, C.byref(nj)))
+        jobs = np.zeros(nj.value, JOB_DTYPE)
+        self.engine._check(lib.rawdtw_batch_build_jobs(*args, _ptr(jobs), len(jobs), C.byref(nj)))
+        return jobs, job_off
+
+    def verify_plan(self):
+        """rawdtw_batch_verify_plan: checks the tile records on the device against the job list; returns True when the
+        tile class was planned on the device.  Raises RawDTWError with the first broken invariant."""
+        from ._lib import RawDTWError
+
+        jobs, _ = self.build_jobs()
+        dev = C.c_int()
+        msg = C.create_string_buffer(512)
+        st = self.engine.lib.rawdtw_batch_verify_plan(self.engine._ctx, self._h, _ptr(jobs), len(jobs), C.byref(dev),
+                                                       C.cast(msg, C.c_void_p), 512)
+        if st != 0:
+            raise RawDTWError(st, msg.value.decode())
+        return bool(dev.value)
+
     def run(self):
         self.engine._check(self.engine.lib.rawdtw_batch_run(self.engine._ctx, self._h))
 

@@ -64,6 +64,10 @@ struct rawdtw_ctx {
     uint32_t lane_max_n = kLaneMaxN;
     uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
     uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
+    bool device_plan = true;  // rawdtw_batch_create plans the tile class on the device (rawdtw_plan.hip)
+    uint64_t device_plan_min_jobs = 65536; // smaller batches plan on the host (fewer round trips)
+    void *d_scratch = nullptr; // device-planning workspace, grow-only, reused by the context's batches
+    size_t scratch_bytes = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
     int fold_mode = 2; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work)
     int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
@@ -108,6 +112,11 @@ struct rawdtw_plan {
     rawdtw_plan_info_t info{};
     bool cells_counted = false;
     int plan_threads_used = 1;
+    // device-planned batches: the host keeps records only for the jobs outside the tile class; h_jobs / order / h_aux
+    // are indexed by (plan position - h_base), and the tile class is known through these totals
+    uint64_t h_base = 0;
+    bool dev_planned = false;
+    uint64_t dev_tile_cells = 0, dev_tile_bytes = 0;
 };
 
 struct rawdtw_index {
@@ -707,6 +716,81 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
     return RAWDTW_OK;
 }
 
+// The tile records against the jobs they were built from: every window staged inside its tile's LDS image at the right
+// place, every record's shape / radius / mask right, records in dispatch order.  tseen[k] = job k has a tile record.
+std::string verify_tile_arrays(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, const rawdtw_plan *pl, bool dev,
+                               const TileDesc *tiles, size_t n_tiles_all, const TileSpan *spans, size_t n_spans_all,
+                               const TileJob *tjobs, size_t n_tjobs, const std::vector<unsigned long long> &masks,
+                               std::vector<uint8_t> &tseen)
+{
+    auto S = [](uint64_t v) { return std::to_string(v); };
+    if (n_tiles_all != pl->n_tiles + pl->n_tiles_hi || n_tjobs != pl->n_tile_jobs) return "tile counts";
+    tseen.assign(n_jobs, 0);
+    uint64_t next_job = 0;
+    for (size_t ti = 0; ti < n_tiles_all; ti++) {
+        TileDesc t = tiles[ti];
+        t.n_spans &= 0x7fffffffu;
+        const bool hi = ti >= pl->n_tiles;
+        const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
+        if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
+        next_job += t.n_jobs;
+        if (t.n_jobs > (hi ? kTileHiMaxJobs : dev ? 2048u : std::max(cfg.tile_max_jobs, cfg.sorted_tile_jobs)) || t.n_spans == 0 ||
+            t.n_spans > (hi ? 2 * kTileHiMaxJobs : dev ? 2048u : std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs)))
+            return "tile " + S(ti) + ": too many jobs or spans";
+        if ((uint64_t)t.span_first + t.n_spans > n_spans_all) return "tile " + S(ti) + ": spans out of range";
+        uint32_t off = 0;
+        for (uint32_t s = 0; s < t.n_spans; s++) {
+            const TileSpan &sp = spans[t.span_first + s];
+            const uint32_t len = 4 * (sp.chunks_arena & 0x7fffffffu);
+            const bool is_ref = sp.chunks_arena >> 31;
+            if (sp.lds_off != off || (sp.src & 3) || len == 0) return "tile " + S(ti) + ": span layout";
+            // the copy reads whole 16-byte chunks: the arenas are allocated with that slack (see upload_*), the
+            // span itself must start inside the arena
+            if (sp.src >= (is_ref ? cfg.n_ref : cfg.n_ev)) return "tile " + S(ti) + ": span outside its arena";
+            off += len;
+        }
+        if (off > budget || off > (hi ? pl->tile_hi_lds_floats : pl->tile_lds_floats)) return "tile " + S(ti) + ": LDS image over budget";
+        for (uint32_t q = 0; q < t.n_jobs; q++) {
+            const TileJob &tj = tjobs[t.job_first + q];
+            const uint32_t k = tj.aux;
+            if (k >= n_jobs || tseen[k]) return "tile job " + S(k) + " duplicated";
+            tseen[k] = 1;
+            const rawdtw_job_t &j = jobs[k];
+            const bool swap = j.n < j.m;
+            const uint64_t a0 = swap ? j.ref_off : j.read_off, b0 = swap ? j.read_off : j.ref_off;
+            const uint32_t NA = swap ? j.m : j.n, NB = swap ? j.n : j.m;
+            if (tj.N != NA || tj.M != NB || ((tj.flags & kFlagExcludeLast) != 0) != (j.exclude_last != 0))
+                return "tile job " + S(k) + ": shape or flags";
+            const int R = slanted_radius(j.n, j.m, j.band_radius);
+            if (tj.R >= 2) { if ((int)tj.R - 2 != R) return "tile job " + S(k) + ": radius"; }
+            else {
+                if (NA > (tj.R == 0 ? 4u : 8u) || tj.pad >= masks.size() || masks[tj.pad] != band_mask8(NA, NB, R))
+                    return "tile job " + S(k) + ": micro mask";
+            }
+            // both windows must lie inside one staged span of the right arena, at the right place
+            for (int w = 0; w < 2; w++) {
+                const uint32_t o = w ? tj.offB : tj.offA, len = w ? NB : NA;
+                const uint64_t g0 = w ? b0 : a0;
+                const bool want_ref = w ? !swap : swap;
+                bool ok = false;
+                for (uint32_t s = 0; s < t.n_spans && !ok; s++) {
+                    const TileSpan &sp = spans[t.span_first + s];
+                    const uint32_t slen = 4 * (sp.chunks_arena & 0x7fffffffu);
+                    if ((bool)(sp.chunks_arena >> 31) != want_ref) continue;
+                    if (o >= sp.lds_off && o + len <= sp.lds_off + slen && sp.src + (o - sp.lds_off) == g0) ok = true;
+                }
+                if (!ok) return "tile job " + S(k) + ": window " + (w ? "B" : "A") + " not staged";
+            }
+        }
+        for (uint32_t q = 1; q < t.n_jobs; q++) { // dispatch order inside the tile
+            const TileJob &x = tjobs[t.job_first + q - 1], &y = tjobs[t.job_first + q];
+            if (x.R > y.R || (x.R == y.R && x.N < y.N)) return "tile " + S(ti) + ": records not sorted";
+        }
+    }
+    if (next_job != pl->n_tile_jobs) return "tiles cover " + S(next_job) + " of " + S(pl->n_tile_jobs) + " tile jobs";
+    return "";
+}
+
 // Self-check of a host plan against the jobs it was built from (rawdtw_plan_dry_run; tests).  Returns an
 // empty string when every invariant the kernels rely on holds.
 std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, const rawdtw_plan *pl,
@@ -729,70 +813,12 @@ std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint6
         covered += L.count;
     }
     if (covered != n_jobs) return "launches cover " + S(covered) + " of " + S(n_jobs) + " jobs";
-    if (ht.tiles.size() != pl->n_tiles + pl->n_tiles_hi || ht.tjobs.size() != pl->n_tile_jobs) return "tile counts";
-    std::vector<uint8_t> tseen(n_jobs, 0);
-    uint64_t next_job = 0;
-    for (size_t ti = 0; ti < ht.tiles.size(); ti++) {
-        TileDesc t = ht.tiles[ti];
-        t.n_spans &= 0x7fffffffu;
-        const bool hi = ti >= pl->n_tiles;
-        const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
-        if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
-        next_job += t.n_jobs;
-        if (t.n_jobs > (hi ? kTileHiMaxJobs : std::max(cfg.tile_max_jobs, cfg.sorted_tile_jobs)) || t.n_spans == 0 ||
-            t.n_spans > (hi ? 2 * kTileHiMaxJobs : std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs)))
-            return "tile " + S(ti) + ": too many jobs or spans";
-        if ((uint64_t)t.span_first + t.n_spans > ht.spans.size()) return "tile " + S(ti) + ": spans out of range";
-        uint32_t off = 0;
-        for (uint32_t s = 0; s < t.n_spans; s++) {
-            const TileSpan &sp = ht.spans[t.span_first + s];
-            const uint32_t len = 4 * (sp.chunks_arena & 0x7fffffffu);
-            const bool is_ref = sp.chunks_arena >> 31;
-            if (sp.lds_off != off || (sp.src & 3) || len == 0) return "tile " + S(ti) + ": span layout";
-            // the copy reads whole 16-byte chunks: the arenas are allocated with that slack (see upload_*), the
-            // span itself must start inside the arena
-            if (sp.src >= (is_ref ? cfg.n_ref : cfg.n_ev)) return "tile " + S(ti) + ": span outside its arena";
-            off += len;
-        }
-        if (off > budget || off > (hi ? pl->tile_hi_lds_floats : pl->tile_lds_floats)) return "tile " + S(ti) + ": LDS image over budget";
-        for (uint32_t q = 0; q < t.n_jobs; q++) {
-            const TileJob &tj = ht.tjobs[t.job_first + q];
-            const uint32_t k = tj.aux;
-            if (k >= n_jobs || tseen[k]) return "tile job " + S(k) + " duplicated";
-            tseen[k] = 1;
-            const rawdtw_job_t &j = jobs[k];
-            const bool swap = j.n < j.m;
-            const uint64_t a0 = swap ? j.ref_off : j.read_off, b0 = swap ? j.read_off : j.ref_off;
-            const uint32_t NA = swap ? j.m : j.n, NB = swap ? j.n : j.m;
-            if (tj.N != NA || tj.M != NB || ((tj.flags & kFlagExcludeLast) != 0) != (j.exclude_last != 0))
-                return "tile job " + S(k) + ": shape or flags";
-            const int R = slanted_radius(j.n, j.m, j.band_radius);
-            if (tj.R >= 2) { if ((int)tj.R - 2 != R) return "tile job " + S(k) + ": radius"; }
-            else {
-                if (NA > (tj.R == 0 ? 4u : 8u) || tj.pad >= ht.masks.size() || ht.masks[tj.pad] != band_mask8(NA, NB, R))
-                    return "tile job " + S(k) + ": micro mask";
-            }
-            // both windows must lie inside one staged span of the right arena, at the right place
-            for (int w = 0; w < 2; w++) {
-                const uint32_t o = w ? tj.offB : tj.offA, len = w ? NB : NA;
-                const uint64_t g0 = w ? b0 : a0;
-                const bool want_ref = w ? !swap : swap;
-                bool ok = false;
-                for (uint32_t s = 0; s < t.n_spans && !ok; s++) {
-                    const TileSpan &sp = ht.spans[t.span_first + s];
-                    const uint32_t slen = 4 * (sp.chunks_arena & 0x7fffffffu);
-                    if ((bool)(sp.chunks_arena >> 31) != want_ref) continue;
-                    if (o >= sp.lds_off && o + len <= sp.lds_off + slen && sp.src + (o - sp.lds_off) == g0) ok = true;
-                }
-                if (!ok) return "tile job " + S(k) + ": window " + (w ? "B" : "A") + " not staged";
-            }
-        }
-        for (uint32_t q = 1; q < t.n_jobs; q++) { // dispatch order inside the tile
-            const TileJob &x = ht.tjobs[t.job_first + q - 1], &y = ht.tjobs[t.job_first + q];
-            if (x.R > y.R || (x.R == y.R && x.N < y.N)) return "tile " + S(ti) + ": records not sorted";
-        }
+    std::vector<uint8_t> tseen;
+    {
+        const std::string e = verify_tile_arrays(cfg, jobs, n_jobs, pl, false, ht.tiles.data(), ht.tiles.size(), ht.spans.data(),
+                                                 ht.spans.size(), ht.tjobs.data(), ht.tjobs.size(), ht.masks, tseen);
+        if (!e.empty()) return e;
     }
-    if (next_job != pl->n_tile_jobs) return "tiles cover " + S(next_job) + " of " + S(pl->n_tile_jobs) + " tile jobs";
     for (uint64_t p = 0; p < pl->n_tile_jobs; p++) if (!tseen[pl->order[p]]) return "tile-class job without a tile";
     return "";
 }
@@ -853,12 +879,17 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
 // cells evaluated by plan positions [p0, p1) (exact band cell sets; reporting only)
 uint64_t count_cells(const rawdtw_plan *pl, uint64_t p0, uint64_t p1)
 {
+    if (pl->dev_planned && p0 < pl->h_base) { // the tile class of a device-planned batch: counted by k_plan_jobs
+        const uint64_t rest = p1 > pl->h_base ? count_cells(pl, pl->h_base, p1) : 0;
+        return pl->dev_tile_cells + rest; // (callers ask for whole launches: [0, h_base) is exactly the tile launch)
+    }
+    if (p1 <= p0) return 0;
     const int T = (int)std::min<uint64_t>(std::max(pl->plan_threads_used, 1), (p1 - p0) / 32768 + 1);
     std::vector<uint64_t> part(T, 0);
     parallel_for(T, [&](int t) {
         uint64_t c = 0;
         for (uint64_t p = p0 + (p1 - p0) * (uint64_t)t / T; p < p0 + (p1 - p0) * (uint64_t)(t + 1) / T; p++) {
-            const DevJob &d = pl->h_jobs[p];
+            const DevJob &d = pl->h_jobs[p - pl->h_base];
             c += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
         }
         part[t] = c;
@@ -950,6 +981,9 @@ int run_all_launches(rawdtw_ctx *ctx, rawdtw_plan *pl, hipEvent_t *ev)
 {
     const size_t nl = pl->launches.size();
     if (nl == 0) return RAWDTW_OK;
+    // hipGetLastError is sticky per thread: an error a library left behind while probing (rocPRIM's device queries
+    // during planning do) would otherwise be reported as the first kernel launch's
+    (void)hipGetLastError();
     const bool fork = nl > 1 && !ctx->serial_launches && ctx->n_side > 0;
     if (fork) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1062,6 +1096,7 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     delete ctx;
     return RAWDTW_OK;
 }
@@ -1087,6 +1122,8 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "sort_r1_n")) { ctx->sort_r1_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
     if (!strcmp(name, "sort_r3")) { ctx->sort_r3 = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
+    if (!strcmp(name, "device_plan")) { ctx->device_plan = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "device_plan_min_jobs")) { ctx->device_plan_min_jobs = (uint64_t)std::max<int64_t>(value, 0); return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
@@ -1485,6 +1522,168 @@ int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const floa
     return st;
 }
 
+// ---- device-side planning of a candidate batch (kernels in rawdtw_plan.hip) -----------------------
+namespace {
+constexpr int kDevPlanFallback = -1000; // not an ABI status: "use the host planner" (anything unusual, or an error it must word)
+
+int ensure_scratch(rawdtw_ctx *ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes) return RAWDTW_OK;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    bytes += bytes / 8;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return RAWDTW_OK;
+}
+
+// Plans the batch's jobs from its anchor lists.  The tile class (99 % of a sparse batch) is binned, tiled and sorted on
+// the device; the jobs of the other classes come back (a few ten thousand records) and go through plan_host as usual.
+int build_plan_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_chains, const uint64_t *anchor_off,
+                      const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
+                      const uint64_t *job_off, uint64_t n_jobs, rawdtw_plan **out)
+{
+    *out = nullptr;
+    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[devplan] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    PlanCfg cfg = cfg_of(ctx);
+    if (cfg.lane_max_radius < 0 || cfg.sort_n || cfg.sort_r1_n || cfg.sort_r3 || cfg.lane_hi) return kDevPlanFallback;
+    if (n_jobs >= (1ull << 31) || n_jobs * 160ull >= (1ull << 40)) return kDevPlanFallback;
+    const uint32_t worst_job = 2u * cfg.lane_max_n + 12u;
+    if (cfg.tile_lds_floats < worst_job + 14u + 1024u || cfg.tile_lds_floats > 16000u) return kDevPlanFallback; // (16-bit LDS offsets)
+    DevPlanArgs a{};
+    a.n_jobs = n_jobs; a.n_chains = n_chains; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
+    a.border = opt->border_constraint; a.banded = opt->fill_method != 0; a.frac = opt->band_radius_frac;
+    a.lane_max_radius = cfg.lane_max_radius; a.lane_max_n = cfg.lane_max_n; a.micro_max_n = (uint32_t)cfg.micro_max_n;
+    a.tile_budget = cfg.tile_lds_floats - 16u; // (the bracket's last job: subtracted on the device, from the batch's largest)
+    // cost floor: k_plan_tiles sorts at most 2048 records per tile.  (A floor at tile_max_jobs = 1024 would inflate the
+    // cost of the tiniest jobs -- 43 % of a sparse batch add fewer than 4.9 floats -- and cost 12 % more tiles.)
+    a.min_cost8 = (8u * a.tile_budget + 2047u) / 2048u;
+    const uint64_t n_anchors = anchor_off[n_chains];
+
+    // workspace: [inputs][planning arrays][other jobs][other aux][counters]
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_joff = al((n_chains + 1) * 8), b_aoff = al((n_chains + 1) * 8), b_anch = al(n_anchors * sizeof(rawdtw_anchor_t)),
+                 b_rbase = al(n_chains * 8), b_qbase = al(n_chains * 4), b_plan = al(dev_plan_scratch_bytes(n_jobs)),
+                 b_oj = al(n_jobs * sizeof(rawdtw_job_t)), b_oa = al(n_jobs * 4), b_cnt = al(kPlanCounters * 8);
+    int st = ensure_scratch(ctx, b_joff + b_aoff + b_anch + b_rbase + b_qbase + b_plan + b_oj + b_oa + b_cnt);
+    if (st != RAWDTW_OK) return st;
+    char *base = static_cast<char *>(ctx->d_scratch);
+    auto take = [&](size_t bytes) { char *q = base; base += bytes; return q; };
+    uint64_t *d_joff = reinterpret_cast<uint64_t *>(take(b_joff));
+    uint64_t *d_aoff = reinterpret_cast<uint64_t *>(take(b_aoff));
+    rawdtw_anchor_t *d_anch = reinterpret_cast<rawdtw_anchor_t *>(take(b_anch));
+    uint64_t *d_rbase = reinterpret_cast<uint64_t *>(take(b_rbase));
+    uint32_t *d_qbase = reinterpret_cast<uint32_t *>(take(b_qbase));
+    void *d_plan = take(b_plan);
+    rawdtw_job_t *d_oj = reinterpret_cast<rawdtw_job_t *>(take(b_oj));
+    uint32_t *d_oa = reinterpret_cast<uint32_t *>(take(b_oa));
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(take(b_cnt));
+    hipStream_t s = ctx->stream;
+    lap("scratch");
+    HIP_TRY(ctx, hipMemcpyAsync(d_joff, job_off, (n_chains + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_aoff, anchor_off, (n_chains + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_anch, anchors, n_anchors * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_rbase, ref_base, n_chains * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qbase, read_base, n_chains * 4, hipMemcpyHostToDevice, s));
+    lap("uploads");
+    DevPlanBuffers buf{};
+    HIP_TRY(ctx, dev_plan_phase1(a, d_joff, d_aoff, d_anch, d_rbase, d_qbase, d_plan, &buf, d_oj, d_oa, d_cnt, s));
+    unsigned long long cnt[kPlanCounters];
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    lap("phase 1");
+    if (cnt[kPlanBad] != ~0ull) return kDevPlanFallback; // let the host planner word the error
+    const uint64_t n_tile_jobs = cnt[kPlanTileJobs], n_tiles = cnt[kPlanTiles], n_runs = cnt[kPlanRuns];
+    const uint64_t n_other = n_jobs - n_tile_jobs;
+    if (getenv("RAWDTW_PLAN_DEBUG"))
+        fprintf(stderr, "[devplan] jobs %llu tile jobs %llu tiles %llu runs %llu bad %llu\n", (unsigned long long)n_jobs,
+                (unsigned long long)n_tile_jobs, (unsigned long long)n_tiles, (unsigned long long)n_runs, cnt[kPlanBad]);
+    if (n_tile_jobs == 0) return kDevPlanFallback;
+
+    rawdtw_plan *pl = new (std::nothrow) rawdtw_plan;
+    if (!pl) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    pl->ctx = ctx;
+    const std::vector<unsigned long long> &masks = micro_masks();
+    if ((st = dev_alloc(ctx, &pl->d_tiles, n_tiles)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_spans, 2 * n_runs)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_tjobs, n_tile_jobs)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)masks.size())) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK) {
+        rawdtw_plan_destroy(pl);
+        return st;
+    }
+    lap("allocs");
+    hipError_t e = dev_plan_phase2(a, (uint32_t)n_tiles, &buf, pl->d_tiles, pl->d_spans, pl->d_tjobs, d_cnt, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(pl->d_masks, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, s);
+    // the other classes: records back to the host, planned there (sorting by shape, launches, workspaces)
+    RawVec<rawdtw_job_t> oj;
+    RawVec<uint32_t> oa;
+    try { oj.resize(n_other); oa.resize(n_other); } catch (const std::bad_alloc &) { rawdtw_plan_destroy(pl); return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    if (e == hipSuccess && n_other) e = hipMemcpyAsync(oj.data(), d_oj, n_other * sizeof(rawdtw_job_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_other) e = hipMemcpyAsync(oa.data(), d_oa, n_other * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { rawdtw_plan_destroy(pl); return hip_fail(ctx, e, "device planning"); }
+    lap("phase 2 + D2H");
+    if (cnt[kPlanTileOverflow] != ~0ull || cnt[kPlanLdsMax] > cfg.tile_lds_floats) { rawdtw_plan_destroy(pl); return kDevPlanFallback; }
+
+    HostTiles ht;
+    std::string err;
+    PlanCfg cfg_other = cfg;
+    cfg_other.lane_max_radius = -1; // nothing left for the tile class
+    try {
+        st = plan_host(cfg_other, oj.data(), n_other, false, pl, ht, err);
+    } catch (const std::bad_alloc &) {
+        st = RAWDTW_ERR_OOM; err = "host allocation failed";
+    }
+    lap("others on host");
+    if (st != RAWDTW_OK) { rawdtw_plan_destroy(pl); return kDevPlanFallback; } // (the host planner names the job in the batch's numbering)
+    // plan_host numbered the other jobs 0..n_other-1: shift them behind the tile class and restore the batch's job indices
+    for (uint64_t q = 0; q < n_other; q++) {
+        pl->h_jobs[q].aux = oa[pl->h_jobs[q].aux];
+        pl->order[q] = oa[pl->order[q]];
+    }
+    for (Launch &L : pl->launches) L.first += n_tile_jobs;
+    pl->launches.insert(pl->launches.begin(), Launch{kKindBandLane, (int32_t)cnt[kPlanLdsMax], 0, n_tile_jobs});
+    pl->run_order.resize(pl->launches.size());
+    for (uint32_t i = 0; i < pl->run_order.size(); i++) pl->run_order[i] = i; // the tile launch first, the rest as plan_host ordered them
+    pl->h_base = n_tile_jobs;
+    pl->dev_planned = true;
+    pl->dev_tile_cells = cnt[kPlanTileCells];
+    pl->dev_tile_bytes = cnt[kPlanTileBytes];
+    pl->n_jobs = n_jobs;
+    pl->n_tile_jobs = n_tile_jobs;
+    pl->n_tiles = n_tiles; pl->n_tiles_hi = 0;
+    pl->tile_lds_floats = (uint32_t)cnt[kPlanLdsMax];
+    rawdtw_plan_info_t &I = pl->info;
+    I.n_jobs = n_jobs;
+    I.algorithmic_bytes += pl->dev_tile_bytes;
+    I.n_lane_jobs = n_tile_jobs;
+    I.n_launches = (uint32_t)pl->launches.size();
+    I.workspace_bytes += n_tiles * sizeof(TileDesc) + 2 * n_runs * sizeof(TileSpan) + n_tile_jobs * (sizeof(TileJob) + 4) + masks.size() * 8;
+    // device records of the other jobs
+    if ((st = dev_alloc(ctx, &pl->d_jobs, n_other)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_aux, n_other)) != RAWDTW_OK ||
+        (st = dev_alloc(ctx, &pl->d_bnd, pl->bnd_floats)) != RAWDTW_OK) {
+        rawdtw_plan_destroy(pl);
+        return st;
+    }
+    if (n_other) {
+        e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data(), n_other * sizeof(DevJob), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data(), n_other * sizeof(FullAux), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { rawdtw_plan_destroy(pl); return hip_fail(ctx, e, "uploading job descriptors"); }
+    }
+    lap("others upload");
+    *out = pl;
+    return RAWDTW_OK;
+}
+} // namespace
+
 // ---- whole-batch form ----------------------------------------------------------------------------
 int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
                         const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
@@ -1503,11 +1702,37 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
                                      0, &n_jobs);
     if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
-    // jobs and chain descriptors, chain ranges spread over the planner's threads
-    RawVec<rawdtw_job_t> jobs;
+    // chain descriptors: from the anchors alone.  The parts' read regions telescope (consecutive parts share their
+    // anchor event), so sum(n) = (last.q - first.q) + parts in the reference's uint32 arithmetic (rmap.cpp:236,292).
     std::vector<ChainDesc> desc(n_chains);
-    try { jobs.resize(n_jobs); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-    {
+    for (uint64_t c = 0; c < n_chains; c++) {
+        const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+        ChainDesc &d = desc[c];
+        d.job_first = job_off[c];
+        d.n_jobs = (uint32_t)(job_off[c + 1] - job_off[c]);
+        d.reserved = 0;
+        if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
+        const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
+        d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
+        d.num_aligned = opt->border_constraint == 0 ? d.span : (last.query_position - first.query_position) + d.n_jobs;
+    }
+    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[batch] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    lap("chains");
+    rawdtw_plan *plan = nullptr;
+    st = kDevPlanFallback;
+    if (ctx->device_plan && n_jobs >= ctx->device_plan_min_jobs)
+        st = build_plan_device(ctx, opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), n_jobs, &plan);
+    if (st == kDevPlanFallback) {
+        // host planning: the job list, chain ranges spread over the planner's threads
+        RawVec<rawdtw_job_t> jobs;
+        try { jobs.resize(n_jobs); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
         int T = ctx->plan_threads;
         if (T <= 0) {
             const unsigned hc = std::thread::hardware_concurrency();
@@ -1524,30 +1749,22 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
             for (uint64_t c = c_lo; c < c_hi; c++) {
                 const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
                 const uint32_t nj = (uint32_t)(job_off[c + 1] - job_off[c]);
-                if (nj) {
-                    int s2 = rawdtw_chain_build_jobs(opt, anchors + a0, (uint32_t)(a1 - a0), ref_base[c], read_base[c], 0,
-                                                     jobs.data() + job_off[c]);
-                    if (s2 != RAWDTW_OK) { status[t] = s2; return; }
-                }
-                ChainDesc &d = desc[c];
-                d.job_first = job_off[c];
-                d.n_jobs = nj;
-                d.reserved = 0;
-                if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
-                const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
-                d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
-                uint32_t na = 0;
-                for (uint64_t k = job_off[c]; k < job_off[c + 1]; k++) na += jobs[k].n; // rmap.cpp:236,292
-                d.num_aligned = na;
+                if (!nj) continue;
+                int s2 = rawdtw_chain_build_jobs(opt, anchors + a0, (uint32_t)(a1 - a0), ref_base[c], read_base[c], 0,
+                                                 jobs.data() + job_off[c]);
+                if (s2 != RAWDTW_OK) { status[t] = s2; return; }
             }
         });
         for (int t = 0; t < T; t++) if (status[t] != RAWDTW_OK) return fail(ctx, status[t], "job building failed");
+        st = build_plan(ctx, jobs.data(), n_jobs, false, &plan);
     }
+    if (st != RAWDTW_OK) return st;
+    lap("plan");
     rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
-    if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    if (!b) { rawdtw_plan_destroy(plan); return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
     b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
-    st = build_plan(ctx, jobs.data(), n_jobs, false, &b->plan);
-    if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chains, n_chains);
+    b->plan = plan;
+    st = dev_alloc(ctx, &b->d_chains, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chain_off, n_reads + 1);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_fold_order, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_full, n_chains);
@@ -1574,8 +1791,54 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
         if (e != hipSuccess) st = hip_fail(ctx, e, "uploading chain descriptors");
     }
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
+    lap("chain records");
     *out = b;
     return RAWDTW_OK;
+}
+
+int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const rawdtw_job_t *jobs, uint64_t n_jobs,
+                             int *device_planned, char *message, uint32_t message_cap)
+{
+    auto say = [&](const std::string &m) { if (message && message_cap) snprintf(message, message_cap, "%s", m.c_str()); };
+    say("");
+    if (!ctx || !batch || batch->ctx != ctx || (n_jobs && !jobs)) return RAWDTW_ERR_INVALID;
+    const rawdtw_plan *pl = batch->plan;
+    if (device_planned) *device_planned = pl->dev_planned ? 1 : 0;
+    if (n_jobs != pl->n_jobs) { say("job count differs from the batch's"); return RAWDTW_ERR_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the tile records as the kernels will read them
+    const size_t n_tiles = pl->n_tiles + pl->n_tiles_hi;
+    std::vector<TileDesc> tiles(n_tiles);
+    std::vector<TileJob> tjobs(pl->n_tile_jobs);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_tiles) HIP_TRY(ctx, hipMemcpy(tiles.data(), pl->d_tiles, n_tiles * sizeof(TileDesc), hipMemcpyDeviceToHost));
+    if (pl->n_tile_jobs) HIP_TRY(ctx, hipMemcpy(tjobs.data(), pl->d_tjobs, pl->n_tile_jobs * sizeof(TileJob), hipMemcpyDeviceToHost));
+    size_t n_spans = 0;
+    for (const TileDesc &t : tiles) n_spans = std::max<size_t>(n_spans, (size_t)t.span_first + (t.n_spans & 0x7fffffffu));
+    std::vector<TileSpan> spans(n_spans);
+    if (n_spans) HIP_TRY(ctx, hipMemcpy(spans.data(), pl->d_spans, n_spans * sizeof(TileSpan), hipMemcpyDeviceToHost));
+    const PlanCfg cfg = cfg_of(ctx);
+    std::vector<uint8_t> tseen;
+    std::string e = verify_tile_arrays(cfg, jobs, n_jobs, pl, pl->dev_planned, tiles.data(), n_tiles, spans.data(), n_spans,
+                                       tjobs.data(), tjobs.size(), micro_masks(), tseen);
+    // every job has exactly one home: a tile record or a record of another class
+    std::vector<uint8_t> oseen(n_jobs, 0);
+    if (e.empty()) {
+        const uint64_t n_other = n_jobs - pl->n_tile_jobs;
+        for (uint64_t q = 0; q < n_other && e.empty(); q++) {
+            const DevJob &d = pl->h_jobs[(pl->dev_planned ? 0 : pl->n_tile_jobs) + q];
+            const uint32_t k = d.aux;
+            if (k >= n_jobs || oseen[k] || tseen[k]) e = "job " + std::to_string(k) + " planned twice";
+            else if (d.n != jobs[k].n || d.m != jobs[k].m || d.ref_off != jobs[k].ref_off || d.read_off != jobs[k].read_off ||
+                     ((d.flags & kFlagExcludeLast) != 0) != (jobs[k].exclude_last != 0))
+                e = "record of job " + std::to_string(k) + " differs from the job";
+            else oseen[k] = 1;
+        }
+        for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
+            if (!tseen[k] && !oseen[k]) e = "job " + std::to_string(k) + " is in no launch";
+    }
+    say(e);
+    return e.empty() ? RAWDTW_OK : RAWDTW_ERR_DEVICE + 100;
 }
 
 int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint64_t *n_chains)
@@ -1713,10 +1976,12 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
     const MergeSel mg = merge_of(batch->ctx, pl);
     uint64_t bytes = 0, cl = 0, nj = 0;
     auto add = [&](const Launch &X) {
-        for (uint64_t p = X.first; p < X.first + X.count; p++) {
-            const DevJob &d = pl->h_jobs[p];
-            bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
-        }
+        if (pl->dev_planned && X.first < pl->h_base) bytes += pl->dev_tile_bytes; // tile launch of a device-planned batch
+        else
+            for (uint64_t p = X.first; p < X.first + X.count; p++) {
+                const DevJob &d = pl->h_jobs[p - pl->h_base];
+                bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
+            }
         if (cells) cl += count_cells(pl, X.first, X.first + X.count);
         nj += X.count;
     };

@@ -90,6 +90,30 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
+// ---- device-side planning (rawdtw_plan.hip) ----
+struct DevPlanArgs {
+    uint64_t n_jobs, n_chains, n_ev, n_ref;
+    int32_t border, banded;      // rawdtw_align_opt_t: border_constraint, fill_method != 0
+    float frac;                  // band_radius_frac
+    int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
+    uint32_t lane_max_n, micro_max_n;
+    uint32_t tile_budget;        // tile_lds_floats minus what a tile's first job can cost beyond its counted cost
+    uint32_t min_cost8;          // least cost of a job in eighths of a float: 8 * tile_budget / tile_max_jobs
+};
+enum : int { kPlanBad = 0, kPlanBadRadius, kPlanTileOverflow, kPlanTileJobs, kPlanTiles, kPlanRuns, kPlanTileCells,
+             kPlanTileBytes, kPlanLdsMax, kPlanMaxCost8, kPlanCounters };
+struct DevPlanBuffers {
+    DevJob *pjobs; uint32_t *chain_of, *cost, *is_tile, *rank, *order_tile, *tile_no, *run_flag, *tile_flag, *tile_idx, *run_idx;
+    uint8_t *run_start; uint64_t *cum; uint32_t *tile_first; void *scan_tmp; size_t scan_tmp_bytes;
+};
+size_t dev_plan_scratch_bytes(uint64_t n_jobs);
+hipError_t dev_plan_phase1(const DevPlanArgs &a, const uint64_t *d_job_off, const uint64_t *d_anchor_off,
+                           const rawdtw_anchor_t *d_anchors, const uint64_t *d_ref_base, const uint32_t *d_read_base,
+                           void *scratch, DevPlanBuffers *buf, rawdtw_job_t *d_other_jobs, uint32_t *d_other_aux,
+                           unsigned long long *d_counters, hipStream_t s);
+hipError_t dev_plan_phase2(const DevPlanArgs &a, uint32_t n_tiles, DevPlanBuffers *buf, TileDesc *d_tiles,
+                           TileSpan *d_spans, TileJob *d_tjobs, unsigned long long *d_counters, hipStream_t s);
+
 hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                               const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,
                               const DevJob *gjobs, uint64_t n_g, const DevJob *hjobs, uint64_t n_h, const float *ev,

@@ -32,8 +32,18 @@ t0 = time.perf_counter(); plan.run(); eng.sync(); t_run = time.perf_counter() - 
 t0 = time.perf_counter(); costs = plan.fetch(); t_d2h = time.perf_counter() - t0
 plan.close()
 t0 = time.perf_counter(); c2 = eng.score_batch(jobs, cb.events); t_oneshot = time.perf_counter() - t0
-t0 = time.perf_counter(); b = ra.Batch(eng, opt, cb); t_batch_create = time.perf_counter() - t0
-print(json.dumps({"reads": reads, "jobs": int(nj.value), "cells": info["cells"], "events_MB": cb.events.nbytes / 1e6,
+t0 = time.perf_counter(); b = ra.Batch(eng, opt, cb); t_batch_create_first = time.perf_counter() - t0
+b.close() if hasattr(b, "close") else None
+t0 = time.perf_counter(); b = ra.Batch(eng, opt, cb); t_batch_create = time.perf_counter() - t0   # steady state: code loaded, workspace allocated
+b.run(); eng.sync()
+t0 = time.perf_counter(); b.run(); eng.sync(); t_batch_run = time.perf_counter() - t0
+eng.set_option("device_plan", 0)
+t0 = time.perf_counter(); b2 = ra.Batch(eng, opt, cb); t_batch_create_host = time.perf_counter() - t0
+from rawalign_amd.dtw import plan_dry_run
+_, host_tiles = plan_dry_run(jobs, len(cb.events), 2 * ((4_600_000 + 3) & ~3) + 64, options={"verify": 0})
+print(json.dumps({"host_planner_tiles": host_tiles, "reads": reads, "jobs": int(nj.value), "cells": info["cells"], "events_MB": cb.events.nbytes / 1e6,
                   "build_jobs_s": t_build, "h2d_events_s": t_h2d, "plan_create_s": t_plan, "run_s": t_run, "fetch_costs_s": t_d2h,
                   "score_batch_oneshot_s": t_oneshot, "GCUPS_pcie_inclusive": info["cells"] / t_oneshot / 1e9,
-                  "batch_create_s": t_batch_create}))
+                  "batch_create_s": t_batch_create, "batch_create_first_s": t_batch_create_first,
+                  "batch_create_host_planner_s": t_batch_create_host, "batch_run_s": t_batch_run,
+                  "GCUPS_batch_create_plus_run": info["cells"] / (t_batch_create + t_batch_run) / 1e9}))

@@ -442,3 +442,37 @@ def test_batch_edge_cases(engine, oracle):
 
     want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
     assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("border,fill", [(1, 1), (0, 1), (1, 0)])
+def test_device_planned_batch_matches_host_planned(oracle, border, fill):
+    """rawdtw_batch_create with the tile class planned on the device (rawdtw_plan.hip): the tile records pass the same
+    self-check as the host planner's, and scores / keeps / per-job costs equal the host-planned batch bit for bit."""
+    from rawalign_amd import synth
+
+    ref = synth.make_reference([150000], seed=91)
+    results = {}
+    for dev in (0, 1):
+        eng = ra.Engine(0)
+        eng.set_option("device_plan", dev)
+        eng.set_option("device_plan_min_jobs", 0)
+        eng.upload_reference(ref.forward, ref.reverse)
+        offs = {(0, st): eng.reference_offset(0, st) for st in (0, 1)}
+        cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=700, max_chunks=4, decoys_per_read=2.0),
+                                           seed=4321 + border)
+        eng.upload_events(cb.events)
+        batch = ra.Batch(eng, ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill), cb)
+        planned_on_device = batch.verify_plan()            # raises on the first broken invariant
+        # full-matrix jobs are never tile jobs: nothing for the device planner to do there (short banded global
+        # chains are tile jobs, so global + banded is planned on the device too)
+        assert planned_on_device == bool(dev and fill == 1)
+        info = batch.info()
+        batch.run()
+        results[dev] = batch.fetch(with_job_costs=True) + (info,)
+        eng.close()
+    (s0, k0, c0, i0), (s1, k1, c1, i1) = results[0], results[1]
+    assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(k0, k1)
+    for key in ("n_jobs", "cells", "algorithmic_bytes", "n_lane_jobs", "n_wave_band_jobs", "n_full_jobs"):
+        assert i0[key] == i1[key], key
