@@ -17,8 +17,10 @@
 //
 // The records written are the ones k_band_tile / k_band_merged read (TileDesc, TileSpan, TileJob); costs do not depend
 // on how jobs are tiled, so host- and device-planned batches give bit-identical results (tests/test_gpu_parity.py).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -121,9 +123,22 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_jobs(DevPlanArgs a, const
     const uint64_t j = (uint64_t)blockIdx.x * kPlanThreads + threadIdx.x;
     unsigned long long my_cells = 0, my_bytes = 0;
     uint32_t my_max = 0;
-    if (j < a.n_jobs) {
-        // chain of job j: last c with job_off[c] <= j
+    // two full binary searches per workgroup (its first and last job) bound everybody else's
+    __shared__ uint64_t s_clo, s_chi;
+    if (threadIdx.x < 2) {
+        const uint64_t jj = threadIdx.x == 0 ? (uint64_t)blockIdx.x * kPlanThreads
+                                             : min((uint64_t)blockIdx.x * kPlanThreads + kPlanThreads - 1, a.n_jobs - 1);
         uint64_t lo = 0, hi = a.n_chains;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (job_off[mid] <= jj) lo = mid; else hi = mid;
+        }
+        if (threadIdx.x == 0) s_clo = lo; else s_chi = lo;
+    }
+    __syncthreads();
+    if (j < a.n_jobs) {
+        // chain of job j: last c with job_off[c] <= j, searched inside the window of chains this workgroup's jobs span
+        uint64_t lo = s_clo, hi = s_chi + 1;
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
             if (job_off[mid] <= j) lo = mid; else hi = mid;
@@ -175,16 +190,26 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_jobs(DevPlanArgs a, const
         is_tile[j] = tile ? 1u : 0u;
         run_start[j] = (tile && starts) ? 1 : 0;
     }
-    // tile-class totals (reporting): one atomic per wave
+    // tile-class totals (reporting) and the largest cost: reduced per workgroup, then one atomic each (same-address
+    // atomics serialise: one per wave cost 1.2 ms at 5 M jobs)
     for (int off = 32; off > 0; off >>= 1) {
         my_cells += __shfl_down(my_cells, off);
         my_bytes += __shfl_down(my_bytes, off);
         my_max = max(my_max, (uint32_t)__shfl_down((int)my_max, off));
     }
-    if ((threadIdx.x & 63) == 0 && (my_cells | my_bytes)) {
-        atomicAdd(&counters[kPlanTileCells], my_cells);
-        atomicAdd(&counters[kPlanTileBytes], my_bytes);
-        atomicMax(&counters[kPlanMaxCost8], (unsigned long long)my_max);
+    __shared__ unsigned long long s_cells[kPlanThreads / 64], s_bytes[kPlanThreads / 64];
+    __shared__ uint32_t s_max[kPlanThreads / 64];
+    if ((threadIdx.x & 63) == 0) { s_cells[threadIdx.x >> 6] = my_cells; s_bytes[threadIdx.x >> 6] = my_bytes; s_max[threadIdx.x >> 6] = my_max; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0, b = 0;
+        uint32_t m = 0;
+        for (int w = 0; w < kPlanThreads / 64; w++) { c += s_cells[w]; b += s_bytes[w]; m = max(m, s_max[w]); }
+        if (c | b) {
+            atomicAdd(&counters[kPlanTileCells], c);
+            atomicAdd(&counters[kPlanTileBytes], b);
+            atomicMax(&counters[kPlanMaxCost8], (unsigned long long)m);
+        }
     }
 }
 
@@ -274,9 +299,13 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
                                                              TileJob *__restrict__ tjobs,
                                                              unsigned long long *__restrict__ counters)
 {
-    using Sort = hipcub::BlockRadixSort<uint32_t, kPlanThreads, kTileItems, TileJob>;
     using Scan = hipcub::BlockScan<uint32_t, kPlanThreads>;
-    __shared__ union { typename Sort::TempStorage sort; typename Scan::TempStorage scan; } tmp;
+    __shared__ union {
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 2, TileJob>::TempStorage sort2;
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 4, TileJob>::TempStorage sort4;
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, kTileItems, TileJob>::TempStorage sort8;
+        typename Scan::TempStorage scan;
+    } tmp;
     __shared__ uint64_t s_read_start[kPlanMaxRuns], s_ref_start[kPlanMaxRuns]; // aligned (4-float) span starts
     __shared__ uint32_t s_last[kPlanMaxRuns];                                  // tile-local index of the run's last job
     __shared__ uint32_t s_read_lds[kPlanMaxRuns], s_ref_lds[kPlanMaxRuns];     // LDS float offsets of the two spans
@@ -339,41 +368,48 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
         }
     }
     __syncthreads();
-    // pass 2: records
-    uint32_t keys[kTileItems];
-    TileJob recs[kTileItems];
+    // pass 2: records, sorted by (kind, longer side desc, shorter side desc); the sort is stable, so job order breaks ties
+    auto records = [&](auto items_tag, auto &sort_storage) {
+        constexpr int ITEMS = decltype(items_tag)::value;
+        using SortT = hipcub::BlockRadixSort<uint32_t, kPlanThreads, ITEMS, TileJob>;
+        uint32_t keys[ITEMS];
+        TileJob recs[ITEMS];
 #pragma unroll
-    for (int k = 0; k < kTileItems; k++) {
-        const uint32_t i = threadIdx.x * kTileItems + k; // blocked arrangement
-        keys[k] = 0xffffffffu;
-        recs[k] = TileJob{0, 0, 0, 0, 255, 0, 0, 0};
-        if (i < n) {
-            const uint32_t pos = first + i;
-            const DevJob d = pjobs[order_tile[pos]];
-            const uint32_t rid = run_of(pos) - run0;
-            const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
-            const uint32_t off_read = s_read_lds[rid] + (uint32_t)((uint64_t)d.read_off - s_read_start[rid]);
-            const uint32_t off_ref = s_ref_lds[rid] + (uint32_t)(d.ref_off - s_ref_start[rid]);
-            const uint32_t NA = swap ? d.m : d.n, NB = swap ? d.n : d.m;
-            TileJob tj;
-            tj.offA = (uint16_t)(swap ? off_ref : off_read);
-            tj.offB = (uint16_t)(swap ? off_read : off_ref);
-            tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
-            tj.aux = d.aux; tj.pad = 0;
-            if (NA <= a.micro_max_n) { // micro path: per-shape band bitmask (host table, same index)
-                tj.pad = ((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + (uint32_t)d.R;
-                tj.R = NA <= 4 ? 0 : 1;
-            } else tj.R = (uint8_t)(2 + d.R);
-            recs[k] = tj;
-            keys[k] = ((uint32_t)tj.R << 27) | ((255u - NA) << 19) | ((255u - NB) << 11) | i;
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = threadIdx.x * ITEMS + k; // blocked arrangement
+            keys[k] = 0xffffffffu;
+            recs[k] = TileJob{0, 0, 0, 0, 255, 0, 0, 0};
+            if (i < n) {
+                const uint32_t pos = first + i;
+                const DevJob d = pjobs[order_tile[pos]];
+                const uint32_t rid = run_of(pos) - run0;
+                const bool swap = d.n < d.m; // dtw.cpp:284-292: A is the longer sequence
+                const uint32_t off_read = s_read_lds[rid] + (uint32_t)((uint64_t)d.read_off - s_read_start[rid]);
+                const uint32_t off_ref = s_ref_lds[rid] + (uint32_t)(d.ref_off - s_ref_start[rid]);
+                const uint32_t NA = swap ? d.m : d.n, NB = swap ? d.n : d.m;
+                TileJob tj;
+                tj.offA = (uint16_t)(swap ? off_ref : off_read);
+                tj.offB = (uint16_t)(swap ? off_read : off_ref);
+                tj.N = (uint8_t)NA; tj.M = (uint8_t)NB; tj.flags = (uint8_t)d.flags;
+                tj.aux = d.aux; tj.pad = 0;
+                if (NA <= a.micro_max_n) { // micro path: per-shape band bitmask (host table, same index)
+                    tj.pad = ((NA - 1) * 8 + (NB - 1)) * (kMaxLaneRadius + 1) + (uint32_t)d.R;
+                    tj.R = NA <= 4 ? 0 : 1;
+                } else tj.R = (uint8_t)(2 + d.R);
+                recs[k] = tj;
+                keys[k] = ((uint32_t)tj.R << 16) | ((255u - NA) << 8) | (255u - NB);
+            }
         }
-    }
-    Sort(tmp.sort).Sort(keys, recs);
+        SortT(sort_storage).Sort(keys, recs, 0, 20); // 4 + 8 + 8 key bits (padding keys are all ones: they sort last)
 #pragma unroll
-    for (int k = 0; k < kTileItems; k++) {
-        const uint32_t i = threadIdx.x * kTileItems + k; // sorted rank (blocked)
-        if (i < n) tjobs[first + i] = recs[k];
-    }
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = threadIdx.x * ITEMS + k; // sorted rank (blocked)
+            if (i < n) tjobs[first + i] = recs[k];
+        }
+    };
+    if (n <= 2u * kPlanThreads) records(std::integral_constant<int, 2>{}, tmp.sort2);
+    else if (n <= 4u * kPlanThreads) records(std::integral_constant<int, 4>{}, tmp.sort4);
+    else records(std::integral_constant<int, kTileItems>{}, tmp.sort8);
     if (threadIdx.x == 0) {
         tiles[t] = TileDesc{first, n, span_first, 2u * n_runs};
         atomicMax(&counters[kPlanLdsMax], (unsigned long long)tile_total);
@@ -387,8 +423,12 @@ inline bool plan_debug() { static const bool on = getenv("RAWDTW_PLAN_DEBUG") !=
 inline hipError_t step(const char *what, hipStream_t s)
 {
     if (!plan_debug()) return hipSuccess;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     const hipError_t e = hipStreamSynchronize(s);
-    fprintf(stderr, "[devplan] %-18s %s\n", what, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[devplan] %-18s %s  (%.3f ms since the previous step)\n", what, e == hipSuccess ? "ok" : hipGetErrorString(e),
+            std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
     return e;
 }
 inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kPlanThreads - 1) / kPlanThreads); }
