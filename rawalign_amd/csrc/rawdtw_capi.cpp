@@ -117,6 +117,7 @@ struct rawdtw_plan {
     uint64_t h_base = 0;
     bool dev_planned = false;
     uint64_t dev_tile_cells = 0, dev_tile_bytes = 0;
+    bool dev_cells_counted = false;
 };
 
 struct rawdtw_index {
@@ -879,7 +880,21 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
 // cells evaluated by plan positions [p0, p1) (exact band cell sets; reporting only)
 uint64_t count_cells(const rawdtw_plan *pl, uint64_t p0, uint64_t p1)
 {
-    if (pl->dev_planned && p0 < pl->h_base) { // the tile class of a device-planned batch: counted by k_plan_jobs
+    if (pl->dev_planned && p0 < pl->h_base) { // the tile class of a device-planned batch: counted on the device, once
+        rawdtw_plan *mp = const_cast<rawdtw_plan *>(pl);
+        if (!mp->dev_cells_counted) {
+            unsigned long long *d_total = nullptr, total = 0;
+            rawdtw_ctx *ctx = pl->ctx;
+            if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d_total), 8) == hipSuccess) {
+                if (dev_count_tile_cells(pl->d_tjobs, pl->n_tile_jobs, d_total, ctx->stream) == hipSuccess &&
+                    hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                    mp->dev_tile_cells = total;
+                    mp->dev_cells_counted = true;
+                }
+                (void)hipFree(d_total);
+            }
+        }
         const uint64_t rest = p1 > pl->h_base ? count_cells(pl, pl->h_base, p1) : 0;
         return pl->dev_tile_cells + rest; // (callers ask for whole launches: [0, h_base) is exactly the tile launch)
     }
@@ -1654,7 +1669,6 @@ int build_plan_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n
     for (uint32_t i = 0; i < pl->run_order.size(); i++) pl->run_order[i] = i; // the tile launch first, the rest as plan_host ordered them
     pl->h_base = n_tile_jobs;
     pl->dev_planned = true;
-    pl->dev_tile_cells = cnt[kPlanTileCells];
     pl->dev_tile_bytes = cnt[kPlanTileBytes];
     pl->n_jobs = n_jobs;
     pl->n_tile_jobs = n_tile_jobs;

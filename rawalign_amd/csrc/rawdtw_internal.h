@@ -107,6 +107,7 @@ struct DevPlanBuffers {
     uint8_t *run_start; uint64_t *cum; uint32_t *tile_first; void *scan_tmp; size_t scan_tmp_bytes;
 };
 size_t dev_plan_scratch_bytes(uint64_t n_jobs);
+hipError_t dev_count_tile_cells(const TileJob *d_tjobs, uint64_t n, unsigned long long *d_total, hipStream_t s);
 hipError_t dev_plan_phase1(const DevPlanArgs &a, const uint64_t *d_job_off, const uint64_t *d_anchor_off,
                            const rawdtw_anchor_t *d_anchors, const uint64_t *d_ref_base, const uint32_t *d_read_base,
                            void *scratch, DevPlanBuffers *buf, rawdtw_job_t *d_other_jobs, uint32_t *d_other_aux,

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -109,41 +110,31 @@ __device__ __forceinline__ bool tile_class(const DevPlanArgs &a, const JobGeom &
 
 } // namespace
 
+// chain numbers per job: every chain with jobs marks its first job with (chain + 1); an inclusive running maximum
+// then carries the mark over the chain's jobs
+__global__ __launch_bounds__(kPlanThreads) void k_mark_chains(uint64_t n_chains, const uint64_t *__restrict__ job_off,
+                                                              uint32_t *__restrict__ mark)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * kPlanThreads + threadIdx.x;
+    if (c < n_chains && job_off[c + 1] > job_off[c]) mark[job_off[c]] = (uint32_t)c + 1u;
+}
+
 // ---- k_plan_jobs -------------------------------------------------------------------------------
 __global__ __launch_bounds__(kPlanThreads) void k_plan_jobs(DevPlanArgs a, const uint64_t *__restrict__ job_off,
                                                             const uint64_t *__restrict__ anchor_off,
                                                             const rawdtw_anchor_t *__restrict__ anchors,
                                                             const uint64_t *__restrict__ ref_base,
                                                             const uint32_t *__restrict__ read_base,
-                                                            DevJob *__restrict__ pjobs, uint32_t *__restrict__ chain_of,
+                                                            DevJob *__restrict__ pjobs, const uint32_t *__restrict__ chain_of,
                                                             uint32_t *__restrict__ cost, uint32_t *__restrict__ is_tile,
                                                             uint8_t *__restrict__ run_start,
                                                             unsigned long long *__restrict__ counters)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * kPlanThreads + threadIdx.x;
     unsigned long long my_cells = 0, my_bytes = 0;
     uint32_t my_max = 0;
-    // two full binary searches per workgroup (its first and last job) bound everybody else's
-    __shared__ uint64_t s_clo, s_chi;
-    if (threadIdx.x < 2) {
-        const uint64_t jj = threadIdx.x == 0 ? (uint64_t)blockIdx.x * kPlanThreads
-                                             : min((uint64_t)blockIdx.x * kPlanThreads + kPlanThreads - 1, a.n_jobs - 1);
-        uint64_t lo = 0, hi = a.n_chains;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (job_off[mid] <= jj) lo = mid; else hi = mid;
-        }
-        if (threadIdx.x == 0) s_clo = lo; else s_chi = lo;
-    }
-    __syncthreads();
-    if (j < a.n_jobs) {
-        // chain of job j: last c with job_off[c] <= j, searched inside the window of chains this workgroup's jobs span
-        uint64_t lo = s_clo, hi = s_chi + 1;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (job_off[mid] <= j) lo = mid; else hi = mid;
-        }
-        const uint32_t c = (uint32_t)lo;
+    // grid-stride: a few thousand workgroups, so that the totals below cost a few thousand same-address atomics
+    for (uint64_t j = (uint64_t)blockIdx.x * kPlanThreads + threadIdx.x; j < a.n_jobs; j += (uint64_t)gridDim.x * kPlanThreads) {
+        const uint32_t c = chain_of[j] - 1u; // (k_mark_chains + a running maximum: no search per job)
         const uint32_t p = (uint32_t)(j - job_off[c]);
         const uint64_t a0 = anchor_off[c];
         const uint32_t na = (uint32_t)(anchor_off[c + 1] - a0);
@@ -175,15 +166,13 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_jobs(DevPlanArgs a, const
         d.flags = g.excl ? kFlagExcludeLast : 0u;
         d.aux = (uint32_t)j;
         pjobs[j] = d;
-        chain_of[j] = c;
         uint32_t cst = 0;
         if (tile) {
             // in eighths of a float, with a floor that bounds the jobs of a tile (k_plan_tiles sorts at most 2048 records)
             // a run start pays both windows, their exact start alignment and up to 3 floats of padding per span end
             cst = 8u * (starts ? g.n + g.m + (g.read_off & 3u) + (uint32_t)(g.ref_off & 3ull) + 6u : g.n + g.m - 2u + hole);
             if (cst < a.min_cost8) cst = a.min_cost8;
-            my_cells = d_banded_cells(g.n, g.m, R);
-            my_bytes = 4ull * ((unsigned long long)g.n + g.m) + 36ull;
+            my_bytes = 4ull * ((unsigned long long)g.n + g.m) + 36ull; // (cells are counted on demand: dev_count_tile_cells)
         }
         cost[j] = cst;
         if (tile) my_max = cst;
@@ -416,6 +405,38 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
     }
 }
 
+// Cells of the tile class, from the tile records (reporting only; the walk costs as much as scoring the jobs, so it
+// runs when somebody asks -- rawdtw_plan_info / launch stats -- not while planning).
+__global__ __launch_bounds__(kPlanThreads) void k_count_tile_cells(const TileJob *__restrict__ tjobs, uint64_t n,
+                                                                   unsigned long long *__restrict__ total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kPlanThreads + threadIdx.x;
+    unsigned long long c = 0;
+    if (i < n) {
+        const TileJob tj = tjobs[i];
+        const int R = tj.R >= 2 ? (int)tj.R - 2 : (int)(tj.pad % (kMaxLaneRadius + 1));
+        c = d_banded_cells(tj.N, tj.M, R);
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    __shared__ unsigned long long s_c[kPlanThreads / 64];
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kPlanThreads / 64; w++) t += s_c[w];
+        if (t) atomicAdd(total, t);
+    }
+}
+
+hipError_t dev_count_tile_cells(const TileJob *d_tjobs, uint64_t n, unsigned long long *d_total, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(k_count_tile_cells, dim3((uint32_t)((n + kPlanThreads - 1) / kPlanThreads)), dim3(kPlanThreads), 0, s,
+                       d_tjobs, n, d_total);
+    return hipGetLastError();
+}
+
 // ---- host-callable driver ----------------------------------------------------------------------
 namespace {
 // bring-up aid: RAWDTW_PLAN_DEBUG=1 synchronises after every planning step and names it on stderr
@@ -440,6 +461,8 @@ size_t dev_plan_scratch_bytes(uint64_t n_jobs)
     size_t scan_tmp = 0, t2 = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_jobs);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_jobs);
+    if (t2 > scan_tmp) scan_tmp = t2;
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, t2, (uint32_t *)nullptr, (uint32_t *)nullptr, hipcub::Max(), (int)n_jobs);
     if (t2 > scan_tmp) scan_tmp = t2;
     size_t b = 0;
     b += align_up(n_jobs * sizeof(DevJob));  // pjobs
@@ -481,6 +504,8 @@ hipError_t dev_plan_phase1(const DevPlanArgs &a, const uint64_t *d_job_off, cons
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_tmp, buf->cost, buf->cum, (int)n);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t2, buf->is_tile, buf->rank, (int)n);
     if (t2 > scan_tmp) scan_tmp = t2;
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, t2, buf->rank, buf->chain_of, hipcub::Max(), (int)n);
+    if (t2 > scan_tmp) scan_tmp = t2;
     buf->scan_tmp = take(scan_tmp);
     buf->scan_tmp_bytes = scan_tmp;
 
@@ -492,7 +517,14 @@ hipError_t dev_plan_phase1(const DevPlanArgs &a, const uint64_t *d_job_off, cons
     if ((e = hipMemcpyAsync(d_counters, init, sizeof(init), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
     if (n == 0) return hipSuccess;
     (void)hipGetLastError(); // (a stale error of an unrelated call must not be blamed on these launches)
-    hipLaunchKernelGGL(k_plan_jobs, dim3(blocks_for(n)), dim3(kPlanThreads), 0, s, a, d_job_off, d_anchor_off, d_anchors,
+    {   // chain of every job (buf->rank serves as the mark array until the rank scan overwrites it)
+        if ((e = hipMemsetAsync(buf->rank, 0, n * 4, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_mark_chains, dim3(blocks_for(a.n_chains)), dim3(kPlanThreads), 0, s, a.n_chains, d_job_off, buf->rank);
+        size_t tbm = buf->scan_tmp_bytes;
+        if ((e = hipcub::DeviceScan::InclusiveScan(buf->scan_tmp, tbm, buf->rank, buf->chain_of, hipcub::Max(), (int)n, s)) != hipSuccess) return e;
+        if ((e = step("chain marks", s)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_plan_jobs, dim3(std::min<uint32_t>(blocks_for(n), 4096u)), dim3(kPlanThreads), 0, s, a, d_job_off, d_anchor_off, d_anchors,
                        d_ref_base, d_read_base, buf->pjobs, buf->chain_of, buf->cost, buf->is_tile, buf->run_start, d_counters);
     if ((e = step("k_plan_jobs", s)) != hipSuccess) return e;
     size_t tb = buf->scan_tmp_bytes;
