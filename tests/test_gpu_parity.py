@@ -407,11 +407,14 @@ def test_planner_options_do_not_change_results(oracle):
         eng.set_option("no_such_option", 1)
 
 
-def test_batch_edge_cases(engine, oracle):
+@pytest.mark.parametrize("device_plan", [0, 1])
+def test_batch_edge_cases(engine, oracle, device_plan):
     """Reads without chains, a batch without any chain, and single-anchor chains (no DTW call at all:
-    align_chain returns 0*bonus - 0, which fails dtw_min_score)."""
+    align_chain returns 0*bonus - 0, which fails dtw_min_score) -- with the host and the device planner."""
     from rawalign_amd.align import CandidateBatch
 
+    engine.set_option("device_plan", device_plan)
+    engine.set_option("device_plan_min_jobs", 0)
     rng = np.random.default_rng(2)
     refsig = rng.normal(size=3000).astype(np.float32)
     engine.upload_reference([refsig], [refsig[::-1].copy()])
@@ -442,6 +445,17 @@ def test_batch_edge_cases(engine, oracle):
 
     want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
     assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
+    assert b.verify_plan() == bool(device_plan)
+    # anchors that do not ascend (a chain the mapper could never produce): both planners refuse the batch, with the
+    # host planner's wording (the device planner hands such batches over to it)
+    bad = a2.copy(); bad["query_position"][1] = 200
+    cbb = CandidateBatch(ev2, np.array([0, 1], np.uint64), np.array([0, 5], np.uint64), bad, np.array([base], np.uint64),
+                         np.zeros(1, np.uint32))
+    with pytest.raises(ra.RawDTWError) as e:
+        ra.Batch(engine, ra.MapOpt(), cbb)
+    assert "job " in str(e.value)
+    engine.set_option("device_plan", 1)
+    engine.set_option("device_plan_min_jobs", 65536)
 
 
 @pytest.mark.gpu
