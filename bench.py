@@ -113,7 +113,7 @@ def main():
     ref = synth.make_reference([args.genome], seed=SEED)
     opt = ra.MapOpt()  # sparse, banded=0.10, bonus 0.4, min score 20 (roptions.c:49-53)
     slots = max(1, args.inflight)
-    engines, batches, cbs, infos = [], [], [], []
+    engines, batches, cbs, infos, create_ms = [], [], [], [], []
     for sl in range(slots):
         e = ra.Engine(local_rank)
         if args.serial_launches:
@@ -126,7 +126,10 @@ def main():
         cb_, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=args.reads),
                                             seed=rank_seed(SEED, rank) + 104729 * sl)
         e.upload_events(cb_.events)
-        b_ = ra.Batch(e, opt, cb_)
+        e.sync()
+        t_c = time.perf_counter()
+        b_ = ra.Batch(e, opt, cb_)   # uploads the anchor lists and plans the batch (on the device by default)
+        create_ms.append((time.perf_counter() - t_c) * 1e3)
         engines.append(e); batches.append(b_); cbs.append(cb_); infos.append(b_.info())
         e.sync()
     eng, batch, cb, info = engines[0], batches[0], cbs[0], infos[0]
@@ -248,6 +251,10 @@ def main():
             "batch0": {"reads": args.reads, "chains": info["n_chains"], "dtw_jobs": info["n_jobs"],
                        "cells": info["cells"], "mapped_reads": mapped_slots[0],
                        "algorithmic_bytes": info["algorithmic_bytes"]},
+            # outside the timed region (inputs resident): what creating a mini-batch costs on the host side
+            "batch_create_ms": {"first": round(create_ms[0], 3), "steady": round(min(create_ms[1:] or create_ms), 3),
+                                "note": "rawdtw_batch_create: anchor upload + planning (device planner unless "
+                                        "RAWDTW_OPTS=device_plan=0); `first` includes code loading and workspace allocation"},
             "whole_step_hbm_frac": bytes_t / T / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

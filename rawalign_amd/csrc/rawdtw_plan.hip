@@ -172,10 +172,10 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_jobs(DevPlanArgs a, const
             // a run start pays both windows, their exact start alignment and up to 3 floats of padding per span end
             cst = 8u * (starts ? g.n + g.m + (g.read_off & 3u) + (uint32_t)(g.ref_off & 3ull) + 6u : g.n + g.m - 2u + hole);
             if (cst < a.min_cost8) cst = a.min_cost8;
-            my_bytes = 4ull * ((unsigned long long)g.n + g.m) + 36ull; // (cells are counted on demand: dev_count_tile_cells)
+            my_bytes += 4ull * ((unsigned long long)g.n + g.m) + 36ull; // (cells are counted on demand: dev_count_tile_cells)
         }
         cost[j] = cst;
-        if (tile) my_max = cst;
+        if (tile) my_max = max(my_max, cst);
         is_tile[j] = tile ? 1u : 0u;
         run_start[j] = (tile && starts) ? 1 : 0;
     }

@@ -459,6 +459,35 @@ def test_batch_edge_cases(engine, oracle, device_plan):
 
 
 @pytest.mark.gpu
+def test_device_planned_batch_at_scale():
+    """More jobs than the planning kernels have threads (grid-stride paths, several tiles per chain, thousands of
+    tiles): plan self-check, batch totals and every per-job cost against the host-planned batch."""
+    from rawalign_amd import synth
+
+    ref = synth.make_reference([600000], seed=93)
+    results = {}
+    for dev in (0, 1):
+        eng = ra.Engine(0)
+        eng.set_option("device_plan", dev)
+        eng.upload_reference(ref.forward, ref.reverse)
+        offs = {(0, st): eng.reference_offset(0, st) for st in (0, 1)}
+        cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=4500), seed=99)
+        eng.upload_events(cb.events)
+        batch = ra.Batch(eng, ra.MapOpt(), cb)
+        assert batch.verify_plan() == bool(dev)
+        info = batch.info()
+        assert info["n_jobs"] > 1_100_000
+        batch.run()
+        results[dev] = batch.fetch(with_job_costs=True) + (info,)
+        eng.close()
+    (s0, k0, c0, i0), (s1, k1, c1, i1) = results[0], results[1]
+    assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32))
+    assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(k0, k1)
+    for key in ("n_jobs", "cells", "algorithmic_bytes", "n_lane_jobs", "n_wave_band_jobs", "n_full_jobs"):
+        assert i0[key] == i1[key], key
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("border,fill", [(1, 1), (0, 1), (1, 0)])
 def test_device_planned_batch_matches_host_planned(oracle, border, fill):
     """rawdtw_batch_create with the tile class planned on the device (rawdtw_plan.hip): the tile records pass the same
