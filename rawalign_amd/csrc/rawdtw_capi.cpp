@@ -66,6 +66,12 @@ struct rawdtw_ctx {
     uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
     bool device_plan = true;  // rawdtw_batch_create plans the tile class on the device (rawdtw_plan.hip)
     uint64_t device_plan_min_jobs = 65536; // smaller batches plan on the host (fewer round trips)
+    uint8_t *d_tb_dir = nullptr; // traceback direction workspace, grow-only (hipFree of 600 MB per call costs 1 ms)
+    uint64_t tb_dir_bytes = 0;
+    void *d_tb_paths = nullptr;  // traceback path buffers (offsets, lengths, i/j end-first, i/j/d start-first), grow-only
+    size_t tb_paths_bytes = 0;
+    void *h_pinned = nullptr;  // pinned host staging (traceback paths), grow-only
+    size_t pinned_bytes = 0;
     void *d_scratch = nullptr; // device-planning workspace, grow-only, reused by the context's batches
     size_t scratch_bytes = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
@@ -118,6 +124,7 @@ struct rawdtw_plan {
     bool dev_planned = false;
     uint64_t dev_tile_cells = 0, dev_tile_bytes = 0;
     bool dev_cells_counted = false;
+    bool dir_borrowed = false; // d_dir is the context's workspace, not the plan's
 };
 
 struct rawdtw_index {
@@ -851,10 +858,20 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)ht.masks.size())) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_aux, n_dev_jobs)) != RAWDTW_OK ||
         (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_bnd, pl->bnd_floats)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_dir, pl->dir_bytes)) != RAWDTW_OK) {
+        (st = dev_alloc(ctx, &pl->d_bnd, pl->bnd_floats)) != RAWDTW_OK) {
         rawdtw_plan_destroy(pl);
         return st;
+    }
+    if (pl->dir_bytes) { // the context's direction workspace (one traceback batch at a time per context)
+        if (ctx->tb_dir_bytes < pl->dir_bytes) {
+            if (ctx->d_tb_dir) (void)hipFree(ctx->d_tb_dir);
+            ctx->d_tb_dir = nullptr; ctx->tb_dir_bytes = 0;
+            const uint64_t want = pl->dir_bytes + pl->dir_bytes / 8;
+            if ((st = dev_alloc(ctx, &ctx->d_tb_dir, want)) != RAWDTW_OK) { rawdtw_plan_destroy(pl); return st; }
+            ctx->tb_dir_bytes = want;
+        }
+        pl->d_dir = ctx->d_tb_dir;
+        pl->dir_borrowed = true;
     }
     if (n_jobs) {
         hipError_t e = hipSuccess;
@@ -1112,6 +1129,9 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->d_tb_dir) (void)hipFree(ctx->d_tb_dir);
+    if (ctx->d_tb_paths) (void)hipFree(ctx->d_tb_paths);
     delete ctx;
     return RAWDTW_OK;
 }
@@ -1371,7 +1391,7 @@ int rawdtw_plan_destroy(rawdtw_plan *plan)
     if (plan->d_masks) (void)hipFree(plan->d_masks);
     if (plan->d_cost) (void)hipFree(plan->d_cost);
     if (plan->d_bnd) (void)hipFree(plan->d_bnd);
-    if (plan->d_dir) (void)hipFree(plan->d_dir);
+    if (plan->d_dir && !plan->dir_borrowed) (void)hipFree(plan->d_dir);
     delete plan;
     return RAWDTW_OK;
 }
@@ -1397,8 +1417,18 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
     if (!ctx) return RAWDTW_ERR_INVALID;
     if (n_jobs && (!jobs || !out_cost || !path_off || !path_len || !path_i || !path_j || !path_d))
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[traceback] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     int st = rawdtw_upload_events(ctx, h_events, n_events);
     if (st != RAWDTW_OK) return st;
+    lap("events H2D");
 
     // sub-batches bounded by the direction-buffer budget
     uint64_t budget = 16ull << 30;
@@ -1419,6 +1449,7 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         rawdtw_plan *pl = nullptr;
         st = build_plan(ctx, jobs + begin, cnt, true, &pl);
         if (st != RAWDTW_OK) return st;
+        lap("plan + alloc");
         // device path buffers in plan order
         std::vector<uint64_t> h_poff(cnt);
         uint64_t acc = 0;
@@ -1426,34 +1457,52 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
             h_poff[p] = acc;
             acc += (uint64_t)pl->h_jobs[p].n + pl->h_jobs[p].m - 1;
         }
-        uint64_t *d_poff = nullptr;
-        uint32_t *d_plen = nullptr, *d_pi = nullptr, *d_pj = nullptr;
-        float *d_pd = nullptr;
-        auto cleanup = [&]() {
-            if (d_poff) (void)hipFree(d_poff);
-            if (d_plen) (void)hipFree(d_plen);
-            if (d_pi) (void)hipFree(d_pi);
-            if (d_pj) (void)hipFree(d_pj);
-            if (d_pd) (void)hipFree(d_pd);
-            rawdtw_plan_destroy(pl);
-        };
-        if ((st = dev_alloc(ctx, &d_poff, cnt)) != RAWDTW_OK || (st = dev_alloc(ctx, &d_plen, cnt)) != RAWDTW_OK ||
-            (st = dev_alloc(ctx, &d_pi, acc)) != RAWDTW_OK || (st = dev_alloc(ctx, &d_pj, acc)) != RAWDTW_OK ||
-            (st = dev_alloc(ctx, &d_pd, acc)) != RAWDTW_OK) {
-            cleanup();
-            return st;
+        // path buffers: one grow-only block of the context, carved up per sub-batch
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t b_off = al(cnt * 8), b_len = al(cnt * 4), b_el = al((size_t)acc * 4);
+        const size_t need = b_off + b_len + 5 * b_el;
+        auto cleanup = [&]() { rawdtw_plan_destroy(pl); };
+        if (ctx->tb_paths_bytes < need) {
+            if (ctx->d_tb_paths) (void)hipFree(ctx->d_tb_paths);
+            ctx->d_tb_paths = nullptr; ctx->tb_paths_bytes = 0;
+            if (hipMalloc(&ctx->d_tb_paths, need + need / 8) != hipSuccess) { cleanup(); return fail(ctx, RAWDTW_ERR_OOM, "path buffer allocation failed"); }
+            ctx->tb_paths_bytes = need + need / 8;
         }
+        char *pb = static_cast<char *>(ctx->d_tb_paths);
+        uint64_t *d_poff = reinterpret_cast<uint64_t *>(pb); pb += b_off;
+        uint32_t *d_plen = reinterpret_cast<uint32_t *>(pb); pb += b_len;
+        uint32_t *d_pi = reinterpret_cast<uint32_t *>(pb); pb += b_el;
+        uint32_t *d_pj = reinterpret_cast<uint32_t *>(pb); pb += b_el;
+        uint32_t *d_ti = reinterpret_cast<uint32_t *>(pb); pb += b_el;
+        uint32_t *d_tj = reinterpret_cast<uint32_t *>(pb); pb += b_el;
+        float *d_pd = reinterpret_cast<float *>(pb);
         hipError_t e = hipMemcpyAsync(d_poff, h_poff.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "path offsets upload"); }
+        lap("path buffers");
         st = rawdtw_plan_run(ctx, pl);
         if (st != RAWDTW_OK) { cleanup(); return st; }
+        lap("fill");
         for (const Launch &L : pl->launches) {
-            e = launch_tb_walk(pl->d_jobs + L.first, L.count, pl->d_aux + L.first, L.param & 255, ctx->d_ev, ctx->d_ref,
-                               pl->d_dir, d_poff + L.first, d_plen + L.first, d_pi, d_pj, d_pd, ctx->stream);
+            // one wave per job over the direction buffer, then start-first order + distances (k_tb_finish)
+            e = launch_tb_walk_wave(pl->d_jobs + L.first, L.count, pl->d_aux + L.first, L.param & 255, ctx->d_ev, ctx->d_ref,
+                                    pl->d_dir, d_poff + L.first, d_plen + L.first, d_ti, d_tj, d_pi, d_pj, d_pd, ctx->stream);
             if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback walk launch"); }
         }
-        std::vector<float> h_cost(cnt), h_pd(acc);
-        std::vector<uint32_t> h_plen(cnt), h_pi(acc), h_pj(acc);
+        lap("walk");
+        std::vector<float> h_cost(cnt);
+        std::vector<uint32_t> h_plen(cnt);
+        // paths land in pinned staging (pageable targets cost 4x the transfer in page faults), then go to the caller's arrays
+        const size_t seg = ((size_t)acc * 4 + 255) & ~(size_t)255;
+        if (ctx->pinned_bytes < 3 * seg) {
+            if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+            ctx->h_pinned = nullptr; ctx->pinned_bytes = 0;
+            const size_t want = 3 * seg + 3 * seg / 8;
+            if (hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault) != hipSuccess) { cleanup(); return fail(ctx, RAWDTW_ERR_OOM, "pinned host allocation failed"); }
+            ctx->pinned_bytes = want;
+        }
+        struct View { char *p; const float *f() const { return reinterpret_cast<const float *>(p); } const uint32_t *u() const { return reinterpret_cast<const uint32_t *>(p); }
+                      void *data() { return p; } };
+        View h_pi{static_cast<char *>(ctx->h_pinned)}, h_pj{static_cast<char *>(ctx->h_pinned) + seg}, h_pd{static_cast<char *>(ctx->h_pinned) + 2 * seg};
         e = hipMemcpyAsync(h_cost.data(), pl->d_cost, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(h_plen.data(), d_plen, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && acc) e = hipMemcpyAsync(h_pi.data(), d_pi, acc * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -1461,22 +1510,23 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         if (e == hipSuccess && acc) e = hipMemcpyAsync(h_pd.data(), d_pd, acc * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback download"); }
+        lap("paths D2H");
         for (uint64_t p = 0; p < cnt; p++) {
             const uint64_t k = begin + pl->order[p];
             out_cost[k] = h_cost[pl->order[p]];
             const uint32_t len = h_plen[p];
-            // device paths are end-first; the reference returns them start-first (dtw.cpp:656-657)
-            // and pops the last element when exclude_last_element is set (dtw.cpp:659-663)
+            // device paths are start-first already (k_tb_finish, dtw.cpp:656-657); the reference pops the last
+            // element when exclude_last_element is set (dtw.cpp:659-663)
             const uint32_t outlen = jobs[k].exclude_last ? len - 1 : len;
             const uint64_t src = h_poff[p], dst = path_off[k];
-            for (uint32_t q = 0; q < outlen; q++) {
-                path_i[dst + q] = h_pi[src + len - 1 - q];
-                path_j[dst + q] = h_pj[src + len - 1 - q];
-                path_d[dst + q] = h_pd[src + len - 1 - q];
-            }
+            memcpy(path_i + dst, h_pi.u() + src, (size_t)outlen * 4);
+            memcpy(path_j + dst, h_pj.u() + src, (size_t)outlen * 4);
+            memcpy(path_d + dst, h_pd.f() + src, (size_t)outlen * 4);
             path_len[k] = outlen;
         }
+        lap("copy out");
         cleanup();
+        lap("free");
         begin = end;
     }
     return RAWDTW_OK;

@@ -133,6 +133,10 @@ hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux
                           const float *ev, const float *ref, const uint8_t *dir_ws,
                           const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                           uint32_t *path_j, float *path_d, hipStream_t s);
+hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl, const float *ev,
+                               const float *ref, const uint8_t *dir_ws, const uint64_t *path_off, uint32_t *path_len,
+                               uint32_t *tmp_i, uint32_t *tmp_j, uint32_t *path_i, uint32_t *path_j, float *path_d,
+                               hipStream_t s);
 
 hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
                              const float *job_cost, float bonus, int fused, float *full_score, float *att_last, hipStream_t s);

@@ -1025,6 +1025,95 @@ __global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs,
     path_len[g] = k;
 }
 
+// Traceback walk, one wave per job.  The lane-per-job walk above chases one direction word per step through HBM
+// (~3.5 us per step, 5 ms for a thousand 1500-step paths).  The direction buffer is laid out in 1-KiB block rows
+// ([strip][block][lane][step in block]) and a path moving up the diagonal stays ~7 steps inside one block row: the
+// wave fetches the block row with one coalesced load into LDS and all lanes then walk it in lockstep on uniform
+// values.  Steps are buffered one per lane and leave as coalesced 64-step stores.  Output: (i, j) end-first; the
+// distances and the start-first order are produced afterwards by k_tb_finish, one thread per path element.
+template <int RPL>
+__global__ __launch_bounds__(64) void k_tb_walk_wave(const DevJob *__restrict__ jobs, const FullAux *__restrict__ aux,
+                                                     const uint8_t *__restrict__ dir_ws,
+                                                     const uint64_t *__restrict__ path_off,
+                                                     uint32_t *__restrict__ path_len, uint32_t *__restrict__ tmp_i,
+                                                     uint32_t *__restrict__ tmp_j)
+{
+    using word_t = typename DirWord<RPL>::type;
+    constexpr uint32_t SPB = 16u / sizeof(word_t);
+    __shared__ __attribute__((aligned(16))) word_t row[64 * SPB]; // one block row: [lane][step in block]
+    const int lane = threadIdx.x;
+    const DevJob jb = jobs[blockIdx.x];
+    const FullAux ax = aux[blockIdx.x];
+    const bool swapped = jb.n > jb.m;
+    const uint32_t NX = swapped ? jb.n : jb.m;
+    const uint64_t TXB = ((uint64_t)NX + 63u + SPB - 1) / SPB; // blocks per strip
+    const uint4 *dirs = reinterpret_cast<const uint4 *>(dir_ws + ax.dir_off);
+    const uint64_t po = path_off[blockIdx.x];
+    uint32_t i = jb.n - 1, j = jb.m - 1, k = 0;
+    uint32_t bi = i, bj = j; // this lane's slot of the 64-step output buffer (lane = step & 63)
+    uint64_t cur = ~0ull;    // block row held in LDS (prefetching the next one was measured: no gain, the walk's own
+                             // dependent chain -- LDS read, decode, branch -- is what a step costs)
+    auto flush = [&](uint32_t upto) { // steps [upto - ((upto - 1) & 63) - 1 .. upto) sit in lanes 0..(upto-1)&63
+        const uint32_t base = (upto - 1) & ~63u;
+        if ((uint32_t)lane <= ((upto - 1) & 63u)) { tmp_i[po + base + lane] = bi; tmp_j[po + base + lane] = bj; }
+    };
+    // step 0: the end cell
+    if (lane == 0) { bi = i; bj = j; }
+    k = 1;
+    while (i > 0 || j > 0) {
+        if (i == 0) j--;
+        else if (j == 0) i--;
+        else {
+            const uint32_t y = swapped ? j : i, x = swapped ? i : j;
+            const uint32_t sidx = y / (64u * RPL), l = (y / RPL) & 63u, kk = y % RPL;
+            const uint32_t t = x + l;
+            const uint64_t key = (uint64_t)sidx * TXB + t / SPB;
+            if (key != cur) {
+                reinterpret_cast<uint4 *>(row)[lane] = dirs[key * 64u + lane];
+                cur = key;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            uint32_t word = row[l * SPB + (t % SPB)];
+            word = (uint32_t)__builtin_amdgcn_readfirstlane((int)word);
+            const uint32_t code = (word >> (2 * kk)) & 3u;
+            if (code == 1u) i--;
+            else if (code == 2u) j--;
+            else { i--; j--; }
+            // (the next block row may overwrite `row` only after every lane has read this word: the barrier above
+            // is the only writer and all lanes reach it together, the walk being uniform)
+        }
+        if ((uint32_t)lane == (k & 63u)) { bi = i; bj = j; }
+        k++;
+        if ((k & 63u) == 0) flush(k);
+    }
+    if ((k & 63u) != 0) flush(k);
+    if (lane == 0) path_len[blockIdx.x] = k;
+}
+
+// Start-first order, the exclude-last pop (dtw.cpp:656-663) and the per-step distance: one thread per path element.
+__global__ __launch_bounds__(256) void k_tb_finish(const DevJob *__restrict__ jobs, uint32_t count,
+                                                   const float *__restrict__ ev, const float *__restrict__ ref,
+                                                   const uint64_t *__restrict__ path_off,
+                                                   const uint32_t *__restrict__ path_len,
+                                                   const uint32_t *__restrict__ tmp_i, const uint32_t *__restrict__ tmp_j,
+                                                   uint32_t *__restrict__ path_i, uint32_t *__restrict__ path_j,
+                                                   float *__restrict__ path_d)
+{
+    const uint32_t g = blockIdx.x;
+    if (g >= count) return;
+    const DevJob jb = jobs[g];
+    const float *a = ev + jb.read_off;
+    const float *b = ref + jb.ref_off;
+    const uint64_t po = path_off[g];
+    const uint32_t len = path_len[g];
+    for (uint32_t q = threadIdx.x; q < len; q += 256) {
+        const uint32_t i = tmp_i[po + len - 1 - q], j = tmp_j[po + len - 1 - q];
+        path_i[po + q] = i; path_j[po + q] = j; path_d[po + q] = dist(a[i], b[j]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-candidate selection: the fold of align_chain (rmap.cpp:238-306) and the best-so-far loop of
 // gen_chains (rmap.cpp:515-524), on the device.  A chain's running `current_max_attainable_score`
@@ -1311,6 +1400,27 @@ hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux
     const uint32_t blocks = (uint32_t)((count + 63) / 64);
     hipLaunchKernelGGL(k_tb_walk, dim3(blocks), dim3(64), 0, s, jobs, (uint32_t)count, aux, rpl, ev, ref,
                        dir_ws, path_off, path_len, path_i, path_j, path_d);
+    return hipGetLastError();
+}
+
+// wave-per-job walk (end-first (i, j) into tmp_i / tmp_j) followed by k_tb_finish (start-first i, j, d)
+hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl, const float *ev,
+                               const float *ref, const uint8_t *dir_ws, const uint64_t *path_off, uint32_t *path_len,
+                               uint32_t *tmp_i, uint32_t *tmp_j, uint32_t *path_i, uint32_t *path_j, float *path_d,
+                               hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    const dim3 grid((uint32_t)count), block(64);
+    switch (rpl) {
+    case 1: hipLaunchKernelGGL(k_tb_walk_wave<1>, grid, block, 0, s, jobs, aux, dir_ws, path_off, path_len, tmp_i, tmp_j); break;
+    case 2: hipLaunchKernelGGL(k_tb_walk_wave<2>, grid, block, 0, s, jobs, aux, dir_ws, path_off, path_len, tmp_i, tmp_j); break;
+    case 4: hipLaunchKernelGGL(k_tb_walk_wave<4>, grid, block, 0, s, jobs, aux, dir_ws, path_off, path_len, tmp_i, tmp_j); break;
+    default: hipLaunchKernelGGL(k_tb_walk_wave<8>, grid, block, 0, s, jobs, aux, dir_ws, path_off, path_len, tmp_i, tmp_j); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tb_finish, grid, dim3(256), 0, s, jobs, (uint32_t)count, ev, ref, path_off, path_len, tmp_i, tmp_j,
+                       path_i, path_j, path_d);
     return hipGetLastError();
 }
 
