@@ -129,10 +129,6 @@ hipError_t launch_band_wave(const DevJob *jobs, uint64_t count, uint32_t lds_flo
 hipError_t launch_full_wave(int rows_per_lane, bool traceback, const DevJob *jobs, uint64_t count,
                             const FullAux *aux, const float *ev, const float *ref, float *out,
                             float *bnd_ws, uint8_t *dir_ws, hipStream_t s);
-hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux, int rows_per_lane,
-                          const float *ev, const float *ref, const uint8_t *dir_ws,
-                          const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
-                          uint32_t *path_j, float *path_d, hipStream_t s);
 hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl, const float *ev,
                                const float *ref, const uint8_t *dir_ws, const uint64_t *path_off, uint32_t *path_len,
                                uint32_t *tmp_i, uint32_t *tmp_j, uint32_t *path_i, uint32_t *path_j, float *path_d,

@@ -3,7 +3,7 @@
 // What they replace (reference file:line):
 //   k_band_tile / k_band_wreg / k_band_wave : DTW_global_slantedbanded_antidiagonalwise  src/dtw.cpp:273-520
 //   k_full_wave<.,false>      : DTW_global                                 src/dtw.cpp:37-66
-//   k_full_wave<.,true> + k_tb_walk : DTW_global_tb                        src/dtw.cpp:595-667
+//   k_full_wave<.,true> + k_tb_walk_wave + k_tb_finish : DTW_global_tb                        src/dtw.cpp:595-667
 //
 // All of them are scalar fp32 min/add recurrences (no MFMA: nothing here is a contraction).
 // Cell values do not depend on evaluation order (min is exact, each cell is one rounded
@@ -977,56 +977,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_full_wave(const DevJob *__restri
     }
 }
 
-// Traceback walk over the packed direction buffer: one lane per job, end-first output.
-__global__ __launch_bounds__(64) void k_tb_walk(const DevJob *__restrict__ jobs, uint32_t count,
-                                                const FullAux *__restrict__ aux, int rpl,
-                                                const float *__restrict__ ev,
-                                                const float *__restrict__ ref,
-                                                const uint8_t *__restrict__ dir_ws,
-                                                const uint64_t *__restrict__ path_off,
-                                                uint32_t *__restrict__ path_len,
-                                                uint32_t *__restrict__ path_i,
-                                                uint32_t *__restrict__ path_j,
-                                                float *__restrict__ path_d)
-{
-    const uint32_t g = blockIdx.x * 64u + threadIdx.x;
-    if (g >= count) return;
-    const DevJob jb = jobs[g];
-    const FullAux ax = aux[g];
-    const float *a = ev + jb.read_off;
-    const float *b = ref + jb.ref_off;
-    const bool swapped = jb.n > jb.m;
-    const uint32_t NX = swapped ? jb.n : jb.m;
-    const uint32_t SPB = rpl == 8 ? 8u : 16u;                 // steps per 16-byte block (k_full_wave)
-    const uint64_t TXB = ((uint64_t)NX + 63u + SPB - 1) / SPB; // blocks per strip
-    const uint8_t *d8 = dir_ws + ax.dir_off;
-    const uint16_t *d16 = reinterpret_cast<const uint16_t *>(d8);
-    const uint64_t po = path_off[g];
-    uint32_t i = jb.n - 1, j = jb.m - 1, k = 0;
-    path_i[po] = i; path_j[po] = j; path_d[po] = dist(a[i], b[j]);
-    k = 1;
-    while (i > 0 || j > 0) {
-        if (i == 0) j--;
-        else if (j == 0) i--;
-        else {
-            const uint32_t y = swapped ? j : i, x = swapped ? i : j;
-            const uint32_t s = y / (64u * rpl), l = (y / rpl) & 63u, kk = y % rpl;
-            const uint32_t t = x + l;
-            const uint64_t at = (((uint64_t)s * TXB + t / SPB) * 64u + l) * SPB + (t % SPB); // word index
-            const uint32_t word = (rpl == 8) ? d16[at] : d8[at];
-            const uint32_t code = (word >> (2 * kk)) & 3u;
-            if (code == 1u) i--;
-            else if (code == 2u) j--;
-            else { i--; j--; }
-        }
-        path_i[po + k] = i; path_j[po + k] = j; path_d[po + k] = dist(a[i], b[j]);
-        k++;
-    }
-    path_len[g] = k;
-}
-
-// Traceback walk, one wave per job.  The lane-per-job walk above chases one direction word per step through HBM
-// (~3.5 us per step, 5 ms for a thousand 1500-step paths).  The direction buffer is laid out in 1-KiB block rows
+// Traceback walk, one wave per job.  (A lane-per-job walk chases one direction word per step through HBM:
+// ~3.5 us per step, 5 ms for a thousand 1500-step paths.)  The direction buffer is laid out in 1-KiB block rows
 // ([strip][block][lane][step in block]) and a path moving up the diagonal stays ~7 steps inside one block row: the
 // wave fetches the block row with one coalesced load into LDS and all lanes then walk it in lockstep on uniform
 // values.  Steps are buffered one per lane and leave as coalesced 64-step stores.  Output: (i, j) end-first; the
@@ -1389,18 +1341,6 @@ hipError_t launch_full_wave(int rpl, bool tb, const DevJob *jobs, uint64_t count
     default: return hipErrorInvalidValue;
     }
 #undef RAWDTW_FULL_CASE
-}
-
-hipError_t launch_tb_walk(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl,
-                          const float *ev, const float *ref, const uint8_t *dir_ws,
-                          const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
-                          uint32_t *path_j, float *path_d, hipStream_t s)
-{
-    if (count == 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)((count + 63) / 64);
-    hipLaunchKernelGGL(k_tb_walk, dim3(blocks), dim3(64), 0, s, jobs, (uint32_t)count, aux, rpl, ev, ref,
-                       dir_ws, path_off, path_len, path_i, path_j, path_d);
-    return hipGetLastError();
 }
 
 // wave-per-job walk (end-first (i, j) into tmp_i / tmp_j) followed by k_tb_finish (start-first i, j, d)
