@@ -246,26 +246,24 @@ __device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
 // antidiagonals once (bit 8*j + i <=> cell (i over the longer sequence, j over the shorter) is in the
 // band's cell set).  Same values as the antidiagonal order: a cell is min3 of its in-band neighbours
 // (absent = 1e10) plus its distance, whatever the evaluation order.
-template <int W>
-__device__ __forceinline__ float micro_job(const float *win, const TileJob &tj, const unsigned long long *masks)
+template <int W, int NC>
+__device__ __forceinline__ float micro_job_cols(const float *LA, const float *LB, const uint32_t N, const uint32_t M,
+                                                const unsigned long long mask)
 {
-    const float *LA = win + tj.offA;
-    const float *LB = win + tj.offB;
-    const uint32_t N = tj.N, M = tj.M;
-    const unsigned long long mask = masks[tj.pad];
-    float a[W], v[W];
+    // NC = columns any lane of the wave needs (its longest job): the grid is W rows x NC columns
+    float a[NC], v[NC];
 #pragma unroll
-    for (int i = 0; i < W; i++) { a[i] = LA[i]; v[i] = kInf; } // columns >= N are never in the mask
+    for (int i = 0; i < NC; i++) { a[i] = LA[i]; v[i] = kInf; } // columns >= N are never in the mask
 #pragma unroll
-    for (int j = 0; j < W; j++) {
-        if (__any((uint32_t)j < M)) {       // wave-uniform: skip rows no lane needs
-            if ((uint32_t)j < M) {          // per lane
+    for (int j = 0; j < NC; j++) {              // (M <= N <= NC: rows beyond NC do not exist either)
+        if (__any((uint32_t)j < M)) {           // wave-uniform: skip rows no lane needs
+            if ((uint32_t)j < M) {              // per lane
                 const float bj = LB[j];
                 const uint32_t rowmask = (uint32_t)(mask >> (8 * j)) & 0xffu;
                 float diag = (j == 0) ? 0.0f : kInf; // virtual corner: D[0][0] = 0 + dist
                 float left = kInf;
 #pragma unroll
-                for (int i = 0; i < W; i++) {
+                for (int i = 0; i < NC; i++) {
                     const float up = v[i];
                     const float val = min3f(up, left, diag) + dist(a[i], bj);
                     const float keep = (rowmask & (1u << i)) ? val : kInf;
@@ -276,7 +274,31 @@ __device__ __forceinline__ float micro_job(const float *win, const TileJob &tj, 
     }
     float res = v[0];
 #pragma unroll
-    for (int i = 1; i < W; i++) res = (N - 1 == (uint32_t)i) ? v[i] : res;
+    for (int i = 1; i < NC; i++) res = (N - 1 == (uint32_t)i) ? v[i] : res;
+    return res;
+}
+
+template <int W>
+__device__ __forceinline__ float micro_job(const float *win, const TileJob &tj, const unsigned long long *masks)
+{
+    const float *LA = win + tj.offA;
+    const float *LB = win + tj.offB;
+    const uint32_t N = tj.N, M = tj.M;
+    const unsigned long long mask = masks[tj.pad];
+    // a tile's records are sorted by longer side, descending, inside a kind: the wave's first active lane has the
+    // longest job, and the grid need not be wider than that
+    const uint32_t Nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);
+    float res;
+    if constexpr (W == 4) {
+        if (Nw <= 2) res = micro_job_cols<4, 2>(LA, LB, N, M, mask);
+        else if (Nw == 3) res = micro_job_cols<4, 3>(LA, LB, N, M, mask);
+        else res = micro_job_cols<4, 4>(LA, LB, N, M, mask);
+    } else {
+        if (Nw <= 5) res = micro_job_cols<8, 5>(LA, LB, N, M, mask);
+        else if (Nw == 6) res = micro_job_cols<8, 6>(LA, LB, N, M, mask);
+        else if (Nw == 7) res = micro_job_cols<8, 7>(LA, LB, N, M, mask);
+        else res = micro_job_cols<8, 8>(LA, LB, N, M, mask);
+    }
     if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
     return res;
 }
