@@ -73,6 +73,11 @@ def cpu_baseline(jobs, events, ref_arena, cells, threads, target_s=1.5):
         out = impl.batch_costs(jobs[:take], events, ref_arena, threads)
     dt = (time.perf_counter() - t0) / reps
     frac = take / n
+    # ... and one thread on a prefix, for the per-core figure (single-threaded and all cores)
+    take1 = int(min(n, max(50000, 1.0 / max(per_job * threads, 1e-9))))
+    t0 = time.perf_counter()
+    impl.batch_costs(jobs[:take1], events, ref_arena, 1)
+    dt1 = time.perf_counter() - t0
     return {
         "value": cells * frac / dt / 1e9,
         "unit": "GCUPS",
@@ -81,6 +86,8 @@ def cpu_baseline(jobs, events, ref_arena, cells, threads, target_s=1.5):
         "sample": f"first {take} of {n} DTW jobs of the same batch ({frac * 100:.0f}% of its cells, cells pro-rated by job count), "
                   f"{reps} repetition(s), {threads} threads pulling jobs from a shared counter, {dt * reps:.1f} s wall",
         "jobs_per_s": take / dt,
+        "single_thread": {"value": cells * (take1 / n) / dt1 / 1e9, "unit": "GCUPS",
+                          "sample": f"first {take1} jobs, one thread, {dt1:.1f} s wall"},
     }, out, take
 
 

@@ -31,7 +31,7 @@ JOB_DTYPE = np.dtype(
         ("m", "<u4"),
         ("band_radius", "<i4"),
         ("exclude_last", "<u4"),
-        ("pad", "<u4"),
+        ("reserved", "<u4"),
     ]
 )
 assert JOB_DTYPE.itemsize == 32
