@@ -1621,7 +1621,7 @@ int build_plan_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n
     if (cfg.lane_max_radius < 0 || cfg.sort_n || cfg.sort_r1_n || cfg.sort_r3 || cfg.lane_hi) return kDevPlanFallback;
     if (n_jobs >= (1ull << 31) || n_jobs * 160ull >= (1ull << 40)) return kDevPlanFallback;
     const uint32_t worst_job = 2u * cfg.lane_max_n + 12u;
-    if (cfg.tile_lds_floats < worst_job + 14u + 1024u || cfg.tile_lds_floats > 16000u) return kDevPlanFallback; // (16-bit LDS offsets)
+    if (cfg.tile_lds_floats < worst_job + 14u + 1024u || cfg.tile_lds_floats > 6000u) return kDevPlanFallback; // (k_plan_tiles' run table: 768 runs of >= 8 floats)
     DevPlanArgs a{};
     a.n_jobs = n_jobs; a.n_chains = n_chains; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
     a.border = opt->border_constraint; a.banded = opt->fill_method != 0; a.frac = opt->band_radius_frac;

@@ -35,7 +35,9 @@ namespace {
 constexpr int kPlanThreads = 256;
 constexpr int kTileItems = 8;                              // records per thread in k_plan_tiles
 constexpr uint32_t kPlanMaxTileJobs = kPlanThreads * kTileItems; // 2048
-constexpr uint32_t kPlanMaxRuns = 1024;                    // runs (chains or chain fragments) per tile
+constexpr uint32_t kPlanMaxRuns = 768;                     // runs (chains or chain fragments) per tile.  A run start costs at
+                                                           // least 8 floats of the tile's budget, so a 5120-float tile holds
+                                                           // at most 640 (the host side refuses larger tile budgets)
 
 __device__ __forceinline__ int d_slanted_radius(uint32_t n, uint32_t m, int r0)
 {
@@ -289,15 +291,24 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
                                                              unsigned long long *__restrict__ counters)
 {
     using Scan = hipcub::BlockScan<uint32_t, kPlanThreads>;
-    __shared__ union {
-        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 2, TileJob>::TempStorage sort2;
-        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 4, TileJob>::TempStorage sort4;
-        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, kTileItems, TileJob>::TempStorage sort8;
-        typename Scan::TempStorage scan;
-    } tmp;
-    __shared__ uint64_t s_read_start[kPlanMaxRuns], s_ref_start[kPlanMaxRuns]; // aligned (4-float) span starts
-    __shared__ uint32_t s_last[kPlanMaxRuns];                                  // tile-local index of the run's last job
-    __shared__ uint32_t s_read_lds[kPlanMaxRuns], s_ref_lds[kPlanMaxRuns];     // LDS float offsets of the two spans
+    // LDS is used in three phases that do not overlap: the run table (pass 1 .. record building), the sort of
+    // (key, tile-local index) pairs, and the exchange that brings each record to its sorted place
+    struct RunTable {
+        uint64_t read_start[kPlanMaxRuns], ref_start[kPlanMaxRuns]; // aligned (4-float) span starts
+        uint32_t last[kPlanMaxRuns];                                // tile-local index of the run's last job
+        uint32_t read_lds[kPlanMaxRuns], ref_lds[kPlanMaxRuns];     // LDS float offsets of the two spans
+    };
+    __shared__ union Lds {
+        RunTable runs;
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 2, uint16_t>::TempStorage sort2;
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, 4, uint16_t>::TempStorage sort4;
+        typename hipcub::BlockRadixSort<uint32_t, kPlanThreads, kTileItems, uint16_t>::TempStorage sort8;
+        TileJob recs[kPlanMaxTileJobs];
+        __device__ Lds() {}
+    } lds;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    uint64_t *const s_read_start = lds.runs.read_start, *const s_ref_start = lds.runs.ref_start;
+    uint32_t *const s_last = lds.runs.last, *const s_read_lds = lds.runs.read_lds, *const s_ref_lds = lds.runs.ref_lds;
 
     const uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
         my_total += lr + lf;
     }
     uint32_t my_base, tile_total;
-    Scan(tmp.scan).ExclusiveSum(my_total, my_base, tile_total);
+    Scan(scan_tmp).ExclusiveSum(my_total, my_base, tile_total);
     __syncthreads();
     const uint32_t span_first = 2u * run0;
 #pragma unroll
@@ -357,16 +368,19 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
         }
     }
     __syncthreads();
-    // pass 2: records, sorted by (kind, longer side desc, shorter side desc); the sort is stable, so job order breaks ties
+    // pass 2: records (blocked arrangement, in registers), then a stable sort of (key, tile-local index) by
+    // (kind, longer side desc, shorter side desc) -- job order breaks ties -- and an exchange through LDS
     auto records = [&](auto items_tag, auto &sort_storage) {
         constexpr int ITEMS = decltype(items_tag)::value;
-        using SortT = hipcub::BlockRadixSort<uint32_t, kPlanThreads, ITEMS, TileJob>;
+        using SortT = hipcub::BlockRadixSort<uint32_t, kPlanThreads, ITEMS, uint16_t>;
         uint32_t keys[ITEMS];
+        uint16_t idx[ITEMS];
         TileJob recs[ITEMS];
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const uint32_t i = threadIdx.x * ITEMS + k; // blocked arrangement
             keys[k] = 0xffffffffu;
+            idx[k] = (uint16_t)i;
             recs[k] = TileJob{0, 0, 0, 0, 255, 0, 0, 0};
             if (i < n) {
                 const uint32_t pos = first + i;
@@ -389,16 +403,24 @@ __global__ __launch_bounds__(kPlanThreads) void k_plan_tiles(DevPlanArgs a, uint
                 keys[k] = ((uint32_t)tj.R << 16) | ((255u - NA) << 8) | (255u - NB);
             }
         }
-        SortT(sort_storage).Sort(keys, recs, 0, 20); // 4 + 8 + 8 key bits (padding keys are all ones: they sort last)
+        __syncthreads(); // the run table is dead from here on
+        SortT(sort_storage).Sort(keys, idx, 0, 20); // 4 + 8 + 8 key bits (padding keys are all ones: they sort last)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const uint32_t i = threadIdx.x * ITEMS + k;
+            if (i < n) lds.recs[i] = recs[k];
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const uint32_t i = threadIdx.x * ITEMS + k; // sorted rank (blocked)
-            if (i < n) tjobs[first + i] = recs[k];
+            if (i < n) tjobs[first + i] = lds.recs[idx[k]];
         }
     };
-    if (n <= 2u * kPlanThreads) records(std::integral_constant<int, 2>{}, tmp.sort2);
-    else if (n <= 4u * kPlanThreads) records(std::integral_constant<int, 4>{}, tmp.sort4);
-    else records(std::integral_constant<int, kTileItems>{}, tmp.sort8);
+    if (n <= 2u * kPlanThreads) records(std::integral_constant<int, 2>{}, lds.sort2);
+    else if (n <= 4u * kPlanThreads) records(std::integral_constant<int, 4>{}, lds.sort4);
+    else records(std::integral_constant<int, kTileItems>{}, lds.sort8);
     if (threadIdx.x == 0) {
         tiles[t] = TileDesc{first, n, span_first, 2u * n_runs};
         atomicMax(&counters[kPlanLdsMax], (unsigned long long)tile_total);
