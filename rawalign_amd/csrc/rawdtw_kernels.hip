@@ -212,6 +212,134 @@ __device__ __forceinline__ float lane_dp(const float *LA, const float *LB, const
     return p1[HP + SH]; // dtw.cpp:506-512
 }
 
+// The same DP for waves whose lanes do NOT share one shape.  There the lanes disagree on `adv` (does the centre row
+// advance at this column?) at almost every column, and a branch on it makes the wave run both bodies of lane_dp --
+// secondary + primary, and the lone primary -- every time.  This variant has one body: the secondary is always
+// computed (its result only matters when the row advances), and the primary takes its neighbours through selects on
+// `adv`; the two cases of lane_dp then differ in operands only:
+//   X  = adv ? (p2 after the secondary) : p1     -- the antidiagonal just before this primary
+//   tl = adv ? p1 : p2                           -- the one before that (shifted by one slot when the row stays)
+// and both end with p1 = the new primary, p2 = X.  About 55 vector instructions per column against ~85 for the two
+// bodies; a wave of one shape is still better off with lane_dp (scalar branch, ~47).
+template <int R>
+__device__ __forceinline__ float lane_dp_sel(const float *LA, const float *LB, const uint32_t N, const uint32_t M)
+{
+    constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
+    constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
+    constexpr int K = (P > S) ? P : S;
+    constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
+    constexpr int HP = P / 2, HS = S / 2;
+    constexpr bool EVEN = (R % 2 == 0);
+    const int iN = (int)N, iM = (int)M;
+
+    float p1[K], p2[K];
+    float aw[K];     // aw[x] = A[col + HP - x]
+    float bw[K + 1]; // bw[x] = B[row - HP - 1 + x]
+#pragma unroll
+    for (int x = 0; x < K; x++) {
+        p1[x] = kInf; p2[x] = kInf;
+        const int ia = HP - x;
+        aw[x] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
+    }
+#pragma unroll
+    for (int x = 0; x <= K; x++) {
+        const int ib = x - HP - 1;
+        bw[x] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+    }
+    p1[HP + SH] = dist(LA[0], LB[0]); // column 0: only the corner (dtw.cpp:317-347)
+
+    int row = 0;
+    uint32_t rem = 0;
+    bool prev_adv = false;
+    float a_next, b_next;
+    {
+        const int ia = 1 + HP, ib = 1 - HP - 1 + K;
+        a_next = LA[ia >= iN ? iN - 1 : ia];
+        b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+    }
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        rem -= adv ? N : 0u;
+        row += adv ? 1 : 0;
+        // a-window: one step per column
+#pragma unroll
+        for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
+        aw[0] = a_next;
+        {
+            const int ia = (int)col + 1 + HP;
+            a_next = LA[ia >= iN ? iN - 1 : ia];
+        }
+        // b-window: one step when the row advances.  (b_next is a function of the row alone: reloading it every column
+        // returns the same value while the row stays.)
+#pragma unroll
+        for (int x = 0; x < K; x++) bw[x] = adv ? bw[x + 1] : bw[x];
+        bw[K] = adv ? b_next : bw[K];
+        {
+            const int ib = row - HP + K;
+            b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+        }
+        // secondary antidiagonal (dtw.cpp:361-414), wanted only when the row advanced
+        float q[K];
+#pragma unroll
+        for (int o = 0; o < K; o++) q[o] = p2[o];
+#pragma unroll
+        for (int o = 0; o < S; o++) {
+            const int i = (int)col + HS - 1 - o;
+            const int j = row - HS + o;
+            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+            const float av = EVEN ? aw[o + 1 < K ? o + 1 : K - 1] : aw[o];
+            const float bv = EVEN ? bw[o + 1] : bw[o];
+            float top, tl, left;
+            if (SH == 0) {
+                top = p1[o]; tl = p2[o]; left = p1[o + 1 < K ? o + 1 : K - 1];
+            } else {
+                top = (o == 0) ? kInf : p1[o];
+                tl = (o == 0 && !prev_adv) ? kInf : p2[o];
+                left = (o == S - 1) ? kInf : p1[o + 1 < K ? o + 1 : K - 1];
+            }
+            const float v = min3f(top, left, tl) + dist(av, bv);
+            q[o] = valid ? v : kInf;
+        }
+        float X[K];
+#pragma unroll
+        for (int x = 0; x < K; x++) X[x] = adv ? q[x] : p1[x];
+        // primary antidiagonal (dtw.cpp:416-485)
+        float nw[P];
+#pragma unroll
+        for (int o = 0; o < P; o++) {
+            const int i = (int)col + HP - o;
+            const int j = row - HP + o;
+            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
+            float top, left, tl;
+            if (SH == 0) {
+                top = (o == 0) ? kInf : X[o > 0 ? o - 1 : 0];
+                left = (o == P - 1) ? (adv ? kInf : X[o]) : X[o];
+                tl = adv ? p1[o] : ((o == 0) ? kInf : p2[o > 0 ? o - 1 : 0]);
+            } else {
+                top = (o == 0) ? (adv ? X[0] : kInf) : X[o];
+                left = X[o + 1 < K ? o + 1 : K - 1];
+                const float tl_stay = (o == 0 && !prev_adv) ? kInf : p2[o];
+                tl = adv ? p1[o + 1 < K ? o + 1 : K - 1] : tl_stay;
+            }
+            const float v = min3f(top, left, tl) + dist(aw[o], bw[o + 1]);
+            nw[o] = valid ? v : kInf;
+        }
+        if (SH == 0) {
+#pragma unroll
+            for (int o = 0; o < P; o++) p1[o] = nw[o];
+        } else {
+            p1[0] = adv ? p1[0] : p2[0];
+#pragma unroll
+            for (int o = 0; o < P; o++) p1[o + 1 < K ? o + 1 : K - 1] = nw[o];
+        }
+#pragma unroll
+        for (int x = 0; x < K; x++) p2[x] = X[x];
+        prev_adv = adv;
+    }
+    return p1[HP + SH]; // dtw.cpp:506-512
+}
+
 // Tile kernel.  A tile is a run of CONSECUTIVE jobs of the batch (consecutive parts of the same
 // chains), so the windows it needs form a few contiguous spans of the event and reference arenas:
 // the workgroup copies each span HBM -> LDS once with coalesced 16-byte loads (adjacent parts share
@@ -234,8 +362,8 @@ __device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
     // column loop and half of the clipping are scalar) and often the whole shape (then everything is)
     if (__all(N == N0)) {
         if (__all(M == M0)) res = lane_dp<R>(LA, LB, N0, M0);
-        else res = lane_dp<R>(LA, LB, N0, M);
-    } else res = lane_dp<R>(LA, LB, N, M);
+        else res = lane_dp_sel<R>(LA, LB, N0, M);
+    } else res = lane_dp_sel<R>(LA, LB, N, M);
     if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
     return res;
 }
