@@ -508,7 +508,9 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
             if (j.band_radius == RAWDTW_FULL) {
                 const int rpl = full_rpl(NY);
                 c = 56 + (rpl == 1 ? 0 : rpl == 2 ? 1 : rpl == 4 ? 2 : 3);
-                if (rpl == 8 && NY > 2 * 512u && cfg.full_wg) c = 60; // >= 3 strips: four waves per job
+                // >= 3 strips: four waves per job.  The pipelined kernel's progress word packs (strip << 21) | columns
+                // (k_full_wave): shapes beyond 2^21 columns or 2^11 strips stay on the one-wave variant.
+                if (rpl == 8 && NY > 2 * 512u && cfg.full_wg && N < (1u << 21) && (NY + 511u) / 512u < (1u << 11)) c = 60;
             } else {
                 if (traceback) {
                     bad(RAWDTW_ERR_UNSUPPORTED, "traceback of a banded job is not implemented (rmap.cpp:223-225 assert(false))");

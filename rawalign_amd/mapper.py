@@ -10,8 +10,9 @@ finishes the round: gen_primary_chains, comp_mapq, the stop rule (532-541, 692).
 
 Event detection and seeding are NOT implemented here (they stay in RawAlign: revent.c, rsketch.c,
 rawindex.cpp); a `SeedSource` supplies each chunk's events and seed hits.  `SyntheticSeeds`
-imitates them for tests and demos.  The scorer is pluggable so that tests can run the same control
-flow with the CPU oracle and compare PAF lines."""
+imitates them for tests and demos.  The scorer is pluggable (`score(reads, opt)`); the product ships
+only the device scorer -- the parity tests plug a CPU checker of their own into the same control flow
+(tests/util.py) and compare PAF lines."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -19,7 +20,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import mapping as M
-from .align import Batch, CandidateBatch, Chain, MapOpt
+from .align import (RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_LOG_SCORES, RI_M_DTW_OUTPUT_CIGAR, Batch, CandidateBatch, Chain,
+                    MapOpt, align_chain)
 from .dtw import ANCHOR_DTYPE
 
 
@@ -88,32 +90,10 @@ class SyntheticSeeds:
         return ev, hits
 
 
-class OracleScorer:
-    """CPU scorer with the oracle (tests only): same interface as the GPU scorer."""
-
-    def __init__(self, oracle, ref):
-        self.oracle = oracle
-        self.ref = ref
-
-    def score(self, reads, opt: MapOpt):
-        from oracle.loader import OrcOpt
-
-        oopt = OrcOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
-                      opt.dtw_min_score, int(opt.fused_score))
-        out = []
-        for events, chains in reads:
-            best = np.float32(0.0)
-            kept = []
-            for ch in chains:
-                arr = self.ref.forward[ch.reference_sequence_index] if ch.strand == 1 else self.ref.reverse[ch.reference_sequence_index]
-                s = self.oracle.align_chain(ch.anchors, arr, events, oopt, float(best))
-                ch.alignment_score = float(s)
-                if s >= np.float32(opt.dtw_min_score):
-                    if s > best:
-                        best = s
-                    kept.append(ch)
-            out.append(kept)
-        return out
+def score_log_line(chain) -> str:
+    """rmap.cpp:308-312: sprintf("chaining_score=%f alignment_score=%f\\n", ...)."""
+    return "chaining_score=%f alignment_score=%f\n" % (float(np.float32(chain.chaining_score)),
+                                                        float(np.float32(chain.alignment_score)))
 
 
 class DeviceScorer:
@@ -133,6 +113,10 @@ class DeviceScorer:
         self.cache = {}       # (read key, seq, strand, t0, q0, t1, q1) -> np.float32 cost without exclusion
         self.jobs_scored = 0
         self.jobs_reused = 0
+
+    def align_cigar(self, chain, read_events, opt: MapOpt):
+        """align_chain(chains[0], ..., cigar=true) of rmap.cpp:715-717: traceback on the device."""
+        return align_chain(self.engine, chain, read_events, opt, cigar=True)
 
     def _offset(self, ch):
         key = (ch.reference_sequence_index, ch.strand)
@@ -262,8 +246,15 @@ class DeviceScorer:
         return r.forward[ch.reference_sequence_index] if ch.strand == 1 else r.reverse[ch.reference_sequence_index]
 
 
-def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(), e: int = 6):
-    """Runs chunk rounds until every read stopped; returns the PAF lines in read order."""
+def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(), e: int = 6, log=None):
+    """Runs chunk rounds until every read stopped; returns the PAF lines in read order.
+
+    Flags (src/roptions.h:13-15): DTW runs when RI_M_DTW_EVALUATE_CHAINS or RI_M_DTW_LOG_SCORES is set
+    (rmap.cpp:509); the chain list is replaced by the surviving chains only under EVALUATE_CHAINS
+    (rmap.cpp:525) -- with LOG_SCORES alone every chain stays, carrying its alignment score (which the
+    sort of gen_primary_chains then sees first, rmap.h:41-45).  With RI_M_DTW_OUTPUT_CIGAR the best chain of
+    a mapped read is aligned once more with traceback (rmap.cpp:715-717).  `log`, when given, receives the
+    lines --dtw-log-scores writes to stderr (rmap.cpp:308-312), in order."""
     copt = M.default_chain_opt(e)
     jobs = {r: seeds.read_job(r) for r in read_ids}
     names = [f"seq{s}" for s in range(len(seeds.lens))]
@@ -301,7 +292,14 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
                                          [c.chaining_score for c in chains])
                 chains = [chains[int(k)] for k in order]
             submission.append((rj.events, chains))
-        kept = scorer.score(submission, opt, read_keys=active) if getattr(scorer, "memoise", False) else scorer.score(submission, opt)
+        runs_dtw = bool(opt.flag & (RI_M_DTW_EVALUATE_CHAINS | RI_M_DTW_LOG_SCORES))  # rmap.cpp:509
+        if runs_dtw:
+            kept = scorer.score(submission, opt, read_keys=active) if getattr(scorer, "memoise", False) else scorer.score(submission, opt)
+            if log is not None and (opt.flag & RI_M_DTW_LOG_SCORES):
+                for _, chains in submission:       # evaluation order; a cut chain returns before the fprintf
+                    log.extend(score_log_line(c) for c in chains if np.float32(c.alignment_score) != np.float32(-1e10))
+        if not (opt.flag & RI_M_DTW_EVALUATE_CHAINS):
+            kept = [chains for _, chains in submission]                                # rmap.cpp:525: list not replaced
         for r, post in zip(active, kept):
             rj = jobs[r]
             rj.chains = M.gen_primary_chains(post, opt, stop) if post else []
@@ -313,6 +311,10 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
     lines = []
     for r in read_ids:
         rj = jobs[r]
+        if (opt.flag & RI_M_DTW_OUTPUT_CIGAR) and M.is_mapped_with_high_confidence(rj.chains, opt, stop):
+            scorer.align_cigar(rj.chains[0], rj.events, opt)                            # rmap.cpp:715-717
+            if log is not None and (opt.flag & RI_M_DTW_LOG_SCORES):
+                log.append(score_log_line(rj.chains[0]))
         rs = M.ReadState(rj.name, rj.qlen, len(rj.events), rj.chunks_done if not rj.broke_early else rj.chunks_done - 1,
                          rj.broke_early, 0.0, rj.chains)
         lines.append(M.paf_line(rs, names, [int(x) for x in seeds.lens], opt, stop))

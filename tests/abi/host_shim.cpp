@@ -1,0 +1,201 @@
+// host_shim.cpp -- a C++11 consumer of include/rawdtw.h, written the way a RawAlign maintainer would bind
+// librawdtw.so inside src/rmap.cpp (INTEGRATION.md sections 2 and 4).  Test infrastructure: built and run by
+// tests/test_abi_shim.py, which compares what it prints with the oracle's results.
+//
+// It mirrors, for one mini-batch read from a file the test wrote:
+//   * index hand-over                                   main.cpp:354 / rawindex.h:32-34  -> rawdtw_upload_reference
+//   * the DTW block of gen_chains for every read        rmap.cpp:509-530                 -> sort, rawdtw_batch_create / run / fetch, filter
+//   * gen_primary_chains, comp_mapq, the stop rule      rmap.cpp:532-536, 594-665        -> rawdtw_gen_primary_chains, rawdtw_is_mapped_...
+//   * --dtw-output-cigar for the best chain             rmap.cpp:715-717, 741-744        -> rawdtw_chain_build_jobs(cigar) + rawdtw_traceback_batch
+//   * the tag text                                      rmap.cpp:580-592 (ostream << float), std::to_string
+//
+// Build: g++ -std=c++11 -I<repo>/include host_shim.cpp -L<repo>/rawalign_amd -lrawdtw
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "rawdtw.h"
+
+namespace {
+
+struct Blob {
+    std::vector<std::vector<float>> fwd, rev;
+    std::vector<float> events;
+    uint64_t n_reads = 0;
+    std::vector<uint64_t> chain_off, anchor_off; // generation order, per read contiguous
+    std::vector<rawdtw_anchor_t> anchors;
+    std::vector<uint32_t> chain_seq;
+    std::vector<int32_t> chain_strand;
+    std::vector<float> chaining_score;
+    std::vector<uint32_t> read_base; // per read: offset of its events
+    rawdtw_align_opt_t opt;
+    int32_t flag = 0;
+};
+
+template <typename T> bool rd(FILE *f, T *p, size_t n) { return n == 0 || fread(p, sizeof(T), n, f) == n; }
+
+bool load(const char *path, Blob &b)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    uint32_t magic = 0, n_seq = 0;
+    bool ok = rd(f, &magic, 1) && magic == 0x52445457u && rd(f, &n_seq, 1);
+    b.fwd.resize(n_seq); b.rev.resize(n_seq);
+    for (uint32_t s = 0; ok && s < n_seq; s++) {
+        uint32_t len = 0;
+        ok = rd(f, &len, 1);
+        b.fwd[s].resize(len); b.rev[s].resize(len);
+        ok = ok && rd(f, b.fwd[s].data(), len) && rd(f, b.rev[s].data(), len);
+    }
+    uint64_t n_ev = 0, n_chains = 0;
+    ok = ok && rd(f, &n_ev, 1);
+    b.events.resize(n_ev);
+    ok = ok && rd(f, b.events.data(), n_ev) && rd(f, &b.n_reads, 1);
+    b.chain_off.resize(b.n_reads + 1);
+    ok = ok && rd(f, b.chain_off.data(), b.n_reads + 1);
+    n_chains = ok ? b.chain_off[b.n_reads] : 0;
+    b.anchor_off.resize(n_chains + 1);
+    ok = ok && rd(f, b.anchor_off.data(), n_chains + 1);
+    b.anchors.resize(ok ? b.anchor_off[n_chains] : 0);
+    b.chain_seq.resize(n_chains); b.chain_strand.resize(n_chains); b.chaining_score.resize(n_chains);
+    b.read_base.resize(b.n_reads);
+    ok = ok && rd(f, b.anchors.data(), b.anchors.size()) && rd(f, b.chain_seq.data(), n_chains) &&
+         rd(f, b.chain_strand.data(), n_chains) && rd(f, b.chaining_score.data(), n_chains) &&
+         rd(f, b.read_base.data(), b.n_reads);
+    int32_t o[2]; float fo[3];
+    ok = ok && rd(f, o, 2) && rd(f, fo, 3) && rd(f, &b.flag, 1);
+    b.opt.border_constraint = o[0]; b.opt.fill_method = o[1];
+    b.opt.band_radius_frac = fo[0]; b.opt.match_bonus = fo[1]; b.opt.min_score = fo[2];
+    b.opt.fused_score = 1;
+    fclose(f);
+    return ok;
+}
+
+#define CHECK(call)                                                                                   \
+    do {                                                                                              \
+        int st_ = (call);                                                                             \
+        if (st_ != RAWDTW_OK) {                                                                       \
+            fprintf(stderr, "%s -> %d (%s): %s\n", #call, st_, rawdtw_status_string(st_), rawdtw_last_error(dtw)); \
+            return 2;                                                                                 \
+        }                                                                                             \
+    } while (0)
+
+unsigned bits(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin\n"); return 1; }
+    Blob b;
+    if (!load(argv[1], b)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    const bool evaluate = b.flag & 0x2, cigar = b.flag & 0x4, log_scores = b.flag & 0x8; // roptions.h:13-15
+
+    // ---- once per process ----
+    rawdtw_ctx *dtw = nullptr;
+    if (rawdtw_create(0, &dtw) != RAWDTW_OK) { fprintf(stderr, "no device\n"); return 3; }
+    const uint32_t n_seq = (uint32_t)b.fwd.size();
+    std::vector<const float *> fwd(n_seq), rev(n_seq);
+    std::vector<uint32_t> len(n_seq);
+    for (uint32_t s = 0; s < n_seq; s++) { fwd[s] = b.fwd[s].data(); rev[s] = b.rev[s].data(); len[s] = (uint32_t)b.fwd[s].size(); }
+    CHECK(rawdtw_upload_reference(dtw, n_seq, fwd.data(), rev.data(), len.data()));
+
+    // ---- one chunk round: chains of every read in evaluation order (rmap.cpp:512) ----
+    const uint64_t n_chains = b.chain_off[b.n_reads];
+    std::vector<uint64_t> order(n_chains); // evaluation position -> chain in generation order
+    std::vector<uint32_t> perm;
+    for (uint64_t r = 0; r < b.n_reads; r++) {
+        const uint64_t c0 = b.chain_off[r], nc = b.chain_off[r + 1] - c0;
+        perm.resize(nc);
+        CHECK(rawdtw_sort_by_chaining_score(b.chaining_score.data() + c0, (uint32_t)nc, perm.data()));
+        for (uint64_t k = 0; k < nc; k++) order[c0 + k] = c0 + perm[k];
+    }
+    std::vector<uint64_t> anchor_off(n_chains + 1, 0), ref_base(n_chains);
+    std::vector<uint32_t> read_base(n_chains);
+    std::vector<rawdtw_anchor_t> anchors;
+    anchors.reserve(b.anchors.size());
+    for (uint64_t r = 0; r < b.n_reads; r++)
+        for (uint64_t e = b.chain_off[r]; e < b.chain_off[r + 1]; e++) {
+            const uint64_t c = order[e];
+            anchors.insert(anchors.end(), b.anchors.begin() + b.anchor_off[c], b.anchors.begin() + b.anchor_off[c + 1]);
+            anchor_off[e + 1] = anchors.size();
+            CHECK(rawdtw_reference_offset(dtw, b.chain_seq[c], b.chain_strand[c], &ref_base[e]));
+            read_base[e] = b.read_base[r];
+        }
+    std::vector<float> score(n_chains, 0.0f);
+    std::vector<uint8_t> keep(n_chains, 0);
+    if (evaluate || log_scores) { // rmap.cpp:509
+        CHECK(rawdtw_upload_events(dtw, b.events.data(), b.events.size()));
+        rawdtw_batch *batch = nullptr;
+        CHECK(rawdtw_batch_create(dtw, &b.opt, b.n_reads, b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(),
+                                  read_base.data(), &batch));
+        CHECK(rawdtw_batch_run(dtw, batch));
+        CHECK(rawdtw_batch_fetch(dtw, batch, score.data(), keep.data(), nullptr));
+        CHECK(rawdtw_batch_destroy(batch));
+    }
+
+    // ---- per read: post_alignment_chains, primary chains, MAPQ, stop rule, tags ----
+    rawdtw_select_opt_t so = {evaluate ? 1 : 0, 1.2f, 5.0f, 2u}; // roptions.c:25,28,31
+    for (uint64_t r = 0; r < b.n_reads; r++) {
+        std::vector<rawdtw_chain_t> cand;
+        for (uint64_t e = b.chain_off[r]; e < b.chain_off[r + 1]; e++) {
+            if (log_scores && score[e] != -1e10f) // a cut chain returns before the fprintf (rmap.cpp:206-209, 265-268, 308-312)
+                printf("log chaining_score=%f alignment_score=%f\n", b.chaining_score[order[e]], score[e]);
+            if (evaluate && !keep[e]) continue; // rmap.cpp:518-529: the list is replaced only under EVALUATE_CHAINS
+            const uint64_t c = order[e];
+            const rawdtw_anchor_t *a = anchors.data() + anchor_off[e];
+            const uint32_t na = (uint32_t)(anchor_off[e + 1] - anchor_off[e]);
+            rawdtw_chain_t ch = {b.chaining_score[c], score[e], b.chain_seq[c], a[na - 1].target_position, a[0].target_position,
+                                 na, b.chain_strand[c], 0u, (uint32_t)e};
+            cand.push_back(ch);
+        }
+        printf("read %llu", (unsigned long long)r);
+        if (cand.empty()) { printf(" nc=0\n"); continue; }
+        std::vector<uint32_t> kept(cand.size());
+        const uint32_t nk = rawdtw_gen_primary_chains(cand.data(), (uint32_t)cand.size(), &so, kept.data());
+        std::vector<rawdtw_chain_t> prim(nk);
+        for (uint32_t k = 0; k < nk; k++) prim[k] = cand[kept[k]];
+        const int mapped = rawdtw_is_mapped_with_high_confidence(prim.data(), nk, &so);
+        printf(" nc=%u mapq=%u mapped=%d primary=", nk, prim[0].mapq, mapped);
+        for (uint32_t k = 0; k < nk; k++) printf("%s%u:%08x", k ? "," : "", prim[k].tag, bits(prim[k].alignment_score));
+        if (mapped && cigar) {
+            // rmap.cpp:715-717: align_chain(chains[0], ..., cigar=true): every part through DTW_global_tb
+            const uint64_t e = prim[0].tag;
+            const rawdtw_anchor_t *a = anchors.data() + anchor_off[e];
+            const uint32_t na = (uint32_t)(anchor_off[e + 1] - anchor_off[e]);
+            const uint32_t nj = rawdtw_chain_job_count(&b.opt, na);
+            std::vector<rawdtw_job_t> jobs(nj);
+            int st = rawdtw_chain_build_jobs(&b.opt, a, na, ref_base[e], read_base[e], 1, jobs.data());
+            if (st == RAWDTW_ERR_UNSUPPORTED) { printf(" cigar=unsupported\n"); continue; } // rmap.cpp:223-225 assert(false)
+            CHECK(st);
+            std::vector<uint64_t> poff(nj + 1, 0);
+            for (uint32_t k = 0; k < nj; k++) poff[k + 1] = poff[k] + jobs[k].n + jobs[k].m - 1;
+            std::vector<uint32_t> plen(nj), pi(poff[nj]), pj(poff[nj]);
+            std::vector<float> pd(poff[nj]), cost(nj);
+            CHECK(rawdtw_traceback_batch(dtw, jobs.data(), nj, b.events.data(), b.events.size(), cost.data(), poff.data(),
+                                         plen.data(), pi.data(), pj.data(), pd.data()));
+            const float alns = rawdtw_chain_replay(&b.opt, a, na, cost.data(), -1e10f); // rmap.cpp:306 on the summed costs
+            std::stringstream ss; // dtwresult_to_string, rmap.cpp:580-592
+            const uint32_t parts = na - 1;
+            for (uint32_t k = 0; k < nj; k++) {
+                // sparse: every element offset by its part's start anchor (rmap.cpp:286-289); global: the offsets are
+                // added to alignment.back() once per element (rmap.cpp:230-233), i.e. only the last tuple moves
+                const rawdtw_anchor_t &s0 = b.opt.border_constraint == 0 ? a[na - 1] : a[parts - k];
+                for (uint32_t q = 0; q < plen[k]; q++) {
+                    size_t i = pi[poff[k] + q], j = pj[poff[k] + q];
+                    if (b.opt.border_constraint != 0) { i += s0.query_position; j += s0.target_position; }
+                    else if (q + 1 == plen[k]) { i += (size_t)plen[k] * s0.query_position; j += (size_t)plen[k] * s0.target_position; }
+                    ss << "(" << i << "," << j << "," << pd[poff[k] + q] << ")";
+                }
+            }
+            printf("\talns:f:%s\taln:s:%s", std::to_string(alns).c_str(), ss.str().c_str()); // rmap.cpp:741-744
+        }
+        printf("\n");
+    }
+    rawdtw_destroy(dtw);
+    return 0;
+}

@@ -178,3 +178,19 @@ def test_batch_build_and_replay_against_oracle_loop(oracle):
             cut += want == np.float32(-1e10)
             c += 1
     assert c == n_chains and cut > 0  # the early-exit path was exercised
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under rawalign_amd/ or include/ may import, load or mention it
+    outside comments."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for base in ("rawalign_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(root, base)):
+            for fn in files:
+                if not fn.endswith((".py", ".h", ".cpp", ".hip")):
+                    continue
+                for ln in open(os.path.join(dp, fn), encoding="utf-8"):
+                    code = ln.split("#")[0] if fn.endswith(".py") else ln.split("//")[0]
+                    assert not re.search(r"\boracle\b|liboracle|_ref/", code), (fn, ln)

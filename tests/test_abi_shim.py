@@ -1,0 +1,186 @@
+"""The boundary consumed from the reference's host language: tests/abi/host_shim.cpp (C++11) links librawdtw.so and
+does what INTEGRATION.md sections 2 and 4 show at src/rmap.cpp:509-530 (DTW block of gen_chains), :715-717
+(--dtw-output-cigar) and :741-744 (alns:f: / aln:s: tags).  Its output is compared with the oracle's results,
+formatted independently here.  Also: the header compiles as C99, and the tag number formats
+(`ostream << float`, std::to_string) agree with the Python mirror's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import rawalign_amd as ra
+from rawalign_amd import mapping, synth
+from rawalign_amd.align import dtwresult_to_string
+from rawalign_amd.dtw import DtwResult
+from tests.golden_util import bits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ABI = os.path.join(ROOT, "tests", "abi")
+
+
+def _build(tmp, name, extra=()):
+    exe = os.path.join(str(tmp), name)
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ABI, name + ".cpp"), "-o", exe, *extra], check=True)
+    return exe
+
+
+def test_header_is_c99():
+    subprocess.run(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ABI, "c99_include.c")], check=True)
+
+
+def test_shim_compiles_and_links(tmp_path):
+    ra.load_library()
+    _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
+
+
+def test_tag_number_formats_match_iostream(tmp_path):
+    """aln:s: differences are written with `ostream << float` (6 significant digits, %g rules), the :f: tags with
+    std::to_string (%f): the Python mirror must print the same characters (rmap.cpp:580-592, 731-742)."""
+    exe = _build(tmp_path, "fmt_tags")
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([
+        np.array([0.0, 1.0, 1e-5, 9.9999e-5, 1e-4, 0.1, 0.5, 123456.0, 999999.5, 1e6, 1234567.0, 1e7, 1e10, 3.14159274,
+                  2.5e-7, 65504.0, 0.000123456789, 100000.0, 999999.0, 1e-45, 3.4e38], np.float32),
+        np.abs(rng.normal(size=300)).astype(np.float32),
+        (10.0 ** rng.uniform(-8, 9, 300)).astype(np.float32),
+    ])
+    out = subprocess.run([exe], input="".join("%08x\n" % u for u in vals.view(np.uint32)), capture_output=True,
+                         text=True, check=True).stdout.split("\n")
+    for v, line in zip(vals, out):
+        want_g, want_f = line.split(" ")
+        res = DtwResult(np.float32(0), np.array([7], np.uint64), np.array([9], np.uint64), np.array([v], np.float32))
+        assert dtwresult_to_string(res) == "(7,9,%s)" % want_g, (v, want_g)
+        assert mapping._to_string(v) == want_f, (v, want_f)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: run the shim
+# ------------------------------------------------------------------------------------------------
+def _make_case(seed, n_reads):
+    ref = synth.make_reference([9000, 14000], seed=20231005 + 6)
+    pad = lambda n: (n + 3) & ~3  # noqa: E731  (arena layout of rawdtw_upload_reference: fwd then rev, 16-byte aligned)
+    offs, at = {}, 0
+    for s in range(ref.n_seq):
+        offs[(s, 1)] = at
+        at += pad(len(ref.forward[s]))
+        offs[(s, 0)] = at
+        at += pad(len(ref.forward[s]))
+    P = synth.SynthParams(n_reads=n_reads, max_chunks=3, mean_chunks=1.5, decoys_per_read=2.0)
+    cb, _ = synth.make_candidate_batch(ref, offs, P, seed=seed)
+    inv = {v: k for k, v in offs.items()}
+    chain_seq = np.array([inv[int(x)][0] for x in cb.ref_base], np.uint32)
+    chain_strand = np.array([inv[int(x)][1] for x in cb.ref_base], np.int32)
+    rng = np.random.default_rng(seed + 1)
+    na = np.diff(cb.anchor_off.astype(np.int64))
+    score = (6.0 * na + rng.integers(0, 4, len(na))).astype(np.float32)  # ties included
+    return ref, cb, chain_seq, chain_strand, score
+
+
+def _write_blob(path, ref, cb, chain_seq, chain_strand, chaining_score, opt, flag):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x52445457, ref.n_seq))
+        for s in range(ref.n_seq):
+            f.write(struct.pack("<I", len(ref.forward[s])))
+            f.write(ref.forward[s].astype("<f4").tobytes())
+            f.write(ref.reverse[s].astype("<f4").tobytes())
+        f.write(struct.pack("<Q", len(cb.events)))
+        f.write(cb.events.astype("<f4").tobytes())
+        f.write(struct.pack("<Q", cb.n_reads))
+        f.write(cb.chain_off.astype("<u8").tobytes())
+        f.write(cb.anchor_off.astype("<u8").tobytes())
+        f.write(cb.anchors.tobytes())
+        f.write(chain_seq.astype("<u4").tobytes())
+        f.write(chain_strand.astype("<i4").tobytes())
+        f.write(chaining_score.astype("<f4").tobytes())
+        rb = np.array([int(cb.read_base[int(cb.chain_off[r])]) if cb.chain_off[r + 1] > cb.chain_off[r] else 0
+                       for r in range(cb.n_reads)], np.uint32)
+        f.write(rb.tobytes())
+        f.write(struct.pack("<iifffi", opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac,
+                            opt.dtw_match_bonus, opt.dtw_min_score, flag))
+
+
+def _expected_lines(oracle, ref, cb, chain_seq, chain_strand, chaining_score, opt, flag):
+    """What rmap.cpp would decide for this mini-batch, from the oracle (sequential loop, rmap.cpp:515-524)."""
+    from oracle.loader import OrcOpt
+    from rawalign_amd.align import evaluation_order
+    from rawalign_amd.mapper import _SortHelper
+
+    oopt = OrcOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                  opt.dtw_min_score, 1)
+    evaluate, cigar, logs = bool(flag & 2), bool(flag & 4), bool(flag & 8)
+    opt2 = ra.MapOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                     opt.dtw_min_score, flag)
+    lines = []
+    for r in range(cb.n_reads):
+        c0, c1 = int(cb.chain_off[r]), int(cb.chain_off[r + 1])
+        perm = evaluation_order(_SortHelper.get(), chaining_score[c0:c1])
+        best = np.float32(0.0)
+        cand = []
+        for k, pk in enumerate(perm):
+            c = c0 + int(pk)
+            a = cb.anchors[int(cb.anchor_off[c]):int(cb.anchor_off[c + 1])]
+            arr = ref.forward[chain_seq[c]] if chain_strand[c] == 1 else ref.reverse[chain_seq[c]]
+            ev = cb.events[int(cb.read_base[c]):]
+            s = np.float32(0.0)
+            if evaluate or logs:
+                s = oracle.align_chain(a, arr, ev, oopt, float(best))
+                if logs and s != np.float32(-1e10):
+                    lines.append("log chaining_score=%f alignment_score=%f" % (float(chaining_score[c]), float(s)))
+                ok = s >= np.float32(opt.dtw_min_score)
+                if ok and s > best:
+                    best = s
+                if evaluate and not ok:
+                    continue
+            ch = ra.Chain(float(chaining_score[c]), int(chain_seq[c]), int(chain_strand[c]), a, float(s))
+            ch.tag = c0 + k
+            ch.ev, ch.arr = ev, arr
+            cand.append(ch)
+        if not cand:
+            lines.append("read %d nc=0" % r)
+            continue
+        prim = mapping.gen_primary_chains(cand, opt2)
+        mapped = mapping.is_mapped_with_high_confidence(prim, opt2)
+        line = "read %d nc=%d mapq=%d mapped=%d primary=%s" % (
+            r, len(prim), prim[0].mapq, int(mapped),
+            ",".join("%d:%08x" % (p.tag, bits(np.float32(p.alignment_score))) for p in prim))
+        if mapped and cigar:
+            if opt.dtw_border_constraint == 0 and opt.dtw_fill_method == 1:
+                line += " cigar=unsupported"
+            else:
+                sc, cost, pi, pj, pd = oracle.align_chain_cigar(prim[0].anchors, prim[0].arr, prim[0].ev, oopt)
+                aln = "".join("(%d,%d,%s)" % (int(i), int(j), "%g" % float(d)) for i, j, d in zip(pi, pj, pd))
+                line += "\talns:f:%f\taln:s:%s" % (float(sc), aln)
+        lines.append(line)
+    return lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("border,fill,flag", [(1, 1, 0x2 | 0x4), (1, 0, 0x2 | 0x4), (0, 0, 0x2 | 0x4), (0, 1, 0x2 | 0x4),
+                                              (1, 1, 0x8), (1, 1, 0x2 | 0x8 | 0x4), (1, 1, 0x2)])
+def test_cpp_shim_matches_oracle(oracle, tmp_path, border, fill, flag):
+    exe = _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
+    ref, cb, cseq, cstr, cscore = _make_case(41 + border * 2 + fill, 40)
+    opt = ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill)
+    blob = os.path.join(str(tmp_path), "batch.bin")
+    _write_blob(blob, ref, cb, cseq, cstr, cscore, opt, flag)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([exe, blob], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr
+    got = run.stdout.rstrip("\n").split("\n")
+    want = _expected_lines(oracle, ref, cb, cseq, cstr, cscore, opt, flag)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+    text = "\n".join(got)
+    if flag & 0x4 and not (border == 0 and fill == 1):
+        assert "aln:s:(" in text and "alns:f:" in text
+        if border == 1:  # interior anchors appear twice in a sparse path (rmap.cpp:283-284)
+            assert any(")(" in ln for ln in got)
+    if flag & 0x8:
+        assert "log chaining_score=" in text
+    if flag == 0x8:  # log-scores alone: nothing is filtered, every chain stays a candidate (rmap.cpp:525)
+        assert sum(int(ln.split("nc=")[1].split(" ")[0]) for ln in got if ln.startswith("read")) > 0

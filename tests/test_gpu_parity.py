@@ -172,6 +172,23 @@ def test_error_behaviour(engine):
     assert len(engine.score_batch(np.zeros(0, JOB_DTYPE), ev)) == 0  # empty batch
 
 
+def test_full_matrix_pipeline_guard(engine, oracle):
+    """The four-wave pipelined full-matrix kernel publishes (strip << 21) | columns: a job with >= 2^21 columns
+    (reachable through rawdtw_score_batch, not from the mapper's shapes) must take the one-wave variant and still
+    match the reference (dtw.cpp:37-66) bit for bit."""
+    rng = np.random.default_rng(77)
+    nx, ny = (1 << 21) + 70, 1030  # >= 3 strips of 512 rows: would otherwise be class 60
+    ref = rng.normal(size=nx).astype(np.float32)
+    ev = rng.normal(size=ny).astype(np.float32)
+    engine.upload_reference([ref], [ref])
+    jobs = np.zeros(2, JOB_DTYPE)
+    jobs[0] = (engine.reference_offset(0, 1), 0, ny, nx, -1, 0, 0)
+    jobs[1] = (engine.reference_offset(0, 1), 0, ny, 3000, -1, 1, 0)  # an ordinary pipelined job next to it
+    got = engine.score_batch(jobs, ev)
+    want = np.array([oracle.dtw_global(ev, ref, 0), oracle.dtw_global(ev, ref[:3000], 1)], np.float32)
+    assert_bits_equal(got, want, "full-matrix guard")
+
+
 def test_properties_at_scale(engine):
     """Size-independent properties on a batch too large to check cell by cell on the CPU:
     DTW(x,x)=0, symmetry of the full DP, band never beats the full DP, identical jobs agree."""

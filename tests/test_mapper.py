@@ -6,6 +6,7 @@ import pytest
 
 import rawalign_amd as ra
 from rawalign_amd import mapper, synth
+from tests.util import OracleScorer
 
 
 def setup(n_reads=24):
@@ -17,7 +18,7 @@ def setup(n_reads=24):
 def test_oracle_path_produces_paf(oracle):
     ref, seeds = setup(12)
     opt = ra.MapOpt()
-    lines, rounds = mapper.map_reads(seeds, list(range(12)), mapper.OracleScorer(oracle, ref), opt)
+    lines, rounds = mapper.map_reads(seeds, list(range(12)), OracleScorer(oracle, ref), opt)
     assert len(lines) == 12 and rounds >= 1
     mapped = [l for l in lines if l.split("\t")[4] in "+-"]
     assert len(mapped) >= 6  # most mappable reads map
@@ -36,7 +37,7 @@ def test_device_path_paf_identical_to_oracle_path(oracle):
     eng.upload_reference(ref.forward, ref.reverse)
     for opt in (ra.MapOpt(), ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=1),
                 ra.MapOpt(dtw_border_constraint=1, dtw_fill_method=0)):
-        a, ra_ = mapper.map_reads(seeds, list(range(40)), mapper.OracleScorer(oracle, ref), opt)
+        a, ra_ = mapper.map_reads(seeds, list(range(40)), OracleScorer(oracle, ref), opt)
         b, rb_ = mapper.map_reads(seeds, list(range(40)), mapper.DeviceScorer(eng), opt)
         assert ra_ == rb_ and a == b
 
@@ -59,7 +60,7 @@ def test_multi_genome_sequence_until_oracle_path(oracle):
     """Metagenomic multi-genome index + real-time sequence-until on the CPU leg (plumbing of configs[4])."""
     ref = synth.make_reference([20000, 35000, 12000], seed=20231005 + 5)
     seeds = mapper.SyntheticSeeds(ref, 40, seed=11, max_chunks=3)
-    lines, _ = mapper.map_reads(seeds, list(range(40)), mapper.OracleScorer(oracle, ref), ra.MapOpt())
+    lines, _ = mapper.map_reads(seeds, list(range(40)), OracleScorer(oracle, ref), ra.MapOpt())
     stop, est = _abundance_stop(lines, 3)
     assert stop > 0 and est.sum() > 0
     # every mapped read landed on the genome and strand it was drawn from
@@ -76,7 +77,7 @@ def test_multi_genome_sequence_until_device_equals_oracle(oracle):
     seeds = mapper.SyntheticSeeds(ref, 60, seed=12, max_chunks=3)
     eng = ra.Engine(0)
     eng.upload_reference(ref.forward, ref.reverse)
-    a, _ = mapper.map_reads(seeds, list(range(60)), mapper.OracleScorer(oracle, ref), ra.MapOpt())
+    a, _ = mapper.map_reads(seeds, list(range(60)), OracleScorer(oracle, ref), ra.MapOpt())
     b, _ = mapper.map_reads(seeds, list(range(60)), mapper.DeviceScorer(eng), ra.MapOpt())
     assert a == b
     sa, ea = _abundance_stop(a, 3)
@@ -102,3 +103,46 @@ def test_cross_chunk_memoisation_is_exact_and_saves_work(oracle):
         b, rb_ = mapper.map_reads(seeds, list(range(40)), memo, opt, never)
         assert a == b and ra_ == rb_ and ra_ > 1
         assert memo.jobs_reused > 0 and memo.jobs_scored < plain.jobs_scored
+
+
+def test_cigar_and_log_scores_flags_oracle_path(oracle):
+    """a-6 on the CPU leg: with RI_M_DTW_OUTPUT_CIGAR a mapped read's line carries alns:f: and aln:s: (rmap.cpp:741-744);
+    with RI_M_DTW_LOG_SCORES alone DTW runs but the chain list is not replaced (rmap.cpp:509, 525)."""
+    from rawalign_amd.align import RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_LOG_SCORES, RI_M_DTW_OUTPUT_CIGAR
+
+    ref, seeds = setup(10)
+    opt = ra.MapOpt(flag=RI_M_DTW_EVALUATE_CHAINS | RI_M_DTW_OUTPUT_CIGAR)
+    lines, _ = mapper.map_reads(seeds, list(range(10)), OracleScorer(oracle, ref), opt)
+    mapped = [l for l in lines if l.split("\t")[4] in "+-"]
+    assert mapped and all("\talns:f:" in l and "\taln:s:(" in l for l in mapped)
+    assert all("aln:s:" not in l for l in lines if l.split("\t")[4] == "*")
+    # log-scores only: every chain that was not cut is logged, and chains that fail dtw_min_score stay in the list
+    log = []
+    ev_lines, _ = mapper.map_reads(seeds, list(range(10)), OracleScorer(oracle, ref), ra.MapOpt())
+    lg_lines, _ = mapper.map_reads(seeds, list(range(10)), OracleScorer(oracle, ref), ra.MapOpt(flag=RI_M_DTW_LOG_SCORES), log=log)
+    assert log and all(l.startswith("chaining_score=") and " alignment_score=" in l and l.endswith("\n") for l in log)
+    nc = lambda ls: sum(int(l.split("nc:i:")[1].split("\t")[0]) for l in ls)  # noqa: E731
+    assert nc(lg_lines) >= nc(ev_lines)
+
+
+@pytest.mark.gpu
+def test_cigar_and_log_scores_flags_device_equals_oracle(oracle):
+    """a-6 through the device: PAF lines with alns:f: / aln:s: and the --dtw-log-scores lines are character-identical to
+    the same control flow on the checker -- sparse (banded and full) and global+full, plus log-scores alone."""
+    from rawalign_amd.align import RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_LOG_SCORES, RI_M_DTW_OUTPUT_CIGAR
+
+    ref, seeds = setup(30)
+    eng = ra.Engine(0)
+    eng.upload_reference(ref.forward, ref.reverse)
+    ec = RI_M_DTW_EVALUATE_CHAINS | RI_M_DTW_OUTPUT_CIGAR
+    for opt in (ra.MapOpt(flag=ec), ra.MapOpt(dtw_fill_method=0, flag=ec),
+                ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0, flag=ec),
+                ra.MapOpt(flag=RI_M_DTW_LOG_SCORES), ra.MapOpt(flag=ec | RI_M_DTW_LOG_SCORES)):
+        la, lb = [], []
+        a, _ = mapper.map_reads(seeds, list(range(30)), OracleScorer(oracle, ref), opt, log=la)
+        b, _ = mapper.map_reads(seeds, list(range(30)), mapper.DeviceScorer(eng), opt, log=lb)
+        assert a == b and la == lb
+        if opt.flag & RI_M_DTW_OUTPUT_CIGAR:
+            assert any("\taln:s:(" in l for l in b)
+        if opt.flag & RI_M_DTW_LOG_SCORES:
+            assert lb

@@ -39,3 +39,46 @@ def assert_bits_equal(got, want, what=""):
     w = np.asarray(want, np.float32).view(np.uint32)
     bad = np.nonzero(g != w)[0]
     assert len(bad) == 0, f"{what}: {len(bad)} of {len(g)} differ, first at {bad[:5]}: got {np.asarray(got)[bad[:5]]} want {np.asarray(want)[bad[:5]]}"
+
+
+class OracleScorer:
+    """CPU scorer built on the oracle (test infrastructure): same `score(reads, opt)` interface as
+    rawalign_amd.mapper.DeviceScorer, so that mapper.map_reads can run the identical control flow on the checker.
+    Follows the DTW block of gen_chains, rmap.cpp:515-524."""
+
+    def __init__(self, oracle, ref):
+        self.oracle = oracle
+        self.ref = ref
+
+    def score(self, reads, opt):
+        from oracle.loader import OrcOpt
+
+        oopt = OrcOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                      opt.dtw_min_score, int(opt.fused_score))
+        out = []
+        for events, chains in reads:
+            best = np.float32(0.0)
+            kept = []
+            for ch in chains:
+                arr = self.ref.forward[ch.reference_sequence_index] if ch.strand == 1 else self.ref.reverse[ch.reference_sequence_index]
+                s = self.oracle.align_chain(ch.anchors, arr, events, oopt, float(best))
+                ch.alignment_score = float(s)
+                if s >= np.float32(opt.dtw_min_score):
+                    if s > best:
+                        best = s
+                    kept.append(ch)
+            out.append(kept)
+        return out
+
+    def align_cigar(self, chain, read_events, opt):
+        """rmap.cpp:715-717 on the checker: align_chain(..., cigar=true)."""
+        from oracle.loader import OrcOpt
+        from rawalign_amd.dtw import DtwResult
+
+        oopt = OrcOpt(opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                      opt.dtw_min_score, int(opt.fused_score))
+        arr = self.ref.forward[chain.reference_sequence_index] if chain.strand == 1 else self.ref.reverse[chain.reference_sequence_index]
+        sc, cost, pi, pj, pd = self.oracle.align_chain_cigar(chain.anchors, arr, read_events, oopt)
+        chain.alignment_score = float(sc)
+        chain.dtw_result = DtwResult(np.float32(cost), pi, pj, pd)
+        return chain
