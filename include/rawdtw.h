@@ -70,7 +70,8 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "micro_max_n" 0/4/8, "grp16" 0/1, "grp8" 0/1, "full_wg" 0/1, "tile_lds_floats", "tile_max_jobs", "tile_max_spans",
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
- *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create bins/tiles the bulk class on the device
+ *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create takes the sync-free path (planning on the device, in LDS)
+ *   "time_plan" 0/1: event pair around a batch's planning kernels; "stream_others_blocks": workgroups that start on the wide-band jobs
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
  *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
  *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)
@@ -108,6 +109,20 @@ int rawdtw_index_close(rawdtw_index *idx);
  * reads of a batch, concatenated by the caller. ---- */
 int rawdtw_upload_events(rawdtw_ctx *ctx, const float *h_events, uint64_t n_floats);
 int rawdtw_set_events_device(rawdtw_ctx *ctx, const float *d_events, uint64_t n_floats);
+/* Incremental form.  A read's event array only grows (ri_map_frag appends each chunk's events, rmap.cpp:554-567), so a
+ * mapper that keeps one slot per read in the arena uploads only the round's NEW events: reserve grows the arena to
+ * n_floats (contents kept; the arena's logical size, against which job windows are checked, becomes at least
+ * n_floats); append copies h_new[seg_src_off[s] .. seg_src_off[s+1]) to arena offset seg_dst_off[s] for every
+ * segment s (one H2D copy of the packed new events + a scatter kernel), asynchronously on the ctx stream.  h_new and
+ * the segment tables must stay valid until the stream has passed the call (rawdtw_sync / a fetch); memory from
+ * rawdtw_host_alloc makes the copies asynchronous. */
+int rawdtw_events_reserve(rawdtw_ctx *ctx, uint64_t n_floats);
+int rawdtw_events_append(rawdtw_ctx *ctx, const float *h_new, uint64_t n_new, uint32_t n_segments,
+                         const uint64_t *seg_src_off, const uint32_t *seg_dst_off);
+/* Page-locked host memory for the arrays handed to rawdtw_batch_create / rawdtw_events_append and for the result
+ * arrays of rawdtw_batch_fetch.  Any host memory works; with pinned memory the copies do not block the caller. */
+int rawdtw_host_alloc(uint64_t bytes, void **out);
+int rawdtw_host_free(void *p);
 
 /* ---- score-only batches: replaces the calls at rmap.cpp:211,215,273,277 ---- */
 /* One shot: upload events, bin + launch, copy costs back (out_cost[k] for jobs[k]). */
@@ -297,6 +312,12 @@ int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const u
  * fold and the per-read accept/cut loop all on the device.  Inputs as rawdtw_batch_build_jobs;
  * events and reference arenas must already be set on the ctx.  Outputs per chain: score[c]
  * (chain.alignment_score, -1e10 when cut) and keep[c] (survives dtw_min_score). ---- */
+/* rawdtw_batch_create is asynchronous for sparse + banded batches (the default options): it enqueues the copies of the
+ * five arrays and the planning kernels on the ctx stream and returns -- no host synchronisation, and no allocation
+ * once the context's workspace pool is warm.  Consequences for the caller: the five arrays must stay valid and
+ * unchanged until rawdtw_batch_fetch has returned (or the batch is destroyed); an invalid batch (anchors not ascending,
+ * a window outside the arenas) is reported by rawdtw_batch_fetch with the status and message rawdtw_plan_create would
+ * give.  Other modes (global border constraint, full fill) and "device_plan"=0 plan on the host inside create. */
 typedef struct rawdtw_batch rawdtw_batch;
 int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads,
                         const uint64_t *chain_off, const uint64_t *anchor_off,
@@ -333,6 +354,8 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
 /* job_cost may be NULL; otherwise receives the per-job costs too */
 int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep,
                        float *job_cost);
+/* GPU time of the batch's planning kernels (HIP events; 0 unless the option "time_plan" was set before create) */
+int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
 int rawdtw_batch_destroy(rawdtw_batch *batch);
 
 #ifdef __cplusplus

@@ -114,6 +114,10 @@ SYMBOLS = {
     "rawdtw_index_close": (I32, [VP]),
     "rawdtw_upload_events": (I32, [VP, VP, U64]),
     "rawdtw_set_events_device": (I32, [VP, VP, U64]),
+    "rawdtw_events_reserve": (I32, [VP, U64]),
+    "rawdtw_events_append": (I32, [VP, VP, U64, U32, VP, VP]),
+    "rawdtw_host_alloc": (I32, [U64, C.POINTER(VP)]),
+    "rawdtw_host_free": (I32, [VP]),
     "rawdtw_score_batch": (I32, [VP, VP, U64, VP, U64, VP]),
     "rawdtw_plan_create": (I32, [VP, VP, U64, C.POINTER(VP)]),
     "rawdtw_plan_info": (I32, [VP, C.POINTER(PlanInfo)]),
@@ -147,6 +151,7 @@ SYMBOLS = {
     "rawdtw_batch_collect": (I32, [VP, VP, VP, VP, U32, C.POINTER(U32), C.POINTER(U32)]),
     "rawdtw_batch_launch_stats": (I32, [VP, U32, C.POINTER(U32), C.POINTER(I32), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)]),
     "rawdtw_batch_fetch": (I32, [VP, VP, VP, VP, VP]),
+    "rawdtw_batch_plan_ms": (I32, [VP, VP, C.POINTER(F32)]),
     "rawdtw_batch_destroy": (I32, [VP]),
     "rawdtw_batch_replay": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, VP]),
 }

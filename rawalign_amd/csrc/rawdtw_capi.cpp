@@ -43,6 +43,12 @@ template <typename T> struct RawVec {
     const T *end() const { return p + n; }
 };
 
+// one pooled workspace of the stream path: a device block and a pinned host block (rawdtw_batch_create carves them up)
+struct StreamWs {
+    char *d = nullptr; size_t d_bytes = 0;
+    char *h = nullptr; size_t h_bytes = 0;
+};
+
 struct rawdtw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -64,16 +70,22 @@ struct rawdtw_ctx {
     uint32_t lane_max_n = kLaneMaxN;
     uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
     uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
-    bool device_plan = true;  // rawdtw_batch_create plans the tile class on the device (rawdtw_plan.hip)
-    uint64_t device_plan_min_jobs = 65536; // smaller batches plan on the host (fewer round trips)
+    bool device_plan = true;  // rawdtw_batch_create takes the sync-free stream path (rawdtw_stream.hip) for sparse + banded batches
+    uint64_t device_plan_min_jobs = 0; // smaller batches go through the job list
+    std::vector<StreamWs> ws_free;     // workspaces of destroyed batches, reused by the next ones (no hipMalloc in the steady state)
+    unsigned long long *d_masks = nullptr; // band bitmasks of the micro shapes (stream path)
+    uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
+    uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
+    bool time_plan = false;            // record an event pair around a batch's planning kernels (rawdtw_batch_plan_ms)
+    std::vector<uint64_t> job_off_scratch;
+    void *d_append = nullptr;          // rawdtw_events_append staging, grow-only
+    size_t append_bytes = 0;
     uint8_t *d_tb_dir = nullptr; // traceback direction workspace, grow-only (hipFree of 600 MB per call costs 1 ms)
     uint64_t tb_dir_bytes = 0;
     void *d_tb_paths = nullptr;  // traceback path buffers (offsets, lengths, i/j end-first, i/j/d start-first), grow-only
     size_t tb_paths_bytes = 0;
     void *h_pinned = nullptr;  // pinned host staging (traceback paths), grow-only
     size_t pinned_bytes = 0;
-    void *d_scratch = nullptr; // device-planning workspace, grow-only, reused by the context's batches
-    size_t scratch_bytes = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
     int fold_mode = 2; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work)
     int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
@@ -118,12 +130,6 @@ struct rawdtw_plan {
     rawdtw_plan_info_t info{};
     bool cells_counted = false;
     int plan_threads_used = 1;
-    // device-planned batches: the host keeps records only for the jobs outside the tile class; h_jobs / order / h_aux
-    // are indexed by (plan position - h_base), and the tile class is known through these totals
-    uint64_t h_base = 0;
-    bool dev_planned = false;
-    uint64_t dev_tile_cells = 0, dev_tile_bytes = 0;
-    bool dev_cells_counted = false;
     bool dir_borrowed = false; // d_dir is the context's workspace, not the plan's
 };
 
@@ -137,19 +143,43 @@ struct rawdtw_index {
 
 struct rawdtw_batch {
     rawdtw_ctx *ctx = nullptr;
-    rawdtw_plan *plan = nullptr;
+    rawdtw_plan *plan = nullptr;   // job-list path
     rawdtw_align_opt_t opt{};
-    uint64_t n_reads = 0, n_chains = 0;
+    uint64_t n_reads = 0, n_chains = 0, n_jobs = 0;
     ChainDesc *d_chains = nullptr;
     uint64_t *d_chain_off = nullptr;
     uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
+    bool own_chain_arrays = false;  // the arrays above are hipMalloc'd (job-list path) rather than carved from `ws`
     std::vector<hipEvent_t> ev; // event pairs of the runs enqueued since the last collect
     uint32_t ev_runs = 0;
+    // stream path
+    bool stream = false;
+    StreamWs ws;
+    StreamArgs sa{};
+    uint32_t stream_lds = 0;
+    unsigned long long *h_cnt = nullptr; // pinned landing zone of the counter block
+    bool cnt_valid = false, cells_counted = false;
+    bool dirty = false;                  // work enqueued since the last host synchronisation
+    size_t ws_bytes = 0;
+    hipEvent_t ev_plan[2] = {nullptr, nullptr};
+    // the caller's arrays (valid until fetch: a declined batch is redone from them through the job list)
+    const uint64_t *in_chain_off = nullptr, *in_anchor_off = nullptr;
+    const rawdtw_anchor_t *in_anchors = nullptr;
+    const uint64_t *in_ref_base = nullptr;
+    const uint32_t *in_read_base = nullptr;
 };
 
 namespace {
+
+// the next `count` elements of a 256-byte aligned block
+template <typename T> T *carve(char *&p, uint64_t count)
+{
+    T *q = reinterpret_cast<T *>(p);
+    p += (count * sizeof(T) + 255) & ~(size_t)255;
+    return q;
+}
 
 int fail(rawdtw_ctx *ctx, int status, const std::string &msg)
 {
@@ -728,7 +758,7 @@ int plan_host(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, boo
 
 // The tile records against the jobs they were built from: every window staged inside its tile's LDS image at the right
 // place, every record's shape / radius / mask right, records in dispatch order.  tseen[k] = job k has a tile record.
-std::string verify_tile_arrays(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, const rawdtw_plan *pl, bool dev,
+std::string verify_tile_arrays(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint64_t n_jobs, const rawdtw_plan *pl,
                                const TileDesc *tiles, size_t n_tiles_all, const TileSpan *spans, size_t n_spans_all,
                                const TileJob *tjobs, size_t n_tjobs, const std::vector<unsigned long long> &masks,
                                std::vector<uint8_t> &tseen)
@@ -744,8 +774,8 @@ std::string verify_tile_arrays(const PlanCfg &cfg, const rawdtw_job_t *jobs, uin
         const uint32_t budget = hi ? kTileHiLdsFloats : cfg.tile_lds_floats;
         if (t.job_first != next_job || t.n_jobs == 0) return "tile " + S(ti) + ": jobs not consecutive";
         next_job += t.n_jobs;
-        if (t.n_jobs > (hi ? kTileHiMaxJobs : dev ? 2048u : std::max(cfg.tile_max_jobs, cfg.sorted_tile_jobs)) || t.n_spans == 0 ||
-            t.n_spans > (hi ? 2 * kTileHiMaxJobs : dev ? 2048u : std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs)))
+        if (t.n_jobs > (hi ? kTileHiMaxJobs : std::max(cfg.tile_max_jobs, cfg.sorted_tile_jobs)) || t.n_spans == 0 ||
+            t.n_spans > (hi ? 2 * kTileHiMaxJobs : std::max(cfg.tile_max_spans, 2 * cfg.sorted_tile_jobs)))
             return "tile " + S(ti) + ": too many jobs or spans";
         if ((uint64_t)t.span_first + t.n_spans > n_spans_all) return "tile " + S(ti) + ": spans out of range";
         uint32_t off = 0;
@@ -825,7 +855,7 @@ std::string verify_host_plan(const PlanCfg &cfg, const rawdtw_job_t *jobs, uint6
     if (covered != n_jobs) return "launches cover " + S(covered) + " of " + S(n_jobs) + " jobs";
     std::vector<uint8_t> tseen;
     {
-        const std::string e = verify_tile_arrays(cfg, jobs, n_jobs, pl, false, ht.tiles.data(), ht.tiles.size(), ht.spans.data(),
+        const std::string e = verify_tile_arrays(cfg, jobs, n_jobs, pl, ht.tiles.data(), ht.tiles.size(), ht.spans.data(),
                                                  ht.spans.size(), ht.tjobs.data(), ht.tjobs.size(), ht.masks, tseen);
         if (!e.empty()) return e;
     }
@@ -899,31 +929,13 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
 // cells evaluated by plan positions [p0, p1) (exact band cell sets; reporting only)
 uint64_t count_cells(const rawdtw_plan *pl, uint64_t p0, uint64_t p1)
 {
-    if (pl->dev_planned && p0 < pl->h_base) { // the tile class of a device-planned batch: counted on the device, once
-        rawdtw_plan *mp = const_cast<rawdtw_plan *>(pl);
-        if (!mp->dev_cells_counted) {
-            unsigned long long *d_total = nullptr, total = 0;
-            rawdtw_ctx *ctx = pl->ctx;
-            if (hipSetDevice(ctx->device) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d_total), 8) == hipSuccess) {
-                if (dev_count_tile_cells(pl->d_tjobs, pl->n_tile_jobs, d_total, ctx->stream) == hipSuccess &&
-                    hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                    hipStreamSynchronize(ctx->stream) == hipSuccess) {
-                    mp->dev_tile_cells = total;
-                    mp->dev_cells_counted = true;
-                }
-                (void)hipFree(d_total);
-            }
-        }
-        const uint64_t rest = p1 > pl->h_base ? count_cells(pl, pl->h_base, p1) : 0;
-        return pl->dev_tile_cells + rest; // (callers ask for whole launches: [0, h_base) is exactly the tile launch)
-    }
     if (p1 <= p0) return 0;
     const int T = (int)std::min<uint64_t>(std::max(pl->plan_threads_used, 1), (p1 - p0) / 32768 + 1);
     std::vector<uint64_t> part(T, 0);
     parallel_for(T, [&](int t) {
         uint64_t c = 0;
         for (uint64_t p = p0 + (p1 - p0) * (uint64_t)t / T; p < p0 + (p1 - p0) * (uint64_t)(t + 1) / T; p++) {
-            const DevJob &d = pl->h_jobs[p - pl->h_base];
+            const DevJob &d = pl->h_jobs[p];
             c += d.R < 0 ? (uint64_t)d.n * d.m : banded_cells(d.n, d.m, d.R);
         }
         part[t] = c;
@@ -1130,7 +1142,9 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    for (StreamWs &w : ctx->ws_free) { if (w.d) (void)hipFree(w.d); if (w.h) (void)hipHostFree(w.h); }
+    if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+    if (ctx->d_append) (void)hipFree(ctx->d_append);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_tb_dir) (void)hipFree(ctx->d_tb_dir);
     if (ctx->d_tb_paths) (void)hipFree(ctx->d_tb_paths);
@@ -1161,6 +1175,8 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "device_plan")) { ctx->device_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "device_plan_min_jobs")) { ctx->device_plan_min_jobs = (uint64_t)std::max<int64_t>(value, 0); return RAWDTW_OK; }
+    if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
+    if (!strcmp(name, "stream_others_blocks")) { ctx->stream_others_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
@@ -1589,185 +1605,170 @@ int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const floa
     return st;
 }
 
-// ---- device-side planning of a candidate batch (kernels in rawdtw_plan.hip) -----------------------
-namespace {
-constexpr int kDevPlanFallback = -1000; // not an ABI status: "use the host planner" (anything unusual, or an error it must word)
-
-int ensure_scratch(rawdtw_ctx *ctx, size_t bytes)
-{
-    if (ctx->scratch_bytes >= bytes) return RAWDTW_OK;
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
-    bytes += bytes / 8;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_scratch, bytes));
-    ctx->scratch_bytes = bytes;
-    return RAWDTW_OK;
-}
-
-// Plans the batch's jobs from its anchor lists.  The tile class (99 % of a sparse batch) is binned, tiled and sorted on
-// the device; the jobs of the other classes come back (a few ten thousand records) and go through plan_host as usual.
-int build_plan_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_chains, const uint64_t *anchor_off,
-                      const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
-                      const uint64_t *job_off, uint64_t n_jobs, rawdtw_plan **out)
-{
-    *out = nullptr;
-    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[devplan] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
-        t_prev = t;
-    };
-    PlanCfg cfg = cfg_of(ctx);
-    if (cfg.lane_max_radius < 0 || cfg.sort_n || cfg.sort_r1_n || cfg.sort_r3 || cfg.lane_hi) return kDevPlanFallback;
-    if (n_jobs >= (1ull << 31) || n_jobs * 160ull >= (1ull << 40)) return kDevPlanFallback;
-    const uint32_t worst_job = 2u * cfg.lane_max_n + 12u;
-    if (cfg.tile_lds_floats < worst_job + 14u + 1024u || cfg.tile_lds_floats > 6000u) return kDevPlanFallback; // (k_plan_tiles' run table: 768 runs of >= 8 floats)
-    DevPlanArgs a{};
-    a.n_jobs = n_jobs; a.n_chains = n_chains; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
-    a.border = opt->border_constraint; a.banded = opt->fill_method != 0; a.frac = opt->band_radius_frac;
-    a.lane_max_radius = cfg.lane_max_radius; a.lane_max_n = cfg.lane_max_n; a.micro_max_n = (uint32_t)cfg.micro_max_n;
-    a.tile_budget = cfg.tile_lds_floats - 16u; // (the bracket's last job: subtracted on the device, from the batch's largest)
-    // cost floor: k_plan_tiles sorts at most 2048 records per tile.  (A floor at tile_max_jobs = 1024 would inflate the
-    // cost of the tiniest jobs -- 43 % of a sparse batch add fewer than 4.9 floats -- and cost 12 % more tiles.)
-    a.min_cost8 = (8u * a.tile_budget + 2047u) / 2048u;
-    const uint64_t n_anchors = anchor_off[n_chains];
-
-    // workspace: [inputs][planning arrays][other jobs][other aux][counters]
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t b_joff = al((n_chains + 1) * 8), b_aoff = al((n_chains + 1) * 8), b_anch = al(n_anchors * sizeof(rawdtw_anchor_t)),
-                 b_rbase = al(n_chains * 8), b_qbase = al(n_chains * 4), b_plan = al(dev_plan_scratch_bytes(n_jobs)),
-                 b_oj = al(n_jobs * sizeof(rawdtw_job_t)), b_oa = al(n_jobs * 4), b_cnt = al(kPlanCounters * 8);
-    int st = ensure_scratch(ctx, b_joff + b_aoff + b_anch + b_rbase + b_qbase + b_plan + b_oj + b_oa + b_cnt);
-    if (st != RAWDTW_OK) return st;
-    char *base = static_cast<char *>(ctx->d_scratch);
-    auto take = [&](size_t bytes) { char *q = base; base += bytes; return q; };
-    uint64_t *d_joff = reinterpret_cast<uint64_t *>(take(b_joff));
-    uint64_t *d_aoff = reinterpret_cast<uint64_t *>(take(b_aoff));
-    rawdtw_anchor_t *d_anch = reinterpret_cast<rawdtw_anchor_t *>(take(b_anch));
-    uint64_t *d_rbase = reinterpret_cast<uint64_t *>(take(b_rbase));
-    uint32_t *d_qbase = reinterpret_cast<uint32_t *>(take(b_qbase));
-    void *d_plan = take(b_plan);
-    rawdtw_job_t *d_oj = reinterpret_cast<rawdtw_job_t *>(take(b_oj));
-    uint32_t *d_oa = reinterpret_cast<uint32_t *>(take(b_oa));
-    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(take(b_cnt));
-    hipStream_t s = ctx->stream;
-    lap("scratch");
-    HIP_TRY(ctx, hipMemcpyAsync(d_joff, job_off, (n_chains + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_aoff, anchor_off, (n_chains + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_anch, anchors, n_anchors * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_rbase, ref_base, n_chains * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_qbase, read_base, n_chains * 4, hipMemcpyHostToDevice, s));
-    lap("uploads");
-    DevPlanBuffers buf{};
-    HIP_TRY(ctx, dev_plan_phase1(a, d_joff, d_aoff, d_anch, d_rbase, d_qbase, d_plan, &buf, d_oj, d_oa, d_cnt, s));
-    unsigned long long cnt[kPlanCounters];
-    HIP_TRY(ctx, hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    lap("phase 1");
-    if (cnt[kPlanBad] != ~0ull) return kDevPlanFallback; // let the host planner word the error
-    const uint64_t n_tile_jobs = cnt[kPlanTileJobs], n_tiles = cnt[kPlanTiles], n_runs = cnt[kPlanRuns];
-    const uint64_t n_other = n_jobs - n_tile_jobs;
-    if (getenv("RAWDTW_PLAN_DEBUG"))
-        fprintf(stderr, "[devplan] jobs %llu tile jobs %llu tiles %llu runs %llu bad %llu\n", (unsigned long long)n_jobs,
-                (unsigned long long)n_tile_jobs, (unsigned long long)n_tiles, (unsigned long long)n_runs, cnt[kPlanBad]);
-    if (n_tile_jobs == 0) return kDevPlanFallback;
-
-    rawdtw_plan *pl = new (std::nothrow) rawdtw_plan;
-    if (!pl) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
-    pl->ctx = ctx;
-    const std::vector<unsigned long long> &masks = micro_masks();
-    if ((st = dev_alloc(ctx, &pl->d_tiles, n_tiles)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_spans, 2 * n_runs)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_tjobs, n_tile_jobs)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_masks, (uint64_t)masks.size())) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_cost, n_jobs)) != RAWDTW_OK) {
-        rawdtw_plan_destroy(pl);
-        return st;
-    }
-    lap("allocs");
-    hipError_t e = dev_plan_phase2(a, (uint32_t)n_tiles, &buf, pl->d_tiles, pl->d_spans, pl->d_tjobs, d_cnt, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(pl->d_masks, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, s);
-    // the other classes: records back to the host, planned there (sorting by shape, launches, workspaces)
-    RawVec<rawdtw_job_t> oj;
-    RawVec<uint32_t> oa;
-    try { oj.resize(n_other); oa.resize(n_other); } catch (const std::bad_alloc &) { rawdtw_plan_destroy(pl); return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-    if (e == hipSuccess && n_other) e = hipMemcpyAsync(oj.data(), d_oj, n_other * sizeof(rawdtw_job_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && n_other) e = hipMemcpyAsync(oa.data(), d_oa, n_other * 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { rawdtw_plan_destroy(pl); return hip_fail(ctx, e, "device planning"); }
-    lap("phase 2 + D2H");
-    if (cnt[kPlanTileOverflow] != ~0ull || cnt[kPlanLdsMax] > cfg.tile_lds_floats) { rawdtw_plan_destroy(pl); return kDevPlanFallback; }
-
-    HostTiles ht;
-    std::string err;
-    PlanCfg cfg_other = cfg;
-    cfg_other.lane_max_radius = -1; // nothing left for the tile class
-    try {
-        st = plan_host(cfg_other, oj.data(), n_other, false, pl, ht, err);
-    } catch (const std::bad_alloc &) {
-        st = RAWDTW_ERR_OOM; err = "host allocation failed";
-    }
-    lap("others on host");
-    if (st != RAWDTW_OK) { rawdtw_plan_destroy(pl); return kDevPlanFallback; } // (the host planner names the job in the batch's numbering)
-    // plan_host numbered the other jobs 0..n_other-1: shift them behind the tile class and restore the batch's job indices
-    for (uint64_t q = 0; q < n_other; q++) {
-        pl->h_jobs[q].aux = oa[pl->h_jobs[q].aux];
-        pl->order[q] = oa[pl->order[q]];
-    }
-    for (Launch &L : pl->launches) L.first += n_tile_jobs;
-    pl->launches.insert(pl->launches.begin(), Launch{kKindBandLane, (int32_t)cnt[kPlanLdsMax], 0, n_tile_jobs});
-    pl->run_order.resize(pl->launches.size());
-    for (uint32_t i = 0; i < pl->run_order.size(); i++) pl->run_order[i] = i; // the tile launch first, the rest as plan_host ordered them
-    pl->h_base = n_tile_jobs;
-    pl->dev_planned = true;
-    pl->dev_tile_bytes = cnt[kPlanTileBytes];
-    pl->n_jobs = n_jobs;
-    pl->n_tile_jobs = n_tile_jobs;
-    pl->n_tiles = n_tiles; pl->n_tiles_hi = 0;
-    pl->tile_lds_floats = (uint32_t)cnt[kPlanLdsMax];
-    rawdtw_plan_info_t &I = pl->info;
-    I.n_jobs = n_jobs;
-    I.algorithmic_bytes += pl->dev_tile_bytes;
-    I.n_lane_jobs = n_tile_jobs;
-    I.n_launches = (uint32_t)pl->launches.size();
-    I.workspace_bytes += n_tiles * sizeof(TileDesc) + 2 * n_runs * sizeof(TileSpan) + n_tile_jobs * (sizeof(TileJob) + 4) + masks.size() * 8;
-    // device records of the other jobs
-    if ((st = dev_alloc(ctx, &pl->d_jobs, n_other)) != RAWDTW_OK || (st = dev_alloc(ctx, &pl->d_aux, n_other)) != RAWDTW_OK ||
-        (st = dev_alloc(ctx, &pl->d_bnd, pl->bnd_floats)) != RAWDTW_OK) {
-        rawdtw_plan_destroy(pl);
-        return st;
-    }
-    if (n_other) {
-        e = hipMemcpyAsync(pl->d_jobs, pl->h_jobs.data(), n_other * sizeof(DevJob), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(pl->d_aux, pl->h_aux.data(), n_other * sizeof(FullAux), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) { rawdtw_plan_destroy(pl); return hip_fail(ctx, e, "uploading job descriptors"); }
-    }
-    lap("others upload");
-    *out = pl;
-    return RAWDTW_OK;
-}
-} // namespace
-
 // ---- whole-batch form ----------------------------------------------------------------------------
-int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
-                        const uint32_t *read_base, rawdtw_batch **out)
+// Two implementations behind rawdtw_batch_*:
+//   stream  (sparse + banded batches, the default): rawdtw_stream.hip -- rawdtw_batch_create only enqueues copies and
+//           planning kernels on the context's stream, no host synchronisation, no allocation in the steady state
+//           (workspaces are pooled per context); every count stays on the device.
+//   job list (everything else, and the rare batch the stream path declines): the jobs are built on the host and go
+//           through plan_host / build_plan like any rawdtw_plan.
+namespace {
+
+struct StreamLayout { // sizes in bytes of one batch's device workspace and pinned host block
+    size_t dev = 0, host = 0, tmp = 0;
+    uint64_t others_cap = 0;
+    uint32_t tiles_cap = 0;
+};
+
+bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)
 {
-    if (!out) return RAWDTW_ERR_INVALID;
-    *out = nullptr;
-    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && n_reads) || !ref_base || !read_base)
-        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
-    if (opt->border_constraint != 0 && opt->border_constraint != 1)
-        return fail(ctx, RAWDTW_ERR_INVALID, "invalid border constraint (rmap.cpp:301-304)");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint64_t n_chains = chain_off[n_reads];
-    std::vector<uint64_t> job_off(n_chains + 1);
-    uint64_t n_jobs = 0;
-    int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
-                                     0, &n_jobs);
-    if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
+    if (!ctx->device_plan || n_jobs < ctx->device_plan_min_jobs || n_jobs == 0 || n_jobs >= (1ull << 31)) return false;
+    if (opt->border_constraint != 1 || opt->fill_method == 0) return false; // sparse + banded only
+    if (ctx->lane_max_radius < 0 || ctx->sort_n || ctx->sort_r1_n || ctx->sort_r3 || ctx->lane_hi || !ctx->merge_small) return false;
+    if (ctx->tile_threads != 256 || ctx->debug_skip_kinds) return false;
+    const uint32_t worst_job = 2u * ctx->lane_max_n + 12u;
+    return ctx->tile_lds_floats >= 4u * worst_job + 16u && ctx->tile_lds_floats <= 16384u;
+}
+
+int ws_acquire(rawdtw_ctx *ctx, size_t dev_bytes, size_t host_bytes, StreamWs *out)
+{
+    int best = -1;
+    for (size_t i = 0; i < ctx->ws_free.size(); i++) {
+        const StreamWs &w = ctx->ws_free[i];
+        if (w.d_bytes >= dev_bytes && w.h_bytes >= host_bytes && (best < 0 || w.d_bytes < ctx->ws_free[best].d_bytes)) best = (int)i;
+    }
+    if (best >= 0) {
+        *out = ctx->ws_free[best];
+        ctx->ws_free.erase(ctx->ws_free.begin() + best);
+        return RAWDTW_OK;
+    }
+    // nothing fits: drop the smallest pooled workspace when the pool is full, then allocate with head room
+    if (ctx->ws_free.size() >= 8) {
+        size_t smallest = 0;
+        for (size_t i = 1; i < ctx->ws_free.size(); i++) if (ctx->ws_free[i].d_bytes < ctx->ws_free[smallest].d_bytes) smallest = i;
+        (void)hipFree(ctx->ws_free[smallest].d); (void)hipHostFree(ctx->ws_free[smallest].h);
+        ctx->ws_free.erase(ctx->ws_free.begin() + smallest);
+    }
+    StreamWs w;
+    w.d_bytes = dev_bytes + dev_bytes / 4; w.h_bytes = host_bytes + host_bytes / 4;
+    if (hipMalloc(reinterpret_cast<void **>(&w.d), w.d_bytes) != hipSuccess) return fail(ctx, RAWDTW_ERR_OOM, "batch workspace allocation failed");
+    if (hipHostMalloc(reinterpret_cast<void **>(&w.h), w.h_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(w.d);
+        return fail(ctx, RAWDTW_ERR_OOM, "pinned batch staging allocation failed");
+    }
+    *out = w;
+    return RAWDTW_OK;
+}
+
+void ws_release(rawdtw_ctx *ctx, StreamWs &w)
+{
+    if (w.d) ctx->ws_free.push_back(w);
+    w = StreamWs{};
+}
+
+int ensure_masks(rawdtw_ctx *ctx)
+{
+    if (ctx->d_masks) return RAWDTW_OK;
+    const std::vector<unsigned long long> &m = micro_masks();
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_masks), m.size() * 8));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_masks, m.data(), m.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    return RAWDTW_OK;
+}
+
+// the stream path: everything rawdtw_batch_create does for a sparse + banded batch
+int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
+                        const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
+                        const uint64_t *job_off_host, uint64_t n_jobs)
+{
+    const uint64_t nc = b->n_chains, nr = b->n_reads, na = anchor_off[nc];
+    const uint32_t lds_floats = ctx->tile_lds_floats;
+    StreamArgs &a = b->sa;
+    a = StreamArgs{};
+    a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
+    a.frac = b->opt.band_radius_frac;
+    a.lane_max_radius = ctx->lane_max_radius; a.lane_max_n = ctx->lane_max_n; a.micro_max_n = (uint32_t)ctx->micro_max_n;
+    a.tile_budget = lds_floats - 16u;
+    a.min_cost8 = (8u * a.tile_budget + kStreamMaxTileJobs - 1) / kStreamMaxTileJobs;
+    a.run_cost8 = (8u * a.tile_budget + kStreamMaxRuns - 3) / (kStreamMaxRuns - 2);
+    const uint64_t worst8 = std::max<uint64_t>(8ull * (2ull * a.lane_max_n + 12ull), std::max(a.min_cost8, a.run_cost8));
+    a.tiles_cap = (uint32_t)std::min<uint64_t>(n_jobs * worst8 / (8ull * a.tile_budget - worst8) + 2, 0x7fffffffull);
+    a.others_cap = std::min<uint64_t>(n_jobs, n_jobs / 4 + 4096);
+    const size_t tmp = std::max(stream_scan_bytes(n_jobs), stream_sort_bytes(nc));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t dev_bytes = al((nc + 1) * 8) * 2 + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) +   // inputs
+                             al(n_jobs * 16) + al(n_jobs * 4) + al(n_jobs * 8) + al(((size_t)a.tiles_cap + 1) * 4) + // per job
+                             2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) + al(tmp) +
+                             al(nc * sizeof(ChainDesc)) + 7 * al(nc * 4) + al(nc) + al(n_jobs * 4);
+    const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8);
+    int st = ws_acquire(ctx, dev_bytes, host_bytes, &b->ws);
+    if (st != RAWDTW_OK) return st;
+    if ((st = ensure_masks(ctx)) != RAWDTW_OK) return st;
+    char *p = b->ws.d;
+    uint64_t *d_job_off = carve<uint64_t>(p, nc + 1), *d_anchor_off = carve<uint64_t>(p, nc + 1);
+    rawdtw_anchor_t *d_anchors = carve<rawdtw_anchor_t>(p, na);
+    uint64_t *d_ref_base = carve<uint64_t>(p, nc);
+    uint32_t *d_read_base = carve<uint32_t>(p, nc);
+    b->d_chain_off = carve<uint64_t>(p, nr + 1);
+    a.jrec = carve<JobRec>(p, n_jobs); a.lds_cost = carve<uint32_t>(p, n_jobs); a.cum = carve<uint64_t>(p, n_jobs);
+    a.tile_first = carve<uint32_t>(p, (uint64_t)a.tiles_cap + 1);
+    a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
+    a.cnt = carve<unsigned long long>(p, kStreamCounters);
+    void *d_tmp = carve<char>(p, tmp);
+    b->d_chains = carve<ChainDesc>(p, nc);
+    uint32_t *d_key = carve<uint32_t>(p, nc), *d_val = carve<uint32_t>(p, nc), *d_key_out = carve<uint32_t>(p, nc);
+    b->d_fold_order = carve<uint32_t>(p, nc);
+    b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
+    b->d_keep = carve<uint8_t>(p, nc);
+    a.out = carve<float>(p, n_jobs);
+    a.job_off = d_job_off; a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
+    a.ev = ctx->d_ev; a.ref = ctx->d_ref; a.masks = ctx->d_masks;
+    char *hp = b->ws.h;
+    uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
+    b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
+    memcpy(h_job_off, job_off_host, (nc + 1) * 8);
+    unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the same pinned block
+    for (int i = 0; i < kStreamCounters; i++) h_init[i] = 0;
+    h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
+    hipStream_t s = ctx->stream;
+    if (ctx->time_plan) {
+        if (!b->ev_plan[0]) { HIP_TRY(ctx, hipEventCreate(&b->ev_plan[0])); HIP_TRY(ctx, hipEventCreate(&b->ev_plan[1])); }
+        HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_job_off, h_job_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
+    hipError_t e = stream_plan(a, b->d_chains, d_key, d_val, d_key_out, b->d_fold_order, d_tmp, tmp, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
+    if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
+    // the persistent grid: what the device holds at this LDS size
+    if (ctx->stream_lds != lds_floats) {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        const int per_cu = stream_blocks_per_cu(lds_floats);
+        if (per_cu <= 0) return fail(ctx, RAWDTW_ERR_DEVICE, "occupancy query failed for the batch kernel");
+        ctx->stream_blocks = (uint32_t)(per_cu * prop.multiProcessorCount);
+        ctx->stream_lds = lds_floats;
+    }
+    b->stream = true;
+    b->stream_lds = lds_floats;
+    b->n_jobs = n_jobs;
+    b->cnt_valid = false;
+    b->dirty = true;
+    b->ws_bytes = dev_bytes;
+    return RAWDTW_OK;
+}
+
+// the job-list path: jobs built on the host (chain ranges spread over the planner's threads), plan_host, chain records
+int batch_create_joblist(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
+                         const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
+                         const std::vector<uint64_t> &job_off, uint64_t n_jobs)
+{
+    const uint64_t n_chains = b->n_chains, n_reads = b->n_reads;
+    const rawdtw_align_opt_t *opt = &b->opt;
     // chain descriptors: from the anchors alone.  The parts' read regions telescope (consecutive parts share their
     // anchor event), so sum(n) = (last.q - first.q) + parts in the reference's uint32 arithmetic (rmap.cpp:236,292).
     std::vector<ChainDesc> desc(n_chains);
@@ -1782,54 +1783,34 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
         d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
         d.num_aligned = opt->border_constraint == 0 ? d.span : (last.query_position - first.query_position) + d.n_jobs;
     }
-    static const bool timing = getenv("RAWDTW_PLAN_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!timing) return;
-        auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[batch] %-14s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
-        t_prev = t;
-    };
-    lap("chains");
-    rawdtw_plan *plan = nullptr;
-    st = kDevPlanFallback;
-    if (ctx->device_plan && n_jobs >= ctx->device_plan_min_jobs)
-        st = build_plan_device(ctx, opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), n_jobs, &plan);
-    if (st == kDevPlanFallback) {
-        // host planning: the job list, chain ranges spread over the planner's threads
-        RawVec<rawdtw_job_t> jobs;
-        try { jobs.resize(n_jobs); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-        int T = ctx->plan_threads;
-        if (T <= 0) {
-            const unsigned hc = std::thread::hardware_concurrency();
-            T = (int)std::min<uint64_t>(std::min<unsigned>(hc ? hc : 1, 16), n_jobs / 32768 + 1);
-        }
-        T = std::max(1, std::min(T, 64));
-        std::vector<int> status(T, RAWDTW_OK);
-        parallel_for(T, [&](int t) {
-            // split by jobs, not chains: chain lengths are skewed
-            const uint64_t j_lo = n_jobs * (uint64_t)t / T, j_hi = n_jobs * (uint64_t)(t + 1) / T;
-            const uint64_t c_lo = std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_lo) - job_off.begin();
-            const uint64_t c_hi = t + 1 == T ? n_chains
-                                             : std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_hi) - job_off.begin();
-            for (uint64_t c = c_lo; c < c_hi; c++) {
-                const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
-                const uint32_t nj = (uint32_t)(job_off[c + 1] - job_off[c]);
-                if (!nj) continue;
-                int s2 = rawdtw_chain_build_jobs(opt, anchors + a0, (uint32_t)(a1 - a0), ref_base[c], read_base[c], 0,
-                                                 jobs.data() + job_off[c]);
-                if (s2 != RAWDTW_OK) { status[t] = s2; return; }
-            }
-        });
-        for (int t = 0; t < T; t++) if (status[t] != RAWDTW_OK) return fail(ctx, status[t], "job building failed");
-        st = build_plan(ctx, jobs.data(), n_jobs, false, &plan);
+    RawVec<rawdtw_job_t> jobs;
+    try { jobs.resize(n_jobs); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    int T = ctx->plan_threads;
+    if (T <= 0) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        T = (int)std::min<uint64_t>(std::min<unsigned>(hc ? hc : 1, 16), n_jobs / 32768 + 1);
     }
+    T = std::max(1, std::min(T, 64));
+    std::vector<int> status(T, RAWDTW_OK);
+    parallel_for(T, [&](int t) {
+        // split by jobs, not chains: chain lengths are skewed
+        const uint64_t j_lo = n_jobs * (uint64_t)t / T, j_hi = n_jobs * (uint64_t)(t + 1) / T;
+        const uint64_t c_lo = std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_lo) - job_off.begin();
+        const uint64_t c_hi = t + 1 == T ? n_chains
+                                         : std::lower_bound(job_off.begin(), job_off.begin() + n_chains, j_hi) - job_off.begin();
+        for (uint64_t c = c_lo; c < c_hi; c++) {
+            const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+            const uint32_t nj = (uint32_t)(job_off[c + 1] - job_off[c]);
+            if (!nj) continue;
+            int s2 = rawdtw_chain_build_jobs(opt, anchors + a0, (uint32_t)(a1 - a0), ref_base[c], read_base[c], 0,
+                                             jobs.data() + job_off[c]);
+            if (s2 != RAWDTW_OK) { status[t] = s2; return; }
+        }
+    });
+    for (int t = 0; t < T; t++) if (status[t] != RAWDTW_OK) return fail(ctx, status[t], "job building failed");
+    int st = build_plan(ctx, jobs.data(), n_jobs, false, &b->plan);
     if (st != RAWDTW_OK) return st;
-    lap("plan");
-    rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
-    if (!b) { rawdtw_plan_destroy(plan); return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-    b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
-    b->plan = plan;
+    b->n_jobs = n_jobs;
     st = dev_alloc(ctx, &b->d_chains, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_chain_off, n_reads + 1);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_fold_order, n_chains);
@@ -1837,27 +1818,113 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_gate, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_score, n_chains);
     if (st == RAWDTW_OK) st = dev_alloc(ctx, &b->d_keep, n_chains);
-    if (st == RAWDTW_OK) {
-        hipError_t e = hipSuccess;
-        // fold order: longest chain first (stable counting sort on the part count)
-        std::vector<uint32_t> fold_order(n_chains);
-        {
-            constexpr uint32_t kB = 65536;
-            std::vector<uint64_t> start(kB + 1, 0);
-            auto bucket = [&](uint64_t c) { return kB - 1 - std::min<uint32_t>(desc[c].n_jobs, kB - 1); };
-            for (uint64_t c = 0; c < n_chains; c++) start[bucket(c) + 1]++;
-            for (uint32_t q = 0; q < kB; q++) start[q + 1] += start[q];
-            for (uint64_t c = 0; c < n_chains; c++) fold_order[start[bucket(c)]++] = (uint32_t)c;
-        }
-        if (n_chains) e = hipMemcpyAsync(b->d_chains, desc.data(), n_chains * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && n_chains)
-            e = hipMemcpyAsync(b->d_fold_order, fold_order.data(), n_chains * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(b->d_chain_off, chain_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) st = hip_fail(ctx, e, "uploading chain descriptors");
+    if (st != RAWDTW_OK) return st;
+    b->own_chain_arrays = true;
+    hipError_t e = hipSuccess;
+    // fold order: longest chain first (stable counting sort on the part count)
+    std::vector<uint32_t> fold_order(n_chains);
+    {
+        constexpr uint32_t kB = 65536;
+        std::vector<uint64_t> start(kB + 1, 0);
+        auto bucket = [&](uint64_t c) { return kB - 1 - std::min<uint32_t>(desc[c].n_jobs, kB - 1); };
+        for (uint64_t c = 0; c < n_chains; c++) start[bucket(c) + 1]++;
+        for (uint32_t q = 0; q < kB; q++) start[q + 1] += start[q];
+        for (uint64_t c = 0; c < n_chains; c++) fold_order[start[bucket(c)]++] = (uint32_t)c;
     }
+    if (n_chains) e = hipMemcpyAsync(b->d_chains, desc.data(), n_chains * sizeof(ChainDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_chains)
+        e = hipMemcpyAsync(b->d_fold_order, fold_order.data(), n_chains * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->d_chain_off, chain_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // (the staging vectors above die with this scope)
+    if (e != hipSuccess) return hip_fail(ctx, e, "uploading chain descriptors");
+    return RAWDTW_OK;
+}
+
+void batch_release_device(rawdtw_batch *b)
+{
+    if (b->plan) { rawdtw_plan_destroy(b->plan); b->plan = nullptr; }
+    if (b->own_chain_arrays) {
+        if (b->d_chains) (void)hipFree(b->d_chains);
+        if (b->d_chain_off) (void)hipFree(b->d_chain_off);
+        if (b->d_fold_order) (void)hipFree(b->d_fold_order);
+        if (b->d_full) (void)hipFree(b->d_full);
+        if (b->d_gate) (void)hipFree(b->d_gate);
+        if (b->d_score) (void)hipFree(b->d_score);
+        if (b->d_keep) (void)hipFree(b->d_keep);
+    }
+    b->d_chains = nullptr; b->d_chain_off = nullptr; b->d_fold_order = nullptr;
+    b->d_full = b->d_gate = b->d_score = nullptr; b->d_keep = nullptr;
+    b->own_chain_arrays = false;
+}
+
+// The counters of a stream batch, read once (after its planning kernels have run).
+int stream_counters(rawdtw_ctx *ctx, rawdtw_batch *b)
+{
+    if (b->cnt_valid) return RAWDTW_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(b->h_cnt, b->sa.cnt, kStreamCounters * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->cnt_valid = true;
+    b->dirty = false;
+    return RAWDTW_OK;
+}
+
+// does the stream path's result stand?  (no invalid job, nothing over a capacity, no band it does not take)
+bool stream_declined(const rawdtw_batch *b)
+{
+    const unsigned long long *c = b->h_cnt;
+    return c[kCntBad] != ~0ull || c[kCntOverflow] != ~0ull || c[kCntUnsupported] != 0 || c[kCntOthers] > b->sa.others_cap;
+}
+
+// Redo a stream batch through the job-list path (which also words the error of an invalid batch).
+int stream_fallback(rawdtw_ctx *ctx, rawdtw_batch *b)
+{
+    const uint64_t nc = b->n_chains;
+    std::vector<uint64_t> job_off(nc + 1);
+    uint64_t n_jobs = 0;
+    int st = rawdtw_batch_build_jobs(&b->opt, nc, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base,
+                                     job_off.data(), nullptr, 0, &n_jobs);
+    if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
+    b->stream = false;
+    ws_release(ctx, b->ws);
+    b->d_chains = nullptr; b->d_chain_off = nullptr; b->d_fold_order = nullptr;
+    b->d_full = b->d_gate = b->d_score = nullptr; b->d_keep = nullptr;
+    st = batch_create_joblist(ctx, b, b->in_chain_off, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
+    if (st != RAWDTW_OK) { batch_release_device(b); return st; }
+    return rawdtw_batch_run(ctx, b);
+}
+
+} // namespace
+
+// a batch whose (deferred) planning failed has neither form left: every entry point but destroy refuses it
+static bool batch_dead(const rawdtw_batch *b) { return !b->stream && !b->plan; }
+
+int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out)
+{
+    if (!out) return RAWDTW_ERR_INVALID;
+    *out = nullptr;
+    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && n_reads) || !ref_base || !read_base)
+        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (opt->border_constraint != 0 && opt->border_constraint != 1)
+        return fail(ctx, RAWDTW_ERR_INVALID, "invalid border constraint (rmap.cpp:301-304)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_chains = chain_off[n_reads];
+    std::vector<uint64_t> &job_off = ctx->job_off_scratch; // (a context is not re-entrant)
+    job_off.resize(n_chains + 1);
+    uint64_t n_jobs = 0;
+    int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
+                                     0, &n_jobs);
+    if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
+    rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
+    if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
+    b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
+    b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
+    if (stream_eligible(ctx, opt, n_jobs))
+        st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base, job_off.data(), n_jobs);
+    else
+        st = batch_create_joblist(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base, job_off, n_jobs);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
-    lap("chain records");
     *out = b;
     return RAWDTW_OK;
 }
@@ -1867,16 +1934,92 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
 {
     auto say = [&](const std::string &m) { if (message && message_cap) snprintf(message, message_cap, "%s", m.c_str()); };
     say("");
-    if (!ctx || !batch || batch->ctx != ctx || (n_jobs && !jobs)) return RAWDTW_ERR_INVALID;
-    const rawdtw_plan *pl = batch->plan;
-    if (device_planned) *device_planned = pl->dev_planned ? 1 : 0;
-    if (n_jobs != pl->n_jobs) { say("job count differs from the batch's"); return RAWDTW_ERR_INVALID; }
+    if (!ctx || !batch || batch->ctx != ctx || (n_jobs && !jobs) || batch_dead(batch)) return RAWDTW_ERR_INVALID;
+    if (device_planned) *device_planned = batch->stream ? 1 : 0;
+    if (n_jobs != batch->n_jobs) { say("job count differs from the batch's"); return RAWDTW_ERR_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    auto S = [](uint64_t v) { return std::to_string(v); };
+    std::string e;
+    if (batch->stream) {
+        // the records k_stream reads: every job's windows, shape, radius and class; the tiles partition the jobs and every
+        // tile's LDS image, job count and run count stay inside the kernel's capacities
+        rawdtw_batch *mb = const_cast<rawdtw_batch *>(batch);
+        int st = stream_counters(ctx, mb);
+        if (st != RAWDTW_OK) return st;
+        const StreamArgs &a = batch->sa;
+        const unsigned long long *cnt = batch->h_cnt;
+        if (stream_declined(batch)) {
+            if (device_planned) *device_planned = 0;
+            say("the stream path declined this batch (it is redone through the job list at fetch)");
+            return RAWDTW_OK;
+        }
+        std::vector<JobRec> jr(n_jobs);
+        std::vector<uint32_t> cost(n_jobs);
+        const uint64_t n_tiles = cnt[kCntTiles];
+        std::vector<uint32_t> tf(n_tiles + 1);
+        if (n_jobs) HIP_TRY(ctx, hipMemcpy(jr.data(), a.jrec, n_jobs * sizeof(JobRec), hipMemcpyDeviceToHost));
+        if (n_jobs) HIP_TRY(ctx, hipMemcpy(cost.data(), a.lds_cost, n_jobs * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(tf.data(), a.tile_first, (n_tiles + 1) * 4, hipMemcpyDeviceToHost));
+        const uint64_t n_other = cnt[kCntOthers];
+        std::vector<DevJob> oj(n_other);
+        if (n_other) HIP_TRY(ctx, hipMemcpy(oj.data(), a.ojobs, n_other * sizeof(DevJob), hipMemcpyDeviceToHost));
+        uint64_t tile_jobs = 0;
+        std::vector<uint8_t> is_tile(n_jobs, 0);
+        for (uint64_t k = 0; k < n_jobs && e.empty(); k++) {
+            const rawdtw_job_t &j = jobs[k];
+            const int R = slanted_radius(j.n, j.m, j.band_radius);
+            const uint32_t N = std::max(j.n, j.m), M = std::min(j.n, j.m);
+            const bool tile = R <= a.lane_max_radius && N <= a.lane_max_n;
+            if (jr[k].ref_off != j.ref_off || jr[k].read_off != j.read_off) e = "job " + S(k) + ": window offsets";
+            else if (((jr[k].meta & kMetaTile) != 0) != tile) e = "job " + S(k) + ": class";
+            else if (tile && ((jr[k].meta & 127u) != N || ((jr[k].meta >> 7) & 127u) != M || ((jr[k].meta >> 14) & 3u) != (uint32_t)R ||
+                              (((jr[k].meta >> 16) & 1u) != 0) != (j.exclude_last != 0) || (((jr[k].meta >> 17) & 1u) != 0) != (j.n < j.m)))
+                e = "job " + S(k) + ": shape, radius or flags";
+            is_tile[k] = tile;
+            tile_jobs += tile;
+        }
+        if (e.empty() && tile_jobs != cnt[kCntTileJobs]) e = "tile job count";
+        if (e.empty() && (tf[0] != 0 || tf[n_tiles] != n_jobs)) e = "tiles do not cover the jobs";
+        for (uint64_t t = 0; t < n_tiles && e.empty(); t++) {
+            if (tf[t + 1] < tf[t]) { e = "tile " + S(t) + ": boundaries not ascending"; break; }
+            const uint64_t n = tf[t + 1] - tf[t];
+            if (n > kStreamMaxTileJobs) { e = "tile " + S(t) + ": too many jobs"; break; }
+            // the LDS image as k_stream lays it out: one span of each arena per run, ends rounded up to 16 bytes
+            uint64_t image = 0, runs = 0, r0 = 0, r1 = 0, f0 = 0, f1 = 0;
+            bool open = false, seen = false;
+            auto close = [&]() { if (open) image += ((r1 - r0 + 3) & ~3ull) + ((f1 - f0 + 3) & ~3ull); open = false; };
+            for (uint64_t k = tf[t]; k < tf[t + 1]; k++) {
+                if (!is_tile[k]) continue;
+                const rawdtw_job_t &j = jobs[k];
+                if ((jr[k].meta & kMetaStarts) || !seen) { close(); open = true; runs++; r0 = j.read_off & ~3u; f0 = j.ref_off & ~3ull; r1 = r0; f1 = f0; }
+                else if (j.read_off + 1 != r1 || j.ref_off + 1 != f1) { e = "job " + S(k) + ": continues a run it does not touch"; break; }
+                seen = true;
+                r1 = (uint64_t)j.read_off + j.n; f1 = j.ref_off + j.m;
+            }
+            close();
+            if (e.empty() && (image > batch->stream_lds || runs > kStreamMaxRuns)) e = "tile " + S(t) + ": LDS image or run count over capacity";
+        }
+        std::vector<uint8_t> oseen(n_jobs, 0);
+        for (uint64_t q = 0; q < n_other && e.empty(); q++) {
+            const DevJob &d = oj[q];
+            const uint32_t k = d.aux;
+            if (k >= n_jobs || oseen[k] || is_tile[k]) e = "side-list job " + S(k) + " duplicated or of the tile class";
+            else if (d.n != jobs[k].n || d.m != jobs[k].m || d.ref_off != jobs[k].ref_off || d.read_off != jobs[k].read_off ||
+                     d.R != slanted_radius(d.n, d.m, jobs[k].band_radius) || ((d.flags & kFlagExcludeLast) != 0) != (jobs[k].exclude_last != 0))
+                e = "side-list record of job " + S(k) + " differs from the job";
+            else oseen[k] = 1;
+        }
+        for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
+            if (!is_tile[k] && !oseen[k]) e = "job " + S(k) + " is in no launch";
+        say(e);
+        return e.empty() ? RAWDTW_OK : RAWDTW_ERR_DEVICE + 100;
+    }
+    const rawdtw_plan *pl = batch->plan;
     // the tile records as the kernels will read them
     const size_t n_tiles = pl->n_tiles + pl->n_tiles_hi;
     std::vector<TileDesc> tiles(n_tiles);
     std::vector<TileJob> tjobs(pl->n_tile_jobs);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n_tiles) HIP_TRY(ctx, hipMemcpy(tiles.data(), pl->d_tiles, n_tiles * sizeof(TileDesc), hipMemcpyDeviceToHost));
     if (pl->n_tile_jobs) HIP_TRY(ctx, hipMemcpy(tjobs.data(), pl->d_tjobs, pl->n_tile_jobs * sizeof(TileJob), hipMemcpyDeviceToHost));
     size_t n_spans = 0;
@@ -1885,23 +2028,23 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
     if (n_spans) HIP_TRY(ctx, hipMemcpy(spans.data(), pl->d_spans, n_spans * sizeof(TileSpan), hipMemcpyDeviceToHost));
     const PlanCfg cfg = cfg_of(ctx);
     std::vector<uint8_t> tseen;
-    std::string e = verify_tile_arrays(cfg, jobs, n_jobs, pl, pl->dev_planned, tiles.data(), n_tiles, spans.data(), n_spans,
-                                       tjobs.data(), tjobs.size(), micro_masks(), tseen);
+    e = verify_tile_arrays(cfg, jobs, n_jobs, pl, tiles.data(), n_tiles, spans.data(), n_spans, tjobs.data(), tjobs.size(),
+                           micro_masks(), tseen);
     // every job has exactly one home: a tile record or a record of another class
     std::vector<uint8_t> oseen(n_jobs, 0);
     if (e.empty()) {
         const uint64_t n_other = n_jobs - pl->n_tile_jobs;
         for (uint64_t q = 0; q < n_other && e.empty(); q++) {
-            const DevJob &d = pl->h_jobs[(pl->dev_planned ? 0 : pl->n_tile_jobs) + q];
+            const DevJob &d = pl->h_jobs[pl->n_tile_jobs + q];
             const uint32_t k = d.aux;
-            if (k >= n_jobs || oseen[k] || tseen[k]) e = "job " + std::to_string(k) + " planned twice";
+            if (k >= n_jobs || oseen[k] || tseen[k]) e = "job " + S(k) + " planned twice";
             else if (d.n != jobs[k].n || d.m != jobs[k].m || d.ref_off != jobs[k].ref_off || d.read_off != jobs[k].read_off ||
                      ((d.flags & kFlagExcludeLast) != 0) != (jobs[k].exclude_last != 0))
-                e = "record of job " + std::to_string(k) + " differs from the job";
+                e = "record of job " + S(k) + " differs from the job";
             else oseen[k] = 1;
         }
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
-            if (!tseen[k] && !oseen[k]) e = "job " + std::to_string(k) + " is in no launch";
+            if (!tseen[k] && !oseen[k]) e = "job " + S(k) + " is in no launch";
     }
     say(e);
     return e.empty() ? RAWDTW_OK : RAWDTW_ERR_DEVICE + 100;
@@ -1909,9 +2052,37 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
 
 int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint64_t *n_chains)
 {
-    if (!batch) return RAWDTW_ERR_INVALID;
+    if (!batch || batch_dead(batch)) return RAWDTW_ERR_INVALID;
     if (n_chains) *n_chains = batch->n_chains;
-    if (info) return rawdtw_plan_info(batch->plan, info);
+    if (!info) return RAWDTW_OK;
+    if (!batch->stream) return rawdtw_plan_info(batch->plan, info);
+    rawdtw_batch *b = const_cast<rawdtw_batch *>(batch);
+    rawdtw_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int st = stream_counters(ctx, b);
+    if (st != RAWDTW_OK) return st;
+    if (stream_declined(b)) { // what the job-list path will run
+        st = stream_fallback(ctx, b);
+        if (st != RAWDTW_OK) return st;
+        return rawdtw_plan_info(b->plan, info);
+    }
+    if (!b->cells_counted) {
+        HIP_TRY(ctx, stream_count_cells(b->sa, b->sa.cnt + kCntCells, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&b->h_cnt[kCntCells], b->sa.cnt + kCntCells, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        b->cells_counted = true;
+    }
+    const unsigned long long *c = b->h_cnt;
+    rawdtw_plan_info_t I{};
+    I.n_jobs = b->n_jobs;
+    I.cells = c[kCntCells];
+    I.algorithmic_bytes = c[kCntTileBytes] + c[kCntOtherBytes];
+    I.n_lane_jobs = c[kCntTileJobs];
+    I.n_wave_band_jobs = c[kCntOthers];
+    I.n_full_jobs = 0;
+    I.workspace_bytes = b->ws_bytes;
+    I.n_launches = 1;
+    *info = I;
     return RAWDTW_OK;
 }
 
@@ -1919,8 +2090,9 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
 {
     hipError_t e;
     if (ctx->debug_skip_kinds & (1u << (which == 0 ? kKindChainFold : kKindReadSelect))) return RAWDTW_OK;
+    const float *job_cost = b->stream ? b->sa.out : b->plan->d_cost;
     if (which == 0)
-        e = launch_chain_fold(ctx->fold_mode, b->d_chains, b->d_fold_order, b->n_chains, b->plan->d_cost, b->opt.match_bonus, b->opt.fused_score,
+        e = launch_chain_fold(ctx->fold_mode, b->d_chains, b->d_fold_order, b->n_chains, job_cost, b->opt.match_bonus, b->opt.fused_score,
                               b->d_full, b->d_gate, ctx->stream);
     else
         e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
@@ -1929,13 +2101,36 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
     return RAWDTW_OK;
 }
 
+// launches of a batch's DTW part (before fold and select): the job-list plan's, or the stream path's one
+static uint32_t batch_dtw_launches(const rawdtw_batch *b) { return b->stream ? 1u : b->plan ? (uint32_t)b->plan->launches.size() : 0u; }
+
+
+static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e)
+{
+    const uint32_t np = batch_dtw_launches(batch);
+    int st = RAWDTW_OK;
+    batch->dirty = true;
+    if (batch->stream) {
+        if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK) {
+            hipError_t he = stream_run(batch->sa, ctx->stream_others_blocks, ctx->stream_blocks, batch->stream_lds, ctx->stream);
+            if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
+        }
+        if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    } else st = run_all_launches(ctx, batch->plan, e);
+    for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
+        if (e && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK) st = batch_tail(ctx, batch, k);
+        if (st == RAWDTW_OK && e && hipEventRecord(e[2 * (np + k) + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+    }
+    return st;
+}
+
 int rawdtw_batch_run(rawdtw_ctx *ctx, rawdtw_batch *batch)
 {
-    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
-    int st = rawdtw_plan_run(ctx, batch->plan);
-    if (st == RAWDTW_OK) st = batch_tail(ctx, batch, 0);
-    if (st == RAWDTW_OK) st = batch_tail(ctx, batch, 1);
-    return st;
+    if (!ctx || !batch || batch->ctx != ctx || batch_dead(batch)) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return batch_enqueue_one(ctx, batch, nullptr);
 }
 
 int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms, uint32_t *launch_kind, uint32_t cap,
@@ -1947,24 +2142,11 @@ int rawdtw_batch_run_timed(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_m
     return st;
 }
 
-static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e)
-{
-    rawdtw_plan *pl = batch->plan;
-    const uint32_t np = (uint32_t)pl->launches.size();
-    int st = run_all_launches(ctx, pl, e);
-    for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
-        if (e && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        if (st == RAWDTW_OK) st = batch_tail(ctx, batch, k);
-        if (st == RAWDTW_OK && e && hipEventRecord(e[2 * (np + k) + 1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-    }
-    return st;
-}
-
 int rawdtw_batch_enqueue(rawdtw_ctx *ctx, rawdtw_batch *batch, int timed)
 {
-    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    if (!ctx || !batch || batch->ctx != ctx || batch_dead(batch)) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t nl = (uint32_t)batch->plan->launches.size() + 2;
+    const uint32_t nl = batch_dtw_launches(batch) + 2;
     hipEvent_t *e = nullptr;
     if (timed) {
         const size_t base = batch->ev.size();
@@ -1980,11 +2162,11 @@ int rawdtw_batch_collect(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms,
                          uint32_t *n_launches, uint32_t *n_runs)
 {
     if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
-    rawdtw_plan *pl = batch->plan;
-    const uint32_t np = (uint32_t)pl->launches.size(), nl = np + 2;
+    const uint32_t np = batch_dtw_launches(batch), nl = np + 2;
     if (n_launches) *n_launches = nl;
     if (n_runs) *n_runs = batch->ev_runs;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    batch->dirty = false;
     int st = RAWDTW_OK;
     for (uint32_t i = 0; i < nl && i < cap; i++) {
         double acc = 0;
@@ -1995,9 +2177,11 @@ int rawdtw_batch_collect(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms,
             acc += ms;
         }
         if (launch_ms) launch_ms[i] = batch->ev_runs ? (float)(acc / batch->ev_runs) : 0.f;
-        if (launch_kind)
-            launch_kind[i] = i < np ? (pl->launches[i].kind | ((uint32_t)pl->launches[i].param << 8))
-                                    : (i == np ? kKindChainFold : kKindReadSelect);
+        if (launch_kind) {
+            if (i >= np) launch_kind[i] = i == np ? kKindChainFold : kKindReadSelect;
+            else if (batch->stream) launch_kind[i] = kKindBandMerged | ((uint32_t)batch->stream_lds << 8);
+            else launch_kind[i] = batch->plan->launches[i].kind | ((uint32_t)batch->plan->launches[i].param << 8);
+        }
     }
     for (auto &e : batch->ev) if (e) (void)hipEventDestroy(e);
     batch->ev.clear();
@@ -2010,22 +2194,24 @@ int rawdtw_batch_run_reps(rawdtw_ctx *ctx, rawdtw_batch *batch, uint32_t reps, f
                           uint32_t cap, uint32_t *n_launches)
 {
     if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
-    if (n_launches) *n_launches = (uint32_t)batch->plan->launches.size() + 2;
+    if (n_launches) *n_launches = batch_dtw_launches(batch) + 2;
     int st = RAWDTW_OK;
     for (uint32_t r = 0; r < reps && st == RAWDTW_OK; r++) st = rawdtw_batch_enqueue(ctx, batch, launch_ms != nullptr);
     if (launch_ms) {
         int st2 = rawdtw_batch_collect(ctx, batch, launch_ms, launch_kind, cap, nullptr, nullptr);
         if (st == RAWDTW_OK) st = st2;
-    } else if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
+    } else {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == RAWDTW_OK) st = RAWDTW_ERR_DEVICE;
+        batch->dirty = false;
+    }
     return st;
 }
 
 int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *kind, int32_t *param, uint64_t *n_jobs,
                               uint64_t *algorithmic_bytes, uint64_t *cells)
 {
-    if (!batch) return RAWDTW_ERR_INVALID;
-    const rawdtw_plan *pl = batch->plan;
-    const uint32_t nl = (uint32_t)pl->launches.size();
+    if (!batch || batch_dead(batch)) return RAWDTW_ERR_INVALID;
+    const uint32_t nl = batch_dtw_launches(batch);
     if (i >= nl + 2) return RAWDTW_ERR_INVALID;
     if (i >= nl) {
         if (kind) *kind = i == nl ? kKindChainFold : kKindReadSelect;
@@ -2034,20 +2220,38 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
         // fold: one 4-byte cost per job + a 24-byte descriptor and two 4-byte results per chain;
         // select: 8 bytes read and 5 written per chain
         if (algorithmic_bytes)
-            *algorithmic_bytes = i == nl ? pl->n_jobs * 4 + batch->n_chains * 32 : batch->n_chains * 13 + batch->n_reads * 8;
+            *algorithmic_bytes = i == nl ? batch->n_jobs * 4 + batch->n_chains * 32 : batch->n_chains * 13 + batch->n_reads * 8;
         if (cells) *cells = 0;
         return RAWDTW_OK;
     }
+    if (batch->stream) {
+        rawdtw_plan_info_t I{};
+        if (cells) { int st = rawdtw_batch_info(batch, &I, nullptr); if (st != RAWDTW_OK) return st; }
+        else {
+            rawdtw_batch *b = const_cast<rawdtw_batch *>(batch);
+            int st = stream_counters(b->ctx, b);
+            if (st != RAWDTW_OK) return st;
+            I.algorithmic_bytes = b->h_cnt[kCntTileBytes] + b->h_cnt[kCntOtherBytes];
+        }
+        if (batch->stream) { // (rawdtw_batch_info may have moved the batch to the job-list path)
+            if (kind) *kind = kKindBandMerged;
+            if (param) *param = (int32_t)batch->stream_lds;
+            if (n_jobs) *n_jobs = batch->n_jobs;
+            if (algorithmic_bytes) *algorithmic_bytes = I.algorithmic_bytes;
+            if (cells) *cells = I.cells;
+            return RAWDTW_OK;
+        }
+        if (i >= batch_dtw_launches(batch)) return RAWDTW_ERR_INVALID;
+    }
+    const rawdtw_plan *pl = batch->plan;
     const Launch &L = pl->launches[i];
     const MergeSel mg = merge_of(batch->ctx, pl);
     uint64_t bytes = 0, cl = 0, nj = 0;
     auto add = [&](const Launch &X) {
-        if (pl->dev_planned && X.first < pl->h_base) bytes += pl->dev_tile_bytes; // tile launch of a device-planned batch
-        else
-            for (uint64_t p = X.first; p < X.first + X.count; p++) {
-                const DevJob &d = pl->h_jobs[p - pl->h_base];
-                bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
-            }
+        for (uint64_t p = X.first; p < X.first + X.count; p++) {
+            const DevJob &d = pl->h_jobs[p];
+            bytes += 4ull * ((uint64_t)d.n + d.m) + 4 + 32;
+        }
         if (cells) cl += count_cells(pl, X.first, X.first + X.count);
         nj += X.count;
     };
@@ -2071,31 +2275,118 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
 
 int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep, float *job_cost)
 {
-    if (!ctx || !batch || batch->ctx != ctx) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
-    if (batch->n_chains) {
-        if (score) HIP_TRY(ctx, hipMemcpyAsync(score, batch->d_score, batch->n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (keep) HIP_TRY(ctx, hipMemcpyAsync(keep, batch->d_keep, batch->n_chains, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx || !batch || batch->ctx != ctx || batch_dead(batch)) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const float *d_cost = batch->stream ? batch->sa.out : batch->plan->d_cost;
+        if (batch->n_chains) {
+            if (score) HIP_TRY(ctx, hipMemcpyAsync(score, batch->d_score, batch->n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (keep) HIP_TRY(ctx, hipMemcpyAsync(keep, batch->d_keep, batch->n_chains, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (job_cost && batch->n_jobs)
+            HIP_TRY(ctx, hipMemcpyAsync(job_cost, d_cost, batch->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (batch->stream && !batch->cnt_valid)
+            HIP_TRY(ctx, hipMemcpyAsync(batch->h_cnt, batch->sa.cnt, kStreamCounters * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        batch->dirty = false;
+        if (!batch->stream) return RAWDTW_OK;
+        batch->cnt_valid = true;
+        if (!stream_declined(batch)) return RAWDTW_OK;
+        int st = stream_fallback(ctx, batch); // invalid anchors (the job-list path words the error) or a shape it does not take
+        if (st != RAWDTW_OK) return st;
     }
-    if (job_cost && batch->plan->n_jobs)
-        HIP_TRY(ctx, hipMemcpyAsync(job_cost, batch->plan->d_cost, batch->plan->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms)
+{
+    if (!ctx || !batch || batch->ctx != ctx || !ms) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to batch_plan_ms");
+    *ms = 0.0f;
+    if (!batch->stream || !batch->ev_plan[0] || !batch->ev_plan[1]) return RAWDTW_OK;
+    HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, batch->ev_plan[0], batch->ev_plan[1]));
     return RAWDTW_OK;
 }
 
 int rawdtw_batch_destroy(rawdtw_batch *b)
 {
     if (!b) return RAWDTW_OK;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    rawdtw_ctx *ctx = b->ctx;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx && b->dirty) (void)hipStreamSynchronize(ctx->stream); // its workspace goes back to the pool
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    rawdtw_plan_destroy(b->plan);
-    if (b->d_chains) (void)hipFree(b->d_chains);
-    if (b->d_chain_off) (void)hipFree(b->d_chain_off);
-    if (b->d_fold_order) (void)hipFree(b->d_fold_order);
-    if (b->d_full) (void)hipFree(b->d_full);
-    if (b->d_gate) (void)hipFree(b->d_gate);
-    if (b->d_score) (void)hipFree(b->d_score);
-    if (b->d_keep) (void)hipFree(b->d_keep);
+    for (auto &e : b->ev_plan) if (e) (void)hipEventDestroy(e);
+    batch_release_device(b);
+    if (ctx) ws_release(ctx, b->ws);
     delete b;
+    return RAWDTW_OK;
+}
+
+// ---- pinned host memory and incremental event upload ------------------------------------------------
+int rawdtw_host_alloc(uint64_t bytes, void **out)
+{
+    if (!out) return RAWDTW_ERR_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return RAWDTW_OK;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? RAWDTW_OK : RAWDTW_ERR_OOM;
+}
+
+int rawdtw_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+    return RAWDTW_OK;
+}
+
+int rawdtw_events_reserve(rawdtw_ctx *ctx, uint64_t n_floats)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (n_floats >= (1ull << 32)) return fail(ctx, RAWDTW_ERR_INVALID, "event arena limited to 2^32-1 floats per batch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->own_ev) { ctx->d_ev = nullptr; ctx->cap_ev = 0; ctx->n_ev = 0; ctx->own_ev = true; }
+    if (ctx->cap_ev < n_floats) { // grow, keeping what is there
+        uint64_t cap = std::max<uint64_t>(n_floats + (n_floats >> 2), 1024);
+        cap = (cap + 63) & ~63ull;
+        float *nw = nullptr;
+        int st = dev_alloc(ctx, &nw, cap);
+        if (st != RAWDTW_OK) return st;
+        if (ctx->d_ev && ctx->n_ev) HIP_TRY(ctx, hipMemcpyAsync(nw, ctx->d_ev, ctx->n_ev * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_ev) (void)hipFree(ctx->d_ev);
+        ctx->d_ev = nw;
+        ctx->cap_ev = cap;
+    }
+    ctx->n_ev = std::max(ctx->n_ev, n_floats);
+    return RAWDTW_OK;
+}
+
+int rawdtw_events_append(rawdtw_ctx *ctx, const float *h_new, uint64_t n_new, uint32_t n_segments,
+                         const uint64_t *seg_src_off, const uint32_t *seg_dst_off)
+{
+    if (!ctx || (n_new && !h_new) || (n_segments && (!seg_src_off || !seg_dst_off))) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (n_segments == 0) return RAWDTW_OK;
+    if (!ctx->own_ev || !ctx->d_ev) return fail(ctx, RAWDTW_ERR_INVALID, "rawdtw_events_reserve first");
+    if (seg_src_off[n_segments] > n_new) return fail(ctx, RAWDTW_ERR_RANGE, "segment sources beyond the new events");
+    for (uint32_t q = 0; q < n_segments; q++)
+        if (seg_src_off[q + 1] < seg_src_off[q] || (uint64_t)seg_dst_off[q] + (seg_src_off[q + 1] - seg_src_off[q]) > ctx->n_ev)
+            return fail(ctx, RAWDTW_ERR_RANGE, "segment outside the reserved event arena");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // staging on the device: the round's events and the two segment tables (grow-only)
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t need = al(n_new * 4) + al(((size_t)n_segments + 1) * 8) + al((size_t)n_segments * 4);
+    if (ctx->append_bytes < need) {
+        if (ctx->d_append) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_append); }
+        ctx->d_append = nullptr; ctx->append_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_append, need + need / 4));
+        ctx->append_bytes = need + need / 4;
+    }
+    char *p = static_cast<char *>(ctx->d_append);
+    float *d_new = carve<float>(p, n_new);
+    uint64_t *d_src = carve<uint64_t>(p, (uint64_t)n_segments + 1);
+    uint32_t *d_dst = carve<uint32_t>(p, n_segments);
+    if (n_new) HIP_TRY(ctx, hipMemcpyAsync(d_new, h_new, n_new * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_src, seg_src_off, ((size_t)n_segments + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, seg_dst_off, (size_t)n_segments * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_events_scatter(d_new, ctx->d_ev, d_src, d_dst, n_segments, ctx->stream));
     return RAWDTW_OK;
 }
 

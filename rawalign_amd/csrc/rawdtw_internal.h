@@ -90,30 +90,62 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-// ---- device-side planning (rawdtw_plan.hip) ----
-struct DevPlanArgs {
-    uint64_t n_jobs, n_chains, n_ev, n_ref;
-    int32_t border, banded;      // rawdtw_align_opt_t: border_constraint, fill_method != 0
-    float frac;                  // band_radius_frac
+// ---- sync-free candidate batches (rawdtw_stream.hip) ----
+// One record per job of the batch, job order: the windows' arena offsets and, for the jobs the lane-per-job DP takes,
+// the packed shape: bits 0-6 longer side, 7-13 shorter side, 14-15 radius after the slant correction (dtw.cpp:298-300),
+// 16 exclude_last_element, 17 swap (the reference window is the longer one, dtw.cpp:284-292), 18 run start, 19 tile class.
+struct JobRec { uint64_t ref_off; uint32_t read_off; uint32_t meta; };
+static_assert(sizeof(JobRec) == 16, "JobRec is 16 bytes");
+constexpr uint32_t kMetaStarts = 1u << 18, kMetaTile = 1u << 19;
+constexpr uint32_t kStreamMaxTileJobs = 1024; // jobs in a tile's range (records live in LDS)
+constexpr uint32_t kStreamMaxRuns = 256;      // runs of consecutive parts per tile (one span of each arena per run)
+// side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
+constexpr uint32_t kStreamClasses = 6, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5;
+enum StreamCounter : int {
+    kCntBad = 0,        // min: first job with invalid anchors or a window outside the arenas (~0 = none)
+    kCntOverflow,       // min: a tile over one of the kernel's capacities (~0 = none): never with a correct planner
+    kCntUnsupported,    // jobs whose band is wider than the side list's kernels take (radius + 1 > 256)
+    kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntMaxCost8, kCntOthers, kCntTiles, kCntQueue, kCntLdsMax,
+    kCntCls0,           // kStreamClasses totals
+    kCntCur0 = kCntCls0 + 6, // kStreamClasses scatter cursors
+    kCntCells = kCntCur0 + 6,
+    kStreamCounters = 32
+};
+struct StreamArgs {
+    uint64_t n_jobs, n_chains, n_reads, n_ev, n_ref, others_cap;
+    float frac;                  // dtw_band_radius_frac
     int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
     uint32_t lane_max_n, micro_max_n;
-    uint32_t tile_budget;        // tile_lds_floats minus what a tile's first job can cost beyond its counted cost
-    uint32_t min_cost8;          // least cost of a job in eighths of a float: 8 * tile_budget / tile_max_jobs
+    uint32_t tile_budget;        // LDS floats of a tile's image minus what a tile's first job can cost beyond its counted cost
+    uint32_t min_cost8, run_cost8; // cost floors in eighths of a float: bound the jobs / the runs of a tile
+    uint32_t tiles_cap;
+    // inputs (device)
+    const uint64_t *job_off, *anchor_off;
+    const rawdtw_anchor_t *anchors;
+    const uint64_t *ref_base;
+    const uint32_t *read_base;
+    const float *ev, *ref;
+    const unsigned long long *masks;
+    // planning arrays and outputs (device)
+    JobRec *jrec;
+    uint32_t *lds_cost;
+    uint64_t *cum;
+    uint32_t *tile_first;
+    DevJob *omix, *ojobs;
+    uint8_t *ocls;
+    unsigned long long *cnt;
+    float *out;
 };
-enum : int { kPlanBad = 0, kPlanBadRadius, kPlanTileOverflow, kPlanTileJobs, kPlanTiles, kPlanRuns, kPlanTileCells,
-             kPlanTileBytes, kPlanLdsMax, kPlanMaxCost8, kPlanCounters };
-struct DevPlanBuffers {
-    DevJob *pjobs; uint32_t *chain_of, *cost, *is_tile, *rank, *order_tile, *tile_no, *run_flag, *tile_flag, *tile_idx, *run_idx;
-    uint8_t *run_start; uint64_t *cum; uint32_t *tile_first; void *scan_tmp; size_t scan_tmp_bytes;
-};
-size_t dev_plan_scratch_bytes(uint64_t n_jobs);
-hipError_t dev_count_tile_cells(const TileJob *d_tjobs, uint64_t n, unsigned long long *d_total, hipStream_t s);
-hipError_t dev_plan_phase1(const DevPlanArgs &a, const uint64_t *d_job_off, const uint64_t *d_anchor_off,
-                           const rawdtw_anchor_t *d_anchors, const uint64_t *d_ref_base, const uint32_t *d_read_base,
-                           void *scratch, DevPlanBuffers *buf, rawdtw_job_t *d_other_jobs, uint32_t *d_other_aux,
-                           unsigned long long *d_counters, hipStream_t s);
-hipError_t dev_plan_phase2(const DevPlanArgs &a, uint32_t n_tiles, DevPlanBuffers *buf, TileDesc *d_tiles,
-                           TileSpan *d_spans, TileJob *d_tjobs, unsigned long long *d_counters, hipStream_t s);
+size_t stream_scan_bytes(uint64_t n_jobs);
+size_t stream_sort_bytes(uint64_t n_chains);
+uint32_t stream_lds_bytes(uint32_t lds_floats);
+int stream_blocks_per_cu(uint32_t lds_floats);
+hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key, uint32_t *d_val, uint32_t *d_key_out,
+                       uint32_t *d_fold_order, void *d_tmp, size_t tmp_bytes, hipStream_t s);
+hipError_t stream_run(const StreamArgs &a, uint32_t others_blocks, uint32_t tile_blocks, uint32_t lds_floats, hipStream_t s);
+hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);
+hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,
+                                 uint32_t n_seg, hipStream_t s);
 
 hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const TileSpan *spans, const TileJob *tjobs,
                               const unsigned long long *masks, uint32_t lds_floats, const DevJob *wjobs, uint64_t n_w,

@@ -11,334 +11,9 @@
 // bit as long as the same cell set and the same neighbour rules are used.  Built with
 // -ffp-contract=off.
 #include "rawdtw_internal.h"
+#include "rawdtw_dp.h"
 
 namespace rawdtw {
-
-__device__ __forceinline__ float min3f(float top, float left, float tl)
-{
-    // std::min(std::min(top,left),topleft); identical for non-NaN operands.  Written as the instruction: through
-    // fminf the compiler must quiet signalling NaNs first (a v_max_f32 x,x per operand it cannot prove canonical,
-    // and two v_min_f32 instead of one v_min3_f32) -- a quarter of the lane DP's VALU work.
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(top), "v"(left), "v"(tl));
-    return r;
-}
-
-__device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float wave_shr1(float v, float fill)
-{
-    // lane l receives lane l-1's value; lane 0 keeps `fill`  (DPP wave_shr:1 = 0x138)
-    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
-                                        0x138, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, r);
-}
-
-__device__ __forceinline__ float read_lane(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-__device__ __forceinline__ float wave_shl1(float v, float fill)
-{
-    // lane l receives lane l+1's value; lane 63 keeps `fill`  (DPP wave_shl:1 = 0x130)
-    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
-                                        0x130, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, r);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Lane-per-job banded kernel.  Sparse-mode segments are tiny (2..~70 events, radius 1..6):
-// intra-job parallelism is a handful of cells per antidiagonal, so each lane owns one job and
-// the antidiagonal buffers live in registers (radius is a template parameter, every buffer index
-// is a compile-time constant).
-//
-// Buffers.  The reference rotates three buffers (dtw.cpp:305-314, 410-413, 487-490); slots an
-// antidiagonal does not overwrite keep stale values, but no in-matrix cell ever reads such a slot
-// (every neighbour read is either a cell of the band's cell set or a guarded/never-written slot
-// holding 1e10 -- the oracle's orc_dtw_banded_cellset states exactly this and is bit-identical to
-// the reference).  So clipped cells are written as 1e10 and two buffers suffice: p1 = latest
-// antidiagonal, p2 = the one before.  A column whose centre row advances computes its secondary
-// antidiagonal in place over p2 and its primary in place over p1 (each cell reads only its own
-// slot of the buffer it overwrites); a column that stays on the row computes its primary over p2
-// and swaps.  No rotation copies.
-//
-// Control.  Jobs are sorted by (longer side, shorter side), so the 64 jobs of a wave almost always
-// share one shape; then the whole band geometry (row advance, clipping) is wave-uniform and the
-// loop runs with scalar control flow (`lane_dp` instantiated on readfirstlane'd lengths).
-//
-// Operands.  The workgroup first stages the windows of its JOBS jobs from HBM into LDS with
-// coalesced 16-byte loads (a lane reading its own window 4 bytes at a time would pull a whole
-// 128-byte line per element through L2).  Each job owns STRIDE floats of LDS: the 16-byte
-// aligned chunks covering its longer window at [0, CAP) and its shorter one at [CAP, 2*CAP);
-// STRIDE/4 is odd so that lanes spread over the banks.  The DP slides both windows through
-// registers -- one new a-value per column, one new b-value when the centre row moves -- fetched
-// from LDS one step ahead of their use.
-// ---------------------------------------------------------------------------------------------
-template <int R>
-__device__ __forceinline__ float lane_dp(const float *LA, const float *LB, const uint32_t N, const uint32_t M)
-{
-    constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
-    constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
-    constexpr int K = (P > S) ? P : S;
-    constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
-    constexpr int HP = P / 2, HS = S / 2;
-    constexpr bool EVEN = (R % 2 == 0);
-    const int iN = (int)N, iM = (int)M;
-
-    float p1[K], p2[K];
-    float aw[K];     // aw[x] = A[col + HP - x]
-    float bw[K + 1]; // bw[x] = B[row - HP - 1 + x]
-#pragma unroll
-    for (int x = 0; x < K; x++) {
-        p1[x] = kInf; p2[x] = kInf;
-        const int ia = HP - x;
-        aw[x] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
-    }
-#pragma unroll
-    for (int x = 0; x <= K; x++) {
-        const int ib = x - HP - 1;
-        bw[x] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-    }
-    // column 0: only the corner (dtw.cpp:317-347)
-    p1[HP + SH] = dist(LA[0], LB[0]);
-
-    int row = 0;
-    uint32_t rem = 0; // M*col - row*N, so "row advances" <=> rem + M >= N  (dtw.cpp:352-359)
-    bool prev_adv = false;
-    // one-ahead operand fetch: a_next = A[col + HP] for the coming column,
-    // b_next = B[row + 1 - HP - 1 + K] for the coming row advance
-    float a_next, b_next;
-    {
-        const int ia = 1 + HP, ib = 1 - HP - 1 + K;
-        a_next = LA[ia >= iN ? iN - 1 : ia];
-        b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-    }
-    for (uint32_t col = 1; col < N; col++) {
-        rem += M;
-        const bool adv = rem >= N;
-#pragma unroll
-        for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
-        aw[0] = a_next;
-        {
-            const int ia = (int)col + 1 + HP;
-            a_next = LA[ia >= iN ? iN - 1 : ia];
-        }
-        if (adv) {
-            rem -= N;
-            row++;
-#pragma unroll
-            for (int x = 0; x < K; x++) bw[x] = bw[x + 1];
-            bw[K] = b_next;
-            {
-                const int ib = row + 1 - HP - 1 + K;
-                b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-            }
-            // secondary antidiagonal (dtw.cpp:361-414), in place over p2
-#pragma unroll
-            for (int o = 0; o < S; o++) {
-                const int i = (int)col + HS - 1 - o;
-                const int j = row - HS + o;
-                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-                const float av = EVEN ? aw[o + 1 < K ? o + 1 : K - 1] : aw[o];
-                const float bv = EVEN ? bw[o + 1] : bw[o];
-                float top, tl, left;
-                if (SH == 0) {
-                    top = p1[o]; tl = p2[o]; left = p1[o + 1 < K ? o + 1 : K - 1];
-                } else {
-                    top = (o == 0) ? kInf : p1[o];
-                    tl = (o == 0 && !prev_adv) ? kInf : p2[o];
-                    left = (o == S - 1) ? kInf : p1[o + 1 < K ? o + 1 : K - 1];
-                }
-                const float v = min3f(top, left, tl) + dist(av, bv);
-                p2[o] = valid ? v : kInf;
-            }
-            // primary, centre row advanced (dtw.cpp:430-436, 459-463): dp1 = the secondary (now p2),
-            // dp0 = the previous primary (p1), in place over p1
-#pragma unroll
-            for (int o = 0; o < P; o++) {
-                const int i = (int)col + HP - o;
-                const int j = row - HP + o;
-                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-                const float av = aw[o];
-                const float bv = bw[o + 1];
-                if (SH == 0) {
-                    const float top = (o == 0) ? kInf : p2[o > 0 ? o - 1 : 0];
-                    const float tl = p1[o];
-                    const float left = (o == P - 1) ? kInf : p2[o];
-                    const float v = min3f(top, left, tl) + dist(av, bv);
-                    p1[o] = valid ? v : kInf;
-                } else {
-                    constexpr int kmax = K - 1;
-                    const float top = p2[o];
-                    const float tl = p1[o + 1 < K ? o + 1 : kmax];
-                    const float left = p2[o + 1 < K ? o + 1 : kmax];
-                    const float v = min3f(top, left, tl) + dist(av, bv);
-                    p1[o + 1 < K ? o + 1 : kmax] = valid ? v : kInf;
-                }
-            }
-        } else {
-            // primary, same centre row (dtw.cpp:437-444, 464-473): dp1 = p1, dp0 = p2; computed in place
-            // over p2 from the highest offset down, then the two buffers trade places
-#pragma unroll
-            for (int o = P - 1; o >= 0; o--) {
-                const int i = (int)col + HP - o;
-                const int j = row - HP + o;
-                const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-                const float av = aw[o];
-                const float bv = bw[o + 1];
-                if (SH == 0) {
-                    const float top = (o == 0) ? kInf : p1[o > 0 ? o - 1 : 0];
-                    const float tl = (o == 0) ? kInf : p2[o > 0 ? o - 1 : 0];
-                    const float left = p1[o];
-                    const float v = min3f(top, left, tl) + dist(av, bv);
-                    p2[o] = valid ? v : kInf;
-                } else {
-                    constexpr int kmax = K - 1;
-                    const float top = (o == 0) ? kInf : p1[o];
-                    const float tl = (o == 0 && !prev_adv) ? kInf : p2[o];
-                    const float left = p1[o + 1 < K ? o + 1 : kmax];
-                    const float v = min3f(top, left, tl) + dist(av, bv);
-                    p2[o + 1 < K ? o + 1 : kmax] = valid ? v : kInf;
-                }
-            }
-#pragma unroll
-            for (int x = 0; x < K; x++) { const float t = p1[x]; p1[x] = p2[x]; p2[x] = t; }
-        }
-        prev_adv = adv;
-    }
-    return p1[HP + SH]; // dtw.cpp:506-512
-}
-
-// The same DP for waves whose lanes do NOT share one shape.  There the lanes disagree on `adv` (does the centre row
-// advance at this column?) at almost every column, and a branch on it makes the wave run both bodies of lane_dp --
-// secondary + primary, and the lone primary -- every time.  This variant has one body: the secondary is always
-// computed (its result only matters when the row advances), and the primary takes its neighbours through selects on
-// `adv`; the two cases of lane_dp then differ in operands only:
-//   X  = adv ? (p2 after the secondary) : p1     -- the antidiagonal just before this primary
-//   tl = adv ? p1 : p2                           -- the one before that (shifted by one slot when the row stays)
-// and both end with p1 = the new primary, p2 = X.  About 55 vector instructions per column against ~85 for the two
-// bodies; a wave of one shape is still better off with lane_dp (scalar branch, ~47).
-template <int R>
-__device__ __forceinline__ float lane_dp_sel(const float *LA, const float *LB, const uint32_t N, const uint32_t M)
-{
-    constexpr int P = R + ((R % 2 == 0) ? 1 : 0); // dtw.cpp:301
-    constexpr int S = R + ((R % 2 == 1) ? 1 : 0); // dtw.cpp:302
-    constexpr int K = (P > S) ? P : S;
-    constexpr int SH = (P > S) ? 0 : 1; // primaries live at index+1 when the secondary is longer
-    constexpr int HP = P / 2, HS = S / 2;
-    constexpr bool EVEN = (R % 2 == 0);
-    const int iN = (int)N, iM = (int)M;
-
-    float p1[K], p2[K];
-    float aw[K];     // aw[x] = A[col + HP - x]
-    float bw[K + 1]; // bw[x] = B[row - HP - 1 + x]
-#pragma unroll
-    for (int x = 0; x < K; x++) {
-        p1[x] = kInf; p2[x] = kInf;
-        const int ia = HP - x;
-        aw[x] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
-    }
-#pragma unroll
-    for (int x = 0; x <= K; x++) {
-        const int ib = x - HP - 1;
-        bw[x] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-    }
-    p1[HP + SH] = dist(LA[0], LB[0]); // column 0: only the corner (dtw.cpp:317-347)
-
-    int row = 0;
-    uint32_t rem = 0;
-    bool prev_adv = false;
-    float a_next, b_next;
-    {
-        const int ia = 1 + HP, ib = 1 - HP - 1 + K;
-        a_next = LA[ia >= iN ? iN - 1 : ia];
-        b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-    }
-    for (uint32_t col = 1; col < N; col++) {
-        rem += M;
-        const bool adv = rem >= N;
-        rem -= adv ? N : 0u;
-        row += adv ? 1 : 0;
-        // a-window: one step per column
-#pragma unroll
-        for (int x = K - 1; x > 0; x--) aw[x] = aw[x - 1];
-        aw[0] = a_next;
-        {
-            const int ia = (int)col + 1 + HP;
-            a_next = LA[ia >= iN ? iN - 1 : ia];
-        }
-        // b-window: one step when the row advances.  (b_next is a function of the row alone: reloading it every column
-        // returns the same value while the row stays.)
-#pragma unroll
-        for (int x = 0; x < K; x++) bw[x] = adv ? bw[x + 1] : bw[x];
-        bw[K] = adv ? b_next : bw[K];
-        {
-            const int ib = row - HP + K;
-            b_next = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
-        }
-        // secondary antidiagonal (dtw.cpp:361-414), wanted only when the row advanced
-        float q[K];
-#pragma unroll
-        for (int o = 0; o < K; o++) q[o] = p2[o];
-#pragma unroll
-        for (int o = 0; o < S; o++) {
-            const int i = (int)col + HS - 1 - o;
-            const int j = row - HS + o;
-            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-            const float av = EVEN ? aw[o + 1 < K ? o + 1 : K - 1] : aw[o];
-            const float bv = EVEN ? bw[o + 1] : bw[o];
-            float top, tl, left;
-            if (SH == 0) {
-                top = p1[o]; tl = p2[o]; left = p1[o + 1 < K ? o + 1 : K - 1];
-            } else {
-                top = (o == 0) ? kInf : p1[o];
-                tl = (o == 0 && !prev_adv) ? kInf : p2[o];
-                left = (o == S - 1) ? kInf : p1[o + 1 < K ? o + 1 : K - 1];
-            }
-            const float v = min3f(top, left, tl) + dist(av, bv);
-            q[o] = valid ? v : kInf;
-        }
-        float X[K];
-#pragma unroll
-        for (int x = 0; x < K; x++) X[x] = adv ? q[x] : p1[x];
-        // primary antidiagonal (dtw.cpp:416-485)
-        float nw[P];
-#pragma unroll
-        for (int o = 0; o < P; o++) {
-            const int i = (int)col + HP - o;
-            const int j = row - HP + o;
-            const bool valid = (uint32_t)i < N && (uint32_t)j < M;
-            float top, left, tl;
-            if (SH == 0) {
-                top = (o == 0) ? kInf : X[o > 0 ? o - 1 : 0];
-                left = (o == P - 1) ? (adv ? kInf : X[o]) : X[o];
-                tl = adv ? p1[o] : ((o == 0) ? kInf : p2[o > 0 ? o - 1 : 0]);
-            } else {
-                top = (o == 0) ? (adv ? X[0] : kInf) : X[o];
-                left = X[o + 1 < K ? o + 1 : K - 1];
-                const float tl_stay = (o == 0 && !prev_adv) ? kInf : p2[o];
-                tl = adv ? p1[o + 1 < K ? o + 1 : K - 1] : tl_stay;
-            }
-            const float v = min3f(top, left, tl) + dist(aw[o], bw[o + 1]);
-            nw[o] = valid ? v : kInf;
-        }
-        if (SH == 0) {
-#pragma unroll
-            for (int o = 0; o < P; o++) p1[o] = nw[o];
-        } else {
-            p1[0] = adv ? p1[0] : p2[0];
-#pragma unroll
-            for (int o = 0; o < P; o++) p1[o + 1 < K ? o + 1 : K - 1] = nw[o];
-        }
-#pragma unroll
-        for (int x = 0; x < K; x++) p2[x] = X[x];
-        prev_adv = adv;
-    }
-    return p1[HP + SH]; // dtw.cpp:506-512
-}
 
 // Tile kernel.  A tile is a run of CONSECUTIVE jobs of the batch (consecutive parts of the same
 // chains), so the windows it needs form a few contiguous spans of the event and reference arenas:
@@ -365,44 +40,6 @@ __device__ __forceinline__ float tile_job(const float *win, const TileJob &tj)
         else res = lane_dp_sel<R>(LA, LB, N0, M);
     } else res = lane_dp_sel<R>(LA, LB, N, M);
     if (tj.flags & kFlagExcludeLast) res = res - dist(LA[N - 1], LB[M - 1]);
-    return res;
-}
-
-// Micro path for the shapes that dominate sparse mode (longer side <= W, W = 4 or 8): the whole
-// band fits a W x W grid, so the DP runs row by row over W statically indexed registers and band
-// membership comes from a per-shape bitmask the planner computed by walking the reference's
-// antidiagonals once (bit 8*j + i <=> cell (i over the longer sequence, j over the shorter) is in the
-// band's cell set).  Same values as the antidiagonal order: a cell is min3 of its in-band neighbours
-// (absent = 1e10) plus its distance, whatever the evaluation order.
-template <int W, int NC>
-__device__ __forceinline__ float micro_job_cols(const float *LA, const float *LB, const uint32_t N, const uint32_t M,
-                                                const unsigned long long mask)
-{
-    // NC = columns any lane of the wave needs (its longest job): the grid is W rows x NC columns
-    float a[NC], v[NC];
-#pragma unroll
-    for (int i = 0; i < NC; i++) { a[i] = LA[i]; v[i] = kInf; } // columns >= N are never in the mask
-#pragma unroll
-    for (int j = 0; j < NC; j++) {              // (M <= N <= NC: rows beyond NC do not exist either)
-        if (__any((uint32_t)j < M)) {           // wave-uniform: skip rows no lane needs
-            if ((uint32_t)j < M) {              // per lane
-                const float bj = LB[j];
-                const uint32_t rowmask = (uint32_t)(mask >> (8 * j)) & 0xffu;
-                float diag = (j == 0) ? 0.0f : kInf; // virtual corner: D[0][0] = 0 + dist
-                float left = kInf;
-#pragma unroll
-                for (int i = 0; i < NC; i++) {
-                    const float up = v[i];
-                    const float val = min3f(up, left, diag) + dist(a[i], bj);
-                    const float keep = (rowmask & (1u << i)) ? val : kInf;
-                    diag = up; left = keep; v[i] = keep;
-                }
-            }
-        }
-    }
-    float res = v[0];
-#pragma unroll
-    for (int i = 1; i < NC; i++) res = (N - 1 == (uint32_t)i) ? v[i] : res;
     return res;
 }
 
@@ -632,260 +269,6 @@ __global__ __launch_bounds__(64) void k_band_wave(const DevJob *__restrict__ job
 // chunks.  With TB the 2-bit move of dtw.cpp:633-646 is decided at fill time from the same
 // three values and packed RPL codes per lane per step.
 // ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// Register-resident wave-per-job banded kernel, band offsets laid across lanes (physical buffer
-// index p = c*64 + lane, C registers per lane per buffer, radius + 1 <= 64*C).  The three
-// rotating antidiagonal buffers, and the operand windows, never leave registers: a neighbour at
-// p-1 / p+1 is a DPP wave shift (plus one v_readlane to carry across a 64-lane boundary), the
-// a-window slides one lane per column, the b-window one lane per centre-row advance, and the
-// single fresh value each of them needs comes out of a 64-wide chunk prefetched one chunk ahead
-// -- so no memory access sits on the antidiagonal-to-antidiagonal dependency chain.
-// Same physical indexing, guards and stale-slot behaviour as dtw.cpp:305-491.
-// ---------------------------------------------------------------------------------------------
-template <int C>
-__device__ __forceinline__ void wreg_body(const DevJob &jb, const int lane, const float *__restrict__ ev,
-                                          const float *__restrict__ ref, float *__restrict__ out)
-{
-    const float *A = ev + jb.read_off;
-    const float *B = ref + jb.ref_off;
-    uint32_t N = jb.n, M = jb.m;
-    if (N < M) {
-        const float *tp = A; A = B; B = tp;
-        uint32_t tn = N; N = M; M = tn;
-    }
-    const int R = jb.R;
-    const int P = R + ((R % 2 == 0) ? 1 : 0);
-    const int S = R + ((R % 2 == 1) ? 1 : 0);
-    const int SH = P > S ? 0 : 1;
-    const int HP = P / 2;
-    const int iN = (int)N, iM = (int)M;
-    auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
-    auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
-
-    float d0[C], d1[C], d2[C], ap[C], bp[C];
-    // windows at column 0 / row 0:  ap(p) = A[col + HP + SH - p],  bp(p) = B[row - HP - SH + p]
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        const int p = c * 64 + lane;
-        d0[c] = kInf; d1[c] = kInf; d2[c] = kInf;
-        ap[c] = ldA(HP + SH - p);
-        bp[c] = ldB(p - HP - SH);
-        if (p == HP + SH) d1[c] = dist(A[0], B[0]); // the corner, already rotated into place
-    }
-    // fresh-value chunks: column col needs A[col + HP + SH]; the r-th row advance needs B[b0 + r - 1]
-    const int a0 = HP + SH + 1, b0 = 64 * C - HP - SH;
-    float acur = ldA(a0 + lane), anxt = ldA(a0 + 64 + lane);
-    float bcur = ldB(b0 + lane), bnxt = ldB(b0 + 64 + lane);
-
-    int row = 0;
-    uint32_t rem = 0;
-    bool prev_adv = false;
-    for (uint32_t col = 1; col < N; col++) {
-        rem += M;
-        const bool adv = rem >= N;
-        const uint32_t ca = (col - 1) & 63u;
-        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 64 + lane); }
-        const float fresh_a = read_lane(acur, (int)ca);
-        if (adv) {
-            rem -= N;
-            row++;
-            const uint32_t cb = (uint32_t)(row - 1) & 63u;
-            if (cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 64 + lane); }
-            const float fresh_b = read_lane(bcur, (int)cb);
-            // b-window: every lane takes its right neighbour's value
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float fill = (c + 1 < C) ? read_lane(bp[c + 1 < C ? c + 1 : c], 0) : fresh_b;
-                bp[c] = wave_shl1(bp[c], fill);
-            }
-            // secondary antidiagonal (dtw.cpp:361-414): cell of lane p is (si - p, sj + p)
-            const int si = (int)col - 1 + HP + SH, sj = row - HP - SH;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int p = c * 64 + lane;
-                const float fill = (c + 1 < C) ? read_lane(d1[c + 1 < C ? c + 1 : c], 0) : kInf;
-                float left = wave_shl1(d1[c], fill); // dp1[p+1]
-                float top = d1[c], tl = d0[c];
-                if (SH) {
-                    if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
-                    if (p == S - 1) left = kInf;
-                }
-                const float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
-                const bool valid = p < S && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
-                if (valid) d2[c] = v;
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++) { const float t = d0[c]; d0[c] = d1[c]; d1[c] = d2[c]; d2[c] = t; }
-        }
-        // a-window: every lane takes its left neighbour's value
-#pragma unroll
-        for (int c = C - 1; c >= 0; c--) {
-            const float fill = (c > 0) ? read_lane(ap[c > 0 ? c - 1 : 0], 63) : fresh_a;
-            ap[c] = wave_shr1(ap[c], fill);
-        }
-        // primary antidiagonal (dtw.cpp:416-485): offset o = p - SH, cell (si - p, sj + p)
-        {
-            const int si = (int)col + HP + SH, sj = row - HP - SH;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const int p = c * 64 + lane;
-                const int o = p - SH;
-                const float f1 = (c > 0) ? read_lane(d1[c > 0 ? c - 1 : 0], 63) : kInf;
-                float top = wave_shr1(d1[c], f1); // dp1[p-1]
-                float tl, left = d1[c];
-                if (adv) {
-                    tl = d0[c];
-                    if (!SH && p == P - 1) left = kInf;
-                } else {
-                    const float f0 = (c > 0) ? read_lane(d0[c > 0 ? c - 1 : 0], 63) : kInf;
-                    tl = wave_shr1(d0[c], f0); // dp0[p-1]
-                    if (o == 0) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
-                }
-                const float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
-                const bool valid = o >= 0 && o < P && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
-                if (valid) d2[c] = v;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < C; c++) { const float t = d0[c]; d0[c] = d1[c]; d1[c] = d2[c]; d2[c] = t; }
-        prev_adv = adv;
-    }
-    const int pstar = P / 2 + SH; // dtw.cpp:506-512
-    float res = 0.0f;
-#pragma unroll
-    for (int c = 0; c < C; c++)
-        if ((pstar >> 6) == c) res = read_lane(d1[c], pstar & 63);
-    if (lane == 0) {
-        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
-        out[jb.aux] = res;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Four jobs per wave: the same register-resident scheme as wreg_body<1>, but for bands that fit 16
-// lanes (radius + 1 <= 16) each job takes one 16-lane DPP row, so a wave advances four jobs per
-// instruction instead of one.  Control values (lengths, centre row, remainder) are per-row vector
-// registers; neighbours move with row_shr/row_shl, the fresh operand of each row comes out of a
-// 16-wide per-row chunk through ds_bpermute.  Two buffers, clipped cells written as 1e10 (lane_dp).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float row_shr1(float v, float fill)
-{
-    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ float row_shl1(float v, float fill)
-{
-    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, false);
-    return __builtin_bit_cast(float, r);
-}
-__device__ __forceinline__ float lane_gather(float v, int src_lane)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
-}
-
-template <int W>
-__device__ __forceinline__ void grp_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
-                                           const float *__restrict__ ev, const float *__restrict__ ref,
-                                           float *__restrict__ out)
-{
-    static_assert(W == 16 || W == 8, "group width");
-    const int p = lane & (W - 1), rowbase = lane & (64 - W);
-    const uint32_t idx = wave * (64u / W) + (uint32_t)(lane / W);
-    // neighbour shifts inside a group: a DPP row shift; 8-lane groups patch the lane at the group's edge
-    auto shl1 = [&](float v, float fill) { const float t = row_shl1(v, fill); return (W == 8 && p == 7) ? fill : t; };
-    auto shr1 = [&](float v, float fill) { const float t = row_shr1(v, fill); return (W == 8 && p == 0) ? fill : t; };
-    const bool have = idx < count;
-    const DevJob jb = jobs[have ? idx : count - 1];
-    const float *A = ev + jb.read_off;
-    const float *B = ref + jb.ref_off;
-    uint32_t N = jb.n, M = jb.m;
-    if (N < M) {
-        const float *tp = A; A = B; B = tp;
-        const uint32_t tn = N; N = M; M = tn;
-    }
-    if (!have) N = 1; // an empty row never enters the column loop
-    const int R = jb.R;
-    const int P = R + ((R % 2 == 0) ? 1 : 0);
-    const int S = R + ((R % 2 == 1) ? 1 : 0);
-    const int SH = P > S ? 0 : 1;
-    const int HP = P / 2;
-    const int iN = (int)N, iM = (int)M;
-    auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
-    auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
-
-    float p1 = (p == HP + SH) ? dist(A[0], B[0]) : kInf, p2 = kInf;
-    float ap = ldA(HP + SH - p), bp = ldB(p - HP - SH);
-    const bool in_sec = p < S, in_prim = (p - SH) >= 0 && (p - SH) < P;
-    const int a0 = HP + SH + 1, b0 = W - HP - SH;
-    float acur = ldA(a0 + p), anxt = ldA(a0 + W + p);
-    float bcur = ldB(b0 + p), bnxt = ldB(b0 + W + p);
-
-    int row = 0;
-    uint32_t rem = 0;
-    bool prev_adv = false;
-    // the wave runs as long as its longest row
-    uint32_t Nmax = 1;
-#pragma unroll
-    for (int g = 0; g < 64; g += W) Nmax = max(Nmax, (uint32_t)__builtin_amdgcn_readlane((int)N, g));
-    for (uint32_t col = 1; col < Nmax; col++) {
-        const bool live = col < N;
-        const uint32_t ca = (col - 1) & (uint32_t)(W - 1);
-        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + W + p); }
-        const float fresh_a = lane_gather(acur, rowbase + (int)ca);
-        bool adv = false;
-        if (live) {
-            rem += M;
-            adv = rem >= N;
-            if (adv) { rem -= N; row++; }
-        }
-        const int cb = (row - 1) & (W - 1);
-        if (adv && cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + W + p); }
-        const float fresh_b = lane_gather(bcur, rowbase + cb);
-        // shifted views of the two buffers (taken before anything is overwritten)
-        const float p1_up = shl1(p1, kInf);   // dp1[p+1]
-        if (adv) {
-            // b-window: every lane takes its right neighbour's value
-            bp = shl1(bp, fresh_b);
-            // secondary antidiagonal (dtw.cpp:361-414), in place over p2: cell of lane p is (si - p, sj + p)
-            const int si = (int)col - 1 + HP + SH, sj = row - HP - SH;
-            float left = p1_up, top = p1, tl = p2;
-            if (SH) {
-                if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
-                if (p == S - 1) left = kInf;
-            }
-            const float v = min3f(top, left, tl) + dist(ap, bp);
-            const bool valid = in_sec && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
-            p2 = valid ? v : kInf;
-        }
-        if (live) {
-            // a-window: every lane takes its left neighbour's value
-            ap = shr1(ap, fresh_a);
-            // primary antidiagonal (dtw.cpp:416-485): offset o = p - SH, cell (si - p, sj + p)
-            const int si = (int)col + HP + SH, sj = row - HP - SH;
-            const bool valid = in_prim && (uint32_t)(si - p) < N && (uint32_t)(sj + p) < M;
-            const float p2_dn = shr1(p2, kInf); // after a secondary: dp1[p-1]; otherwise dp0[p-1]
-            if (adv) {
-                float left = p2;
-                if (!SH && p == P - 1) left = kInf;
-                const float v = min3f(p2_dn, left, p1) + dist(ap, bp);
-                p1 = valid ? v : kInf;
-            } else {
-                float top = shr1(p1, kInf), tl = p2_dn;
-                if (p - SH == 0) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
-                const float v = min3f(top, p1, tl) + dist(ap, bp);
-                p2 = p1;
-                p1 = valid ? v : kInf;
-            }
-            prev_adv = adv;
-        }
-    }
-    if (have && p == P / 2 + SH) { // dtw.cpp:506-512
-        float res = p1;
-        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
-        out[jb.aux] = res;
-    }
-}
-
 __global__ __launch_bounds__(64) void k_band_grp16(const DevJob *__restrict__ jobs, uint32_t count,
                                                    const float *__restrict__ ev,
                                                    const float *__restrict__ ref,
@@ -910,19 +293,6 @@ __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ job
                                                   float *__restrict__ out)
 {
     wreg_body<C>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
-}
-
-// One launch for every job whose band fits 256 lanes-slots (radius + 1 <= 256): the registers-per-lane
-// variant is picked per job (wave-uniform).  Jobs are sorted longest first, so the few long jobs
-// that bound the launch's duration start first and the many short ones fill in around them --
-// as separate launches they were separate long poles on separate streams.
-__device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const float *__restrict__ ev,
-                                               const float *__restrict__ ref, float *__restrict__ out)
-{
-    const int K = jb.R + 1;
-    if (K <= 64) wreg_body<1>(jb, lane, ev, ref, out);
-    else if (K <= 128) wreg_body<2>(jb, lane, ev, ref, out);
-    else wreg_body<4>(jb, lane, ev, ref, out);
 }
 
 __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict__ jobs,

@@ -463,7 +463,7 @@ def test_planner_options_do_not_change_results(oracle):
 @pytest.mark.parametrize("device_plan", [0, 1])
 def test_batch_edge_cases(engine, oracle, device_plan):
     """Reads without chains, a batch without any chain, and single-anchor chains (no DTW call at all:
-    align_chain returns 0*bonus - 0, which fails dtw_min_score) -- with the host and the device planner."""
+    align_chain returns 0*bonus - 0, which fails dtw_min_score) -- through the job list and through the sync-free path."""
     from rawalign_amd.align import CandidateBatch
 
     engine.set_option("device_plan", device_plan)
@@ -499,22 +499,24 @@ def test_batch_edge_cases(engine, oracle, device_plan):
     want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
     assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
     assert b.verify_plan() == bool(device_plan)
-    # anchors that do not ascend (a chain the mapper could never produce): both planners refuse the batch, with the
-    # host planner's wording (the device planner hands such batches over to it)
+    # anchors that do not ascend (a chain the mapper could never produce): both paths refuse the batch, with the
+    # host planner's wording (the sync-free path hands such batches over to it)
     bad = a2.copy(); bad["query_position"][1] = 200
     cbb = CandidateBatch(ev2, np.array([0, 1], np.uint64), np.array([0, 5], np.uint64), bad, np.array([base], np.uint64),
                          np.zeros(1, np.uint32))
-    with pytest.raises(ra.RawDTWError) as e:
-        ra.Batch(engine, ra.MapOpt(), cbb)
+    with pytest.raises(ra.RawDTWError) as e:   # (the sync-free path reports it when the results are fetched)
+        bb = ra.Batch(engine, ra.MapOpt(), cbb)
+        bb.run()
+        bb.fetch()
     assert "job " in str(e.value)
     engine.set_option("device_plan", 1)
-    engine.set_option("device_plan_min_jobs", 65536)
+    engine.set_option("device_plan_min_jobs", 0)
 
 
 @pytest.mark.gpu
 def test_device_planned_batch_at_scale():
-    """More jobs than the planning kernels have threads (grid-stride paths, several tiles per chain, thousands of
-    tiles): plan self-check, batch totals and every per-job cost against the host-planned batch."""
+    """A million jobs (several tiles per chain, thousands of tiles, the persistent grid's queue): plan self-check, batch
+    totals and every per-job cost of the sync-free path against the host-planned batch."""
     from rawalign_amd import synth
 
     ref = synth.make_reference([600000], seed=93)
@@ -543,8 +545,9 @@ def test_device_planned_batch_at_scale():
 @pytest.mark.gpu
 @pytest.mark.parametrize("border,fill", [(1, 1), (0, 1), (1, 0)])
 def test_device_planned_batch_matches_host_planned(oracle, border, fill):
-    """rawdtw_batch_create with the tile class planned on the device (rawdtw_plan.hip): the tile records pass the same
-    self-check as the host planner's, and scores / keeps / per-job costs equal the host-planned batch bit for bit."""
+    """rawdtw_batch_create through the sync-free path (rawdtw_stream.hip: planning on the device, tiles laid out in LDS):
+    its job records and tile boundaries pass the self-check, and scores / keeps / per-job costs equal the host-planned
+    batch bit for bit."""
     from rawalign_amd import synth
 
     ref = synth.make_reference([150000], seed=91)
@@ -560,9 +563,8 @@ def test_device_planned_batch_matches_host_planned(oracle, border, fill):
         eng.upload_events(cb.events)
         batch = ra.Batch(eng, ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill), cb)
         planned_on_device = batch.verify_plan()            # raises on the first broken invariant
-        # full-matrix jobs are never tile jobs: nothing for the device planner to do there (short banded global
-        # chains are tile jobs, so global + banded is planned on the device too)
-        assert planned_on_device == bool(dev and fill == 1)
+        # the sync-free path takes sparse + banded batches; everything else is planned on the host from the job list
+        assert planned_on_device == bool(dev and fill == 1 and border == 1)
         info = batch.info()
         batch.run()
         results[dev] = batch.fetch(with_job_costs=True) + (info,)
