@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- DTW hot path of RawAlign on MI355X: DTW GCUPS (+ reads/s) and % of the HBM roofline.
+"""bench.py -- DTW hot path of RawAlign on MI355X: DTW GCUPS + mapped reads/s, and % of the HBM roofline.
 
-One "step" = one pass of the hot path over one batch: every DTW job of every candidate chain of
-every read of a chunk round (sparse border constraint, banded=0.10 fill: BASELINE.json configs[1]),
-the align_chain fold and the per-read accept/cut loop -- all on the device, inputs resident in HBM.
+Workload = BASELINE.json configs[1]: E. coli K-12 (4.6 Mb), r9.4-like reads, sparse border constraint, banded=0.10
+fill.  One "step" = one pass of the hot path over one batch = one chunk round of `--reads` reads per GPU: every DTW
+job of every candidate chain (src/rmap.cpp:509-530), the align_chain fold and the per-read accept/cut loop.
+
+Three figures come out of one run (all in the one JSON line):
+
+  value / mapped_reads_per_s   every step is a FRESH batch: rawdtw_batch_create (planning on the device), run, fetch of
+                               score/keep, destroy -- `--inflight` contexts deep, as the reference's kt_pipeline keeps
+                               mini-batches in flight (rmap.cpp:1033).  Inputs (event arenas, anchor lists) are resident
+                               in HBM when the timed region starts; nothing is cached between steps.
+  pipeline_pcie                the same loop with the host-side hand-over inside the step: the round's NEW events
+                               (rmap.cpp:554-567 is append-only) and the anchor lists cross PCIe from pinned memory.
+  kernel_replay                the launches of pre-planned resident batches only (what round 1 reported as `value`).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # launches N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Multi-GPU: reads shard across ranks (each rank holds a full replica of the reference signal and
-its own reads); no data-path collective; RCCL is used only for the final counters and the
-max-over-ranks time.  Weak scaling: per-GPU work is fixed.
+The timed region is exactly K steps between barrier + synchronize pairs; because K steps can be a few milliseconds, the
+region is repeated (`repeats` in the line, at least 100 ms in total) and the MEDIAN repetition is reported (max over
+ranks per repetition).  Multi-GPU: reads shard across ranks, reference replicated, no data-path collective; RCCL only
+reduces the final counters and the times.  Weak scaling.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,25 +46,51 @@ SEED = 20231005 + 2  # seed = 20231005 + config id
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="mini-batches in flight per GPU (the reference's kt_pipeline keeps 2, rmap.cpp:1033); "
-                         "step k runs batch k %% inflight, each on its own context/streams")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+                    help="contexts = mini-batches in flight per GPU (the reference's kt_pipeline keeps 2, rmap.cpp:1033)")
+    ap.add_argument("--min-region-ms", type=float, default=100.0, help="repeat the K-step region until this much is timed")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU baseline budget per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-merge", action="store_true",
-                    help="launch the tile kernel and the two small banded kernels of a batch separately")
-    ap.add_argument("--serial-launches", action="store_true",
-                    help="run the launches of a step one after another (profiling: per-kernel counters without overlap)")
+    ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
+    ap.add_argument("--decoy-gap-median", type=float, default=None, help="workload sensitivity: decoy chain gap (events)")
+    ap.add_argument("--decoys-per-read", type=float, default=None)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / reduction plumbing only: no device work, synthetic counters (CPU tests)")
     return ap.parse_args()
 
 
-def cpu_baseline(jobs, events, ref_arena, cells, threads, target_s=1.5):
-    """The same job list on the host cores, through the REFERENCE's own compiled dtw.cpp when
-    oracle/_ref is present ("reference"), else through the oracle's C restatement ("port")."""
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks before anything touches a GPU, relay rank 0's line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in run.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if run.returncode != 0 or line is None:
+        sys.stderr.write(run.stdout[-4000:] + "\n" + run.stderr[-8000:] + "\n")
+        sys.exit(run.returncode or 1)
+    print(line)
+    sys.exit(0)
+
+
+def cpu_baseline(jobs, events, ref_arena, cells, seconds):
+    """The same job list on the host cores, through the REFERENCE's own compiled dtw.cpp when oracle/_ref is present
+    ("reference"), else through the oracle's C restatement ("port").  Thread counts: 1, 16, every core the process may
+    run on; each on a bounded sample of whole jobs (cells pro-rated by job count)."""
     from oracle.loader import Oracle, RefDTW, build_oracle
 
     if RefDTW.available():
@@ -59,253 +98,406 @@ def cpu_baseline(jobs, events, ref_arena, cells, threads, target_s=1.5):
     else:
         build_oracle(march_native=True)
         impl, kind = Oracle(), "port"
-    # bounded sample: the whole batch if it is small enough, else a prefix of whole reads' jobs
     n = len(jobs)
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = nproc
     t0 = time.perf_counter()
-    impl.batch_costs(jobs[: min(n, 200000)], events, ref_arena, threads)
-    probe = time.perf_counter() - t0
-    per_job = probe / min(n, 200000)
-    take = int(min(n, max(200000, target_s / max(per_job, 1e-9))))
-    reps = max(1, int(round(target_s / max(per_job * take, 1e-6))))
-    reps = min(reps, 50)
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    impl.batch_costs(jobs[:100000], events, ref_arena, 1)
+    per_job_1 = (time.perf_counter() - t0) / min(n, 100000)
+    runs = []
+    out_full = None
+    for threads in sorted({1, min(16, usable), usable}):
+        take = int(min(n, max(50000, seconds * threads * 0.7 / max(per_job_1, 1e-9))))
+        t0 = time.perf_counter()
         out = impl.batch_costs(jobs[:take], events, ref_arena, threads)
-    dt = (time.perf_counter() - t0) / reps
-    frac = take / n
-    # ... and one thread on a prefix, for the per-core figure (single-threaded and all cores)
-    take1 = int(min(n, max(50000, 1.0 / max(per_job * threads, 1e-9))))
-    t0 = time.perf_counter()
-    impl.batch_costs(jobs[:take1], events, ref_arena, 1)
-    dt1 = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        reps = 1
+        while dt * reps < seconds * 0.5 and reps < 64:  # short sample: repeat it
+            t1 = time.perf_counter()
+            impl.batch_costs(jobs[:take], events, ref_arena, threads)
+            dt = min(dt, time.perf_counter() - t1)
+            reps += 1
+        runs.append({"threads": threads, "value": cells * (take / n) / dt / 1e9, "jobs": take, "seconds": round(dt, 3),
+                     "repetitions": reps})
+        if out_full is None or take > len(out_full):
+            out_full = out
+    best = max(runs, key=lambda r: r["value"])
     return {
-        "value": cells * frac / dt / 1e9,
-        "unit": "GCUPS",
-        "cores": threads,
-        "kind": kind,
-        "sample": f"first {take} of {n} DTW jobs of the same batch ({frac * 100:.0f}% of its cells, cells pro-rated by job count), "
-                  f"{reps} repetition(s), {threads} threads pulling jobs from a shared counter, {dt * reps:.1f} s wall",
-        "jobs_per_s": take / dt,
-        "single_thread": {"value": cells * (take1 / n) / dt1 / 1e9, "unit": "GCUPS",
-                          "sample": f"first {take1} jobs, one thread, {dt1:.1f} s wall"},
-    }, out, take
+        "value": best["value"], "unit": "GCUPS", "cores": best["threads"], "kind": kind,
+        "nproc": nproc, "usable_cores": usable,
+        "sample": f"first {best['jobs']} of {n} DTW jobs of one batch of the same workload ({best['jobs'] / n * 100:.0f}% of its "
+                  f"cells, pro-rated by job count), {best['threads']} threads pulling jobs from a shared counter (one task per "
+                  f"job range, as kt_for deals reads: kthread.c:54-72), best of {best['repetitions']} run(s) of {best['seconds']} s",
+        "by_threads": runs,
+    }, out_full
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Pinned:
+    """numpy arrays in page-locked host memory (rawdtw_host_alloc)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.ptrs = []
+
+    def copy(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        st = self.lib.rawdtw_host_alloc(max(arr.nbytes, 8), C.byref(p))
+        assert st == 0 and p.value
+        self.ptrs.append(p)
+        buf = (C.c_char * max(arr.nbytes, 8)).from_address(p.value)
+        out = np.frombuffer(buf, dtype=arr.dtype, count=arr.size).reshape(arr.shape)
+        out[...] = arr
+        return out
+
+    def empty(self, n, dtype):
+        return self.copy(np.zeros(n, dtype))
+
+    def free(self):
+        for p in self.ptrs:
+            self.lib.rawdtw_host_free(p)
+        self.ptrs = []
+
+
+def vp(a):
+    return C.c_void_p(a.ctypes.data)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
     dist = None
+    backend = os.environ.get("RAWDTW_BENCH_BACKEND", "gloo" if args.dry_run else "nccl")
+    if "RAWDTW_BENCH_DEVICE" in os.environ:  # rehearsal: several ranks on a one-GPU box
+        local_rank = int(os.environ["RAWDTW_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        # rehearsal knobs (several ranks on a one-GPU box): RAWDTW_BENCH_BACKEND=gloo, RAWDTW_BENCH_DEVICE=0
-        backend = os.environ.get("RAWDTW_BENCH_BACKEND", "nccl")
-        if "RAWDTW_BENCH_DEVICE" in os.environ:
-            local_rank = int(os.environ["RAWDTW_BENCH_DEVICE"])
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    import rawalign_amd as ra
     from rawalign_amd import synth
-    from rawalign_amd.shard import rank_seed
+    from rawalign_amd.shard import rank_seed, reduce_counters
 
-    # reference signal (same on every rank), one resident replica per in-flight context
-    ref = synth.make_reference([args.genome], seed=SEED)
-    opt = ra.MapOpt()  # sparse, banded=0.10, bonus 0.4, min score 20 (roptions.c:49-53)
-    slots = max(1, args.inflight)
-    engines, batches, cbs, infos, create_ms = [], [], [], [], []
-    for sl in range(slots):
-        e = ra.Engine(local_rank)
-        if args.serial_launches:
-            e.set_option("serial_launches", 1)
-        if args.no_merge:
-            e.set_option("merge_small", 0)
-        e.upload_reference(ref.forward, ref.reverse)
-        offs = {(s_, st): e.reference_offset(s_, st) for s_ in range(ref.n_seq) for st in (0, 1)}
-        # this rank's reads for this slot (distinct shards)
-        cb_, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=args.reads),
-                                            seed=rank_seed(SEED, rank) + 104729 * sl)
-        e.upload_events(cb_.events)
-        e.sync()
-        t_c = time.perf_counter()
-        b_ = ra.Batch(e, opt, cb_)   # uploads the anchor lists and plans the batch (on the device by default)
-        create_ms.append((time.perf_counter() - t_c) * 1e3)
-        engines.append(e); batches.append(b_); cbs.append(cb_); infos.append(b_.info())
-        e.sync()
-    eng, batch, cb, info = engines[0], batches[0], cbs[0], infos[0]
+    red_dev = torch.device("cuda", local_rank) if (dist is not None and backend == "nccl") else None
+    sp = synth.SynthParams(n_reads=args.reads)
+    if args.hit_prob is not None:
+        sp.hit_prob = args.hit_prob
+    if args.decoy_gap_median is not None:
+        sp.decoy_gap_median = args.decoy_gap_median
+    if args.decoys_per_read is not None:
+        sp.decoys_per_read = args.decoys_per_read
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def sync_all():
+    if args.dry_run:
+        # no device: counters from the synthetic generator only, a nominal time -- exercises launch, sharding seeds,
+        # the counter reduction and the line's shape
+        ref = synth.make_reference([min(args.genome, 200_000)], seed=SEED)
+        offs = {(0, 1): 0, (0, 0): (len(ref.forward[0]) + 3) & ~3}
+        cb, info = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=min(args.reads, 256)), seed=rank_seed(SEED, rank))
+        jobs = int(np.maximum(np.diff(cb.anchor_off.astype(np.int64)) - 1, 0).sum())
+        barrier()
+        (reads_t, chains_t, jobs_t), T = reduce_counters(dist, [cb.n_reads * args.steps, cb.n_chains * args.steps, jobs * args.steps],
+                                                         1e-3 * args.steps, device=None)
+        if rank == 0:
+            print(json.dumps({"metric": "DTW GCUPS", "value": 0.0, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": T / args.steps * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                              "config": {"workload": WORKLOAD, "reads_per_gpu": cb.n_reads},
+                              "totals_over_timed_steps": {"reads": reads_t, "chains": chains_t, "dtw_jobs": jobs_t}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    torch.cuda.set_device(local_rank)
+    torch.cuda.init()
+    import rawalign_amd as ra
+
+    lib = ra.load_library()
+    slots = max(1, args.inflight)
+    # ---- contexts: ONE resident reference arena per GPU, shared by the in-flight contexts ----
+    ref = synth.make_reference([args.genome], seed=SEED)
+    opt = ra.MapOpt()  # sparse, banded=0.10, bonus 0.4, min score 20 (roptions.c:49-53)
+    copt = opt.c_struct()
+    engines = [ra.Engine(local_rank) for _ in range(slots)]
+    engines[0].upload_reference(ref.forward, ref.reverse)
+    for e in engines[1:]:
+        e._check(lib.rawdtw_share_reference(e._ctx, engines[0]._ctx))
+    offs = {(s_, st): engines[0].reference_offset(s_, st) for s_ in range(ref.n_seq) for st in (0, 1)}
+
+    # ---- this rank's batches: one distinct shard per context, host arrays in pinned memory ----
+    pin = Pinned(lib)
+    B = []
+    for sl in range(slots):
+        cb, inf = synth.make_candidate_batch(ref, offs, sp, seed=rank_seed(SEED, rank) + 104729 * sl)
+        ev_off = inf["ev_off"].astype(np.int64)
+        n_ev = np.diff(ev_off)
+        new_len = np.minimum(n_ev, inf["events_per_chunk"])           # the events the read's last chunk added
+        seg_src = np.concatenate([[0], np.cumsum(new_len)]).astype(np.uint64)
+        seg_dst = (ev_off[1:] - new_len).astype(np.uint32)
+        idx = np.repeat(seg_dst.astype(np.int64), new_len) + (np.arange(int(new_len.sum())) - np.repeat(seg_src[:-1].astype(np.int64), new_len))
+        d = {
+            "cb": cb, "n_reads": cb.n_reads, "n_chains": cb.n_chains,
+            "events": pin.copy(cb.events), "chain_off": pin.copy(cb.chain_off.astype(np.uint64)),
+            "anchor_off": pin.copy(cb.anchor_off.astype(np.uint64)), "anchors": pin.copy(cb.anchors),
+            "ref_base": pin.copy(cb.ref_base.astype(np.uint64)), "read_base": pin.copy(cb.read_base.astype(np.uint32)),
+            "new_events": pin.copy(cb.events[idx]), "seg_src": pin.copy(seg_src), "seg_dst": pin.copy(seg_dst),
+            "score": pin.empty(cb.n_chains, np.float32), "keep": pin.empty(cb.n_chains, np.uint8),
+        }
+        # device-resident copies of the three big arrays (the `value` loop uses them in place)
+        d["t_anchors"] = torch.from_numpy(cb.anchors.view(np.uint8).copy()).cuda(local_rank)
+        d["t_ref_base"] = torch.from_numpy(cb.ref_base.astype(np.uint64).view(np.uint8).copy()).cuda(local_rank)
+        d["t_read_base"] = torch.from_numpy(cb.read_base.astype(np.uint32).view(np.uint8).copy()).cuda(local_rank)
+        B.append(d)
+        e = engines[sl]
+        e._check(lib.rawdtw_events_reserve(e._ctx, len(cb.events)))
+        e._check(lib.rawdtw_upload_events(e._ctx, vp(d["events"]), len(cb.events)))
+        e.sync()
+    torch.cuda.synchronize()
+
+    handles = [C.c_void_p() for _ in range(slots)]
+    live = [False] * slots
+
+    def create(sl, resident):
+        d, e = B[sl], engines[sl]
+        if resident:
+            st = lib.rawdtw_batch_create(e._ctx, C.byref(copt), d["n_reads"], vp(d["chain_off"]), vp(d["anchor_off"]),
+                                         C.c_void_p(d["t_anchors"].data_ptr()), C.c_void_p(d["t_ref_base"].data_ptr()),
+                                         C.c_void_p(d["t_read_base"].data_ptr()), C.byref(handles[sl]))
+        else:
+            st = lib.rawdtw_batch_create(e._ctx, C.byref(copt), d["n_reads"], vp(d["chain_off"]), vp(d["anchor_off"]),
+                                         vp(d["anchors"]), vp(d["ref_base"]), vp(d["read_base"]), C.byref(handles[sl]))
+        e._check(st)
+        live[sl] = True
+
+    def fetch_destroy(sl, job_cost=None):
+        d, e = B[sl], engines[sl]
+        e._check(lib.rawdtw_batch_fetch(e._ctx, handles[sl], vp(d["score"]), vp(d["keep"]), vp(job_cost) if job_cost is not None else None))
+        lib.rawdtw_batch_destroy(handles[sl])
+        live[sl] = False
+
+    def collect(sl, sink):
+        ms = np.zeros(8, np.float32); kind = np.zeros(8, np.uint32); nl = C.c_uint32(); nr = C.c_uint32()
+        engines[sl]._check(lib.rawdtw_batch_collect(engines[sl]._ctx, handles[sl], vp(ms), vp(kind), 8, C.byref(nl), C.byref(nr)))
+        sink.append(ms[:nl.value].copy())
+
+    def pipeline(K, pcie, timed_launches=None):
+        """K steps, every one a fresh batch; context k % slots; a context's previous batch is fetched before its next."""
+        for e in engines:
+            e.set_option("resident_arrays", 0 if pcie else 1)
+        for k in range(K):
+            sl = k % slots
+            d, e = B[sl], engines[sl]
+            if live[sl]:
+                if timed_launches is not None:
+                    collect(sl, timed_launches)
+                fetch_destroy(sl)
+            if pcie:  # the round's new events: one H2D of the packed chunk events + a scatter into the per-read arrays
+                e._check(lib.rawdtw_events_append(e._ctx, vp(d["new_events"]), len(d["new_events"]), d["n_reads"],
+                                                  vp(d["seg_src"]), vp(d["seg_dst"])))
+            create(sl, not pcie)
+            if timed_launches is None:
+                e._check(lib.rawdtw_batch_run(e._ctx, handles[sl]))
+            else:  # HIP event pair around every launch, read when the context comes round again
+                e._check(lib.rawdtw_batch_enqueue(e._ctx, handles[sl], 1))
+        for sl in range(slots):
+            if live[sl]:
+                if timed_launches is not None:
+                    collect(sl, timed_launches)
+                fetch_destroy(sl)
+
+    def timed_region(fn):
+        """exactly K steps between barrier + synchronize pairs; returns seconds"""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
         for e in engines:
             e.sync()
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
 
-    for k in range(max(args.warmup, 0)):
-        batches[k % slots].enqueue(timed=False)
-    sync_all()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):  # K steps, no host synchronisation in between, HIP events around every launch
-        batches[k % slots].enqueue(timed=True)
-    t_enq = time.perf_counter() - t0
-    sync_all()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, _ = batch.collect()
-    for b_ in batches[1:]:
-        b_.collect()
-    runs_of_slot = [len(range(sl, args.steps, slots)) for sl in range(slots)]
+    def repeat_region(fn):
+        first = timed_region(fn)
+        reps = int(min(200, max(3, np.ceil(args.min_region_ms * 1e-3 / max(first, 1e-6)))))
+        ts = [first] + [timed_region(fn) for _ in range(reps - 1)]
+        return ts
 
-    stats_timed = batch.launch_stats(with_cells=False)  # as launched in the timed region (small classes merged in)
-    # a second, untimed pass with every kernel launched on its own, one after another: clean per-kernel durations
-    eng.set_option("serial_launches", 1)
-    eng.set_option("merge_small", 0)
-    isolated = batch.run_reps(max(3, min(args.steps, 10)), timed=True)
-    stats = batch.launch_stats(with_cells=False)        # per kernel
-    eng.set_option("merge_small", 0 if args.no_merge else 1)
-    eng.set_option("serial_launches", 1 if args.serial_launches else 0)
-
-    mapped_slots = []
-    job_cost = None
+    K = args.steps
+    # ---- warm-up (workspace pools, code objects), then the three timed loops ----
+    pipeline(max(args.warmup, slots), pcie=False)
+    pipeline(slots, pcie=True)
+    t_fresh = repeat_region(lambda: pipeline(K, pcie=False))
+    t_pcie = repeat_region(lambda: pipeline(K, pcie=True))
+    # host cost of one create call, steady state (inputs resident / from pinned host memory)
+    create_ms = {}
+    for mode, pc in (("resident", False), ("from_host", True)):
+        for e in engines:
+            e.set_option("resident_arrays", 0 if pc else 1)
+        ts = []
+        for rep in range(5):
+            t0 = time.perf_counter()
+            create(0, not pc)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            engines[0]._check(lib.rawdtw_batch_run(engines[0]._ctx, handles[0]))
+            fetch_destroy(0)
+        create_ms[mode] = round(float(np.median(ts)), 4)
+    # launch durations inside the pipeline (HIP events on the context's stream), and the planning kernels' GPU time
+    launches_in_pipeline = []
+    for e in engines:
+        e.set_option("time_plan", 1)
+    pipeline(max(K, 2 * slots), pcie=False, timed_launches=launches_in_pipeline)
+    plan_ms = []
     for sl in range(slots):
-        if sl == 0:
-            score, keep, job_cost = batches[sl].fetch(with_job_costs=True)
-        else:
-            score, keep = batches[sl].fetch()
-        roc = np.repeat(np.arange(cbs[sl].n_reads), np.diff(cbs[sl].chain_off.astype(np.int64)))
-        mapped_slots.append(int(len(np.unique(roc[keep.astype(bool)]))))  # reads with >= 1 surviving chain
+        create(sl, True)
+        engines[sl]._check(lib.rawdtw_batch_run(engines[sl]._ctx, handles[sl]))
+    for sl in range(slots):
+        ms = C.c_float()
+        engines[sl].sync()
+        lib.rawdtw_batch_plan_ms(engines[sl]._ctx, handles[sl], C.byref(ms))
+        plan_ms.append(ms.value)
+    for e in engines:
+        e.set_option("time_plan", 0)
+    # ---- kernel replay: the resident planned batches' launches only ----
+    infos = []
+    for sl in range(slots):
+        pi, nc = ra._lib.PlanInfo(), C.c_uint64()
+        engines[sl]._check(lib.rawdtw_batch_info(handles[sl], C.byref(pi), C.byref(nc)))
+        infos.append({k: int(getattr(pi, k)) for k, _ in ra._lib.PlanInfo._fields_})
 
-    def total(key_or_list):
-        vals = key_or_list if isinstance(key_or_list, list) else [i[key_or_list] for i in infos]
-        return int(sum(v * r for v, r in zip(vals, runs_of_slot)))
+    def replay():
+        for k in range(K):
+            sl = k % slots
+            engines[sl]._check(lib.rawdtw_batch_enqueue(engines[sl]._ctx, handles[sl], 0))
+    replay()
+    t_replay = repeat_region(replay)
+    # one context alone, launches back to back: the dominant kernel without neighbours
+    ms = np.zeros(8, np.float32); kind = np.zeros(8, np.uint32); nl = C.c_uint32()
+    engines[0]._check(lib.rawdtw_batch_run_reps(engines[0]._ctx, handles[0], 10, vp(ms), vp(kind), 8, C.byref(nl)))
+    alone_ms = ms[:nl.value].copy()
+    # results: mapped reads per batch, and the per-job costs of batch 0 for the CPU cross-check
+    job_cost = np.zeros(infos[0]["n_jobs"], np.float32)
+    mapped = []
+    for sl in range(slots):
+        fetch_destroy(sl, job_cost if sl == 0 else None)
+        cb = B[sl]["cb"]
+        roc = np.repeat(np.arange(cb.n_reads), np.diff(cb.chain_off.astype(np.int64)))
+        mapped.append(int(len(np.unique(roc[B[sl]["keep"].astype(bool)]))))  # reads with >= 1 surviving chain
 
-    from rawalign_amd.shard import reduce_counters
+    # ---- reduce: counters summed, each repetition's time = max over ranks ----
+    steps_of_slot = [len(range(sl, K, slots)) for sl in range(slots)]
 
-    # the path's only collective: final counters (sum) and the step time (max over ranks)
-    # (totals over the K timed steps of this rank)
-    (reads_t, chains_t, jobs_t, cells_t, mapped_t, bytes_t), T = reduce_counters(
-        dist, [args.reads * args.steps, total("n_chains"), total("n_jobs"), total("cells"), total(mapped_slots),
-               total("algorithmic_bytes")],
-        elapsed, device=torch.device("cuda", local_rank)
-        if (dist is not None and os.environ.get("RAWDTW_BENCH_BACKEND", "nccl") == "nccl") else None)
+    def total(vals):
+        return int(sum(v * r for v, r in zip(vals, steps_of_slot)))
+    counters = [args.reads * K, total([d["n_chains"] for d in B]), total([i["n_jobs"] for i in infos]),
+                total([i["cells"] for i in infos]), total(mapped), total([i["algorithmic_bytes"] for i in infos])]
+
+    def reduce_times(ts):
+        t = torch.tensor(ts, dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            n = torch.tensor([len(ts)], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(n, op=dist.ReduceOp.MIN)
+            t = t[: int(n.item())].contiguous()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+    (reads_t, chains_t, jobs_t, cells_t, mapped_t, bytes_t), _ = reduce_counters(dist, counters, 0.0, device=red_dev)
+    r_fresh, r_pcie, r_replay = reduce_times(t_fresh), reduce_times(t_pcie), reduce_times(t_replay)
 
     if rank == 0:
-        # dominant kernel = the launch with the largest duration when run alone; its duration inside the
-        # timed region (where launches overlap on several streams) is what `achieved` is priced with
-        def waves(i):  # wavefronts launch i puts on the machine
-            k = isolated[i][0]
-            return stats[i]["n_jobs"] / 64.0 if k in (1, 7, 9) else stats[i]["n_jobs"]
-        # ... among the launches that can fill the chip (>= 256 CUs x 8 waves); a launch of three long jobs
-        # has the longest duration but occupies three wavefronts
-        # ... and that carries the bytes: a launch of a few long jobs can have the longest duration (it is
-        # a latency pole that overlaps other work) while occupying a handful of wavefronts
-        filling = [i for i in range(len(isolated)) if waves(i) >= 2048] or list(range(len(isolated)))
-        dom = max(filling, key=lambda i: stats[i]["algorithmic_bytes"])
-        dms = launches[dom][2]
-        dkind, dparam = stats_timed[dom]["kind"], stats_timed[dom]["param"]
-        dbytes = stats_timed[dom]["algorithmic_bytes"]   # everything that launch carried in the timed region
-        dbytes_iso = stats[dom]["algorithmic_bytes"]     # the kernel's own jobs (isolated pass: nothing merged in)
-        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-
-        def kernel_name(kind, param):
-            if kind == 8 and param in (-16, -8):
-                return "band_grp16" if param == -16 else "band_grp8"
-            return ra.Engine.KIND_NAMES.get(kind, str(kind))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        T, Tp, Tr = float(np.median(r_fresh)), float(np.median(r_pcie)), float(np.median(r_replay))
+        lp = np.array(launches_in_pipeline)  # rows: steps, columns: [stream kernel, fold, select]
+        dms = float(lp[:, 0].mean())
+        dbytes = infos[0]["algorithmic_bytes"]
+        achieved = dbytes / (dms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == WORKLOAD and tj.get("reads") == args.reads:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/traffic_r02.json (PMC passes of this command, collected separately; not measured by this run)"
             except Exception:
-                traffic = None
-        kname = kernel_name(dkind, dparam)
+                pass
         out = {
-            "metric": "DTW GCUPS",
-            "value": cells_t / T / 1e9,
-            "unit": "GCUPS",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": T / args.steps * 1e3,
-            "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
+            "metric": "DTW GCUPS", "value": cells_t / T / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": T / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD, "reads_per_gpu": args.reads, "genome_bp": args.genome,
                        "border_constraint": "sparse", "fill_method": "banded=0.10", "batches_in_flight": slots,
-                       "sharding": f"reads over {world} gpu(s), reference replicated"},
-            "reads_per_s": reads_t / T,
-            "mapped_reads_per_s": mapped_t / T,
-            "jobs_per_s": jobs_t / T,
+                       "sharding": f"reads over {world} gpu(s), one resident reference arena per gpu",
+                       "synth": {"hit_prob": sp.hit_prob, "decoy_gap_median": sp.decoy_gap_median, "decoys_per_read": sp.decoys_per_read}},
+            "value_is": "fresh batch every step (rawdtw_batch_create with planning on the device + run + fetch of score/keep + destroy), "
+                        "inputs resident in HBM, median of `repeats` regions of exactly `steps` steps",
+            "repeats": len(r_fresh), "timed_region_ms_total": round(sum(r_fresh) * 1e3, 3),
+            "region_ms": {"median": round(T * 1e3, 4), "min": round(min(r_fresh) * 1e3, 4), "max": round(max(r_fresh) * 1e3, 4)},
+            "reads_per_s": reads_t / T, "mapped_reads_per_s": mapped_t / T, "jobs_per_s": jobs_t / T,
+            "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "mapped_reads_per_s": mapped_t / Tp, "ms_per_step": Tp / K * 1e3,
+                              "repeats": len(r_pcie),
+                              "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["anchors"].nbytes + B[0]["ref_base"].nbytes + B[0]["read_base"].nbytes),
+                              "note": "same loop with the step's host hand-over inside: the round's new events (last chunk of "
+                                      "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory"},
+            "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / K * 1e3, "repeats": len(r_replay),
+                              "note": "launches of pre-planned resident batches only (round 1's headline)"},
+            "batch_create_ms": {"steady": create_ms["resident"], "from_pinned_host": create_ms["from_host"],
+                                "note": "host wall time of one rawdtw_batch_create call, steady state: it only enqueues (no "
+                                        "synchronisation, no allocation); `planning_gpu_ms` is what its kernels cost the device",
+                                "planning_gpu_ms": round(float(np.median(plan_ms)), 4)},
             "totals_over_timed_steps": {"reads": reads_t, "chains": chains_t, "dtw_jobs": jobs_t, "cells": cells_t,
                                         "mapped_reads": mapped_t, "algorithmic_bytes": bytes_t},
-            "batch0": {"reads": args.reads, "chains": info["n_chains"], "dtw_jobs": info["n_jobs"],
-                       "cells": info["cells"], "mapped_reads": mapped_slots[0],
-                       "algorithmic_bytes": info["algorithmic_bytes"]},
-            # outside the timed region (inputs resident): what creating a mini-batch costs on the host side
-            "batch_create_ms": {"first": round(create_ms[0], 3), "steady": round(min(create_ms[1:] or create_ms), 3),
-                                "note": "rawdtw_batch_create: anchor upload + planning (device planner unless "
-                                        "RAWDTW_OPTS=device_plan=0); `first` includes code loading and workspace allocation"},
+            "batch0": {"reads": args.reads, "chains": B[0]["n_chains"], "dtw_jobs": infos[0]["n_jobs"], "cells": infos[0]["cells"],
+                       "mapped_reads": mapped[0], "algorithmic_bytes": infos[0]["algorithmic_bytes"],
+                       "tile_class_jobs": infos[0]["n_lane_jobs"], "wide_band_jobs": infos[0]["n_wave_band_jobs"]},
             "whole_step_hbm_frac": bytes_t / T / 1e9 / (HBM_PEAK_GBS * world),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"{kname}(param={dparam})", "launch_ms": dms,
-                         "note": "launch_ms is the HIP-event bracket inside the timed region, where this launch shares "
-                                 "the chip with the other batches in flight (and, when merged, carries the batch's two "
-                                 "small banded classes, whose longest job can outlast the tiles); `isolated` is the "
-                                 "kernel's own jobs launched alone on an idle chip (second pass, nothing merged)",
-                         "isolated": {"kernel": kernel_name(stats[dom]["kind"], stats[dom]["param"]),
-                                      "launch_ms": isolated[dom][2],
-                                      "achieved": dbytes_iso / (isolated[dom][2] * 1e-3) / 1e9 if isolated[dom][2] > 0 else 0.0,
-                                      "frac": (dbytes_iso / (isolated[dom][2] * 1e-3) / 1e9 / HBM_PEAK_GBS) if isolated[dom][2] > 0 else 0.0,
-                                      "algorithmic_bytes_per_launch": dbytes_iso, "jobs_per_launch": stats[dom]["n_jobs"]},
-                         "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": stats_timed[dom]["n_jobs"]},
-            "launches": [{"kernel": kernel_name(stats_timed[i]["kind"], stats_timed[i]["param"]),
-                          "param": stats_timed[i]["param"], "ms": round(ms, 5),
-                          "jobs": stats_timed[i]["n_jobs"], "algorithmic_bytes": stats_timed[i]["algorithmic_bytes"],
-                          "alone": {"kernel": kernel_name(stats[i]["kind"], stats[i]["param"]), "ms": round(isolated[i][2], 5),
-                                    "jobs": stats[i]["n_jobs"], "algorithmic_bytes": stats[i]["algorithmic_bytes"]}}
-                         for i, (_, _, ms) in enumerate(launches)],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_stream", "launch_ms": dms,
+                         "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": infos[0]["n_jobs"],
+                         "note": "launch_ms = mean HIP-event bracket of the batch's one DTW launch inside the fresh-batch pipeline "
+                                 "(recorded on the launch's own stream), where it shares the chip with the other contexts' "
+                                 "planning and DTW launches; `alone` = the same launch repeated on an idle chip",
+                         "alone": {"launch_ms": float(alone_ms[0]), "achieved": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9,
+                                   "frac": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "launches": {"in_pipeline_ms": {"k_stream": round(dms, 5), "chain_fold": round(float(lp[:, 1].mean()), 5),
+                                            "read_select": round(float(lp[:, 2].mean()), 5)},
+                         "alone_ms": {"k_stream": round(float(alone_ms[0]), 5), "chain_fold": round(float(alone_ms[1]), 5),
+                                      "read_select": round(float(alone_ms[2]), 5)}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            # rebuild the job list exactly as the device batch built it
-            import ctypes as C
-
-            lib = eng.lib
-            copt = opt.c_struct()
-            p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            cb = B[0]["cb"]
             job_off = np.zeros(cb.n_chains + 1, np.uint64)
             nj = C.c_uint64()
-            jobs = np.zeros(info["n_jobs"], ra.JOB_DTYPE)
-            lib.rawdtw_batch_build_jobs(C.byref(copt), cb.n_chains, p(cb.anchor_off), p(cb.anchors), p(cb.ref_base),
-                                        p(cb.read_base), p(job_off), p(jobs), len(jobs), C.byref(nj))
+            jobs = np.zeros(infos[0]["n_jobs"], ra.JOB_DTYPE)
+            lib.rawdtw_batch_build_jobs(C.byref(copt), cb.n_chains, vp(B[0]["anchor_off"]), vp(B[0]["anchors"]), vp(B[0]["ref_base"]),
+                                        vp(B[0]["read_base"]), vp(job_off), vp(jobs), len(jobs), C.byref(nj))
             n = len(ref.forward[0])
             pad = (n + 3) & ~3
             arena = np.zeros(2 * pad, np.float32)
             arena[:n] = ref.forward[0]
             arena[pad:pad + n] = ref.reverse[0]
-            base, cpu_costs, take = cpu_baseline(jobs, cb.events, arena, info["cells"], args.cpu_threads)
+            base, cpu_costs = cpu_baseline(jobs, cb.events, arena, infos[0]["cells"], args.cpu_seconds)
             out["cpu_baseline"] = base
             # free check: the CPU leg and the device leg computed the same jobs
-            same = bool(np.array_equal(cpu_costs.view(np.uint32), job_cost[:take].view(np.uint32)))
-            out["cpu_gpu_costs_identical"] = same
+            out["cpu_gpu_costs_identical"] = bool(np.array_equal(cpu_costs.view(np.uint32), job_cost[:len(cpu_costs)].view(np.uint32)))
+            out["cpu_gpu_costs_compared"] = int(len(cpu_costs))
         print(json.dumps(out))
+    pin.free()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -71,6 +71,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
  *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create takes the sync-free path (planning on the device, in LDS)
+ *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
  *   "time_plan" 0/1: event pair around a batch's planning kernels; "stream_others_blocks": workgroups that start on the wide-band jobs
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
  *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
@@ -89,6 +90,9 @@ int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const 
 int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uint64_t *off);
 /* Adopt a device-resident arena instead (caller keeps ownership; 16-byte aligned). */
 int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats);
+/* Several contexts on one device (one per pipeline worker, rmap.cpp:1033) share ONE resident copy: `ctx` adopts the
+ * arena and the sequence table of `owner`, which keeps ownership and must outlive it. */
+int rawdtw_share_reference(rawdtw_ctx *ctx, const rawdtw_ctx *owner);
 
 /* ---- index file reader: the part of ri_idx_load (src/rawindex.cpp:317-377) the DTW path needs --
  * header, sequence table and the per-sequence forward/reverse signal arrays of a RawAlign `.ind`

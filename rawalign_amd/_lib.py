@@ -106,6 +106,7 @@ SYMBOLS = {
     "rawdtw_upload_reference": (I32, [VP, U32, VP, VP, VP]),
     "rawdtw_reference_offset": (I32, [VP, U32, I32, C.POINTER(U64)]),
     "rawdtw_set_reference_device": (I32, [VP, VP, U64]),
+    "rawdtw_share_reference": (I32, [VP, VP]),
     "rawdtw_index_open": (I32, [C.c_char_p, C.POINTER(VP)]),
     "rawdtw_index_info": (I32, [VP, C.POINTER(U32), VP]),
     "rawdtw_index_seq": (I32, [VP, U32, C.POINTER(C.c_char_p), C.POINTER(U32)]),

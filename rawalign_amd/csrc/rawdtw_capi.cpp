@@ -76,6 +76,7 @@ struct rawdtw_ctx {
     unsigned long long *d_masks = nullptr; // band bitmasks of the micro shapes (stream path)
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
+    bool resident_arrays = false;      // rawdtw_batch_create: anchors / ref_base / read_base are DEVICE pointers (used in place)
     bool time_plan = false;            // record an event pair around a batch's planning kernels (rawdtw_batch_plan_ms)
     std::vector<uint64_t> job_off_scratch;
     void *d_append = nullptr;          // rawdtw_events_append staging, grow-only
@@ -169,6 +170,11 @@ struct rawdtw_batch {
     const rawdtw_anchor_t *in_anchors = nullptr;
     const uint64_t *in_ref_base = nullptr;
     const uint32_t *in_read_base = nullptr;
+    // "resident_arrays": the three big arrays are device pointers; host copies are made only if the job list is needed
+    bool in_resident = false;
+    std::vector<rawdtw_anchor_t> host_anchors;
+    std::vector<uint64_t> host_ref_base;
+    std::vector<uint32_t> host_read_base;
 };
 
 namespace {
@@ -1175,6 +1181,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "device_plan")) { ctx->device_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "device_plan_min_jobs")) { ctx->device_plan_min_jobs = (uint64_t)std::max<int64_t>(value, 0); return RAWDTW_OK; }
+    if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "stream_others_blocks")) { ctx->stream_others_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
@@ -1249,6 +1256,16 @@ int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_
     ctx->own_ref = false;
     ctx->ref_off.clear();
     ctx->ref_len.clear();
+    return RAWDTW_OK;
+}
+
+int rawdtw_share_reference(rawdtw_ctx *ctx, const rawdtw_ctx *owner)
+{
+    if (!ctx || !owner || ctx == owner) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to share_reference");
+    if (ctx->device != owner->device) return fail(ctx, RAWDTW_ERR_INVALID, "contexts on different devices cannot share an arena");
+    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    ctx->d_ref = owner->d_ref; ctx->n_ref = owner->n_ref; ctx->own_ref = false;
+    ctx->ref_off = owner->ref_off; ctx->ref_len = owner->ref_len;
     return RAWDTW_OK;
 }
 
@@ -1721,6 +1738,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->d_keep = carve<uint8_t>(p, nc);
     a.out = carve<float>(p, n_jobs);
     a.job_off = d_job_off; a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
+    if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
     a.ev = ctx->d_ev; a.ref = ctx->d_ref; a.masks = ctx->d_masks;
     char *hp = b->ws.h;
     uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
@@ -1737,9 +1755,11 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_job_off, h_job_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+    if (!b->in_resident) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
     hipError_t e = stream_plan(a, b->d_chains, d_key, d_val, d_key_out, b->d_fold_order, d_tmp, tmp, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
@@ -1759,6 +1779,21 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->cnt_valid = false;
     b->dirty = true;
     b->ws_bytes = dev_bytes;
+    return RAWDTW_OK;
+}
+
+// "resident_arrays": bring the three device-resident arrays to the host (the job-list path reads them there)
+int materialise_host_arrays(rawdtw_ctx *ctx, rawdtw_batch *b)
+{
+    if (!b->in_resident) return RAWDTW_OK;
+    const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
+    try { b->host_anchors.resize(na); b->host_ref_base.resize(nc); b->host_read_base.resize(nc); }
+    catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    if (na) HIP_TRY(ctx, hipMemcpy(b->host_anchors.data(), b->in_anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost));
+    if (nc) HIP_TRY(ctx, hipMemcpy(b->host_ref_base.data(), b->in_ref_base, nc * 8, hipMemcpyDeviceToHost));
+    if (nc) HIP_TRY(ctx, hipMemcpy(b->host_read_base.data(), b->in_read_base, nc * 4, hipMemcpyDeviceToHost));
+    b->in_anchors = b->host_anchors.data(); b->in_ref_base = b->host_ref_base.data(); b->in_read_base = b->host_read_base.data();
+    b->in_resident = false;
     return RAWDTW_OK;
 }
 
@@ -1881,7 +1916,9 @@ int stream_fallback(rawdtw_ctx *ctx, rawdtw_batch *b)
     const uint64_t nc = b->n_chains;
     std::vector<uint64_t> job_off(nc + 1);
     uint64_t n_jobs = 0;
-    int st = rawdtw_batch_build_jobs(&b->opt, nc, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base,
+    int st = materialise_host_arrays(ctx, b);
+    if (st != RAWDTW_OK) return st;
+    st = rawdtw_batch_build_jobs(&b->opt, nc, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base,
                                      job_off.data(), nullptr, 0, &n_jobs);
     if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
     b->stream = false;
@@ -1920,10 +1957,14 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
     b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
+    b->in_resident = ctx->resident_arrays;
     if (stream_eligible(ctx, opt, n_jobs))
         st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base, job_off.data(), n_jobs);
-    else
-        st = batch_create_joblist(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base, job_off, n_jobs);
+    else {
+        st = materialise_host_arrays(ctx, b);
+        if (st == RAWDTW_OK)
+            st = batch_create_joblist(ctx, b, chain_off, anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
+    }
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
     *out = b;
     return RAWDTW_OK;

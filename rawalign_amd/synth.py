@@ -209,5 +209,7 @@ def make_candidate_batch(ref: Reference, ref_offsets, params: SynthParams, seed:
     cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
     info = {"n_reads": R, "n_events": int(len(events)), "n_chains": int(n_chains),
             "n_true_chains": int(len(true_reads)), "n_decoy_chains": int(len(dec_ids)),
-            "n_anchors": int(len(anchors)), "mappable_reads": int(mappable.sum())}
+            "n_anchors": int(len(anchors)), "mappable_reads": int(mappable.sum()),
+            # per read: offset of its event array in `events` (n_reads + 1 entries) and the events its last chunk added
+            "ev_off": ev_off.astype(np.uint64), "events_per_chunk": int(round(P.bases_per_chunk * 1.28))}
     return cb, info

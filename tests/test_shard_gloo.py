@@ -105,3 +105,25 @@ def test_shard_is_world_size_independent():
     from rawalign_amd.shard import shard_reads
 
     assert [shard_reads(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (before anything touches a GPU), reduces
+    the counters over gloo and relays ONE line with n_gpus = 2.  --dry-run: launcher and reduction plumbing only."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0 and two.returncode == 0, two.stderr[-2000:]
+    l1 = json.loads(one.stdout.strip().splitlines()[-1])
+    l2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["steps"] == 3 and l2["scaling"] == "weak"
+    # weak scaling: rank 0's shard is the same in both runs, rank 1 adds its own
+    assert l2["totals_over_timed_steps"]["reads"] == 2 * l1["totals_over_timed_steps"]["reads"]
+    assert l2["totals_over_timed_steps"]["dtw_jobs"] > l1["totals_over_timed_steps"]["dtw_jobs"]
