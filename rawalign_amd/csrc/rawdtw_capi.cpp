@@ -75,7 +75,11 @@ struct rawdtw_ctx {
     std::vector<StreamWs> ws_free;     // workspaces of destroyed batches, reused by the next ones (no hipMalloc in the steady state)
     unsigned long long *d_masks = nullptr; // band bitmasks of the micro shapes (stream path)
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
+    int stream_threads = 256;                   // workgroup size of k_stream (256 or 512: 1024 / 2048 jobs per tile)
+    int stream_threads_cached = 0;
     uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
+    uint32_t stream_debug = 0;         // StreamArgs::debug
+    std::vector<uint32_t> unit_chain_scratch;
     bool resident_arrays = false;      // rawdtw_batch_create: anchors / ref_base / read_base are DEVICE pointers (used in place)
     bool time_plan = false;            // record an event pair around a batch's planning kernels (rawdtw_batch_plan_ms)
     std::vector<uint64_t> job_off_scratch;
@@ -160,6 +164,7 @@ struct rawdtw_batch {
     StreamWs ws;
     StreamArgs sa{};
     uint32_t stream_lds = 0;
+    int stream_threads = 256;
     unsigned long long *h_cnt = nullptr; // pinned landing zone of the counter block
     bool cnt_valid = false, cells_counted = false;
     bool dirty = false;                  // work enqueued since the last host synchronisation
@@ -1181,6 +1186,8 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "device_plan")) { ctx->device_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "device_plan_min_jobs")) { ctx->device_plan_min_jobs = (uint64_t)std::max<int64_t>(value, 0); return RAWDTW_OK; }
+    if (!strcmp(name, "stream_threads")) { ctx->stream_threads = value >= 512 ? 512 : 256; return RAWDTW_OK; }
+    if (!strcmp(name, "stream_debug")) { ctx->stream_debug = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "stream_others_blocks")) { ctx->stream_others_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1024); return RAWDTW_OK; }
@@ -1644,7 +1651,7 @@ bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint6
     if (ctx->lane_max_radius < 0 || ctx->sort_n || ctx->sort_r1_n || ctx->sort_r3 || ctx->lane_hi || !ctx->merge_small) return false;
     if (ctx->tile_threads != 256 || ctx->debug_skip_kinds) return false;
     const uint32_t worst_job = 2u * ctx->lane_max_n + 12u;
-    return ctx->tile_lds_floats >= 4u * worst_job + 16u && ctx->tile_lds_floats <= 16384u;
+    return ctx->tile_lds_floats >= 4u * worst_job + kStreamSlack && ctx->tile_lds_floats <= 16384u;
 }
 
 int ws_acquire(rawdtw_ctx *ctx, size_t dev_bytes, size_t host_bytes, StreamWs *out)
@@ -1704,19 +1711,24 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
     a.frac = b->opt.band_radius_frac;
     a.lane_max_radius = ctx->lane_max_radius; a.lane_max_n = ctx->lane_max_n; a.micro_max_n = (uint32_t)ctx->micro_max_n;
-    a.tile_budget = lds_floats - 16u;
-    a.min_cost8 = (8u * a.tile_budget + kStreamMaxTileJobs - 1) / kStreamMaxTileJobs;
-    a.run_cost8 = (8u * a.tile_budget + kStreamMaxRuns - 3) / (kStreamMaxRuns - 2);
-    const uint64_t worst8 = std::max<uint64_t>(8ull * (2ull * a.lane_max_n + 12ull), std::max(a.min_cost8, a.run_cost8));
-    a.tiles_cap = (uint32_t)std::min<uint64_t>(n_jobs * worst8 / (8ull * a.tile_budget - worst8) + 2, 0x7fffffffull);
+    // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the
+    // bracket by at most the largest cost a job can have, so the image needs at most tile_budget floats
+    const uint32_t tile_budget = lds_floats - kStreamSlack;
+    const uint32_t max_tile_jobs = 4u * (uint32_t)ctx->stream_threads;
+    a.min_cost8 = (8u * tile_budget + max_tile_jobs - 1) / max_tile_jobs;
+    const uint64_t worst8 = std::max<uint64_t>(8ull * (2ull * a.lane_max_n + 12ull), a.min_cost8);
+    a.width8 = 8ull * tile_budget - worst8;
+    // every bracket holds at most width8 / min_cost8 + 1 jobs: with the floor above that is below kStreamMaxTileJobs
+    a.tiles_cap = (uint32_t)std::min<uint64_t>(n_jobs * worst8 / a.width8 + 2, 0x7fffffffull);
     a.others_cap = std::min<uint64_t>(n_jobs, n_jobs / 4 + 4096);
     const size_t tmp = std::max(stream_scan_bytes(n_jobs), stream_sort_bytes(nc));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const uint64_t n_units = (n_jobs + 1023) / 1024;
     const size_t dev_bytes = al((nc + 1) * 8) * 2 + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) +   // inputs
-                             al(n_jobs * 16) + al(n_jobs * 4) + al(n_jobs * 8) + al(((size_t)a.tiles_cap + 1) * 4) + // per job
+                             al(n_jobs * 16) + al(n_jobs * 16) + al(((size_t)a.tiles_cap + 1) * sizeof(TileInfo)) + // per job: record, scan
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) + al(tmp) +
-                             al(nc * sizeof(ChainDesc)) + 7 * al(nc * 4) + al(nc) + al(n_jobs * 4);
-    const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8);
+                             al(nc * sizeof(ChainDesc)) + 7 * al(nc * 4) + al(nc) + al(n_jobs * 4) + al((n_units + 1) * 4) + al(n_units * 24);
+    const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8) + al((n_units + 1) * 4);
     int st = ws_acquire(ctx, dev_bytes, host_bytes, &b->ws);
     if (st != RAWDTW_OK) return st;
     if ((st = ensure_masks(ctx)) != RAWDTW_OK) return st;
@@ -1726,8 +1738,8 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
-    a.jrec = carve<JobRec>(p, n_jobs); a.lds_cost = carve<uint32_t>(p, n_jobs); a.cum = carve<uint64_t>(p, n_jobs);
-    a.tile_first = carve<uint32_t>(p, (uint64_t)a.tiles_cap + 1);
+    a.jrec = carve<JobRec>(p, n_jobs); a.cum = carve<Cum>(p, n_jobs);
+    a.tiles = carve<TileInfo>(p, (uint64_t)a.tiles_cap + 1);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     a.cnt = carve<unsigned long long>(p, kStreamCounters);
     void *d_tmp = carve<char>(p, tmp);
@@ -1737,13 +1749,27 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
     b->d_keep = carve<uint8_t>(p, nc);
     a.out = carve<float>(p, n_jobs);
+    uint32_t *d_unit_chain = carve<uint32_t>(p, n_units + 1);
+    a.unit_chain = d_unit_chain;
+    a.unit_stats = carve<unsigned long long>(p, 3 * n_units);
+    a.debug = ctx->stream_debug;
     a.job_off = d_job_off; a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
     if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
     a.ev = ctx->d_ev; a.ref = ctx->d_ref; a.masks = ctx->d_masks;
     char *hp = b->ws.h;
     uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
+    uint32_t *h_unit_chain = carve<uint32_t>(hp, n_units + 1);
     memcpy(h_job_off, job_off_host, (nc + 1) * 8);
+    {   // unit u (jobs [1024 u, 1024 u + 1024)) starts inside chain unit_chain[u]: one merge walk over the chains
+        uint64_t c = 0;
+        for (uint64_t u = 0; u < n_units; u++) {
+            const uint64_t j0 = u * 1024;
+            while (job_off_host[c + 1] <= j0) c++;
+            h_unit_chain[u] = (uint32_t)c;
+        }
+        h_unit_chain[n_units] = (uint32_t)(nc ? nc - 1 : 0);
+    }
     unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the same pinned block
     for (int i = 0; i < kStreamCounters; i++) h_init[i] = 0;
     h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
@@ -1754,6 +1780,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     }
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_job_off, h_job_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_unit_chain, h_unit_chain, (n_units + 1) * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     if (!b->in_resident) {
         HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
@@ -1765,16 +1792,18 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
     // the persistent grid: what the device holds at this LDS size
-    if (ctx->stream_lds != lds_floats) {
+    if (ctx->stream_lds != lds_floats || ctx->stream_threads_cached != ctx->stream_threads) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        const int per_cu = stream_blocks_per_cu(lds_floats);
+        const int per_cu = stream_blocks_per_cu(lds_floats, ctx->stream_threads);
         if (per_cu <= 0) return fail(ctx, RAWDTW_ERR_DEVICE, "occupancy query failed for the batch kernel");
         ctx->stream_blocks = (uint32_t)(per_cu * prop.multiProcessorCount);
         ctx->stream_lds = lds_floats;
+        ctx->stream_threads_cached = ctx->stream_threads;
     }
     b->stream = true;
     b->stream_lds = lds_floats;
+    b->stream_threads = ctx->stream_threads;
     b->n_jobs = n_jobs;
     b->cnt_valid = false;
     b->dirty = true;
@@ -1996,17 +2025,21 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
             return RAWDTW_OK;
         }
         std::vector<JobRec> jr(n_jobs);
-        std::vector<uint32_t> cost(n_jobs);
+        std::vector<Cum> cum(n_jobs);
         const uint64_t n_tiles = cnt[kCntTiles];
+        std::vector<TileInfo> ti(n_tiles + 1);
         std::vector<uint32_t> tf(n_tiles + 1);
         if (n_jobs) HIP_TRY(ctx, hipMemcpy(jr.data(), a.jrec, n_jobs * sizeof(JobRec), hipMemcpyDeviceToHost));
-        if (n_jobs) HIP_TRY(ctx, hipMemcpy(cost.data(), a.lds_cost, n_jobs * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(tf.data(), a.tile_first, (n_tiles + 1) * 4, hipMemcpyDeviceToHost));
+        if (n_jobs) HIP_TRY(ctx, hipMemcpy(cum.data(), a.cum, n_jobs * sizeof(Cum), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(ti.data(), a.tiles, (n_tiles + 1) * sizeof(TileInfo), hipMemcpyDeviceToHost));
+        for (uint64_t t = 0; t <= n_tiles; t++) tf[t] = ti[t].first;
+        if (ti[n_tiles].n != 0) e = "no end marker behind the last tile";
         const uint64_t n_other = cnt[kCntOthers];
         std::vector<DevJob> oj(n_other);
         if (n_other) HIP_TRY(ctx, hipMemcpy(oj.data(), a.ojobs, n_other * sizeof(DevJob), hipMemcpyDeviceToHost));
         uint64_t tile_jobs = 0;
         std::vector<uint8_t> is_tile(n_jobs, 0);
+        Cum run{0u, 0u, 0ull};
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++) {
             const rawdtw_job_t &j = jobs[k];
             const int R = slanted_radius(j.n, j.m, j.band_radius);
@@ -2017,29 +2050,71 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
             else if (tile && ((jr[k].meta & 127u) != N || ((jr[k].meta >> 7) & 127u) != M || ((jr[k].meta >> 14) & 3u) != (uint32_t)R ||
                               (((jr[k].meta >> 16) & 1u) != 0) != (j.exclude_last != 0) || (((jr[k].meta >> 17) & 1u) != 0) != (j.n < j.m)))
                 e = "job " + S(k) + ": shape, radius or flags";
+            const Cum d = job_cum(jr[k], a.min_cost8);
+            run = Cum{run.read + d.read, run.ref + d.ref, run.cost + d.cost};
+            if (e.empty() && (cum[k].read != run.read || cum[k].ref != run.ref || cum[k].cost != run.cost)) e = "job " + S(k) + ": running sums";
             is_tile[k] = tile;
             tile_jobs += tile;
         }
         if (e.empty() && tile_jobs != cnt[kCntTileJobs]) e = "tile job count";
         if (e.empty() && (tf[0] != 0 || tf[n_tiles] != n_jobs)) e = "tiles do not cover the jobs";
+        // every tile: its range fits the record capacity; every job's windows lie inside the image at a place congruent to
+        // the arena offset; a continuing part starts on its predecessor's last element; distinct runs do not overlap
         for (uint64_t t = 0; t < n_tiles && e.empty(); t++) {
-            if (tf[t + 1] < tf[t]) { e = "tile " + S(t) + ": boundaries not ascending"; break; }
-            const uint64_t n = tf[t + 1] - tf[t];
-            if (n > kStreamMaxTileJobs) { e = "tile " + S(t) + ": too many jobs"; break; }
-            // the LDS image as k_stream lays it out: one span of each arena per run, ends rounded up to 16 bytes
-            uint64_t image = 0, runs = 0, r0 = 0, r1 = 0, f0 = 0, f1 = 0;
-            bool open = false, seen = false;
-            auto close = [&]() { if (open) image += ((r1 - r0 + 3) & ~3ull) + ((f1 - f0 + 3) & ~3ull); open = false; };
-            for (uint64_t k = tf[t]; k < tf[t + 1]; k++) {
+            if (tf[t + 1] <= tf[t]) { e = "tile " + S(t) + ": empty or boundaries not ascending"; break; }
+            const uint64_t first = tf[t], n = tf[t + 1] - tf[t];
+            if (n > 4u * (uint32_t)batch->stream_threads) { e = "tile " + S(t) + ": too many jobs"; break; }
+            // geometry as k_tile_first fixes it: from the first tile-class job's first chunk to the last one's last element
+            uint64_t f = first, l = first + n;
+            while (f < first + n && !is_tile[f]) f++;
+            while (l > f && !is_tile[l - 1]) l--;
+            if (f == first + n) {
+                if (ti[t].image != 0 || ti[t].first_tile != n) e = "tile " + S(t) + ": geometry of a tile without tile-class jobs";
+                continue;
+            }
+            auto pos_of = [&](uint64_t k, bool ref) -> uint64_t {
+                const Cum ce = k ? cum[k - 1] : Cum{0u, 0u, 0ull};
+                const bool st = (jr[k].meta & kMetaStarts) != 0;
+                return ref ? image_pos(ce.ref, jobs[k].ref_off, st) : image_pos(ce.read, jobs[k].read_off, st);
+            };
+            const uint32_t base_read = (uint32_t)pos_of(f, false) & ~3u, base_ref = (uint32_t)pos_of(f, true) & ~3u;
+            const uint32_t read_end = (uint32_t)pos_of(l - 1, false) + jobs[l - 1].n, ref_end = (uint32_t)pos_of(l - 1, true) + jobs[l - 1].m;
+            const uint32_t ref_region = (read_end - base_read + 3u) & ~3u, image = ref_region + ((ref_end - base_ref + 3u) & ~3u);
+            if (image > batch->stream_lds) { e = "tile " + S(t) + ": image of " + S(image) + " floats over the LDS budget"; break; }
+            if (ti[t].n != n || ti[t].base_read != base_read || ti[t].base_ref != base_ref || ti[t].ref_region != ref_region ||
+                ti[t].image != image || ti[t].first_tile != f - first) {
+                e = "tile " + S(t) + ": geometry record"; break;
+            }
+            // every job's windows lie inside the image at a place congruent to the arena offset; a continuing part starts on
+            // its predecessor's last element; runs do not share a 16-byte chunk; and every chunk of the image is owned by a
+            // job's window or is the one chunk of slack in front of a run start (the kernel has no clearing pass)
+            std::vector<uint8_t> owned(image / 4, 0);
+            uint64_t prev_end_read = 0, prev_end_ref = 0;
+            bool seen = false;
+            for (uint64_t k = first; k < first + n && e.empty(); k++) {
                 if (!is_tile[k]) continue;
                 const rawdtw_job_t &j = jobs[k];
-                if ((jr[k].meta & kMetaStarts) || !seen) { close(); open = true; runs++; r0 = j.read_off & ~3u; f0 = j.ref_off & ~3ull; r1 = r0; f1 = f0; }
-                else if (j.read_off + 1 != r1 || j.ref_off + 1 != f1) { e = "job " + S(k) + ": continues a run it does not touch"; break; }
+                const Cum ce = k ? cum[k - 1] : Cum{0u, 0u, 0ull};
+                const bool starts = (jr[k].meta & kMetaStarts) != 0;
+                const uint64_t pr = pos_of(k, false), pf = pos_of(k, true);
+                if (pr < base_read || pf < base_ref || pr - base_read + j.n > ref_region || pf - base_ref + ref_region + j.m > image)
+                    e = "job " + S(k) + ": window outside its tile's image";
+                else if (((pr ^ j.read_off) & 3u) || ((pf ^ j.ref_off) & 3u)) e = "job " + S(k) + ": image position not congruent to the arena offset";
+                else if (seen && !starts && (pr + 1 != prev_end_read || pf + 1 != prev_end_ref)) e = "job " + S(k) + ": continues a run it does not touch";
+                else if (seen && starts && (pr / 4 < (prev_end_read + 3) / 4 || pf / 4 < (prev_end_ref + 3) / 4)) e = "job " + S(k) + ": run shares a 16-byte chunk with the run before it";
+                if (!e.empty()) break;
+                for (uint64_t c4 = (pr - base_read) / 4; c4 * 4 < pr - base_read + j.n; c4++) owned[c4] = 1;
+                for (uint64_t c4 = (pf - base_ref + ref_region) / 4; c4 * 4 < pf - base_ref + ref_region + j.m; c4++) owned[c4] = 1;
+                if (starts && k != f) {
+                    const uint64_t g0 = (ce.read - base_read) / 4, g1 = (ce.ref - base_ref + ref_region) / 4;
+                    if (g0 < (pr - base_read) / 4) owned[g0] = 1;
+                    if (g1 < (pf - base_ref + ref_region) / 4) owned[g1] = 1;
+                }
+                prev_end_read = pr + j.n; prev_end_ref = pf + j.m;
                 seen = true;
-                r1 = (uint64_t)j.read_off + j.n; f1 = j.ref_off + j.m;
             }
-            close();
-            if (e.empty() && (image > batch->stream_lds || runs > kStreamMaxRuns)) e = "tile " + S(t) + ": LDS image or run count over capacity";
+            for (size_t q = 0; q < owned.size() && e.empty(); q++)
+                if (!owned[q]) e = "tile " + S(t) + ": chunk " + S(q) + " of the image belongs to no job";
         }
         std::vector<uint8_t> oseen(n_jobs, 0);
         for (uint64_t q = 0; q < n_other && e.empty(); q++) {
@@ -2154,7 +2229,7 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
     if (batch->stream) {
         if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) {
-            hipError_t he = stream_run(batch->sa, ctx->stream_others_blocks, ctx->stream_blocks, batch->stream_lds, ctx->stream);
+            hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, ctx->stream);
             if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
         }
         if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;

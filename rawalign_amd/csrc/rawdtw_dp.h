@@ -332,6 +332,127 @@ __device__ __forceinline__ float lane_dp_sel(const float *LA, const float *LB, c
     return p1[HP + SH]; // dtw.cpp:506-512
 }
 
+// One body for every radius 1..3 and every shape, for waves whose lanes hold DIFFERENT radii (the tile kernel of the
+// sync-free path sorts its lane-class jobs by longer side only: radii 1 and 3 are too rare inside a tile to fill waves of
+// their own -- a quarter-full wave costs as much as a full one).  Physical-slot form of dtw.cpp:305-491 with K = 4 slots
+// in registers: slot p of a secondary antidiagonal is cell (col - 1 + off - p, row - off + p), of a primary
+// (col + off - p, row - off + p), off = P/2 + SH; primaries live at slot o + SH.  Two buffers: d1 = latest antidiagonal,
+// d0 = the one before; every column computes the secondary (its result only counts when the centre row advances) and
+// feeds the primary through selects on `adv` (see lane_dp_sel).
+//
+// What makes it cheap: NO per-cell validity.  (a) Slots outside an antidiagonal's extent (p >= S, o outside [0, P)) and
+// cells beyond the matrix on the HIGH side (i >= N or j >= M) may hold anything: a cell reads (i-1, j), (i, j-1),
+// (i-1, j-1) only, so a cell inside the matrix never reads one beyond it, and every read of a slot outside the extent
+// is one of the reference's guarded reads (is_first / is_last / previous_increment_center_row, dtw.cpp:373-375, 392-397,
+// 428-441, 461-473), reproduced below.  (b) Cells beyond the matrix on the LOW side (i < 0 or j < 0) must read as 1e10:
+// they exist only while row < off, i.e. in the first columns of a job, which run in a masked copy of the step; the wave
+// leaves it as soon as no lane needs it.  Operands beyond a window's end are read unclamped: they feed only cells beyond
+// the matrix (the tile's LDS image has slack behind the last window).
+struct GenLane {
+    float d0[4], d1[4], ap[4], bp[4];
+    float a_next, b_next, res;
+    uint32_t rem;
+    int row;
+    bool prev_adv;
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const float *LB, const uint32_t N, const uint32_t M,
+                                              const int off, const bool sh, const bool r1, const bool r2, const uint32_t col)
+{
+    g.rem += M;
+    const bool adv = g.rem >= N;
+    g.rem -= adv ? N : 0u;
+    g.row += adv ? 1 : 0;
+    // b-window: one step when the row advances (b_next is a function of the row alone)
+    float bn[4];
+#pragma unroll
+    for (int p = 0; p < 3; p++) bn[p] = adv ? g.bp[p + 1] : g.bp[p];
+    bn[3] = adv ? g.b_next : g.bp[3];
+    g.b_next = LB[g.row + 4 - off];
+    // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column, b-window of the new row
+    float X[4];
+    {
+        const float top0 = sh ? kInf : g.d1[0];                          // is_first
+        const float tl0 = (sh && !g.prev_adv) ? kInf : g.d0[0];          // previous_increment_center_row
+        const float left1 = r1 ? kInf : g.d1[2];                         // is_last (radius 1: S - 1 = 1; radius 3: slot 3 below)
+        float sec[4];
+        sec[0] = min3f(top0, g.d1[1], tl0) + dist(g.ap[0], bn[0]);
+        sec[1] = min3f(g.d1[1], left1, g.d0[1]) + dist(g.ap[1], bn[1]);
+        sec[2] = min3f(g.d1[2], g.d1[3], g.d0[2]) + dist(g.ap[2], bn[2]);
+        sec[3] = min3f(g.d1[3], kInf, g.d0[3]) + dist(g.ap[3], bn[3]);
+        if (MASKED) { // low side: j = row - off + p >= 0 and i = col - 1 + off - p >= 0
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (p < off - g.row || p > (int)col - 1 + off) sec[p] = kInf;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) X[p] = adv ? sec[p] : g.d1[p]; // the antidiagonal just before this column's primary
+    }
+    // a-window: one step per column
+    g.ap[3] = g.ap[2]; g.ap[2] = g.ap[1]; g.ap[1] = g.ap[0]; g.ap[0] = g.a_next;
+    g.a_next = LA[col + 1 + off];
+    // primary antidiagonal (dtw.cpp:416-485)
+    {
+        const float top1 = (sh && !adv) ? kInf : X[0];                   // o == 0 of an odd radius when the row stays
+        const float left2 = (r2 && adv) ? kInf : X[2];                   // last offset of an even radius after a secondary
+        const float t1 = g.prev_adv ? g.d0[0] : kInf;                    // (o == 0, odd radius: only after an advance)
+        const float tl0 = adv ? g.d1[0] : kInf;
+        const float tl1 = adv ? g.d1[1] : (sh ? t1 : g.d0[0]);
+        const float tl2 = adv ? g.d1[2] : g.d0[1];
+        const float tl3 = adv ? g.d1[3] : g.d0[2];
+        float pr[4];
+        pr[0] = min3f(kInf, X[0], tl0) + dist(g.ap[0], bn[0]);
+        pr[1] = min3f(top1, X[1], tl1) + dist(g.ap[1], bn[1]);
+        pr[2] = min3f(X[1], left2, tl2) + dist(g.ap[2], bn[2]);
+        pr[3] = min3f(X[2], X[3], tl3) + dist(g.ap[3], bn[3]);
+        if (MASKED) { // low side: j = row - off + p >= 0 (i = col + off - p >= 0 for every slot of the antidiagonal)
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (p < off - g.row) pr[p] = kInf;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) { g.d0[p] = X[p]; g.d1[p] = pr[p]; g.bp[p] = bn[p]; }
+    }
+    g.prev_adv = adv;
+    // dtw.cpp:506-512: the centre of the last primary
+    const float centre = off == 1 ? g.d1[1] : g.d1[2];
+    g.res = (col == N - 1u) ? centre : g.res;
+}
+
+// N, M, R per lane (R in 1..3, N >= M, N >= 2); n_max = the largest N of the wave.  Lanes past their last column keep
+// stepping on values nobody reads.
+__device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t R,
+                                             const uint32_t n_max)
+{
+    const bool sh = R & 1u;                 // odd radius: P = R, S = R + 1, primaries at slot o + 1 (dtw.cpp:301-303, 459, 479)
+    const int off = (int)((R + 1u) >> 1);   // P/2 + SH, the centre slot: radius 1 -> 1, 2 -> 1, 3 -> 2
+    const bool r1 = R == 1u, r2 = R == 2u;
+    const int iN = (int)N, iM = (int)M;
+    GenLane g;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        g.d0[p] = kInf; g.d1[p] = kInf;
+        const int ia = off - p, ib = p - off;
+        g.ap[p] = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
+        g.bp[p] = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+    }
+    {   // column 0: only the corner (dtw.cpp:317-347), at the centre slot
+        const float c = dist(LA[0], LB[0]);
+        g.d1[1] = off == 1 ? c : kInf;
+        g.d1[2] = off == 2 ? c : kInf;
+    }
+    g.res = g.d1[off == 1 ? 1 : 2]; // (N == 1 cannot occur here; kept for completeness)
+    g.rem = 0; g.row = 0; g.prev_adv = false;
+    g.a_next = LA[1 + off];
+    g.b_next = LB[4 - off];
+    uint32_t col = 1;
+    // first columns: some lane still has cells above row 0 (or left of column 0) inside its band
+    for (; col < n_max && __any((g.row < off || col < 3u) && col < N); col++) lane_gen_step<true>(g, LA, LB, N, M, off, sh, r1, r2, col);
+    for (; col < n_max; col++) lane_gen_step<false>(g, LA, LB, N, M, off, sh, r1, r2, col);
+    return g.res;
+}
+
 // Micro path for the shapes that dominate sparse mode (longer side <= W, W = 4 or 8): the whole
 // band fits a W x W grid, so the DP runs row by row over W statically indexed registers and band
 // membership comes from a per-shape bitmask the planner computed by walking the reference's
@@ -499,6 +620,136 @@ __device__ __forceinline__ void wreg_body(const DevJob &jb, const int lane, cons
     }
 }
 
+// The same wave-per-job scheme without per-cell validity (see lane_dp_gen for the argument: slots outside an
+// antidiagonal's extent and cells beyond the matrix on the high side are never read by a cell inside it, except through
+// the reference's guarded reads; cells beyond the matrix on the LOW side exist only in a job's first columns, which take
+// the masked copy of the step).  Two buffers (d1 = latest antidiagonal, d0 = the one before), control flow scalar: the
+// job is the wave's, so `adv` is uniform.  About half the instructions of wreg_body per antidiagonal -- it is the
+// longest wide-band job of a batch that decides when the batch's DTW launch ends.
+template <int C, bool MASKED>
+__device__ __forceinline__ void wreg_gen_step(float (&d0)[C], float (&d1)[C], float (&ap)[C], float (&bp)[C], const bool adv,
+                                              const bool prev_adv, const float fresh_a, const float fresh_b, const int lane,
+                                              const int SH, const int S, const int P, const int off, const int row, const int col)
+{
+    float X[C];
+    if (adv) {
+        // b-window: every lane takes its right neighbour's value
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float fill = (c + 1 < C) ? read_lane(bp[c + 1 < C ? c + 1 : c], 0) : fresh_b;
+            bp[c] = wave_shl1(bp[c], fill);
+        }
+        // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int p = c * 64 + lane;
+            const float fill = (c + 1 < C) ? read_lane(d1[c + 1 < C ? c + 1 : c], 0) : kInf;
+            float left = wave_shl1(d1[c], fill), top = d1[c], tl = d0[c];
+            if (SH) {
+                if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
+                if (p == S - 1) left = kInf;
+            }
+            float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
+            if (MASKED && (p < off - row || p > col - 1 + off)) v = kInf;
+            X[c] = v;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) X[c] = d1[c];
+    }
+    // a-window: every lane takes its left neighbour's value
+#pragma unroll
+    for (int c = C - 1; c >= 0; c--) {
+        const float fill = (c > 0) ? read_lane(ap[c > 0 ? c - 1 : 0], 63) : fresh_a;
+        ap[c] = wave_shr1(ap[c], fill);
+    }
+    // primary antidiagonal (dtw.cpp:416-485)
+    float pr[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int p = c * 64 + lane;
+        const float f1 = (c > 0) ? read_lane(X[c > 0 ? c - 1 : 0], 63) : kInf;
+        float top = wave_shr1(X[c], f1), left = X[c], tl;
+        if (adv) {
+            tl = d1[c];
+            if (!SH && p == P - 1) left = kInf;
+        } else {
+            const float f0 = (c > 0) ? read_lane(d0[c > 0 ? c - 1 : 0], 63) : kInf;
+            tl = wave_shr1(d0[c], f0);
+            if (p == SH) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
+        }
+        float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
+        if (MASKED && p < off - row) v = kInf;
+        pr[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) { d0[c] = X[c]; d1[c] = pr[c]; }
+}
+
+template <int C>
+__device__ __forceinline__ void wreg_gen(const DevJob &jb, const int lane, const float *__restrict__ ev,
+                                         const float *__restrict__ ref, float *__restrict__ out)
+{
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        uint32_t tn = N; N = M; M = tn;
+    }
+    const int R = jb.R;
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int SH = P > S ? 0 : 1;
+    const int off = P / 2 + SH, K = P > S ? P : S;
+    const int iN = (int)N, iM = (int)M;
+    auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
+    auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
+    float d0[C], d1[C], ap[C], bp[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int p = c * 64 + lane;
+        d0[c] = kInf; d1[c] = kInf;
+        ap[c] = ldA(off - p);
+        bp[c] = ldB(p - off);
+        if (p == off) d1[c] = dist(A[0], B[0]); // the corner (dtw.cpp:317-347)
+    }
+    // fresh-value chunks: column col needs A[col + off]; the r-th row advance needs B[b0 + r - 1]
+    const int a0 = off + 1, b0 = 64 * C - off;
+    float acur = ldA(a0 + lane), anxt = ldA(a0 + 64 + lane);
+    float bcur = ldB(b0 + lane), bnxt = ldB(b0 + 64 + lane);
+    int row = 0;
+    uint32_t rem = 0;
+    bool prev_adv = false;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        const uint32_t ca = (col - 1) & 63u;
+        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 64 + lane); }
+        const float fresh_a = read_lane(acur, (int)ca);
+        float fresh_b = 0.0f;
+        if (adv) {
+            rem -= N;
+            row++;
+            const uint32_t cb = (uint32_t)(row - 1) & 63u;
+            if (cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 64 + lane); }
+            fresh_b = read_lane(bcur, (int)cb);
+        }
+        // cells above row 0 or left of column 0 exist while row < off or col - 1 + off < K - 1
+        if (row < off || (int)col < K - off + 1) wreg_gen_step<C, true>(d0, d1, ap, bp, adv, prev_adv, fresh_a, fresh_b, lane, SH, S, P, off, row, (int)col);
+        else wreg_gen_step<C, false>(d0, d1, ap, bp, adv, prev_adv, fresh_a, fresh_b, lane, SH, S, P, off, row, (int)col);
+        prev_adv = adv;
+    }
+    float res = 0.0f; // dtw.cpp:506-512: the centre of the last primary
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        if ((off >> 6) == c) res = read_lane(d1[c], off & 63);
+    if (lane == 0) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Four jobs per wave: the same register-resident scheme as wreg_body<1>, but for bands that fit 16
 // lanes (radius + 1 <= 16) each job takes one 16-lane DPP row, so a wave advances four jobs per
@@ -632,9 +883,9 @@ __device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const
                                                const float *__restrict__ ref, float *__restrict__ out)
 {
     const int K = jb.R + 1;
-    if (K <= 64) wreg_body<1>(jb, lane, ev, ref, out);
-    else if (K <= 128) wreg_body<2>(jb, lane, ev, ref, out);
-    else wreg_body<4>(jb, lane, ev, ref, out);
+    if (K <= 64) wreg_gen<1>(jb, lane, ev, ref, out);
+    else if (K <= 128) wreg_gen<2>(jb, lane, ev, ref, out);
+    else wreg_gen<4>(jb, lane, ev, ref, out);
 }
 
 } // namespace rawdtw

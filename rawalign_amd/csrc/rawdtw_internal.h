@@ -97,29 +97,69 @@ struct FullAux {
 struct JobRec { uint64_t ref_off; uint32_t read_off; uint32_t meta; };
 static_assert(sizeof(JobRec) == 16, "JobRec is 16 bytes");
 constexpr uint32_t kMetaStarts = 1u << 18, kMetaTile = 1u << 19;
-constexpr uint32_t kStreamMaxTileJobs = 1024; // jobs in a tile's range (records live in LDS)
-constexpr uint32_t kStreamMaxRuns = 256;      // runs of consecutive parts per tile (one span of each arena per run)
+constexpr uint32_t kStreamMaxTileJobs = 2048; // jobs in a tile's range, 512-thread workgroups (256-thread: half)
+constexpr uint32_t kStreamSlack = 32;         // LDS floats of a tile's image kept free for region alignment
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
 constexpr uint32_t kStreamClasses = 6, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5;
+
+// Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive parts of a chain
+// (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every job
+// adds `read` / `ref` floats to the regions: a run start its whole window plus 3 floats of slack, a continuing part its
+// window minus the shared first element, and a run's last part the padding that rounds the run's END up to a 16-byte
+// boundary of the arena.  With c = the running sum BEFORE the job (a global exclusive scan) the job's window starts at
+//     start:       c + ((off - c) & 3)            continuing:  c - 4 + ((off - c) & 3)
+// (off = the window's arena offset): a closed form of the job's own scan value that is congruent to the arena offset
+// modulo 4 -- 16-byte chunks of the image are 16-byte chunks of the arena -- consistent along a run, and such that two
+// runs never share a chunk.  So a tile is staged by a flat, fully coalesced copy of chunks, with no per-tile run
+// table and no per-tile scan.  `cost` (eighths of a float, with a floor that bounds the jobs of a tile) cuts the batch
+// into tiles: tile k = the jobs whose exclusive cost lies in [k w, (k + 1) w).
+constexpr uint32_t kMetaEnds = 1u << 20; // the run's last part (the next part of the chain is not a tile job)
+struct Cum { uint32_t read, ref; uint64_t cost; };
+static_assert(sizeof(Cum) == 16, "Cum is 16 bytes");
+__host__ __device__ inline Cum job_cum(const JobRec &r, uint32_t min_cost8)
+{
+    Cum c{0u, 0u, (uint64_t)min_cost8};
+    const uint32_t meta = r.meta;
+    if (!(meta & kMetaTile)) return c;
+    const uint32_t N = meta & 127u, M = (meta >> 7) & 127u;
+    const bool swap = (meta >> 17) & 1u, starts = (meta >> 18) & 1u, ends = (meta >> 20) & 1u;
+    const uint32_t n_read = swap ? M : N, n_ref = swap ? N : M;
+    c.read = (starts ? n_read + 3u : n_read - 1u) + (ends ? (0u - (r.read_off + n_read)) & 3u : 0u);
+    c.ref = (starts ? n_ref + 3u : n_ref - 1u) + (ends ? (0u - ((uint32_t)r.ref_off + n_ref)) & 3u : 0u);
+    const uint32_t c8 = 8u * (c.read + c.ref);
+    c.cost = c8 > min_cost8 ? c8 : min_cost8;
+    return c;
+}
+__host__ __device__ inline uint32_t image_pos(uint32_t c_excl, uint64_t arena_off, bool starts)
+{
+    return (starts ? c_excl : c_excl - 4u) + (((uint32_t)arena_off - c_excl) & 3u);
+}
+// One tile: its job range and the geometry of its image (k_tile_first)
+struct TileInfo { uint32_t first, n, base_read, base_ref, ref_region, image, first_tile /* index in the range of its first tile-class job */, pad1; };
+static_assert(sizeof(TileInfo) == 32, "TileInfo is 32 bytes");
+
 enum StreamCounter : int {
     kCntBad = 0,        // min: first job with invalid anchors or a window outside the arenas (~0 = none)
     kCntOverflow,       // min: a tile over one of the kernel's capacities (~0 = none): never with a correct planner
     kCntUnsupported,    // jobs whose band is wider than the side list's kernels take (radius + 1 > 256)
-    kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntMaxCost8, kCntOthers, kCntTiles, kCntQueue, kCntLdsMax,
+    kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntOthers, kCntTiles, kCntLdsMax,
     kCntCls0,           // kStreamClasses totals
     kCntCur0 = kCntCls0 + 6, // kStreamClasses scatter cursors
     kCntCells = kCntCur0 + 6,
-    kStreamCounters = 32
+    kCntHeads = 32,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
+    kStreamCounters = kCntHeads + 8 * 16
 };
 struct StreamArgs {
     uint64_t n_jobs, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
     int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
     uint32_t lane_max_n, micro_max_n;
-    uint32_t tile_budget;        // LDS floats of a tile's image minus what a tile's first job can cost beyond its counted cost
-    uint32_t min_cost8, run_cost8; // cost floors in eighths of a float: bound the jobs / the runs of a tile
+    uint32_t min_cost8;          // cost floor in eighths of a float: bounds the jobs of a tile's range
+    uint64_t width8;             // bracket width of the tile rule: 8 * (image floats - slack) - the largest cost a job can have
     uint32_t tiles_cap;
+    uint32_t debug;              // timing experiments only (results wrong): 1 no DP, 2 no staging, 4 no side list
     // inputs (device)
+    const uint32_t *unit_chain;  // per k_pre unit of 1024 jobs: the chain its first job belongs to (n_units + 1 entries)
     const uint64_t *job_off, *anchor_off;
     const rawdtw_anchor_t *anchors;
     const uint64_t *ref_base;
@@ -128,9 +168,9 @@ struct StreamArgs {
     const unsigned long long *masks;
     // planning arrays and outputs (device)
     JobRec *jrec;
-    uint32_t *lds_cost;
-    uint64_t *cum;
-    uint32_t *tile_first;
+    Cum *cum;                    // inclusive scan of job_cum over the jobs
+    TileInfo *tiles;             // tiles_cap + 1 entries; tiles[n_tiles].n = 0
+    unsigned long long *unit_stats; // per k_pre unit: tile jobs, tile bytes, side-list bytes
     DevJob *omix, *ojobs;
     uint8_t *ocls;
     unsigned long long *cnt;
@@ -139,10 +179,10 @@ struct StreamArgs {
 size_t stream_scan_bytes(uint64_t n_jobs);
 size_t stream_sort_bytes(uint64_t n_chains);
 uint32_t stream_lds_bytes(uint32_t lds_floats);
-int stream_blocks_per_cu(uint32_t lds_floats);
+int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key, uint32_t *d_val, uint32_t *d_key_out,
                        uint32_t *d_fold_order, void *d_tmp, size_t tmp_bytes, hipStream_t s);
-hipError_t stream_run(const StreamArgs &a, uint32_t others_blocks, uint32_t tile_blocks, uint32_t lds_floats, hipStream_t s);
+hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, hipStream_t s);
 hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);
 hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,
                                  uint32_t n_seg, hipStream_t s);

@@ -4,20 +4,21 @@
 // of DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520) that align_chain (src/rmap.cpp:238-300) issues.
 //
 // Round 1 planned a batch in eleven launches with two host round trips and wrote 16-byte tile records for every job to
-// HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here nothing
-// about a tile ever reaches HBM:
+// HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here:
 //
 //   k_pre          one thread per job: the job's windows from its chain's anchors (rmap.cpp:251-254, 270, 276), the
-//                  slant-corrected radius (dtw.cpp:298-300), its class, and what it adds to a tile's LDS image.  Writes
-//                  one 16-byte record per job (offsets + packed shape) and the cost; the rare jobs the lane-per-job DP
-//                  does not take (radius > 3 or longer side > 73) are appended to a side list as full job records.
-//   scan           running cost (hipcub) -> a tile = the jobs whose running cost starts inside one budget-wide bracket
+//                  slant-corrected radius (dtw.cpp:298-300) and its class.  Writes one 16-byte record per job (arena
+//                  offsets + packed shape); the rare jobs the lane-per-job DP does not take (radius > 3 or longer
+//                  side > 73) are appended to a side list as full job records.
+//   scan           ONE hipcub scan of (event floats, reference floats, cost) per job (rawdtw_internal.h: Cum): it fixes
+//                  every job's place in its tile's LDS image in closed form and cuts the batch into tiles
 //   k_tile_first   one binary search per tile boundary
 //   k_others       the side list ordered by class and length (wave-per-job first, longest first)
-//   k_stream       ONE persistent launch per batch: workgroups first take the side list's wave-cooperative jobs, then pull
-//                  tiles from a queue.  Per tile, in LDS: the runs of consecutive parts (one span of each arena per
-//                  run), their layout, the job records, a counting sort by (kind, longer side), the staged windows --
-//                  then the lane-per-job DP of rawdtw_dp.h.
+//   k_stream       ONE persistent launch per batch: every wave first takes its share of the side list's wave-cooperative
+//                  jobs, then workgroups pull tiles from an eight-headed queue.  Per tile: each lane turns its jobs'
+//                  scan values into LDS offsets and copies the jobs' own new elements (16-byte chunks of the arenas are
+//                  16-byte chunks of the image); a counting sort by (kind, longer side) in LDS; the lane-per-job DP of
+//                  rawdtw_dp.h.  Nothing about a tile is ever written to HBM.
 //
 // No step needs a number on the host: grids are sized by the job count (known from the anchor offsets) or are
 // persistent, every count lives in a device counter block.  rawdtw_batch_create only enqueues; errors and the rare
@@ -33,8 +34,8 @@ namespace {
 
 constexpr int kT = 256;                 // threads per workgroup, everywhere in this file
 constexpr uint32_t kPreUnit = 1024;     // jobs per k_pre workgroup
-constexpr uint32_t kItems = kStreamMaxTileJobs / kT; // jobs per thread in the tile prologue (blocked)
-static_assert(kStreamMaxTileJobs % kT == 0 && kItems >= 1, "tile job capacity");
+constexpr uint32_t kItems = 4;          // jobs per thread in the tile prologue (blocked): a tile's range holds 4 * threads jobs
+static_assert(kStreamMaxTileJobs == kItems * 512, "tile job capacity of the 512-thread instance");
 
 __device__ __forceinline__ int d_slanted_radius(uint32_t n, uint32_t m, int r0)
 {
@@ -70,9 +71,9 @@ __device__ uint32_t d_banded_cells(uint32_t n, uint32_t m, int R)
     return cells;
 }
 
-// inclusive scan of one value per thread over the workgroup (kT threads); `tmp` holds kT/64 words.  *excl (optional)
+// inclusive scan of one value per thread over the workgroup (NT threads); `tmp` holds NT/64 words.  *excl (optional)
 // receives the exclusive value, *total the reduction over all threads.
-template <typename Op>
+template <int NT = kT, typename Op>
 __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *tmp, Op op, uint32_t identity, uint32_t *total,
                                                     uint32_t *excl = nullptr)
 {
@@ -87,7 +88,7 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *tmp, O
     __syncthreads();
     uint32_t pre = identity, all = identity;
 #pragma unroll
-    for (int w = 0; w < kT / 64; w++) {
+    for (int w = 0; w < NT / 64; w++) {
         const uint32_t x = tmp[w];
         if (w < wv) pre = op(pre, x);
         all = op(all, x);
@@ -101,124 +102,109 @@ __device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t *tmp, O
 struct OpAdd { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
 struct OpMax { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 
-// first index in [0, n) with a[i] > key (n when none)
-__device__ __forceinline__ uint64_t upper_bound_u64(const uint64_t *a, uint64_t n, uint64_t key)
-{
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (a[mid] > key) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-// first index in [0, n) with a[i] >= key (n when none)
-__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t *a, uint64_t n, uint64_t key)
-{
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (a[mid] >= key) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_pre
 // ---------------------------------------------------------------------------------------------------------------------
+// Latency is what this kernel costs (its arithmetic is ~20 M wave instructions, its traffic ~120 MB): every job needs
+// its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs and
+// every stage below issues the loads of all of them before anything waits, and nothing in the job path crosses a
+// workgroup barrier.
 __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 {
-    __shared__ uint32_t s_cidx[kPreUnit]; // chain (relative, +1) that starts at this job of the unit; then: chain of every job
-    __shared__ uint32_t s_tmp[kT / 64];
-    __shared__ uint64_t s_c[2];
+    constexpr uint32_t kPer = kPreUnit / kT;
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses];
-    __shared__ unsigned long long s_bytes, s_obytes;
-    __shared__ uint32_t s_tiles, s_maxc;
+    __shared__ unsigned long long s_stats[3]; // tile jobs, tile bytes, side-list bytes
     const int tid = threadIdx.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * kPreUnit;
-    const uint32_t cnt = (uint32_t)min<uint64_t>(kPreUnit, a.n_jobs - j0);
-    if (tid == 0) {
-        // chains [c_lo, c_hi) own the unit's jobs: job_off[c_lo] <= j0 < job_off[c_lo + 1]; job_off[c_hi] >= j0 + cnt
-        s_c[0] = upper_bound_u64(a.job_off, a.n_chains + 1, j0) - 1;
-        s_c[1] = lower_bound_u64(a.job_off, a.n_chains + 1, j0 + cnt);
-        s_ocnt = 0; s_bytes = 0; s_obytes = 0; s_tiles = 0; s_maxc = 0;
-    }
+    if (tid == 0) s_ocnt = 0;
+    if (tid < 3) s_stats[tid] = 0;
     if (tid < (int)kStreamClasses) s_cls[tid] = 0;
-    for (uint32_t i = tid; i < kPreUnit; i += kT) s_cidx[i] = 0;
-    __syncthreads();
-    const uint64_t c_lo = s_c[0], c_hi = s_c[1];
-    for (uint64_t c = c_lo + tid; c < c_hi; c += kT) {
-        const uint64_t b = a.job_off[c], e = a.job_off[c + 1];
-        if (e > b) atomicMax(&s_cidx[(uint32_t)((b > j0 ? b : j0) - j0)], (uint32_t)(c - c_lo) + 1u);
+    // chains [c_lo, c_hi] own the unit's jobs: job_off[c_lo] <= j0 < job_off[c_lo + 1], c_hi = the chain of the next unit's
+    // first job (the host tabulates the unit -> chain map while it counts the jobs; the table ends with n_chains - 1)
+    const uint64_t c_lo = a.unit_chain[blockIdx.x], c_hi = a.unit_chain[blockIdx.x + 1];
+    const uint64_t jf = j0 + (uint64_t)tid * kPer; // this thread's first job
+    // ---- stage 1: the chain of the thread's first job (last chain c in [c_lo, c_hi] with job_off[c] <= jf; the step count
+    // is the same for the whole workgroup), then of the following jobs (usually the same chain) ----
+    uint64_t c[kPer];
+    {
+        uint64_t lo = c_lo, hi = c_hi; // invariant: job_off[lo] <= jf, answer in [lo, hi]
+        for (uint64_t span = c_hi - c_lo; span > 0; span >>= 1) {
+            const uint64_t mid = lo + ((hi - lo + 1) >> 1);
+            if (hi > lo) { if (a.job_off[mid] <= jf) lo = mid; else hi = mid - 1; }
+        }
+        // chains without jobs share their successor's offset: the search lands on the LAST of them, which owns the job
+        c[0] = lo;
     }
-    __syncthreads();
-    {   // running maximum over the unit: thread t owns entries [4t, 4t + 4)
-        constexpr uint32_t PER = kPreUnit / kT;
-        uint32_t v[PER];
-        uint32_t run = 0;
+    bool have[kPer];
 #pragma unroll
-        for (uint32_t k = 0; k < PER; k++) { run = max(run, s_cidx[tid * PER + k]); v[k] = run; }
-        uint32_t excl = 0;
-        (void)block_scan_incl(run, s_tmp, OpMax(), 0u, nullptr, &excl);
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) s_cidx[tid * PER + k] = max(v[k], excl);
+    for (uint32_t k = 0; k < kPer; k++) {
+        have[k] = jf + k < a.n_jobs;
+        if (k) c[k] = c[k - 1];
+        if (have[k]) while (a.job_off[c[k] + 1] <= jf + k) c[k]++;
     }
-    __syncthreads();
-
-    uint32_t my_tiles = 0, my_max = 0;
+    // ---- stage 2: the chains' offsets ----
+    uint64_t jo[kPer], a0[kPer], a1[kPer], rb[kPer];
+    uint32_t qb[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const uint64_t cc = have[k] ? c[k] : c_lo;
+        jo[k] = a.job_off[cc]; a0[k] = a.anchor_off[cc]; a1[k] = a.anchor_off[cc + 1]; rb[k] = a.ref_base[cc]; qb[k] = a.read_base[cc];
+    }
+    // ---- stage 3: the anchors: this part's (s, e), the end of the part before (sp) and of the part after (en) ----
+    rawdtw_anchor_t S[kPer], E[kPer], SP[kPer], EN[kPer];
+    uint32_t P[kPer], parts[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        parts[k] = (uint32_t)(a1[k] - a0[k]) - 1u;
+        P[k] = (uint32_t)(jf + k - jo[k]);
+        const uint64_t g = a0[k] + parts[k] - P[k]; // rmap.cpp:253-254: part p runs from anchors[parts - p] to anchors[parts - p - 1]
+        S[k] = E[k] = SP[k] = EN[k] = rawdtw_anchor_t{0, 0};
+        if (have[k]) {
+            S[k] = a.anchors[g]; E[k] = a.anchors[g - 1];
+            if (P[k] > 0) SP[k] = a.anchors[g + 1];
+            if (P[k] + 1 < parts[k]) EN[k] = a.anchors[g - 2];
+        }
+    }
+    // ---- stage 4: geometry, class, record ----
+    uint32_t my_tiles = 0;
     unsigned long long my_bytes = 0, my_obytes = 0;
-    DevJob oj[kPreUnit / kT];
-    uint32_t oslot[kPreUnit / kT];
-    uint8_t ocl[kPreUnit / kT];
+    auto tile_class = [&](const rawdtw_anchor_t &s, const rawdtw_anchor_t &e) { // would the part s -> e be a tile job?
+        if (!(e.target_position >= s.target_position && e.query_position >= s.query_position)) return false;
+        const uint32_t m = e.target_position - s.target_position + 1, n = e.query_position - s.query_position + 1;
+        int r = (int)((float)n * a.frac);
+        r = r > 1 ? r : 1;
+        return d_slanted_radius(n, m, r) <= a.lane_max_radius && max(n, m) <= a.lane_max_n; // (r >= 1)
+    };
 #pragma unroll
-    for (uint32_t k = 0; k < kPreUnit / kT; k++) {
-        const uint32_t i = k * kT + tid; // strided: coalesced stores
-        oslot[k] = 0xffffffffu;
-        if (i >= cnt) continue;
-        const uint64_t j = j0 + i;
-        const uint64_t c = c_lo + s_cidx[i] - 1u;
-        const uint32_t p = (uint32_t)(j - a.job_off[c]);
-        const uint64_t a0 = a.anchor_off[c];
-        const uint32_t parts = (uint32_t)(a.anchor_off[c + 1] - a0) - 1u;
-        const rawdtw_anchor_t s = a.anchors[a0 + parts - p];     // rmap.cpp:253
-        const rawdtw_anchor_t e = a.anchors[a0 + parts - p - 1]; // rmap.cpp:254
+    for (uint32_t k = 0; k < kPer; k++) {
+        if (!have[k]) continue;
+        const uint64_t j = jf + k;
+        const rawdtw_anchor_t s = S[k], e = E[k];
         bool ok = e.target_position >= s.target_position && e.query_position >= s.query_position;
-        const uint64_t ref_off = a.ref_base[c] + s.target_position;
-        const uint32_t read_off = a.read_base[c] + s.query_position;
+        const uint64_t ref_off = rb[k] + s.target_position;
+        const uint32_t read_off = qb[k] + s.query_position;
         const uint32_t m = e.target_position - s.target_position + 1;
         const uint32_t n = e.query_position - s.query_position + 1;
-        if ((uint64_t)a.read_base[c] + s.query_position + n > a.n_ev || ref_off + m > a.n_ref || n >= 0x7fffffffu || m >= 0x7fffffffu)
-            ok = false;
-        const bool excl = p != parts - 1; // rmap.cpp:270
+        if ((uint64_t)qb[k] + s.query_position + n > a.n_ev || ref_off + m > a.n_ref || n >= 0x7fffffffu || m >= 0x7fffffffu) ok = false;
+        const bool excl = P[k] != parts[k] - 1; // rmap.cpp:270
         int r0 = (int)((float)n * a.frac); // rmap.cpp:276, fp32 product
         r0 = r0 > 1 ? r0 : 1;
         const int R = ok ? d_slanted_radius(n, m, r0) : 0;
         const uint32_t N = n > m ? n : m, M = n > m ? m : n;
-        const bool tile = ok && R <= a.lane_max_radius && N <= a.lane_max_n;
-        uint32_t meta = 0, cost8 = a.min_cost8;
+        const bool tile = ok && R >= 1 && R <= a.lane_max_radius && N <= a.lane_max_n; // (radius 0 cannot come from rmap.cpp:276)
+        uint32_t meta = 0;
         if (!ok) atomicMin(&a.cnt[kCntBad], (unsigned long long)j);
         if (tile) {
-            // a tile job continues its chain's run when the part before it is a tile job too: consecutive parts share their
-            // anchor element, so the run is one contiguous span of each arena
-            bool starts = true;
-            if (p > 0) {
-                const rawdtw_anchor_t sp = a.anchors[a0 + parts - p + 1];
-                const bool okp = s.target_position >= sp.target_position && s.query_position >= sp.query_position;
-                const uint32_t mp = s.target_position - sp.target_position + 1, np = s.query_position - sp.query_position + 1;
-                int rp = (int)((float)np * a.frac);
-                rp = rp > 1 ? rp : 1;
-                const int Rp = okp ? d_slanted_radius(np, mp, rp) : 99;
-                if (okp && Rp <= a.lane_max_radius && max(np, mp) <= a.lane_max_n) starts = false;
-            }
+            // a tile job continues its chain's run when the part before it is a tile job too (consecutive parts share their
+            // anchor element: the run is one contiguous piece of each arena), and ends the run when the part after it is
+            // not one: the run's end is then padded to a 16-byte boundary, so that two runs never share a chunk of the image
+            const bool starts = !(P[k] > 0 && tile_class(SP[k], s));
+            const bool ends = !(P[k] + 1 < parts[k] && tile_class(e, EN[k]));
             meta = N | (M << 7) | ((uint32_t)R << 14) | ((excl ? 1u : 0u) << 16) | ((n < m ? 1u : 0u) << 17) |
-                   ((starts ? 1u : 0u) << 18) | kMetaTile;
-            // in eighths of a float; a run start pays both windows, their start alignment and the padding of two span ends
-            cost8 = 8u * (starts ? n + m + (read_off & 3u) + (uint32_t)(ref_off & 3ull) + 6u : n + m - 2u);
-            if (starts && cost8 < a.run_cost8) cost8 = a.run_cost8; // bounds the runs of a tile
-            if (cost8 < a.min_cost8) cost8 = a.min_cost8;           // bounds the jobs of a tile
+                   ((starts ? 1u : 0u) << 18) | kMetaTile | (ends ? kMetaEnds : 0u);
             my_tiles++;
-            my_max = max(my_max, cost8);
             my_bytes += 4ull * ((unsigned long long)n + m) + 36ull;
         } else if (ok) {
             const uint32_t K = (uint32_t)R + 1u;
@@ -228,48 +214,49 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
             else cls = 0xff;
             if (cls == 0xff) atomicAdd(&a.cnt[kCntUnsupported], 1ull);
-            else {
-                oslot[k] = atomicAdd(&s_ocnt, 1u);
-                atomicAdd(&s_cls[cls], 1u);
-                ocl[k] = (uint8_t)cls;
-                oj[k].ref_off = ref_off; oj[k].read_off = read_off; oj[k].n = n; oj[k].m = m; oj[k].R = R;
-                oj[k].flags = excl ? kFlagExcludeLast : 0u; oj[k].aux = (uint32_t)j;
-                my_obytes += 4ull * ((unsigned long long)n + m) + 36ull;
-            }
+            else meta = (cls + 1u) | ((uint32_t)R << 8); // (side list: class and radius travel in the record until the append below)
+            my_obytes += 4ull * ((unsigned long long)n + m) + 36ull;
         }
-        a.jrec[j] = JobRec{ref_off, read_off, meta};
-        a.lds_cost[j] = cost8;
+        a.jrec[j] = JobRec{ref_off, read_off, (meta & kMetaTile) ? meta : 0u};
+        // the side list: rare (a few jobs per workgroup)
+        if (!(meta & kMetaTile) && meta) {
+            const uint32_t cls = (meta & 0xffu) - 1u;
+            const uint32_t slot = atomicAdd(&s_ocnt, 1u);
+            atomicAdd(&s_cls[cls], 1u);
+            // parked in registers-free form: recomputed from the record at append time (below) would need the shape again,
+            // so stage it in the side list's own staging slot right away: the slot index is fixed, only the base is not
+            P[k] = slot; parts[k] = cls | 0x80000000u;
+            S[k] = rawdtw_anchor_t{n, m}; E[k] = rawdtw_anchor_t{(uint32_t)R, excl ? kFlagExcludeLast : 0u};
+            SP[k] = rawdtw_anchor_t{read_off, (uint32_t)j}; jo[k] = ref_off;
+        } else parts[k] = 0;
     }
-    // totals: one atomic per workgroup and counter
+    // totals: per workgroup, then one record per unit (reduced by k_others); the side list's base: one returning atomic per
+    // workgroup that has side-list jobs
     for (int off = 32; off > 0; off >>= 1) {
         my_tiles += __shfl_down((int)my_tiles, off);
-        my_max = max(my_max, (uint32_t)__shfl_down((int)my_max, off));
         my_bytes += __shfl_down(my_bytes, off);
         my_obytes += __shfl_down(my_obytes, off);
     }
     if ((tid & 63) == 0) {
-        atomicAdd(&s_tiles, my_tiles); atomicMax(&s_maxc, my_max);
-        atomicAdd(&s_bytes, my_bytes); atomicAdd(&s_obytes, my_obytes);
+        atomicAdd(&s_stats[0], (unsigned long long)my_tiles); atomicAdd(&s_stats[1], my_bytes); atomicAdd(&s_stats[2], my_obytes);
     }
     __syncthreads();
-    if (tid == 0) {
-        if (s_tiles) { atomicAdd(&a.cnt[kCntTileJobs], (unsigned long long)s_tiles); atomicAdd(&a.cnt[kCntTileBytes], s_bytes); }
-        if (s_maxc) atomicMax(&a.cnt[kCntMaxCost8], (unsigned long long)s_maxc);
-        if (s_obytes) atomicAdd(&a.cnt[kCntOtherBytes], s_obytes);
-        uint32_t base = 0;
-        if (s_ocnt) base = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
-        s_obase = base;
-    }
+    if (tid == 0) s_obase = s_ocnt ? (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt) : 0u;
+    if (tid < 3) a.unit_stats[3ull * blockIdx.x + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     __syncthreads();
     if (s_ocnt) {
         const uint64_t base = s_obase;
 #pragma unroll
-        for (uint32_t k = 0; k < kPreUnit / kT; k++) {
-            if (oslot[k] == 0xffffffffu) continue;
-            const uint64_t q = base + oslot[k];
-            if (q < a.others_cap) { a.omix[q] = oj[k]; a.ocls[q] = ocl[k]; }
-            // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
+        for (uint32_t k = 0; k < kPer; k++) {
+            if (!have[k] || !(parts[k] & 0x80000000u)) continue;
+            const uint64_t q = base + P[k];
+            if (q < a.others_cap) { // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
+                DevJob d;
+                d.ref_off = jo[k]; d.read_off = SP[k].target_position; d.n = S[k].target_position; d.m = S[k].query_position;
+                d.R = (int32_t)E[k].target_position; d.flags = E[k].query_position; d.aux = SP[k].query_position;
+                a.omix[q] = d; a.ocls[q] = (uint8_t)(parts[k] & 0xffu);
+            }
         }
     }
 }
@@ -281,15 +268,52 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kT + threadIdx.x;
-    const uint64_t width8 = 8ull * a.tile_budget - a.cnt[kCntMaxCost8];
     const uint64_t n = a.n_jobs;
-    const uint64_t n_tiles = (n >= 2 ? a.cum[n - 2] / width8 : 0ull) + 1ull;
+    const uint64_t n_tiles = (n >= 2 ? a.cum[n - 2].cost / a.width8 : 0ull) + 1ull;
     if (k == 0) {
         a.cnt[kCntTiles] = n_tiles;
         if (n_tiles > a.tiles_cap) atomicMin(&a.cnt[kCntOverflow], 0ull);
     }
     if (k > n_tiles || k > a.tiles_cap) return;
-    a.tile_first[k] = k == 0 ? 0u : k == n_tiles ? (uint32_t)n : (uint32_t)(1ull + lower_bound_u64(a.cum, n, k * width8));
+    auto first_of = [&](uint64_t q) -> uint64_t {
+        if (q == 0) return 0;
+        if (q >= n_tiles) return n;
+        const uint64_t key = q * a.width8;
+        uint64_t lo = 0, hi = n; // first job whose inclusive cost reaches the key
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (a.cum[mid].cost >= key) hi = mid; else lo = mid + 1;
+        }
+        return lo + 1;
+    };
+    TileInfo t{};
+    const uint64_t first = first_of(k), end = first_of(k + 1);
+    t.first = (uint32_t)first;
+    t.n = (uint32_t)(end - first);
+    t.first_tile = t.n;
+    if (t.n) {
+        // The regions run from the first tile-class job's first chunk to the last one's last element: with these exact
+        // bounds every chunk of the image belongs to a job (k_stream needs no clearing pass).  Jobs of other classes
+        // inside the range are rare: the walks below are one or two steps.
+        uint64_t f = first, l = end;
+        while (f < end && !(a.jrec[f].meta & kMetaTile)) f++;
+        while (l > f && !(a.jrec[l - 1].meta & kMetaTile)) l--;
+        if (f < end) {
+            const JobRec rf = a.jrec[f], rl = a.jrec[l - 1];
+            const Cum cf = f ? a.cum[f - 1] : Cum{0u, 0u, 0ull};
+            const Cum cl = l - 1 ? a.cum[l - 2] : Cum{0u, 0u, 0ull};
+            const bool sf = (rf.meta >> 18) & 1u, sl = (rl.meta >> 18) & 1u, swl = (rl.meta >> 17) & 1u;
+            const uint32_t Nl = rl.meta & 127u, Ml = (rl.meta >> 7) & 127u;
+            t.base_read = image_pos(cf.read, rf.read_off, sf) & ~3u;
+            t.base_ref = image_pos(cf.ref, rf.ref_off, sf) & ~3u;
+            const uint32_t read_end = image_pos(cl.read, rl.read_off, sl) + (swl ? Ml : Nl);
+            const uint32_t ref_end = image_pos(cl.ref, rl.ref_off, sl) + (swl ? Nl : Ml);
+            t.ref_region = (read_end - t.base_read + 3u) & ~3u; // LDS float offset of the reference region
+            t.image = t.ref_region + ((ref_end - t.base_ref + 3u) & ~3u);
+            t.first_tile = (uint32_t)(f - first);
+        }
+    }
+    a.tiles[k] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -297,13 +321,29 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
 {
+    if (blockIdx.x == gridDim.x - 1) { // the last workgroup adds up k_pre's per-unit totals instead (a few thousand records)
+        const uint64_t n_units = (a.n_jobs + kPreUnit - 1) / kPreUnit;
+        unsigned long long t[3] = {0, 0, 0};
+        for (uint64_t u = threadIdx.x; u < n_units; u += kT)
+            for (int q = 0; q < 3; q++) t[q] += a.unit_stats[3 * u + q];
+        __shared__ unsigned long long s_t[3];
+        if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
+        __syncthreads();
+        for (int q = 0; q < 3; q++) {
+            for (int off = 32; off > 0; off >>= 1) t[q] += __shfl_down(t[q], off);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_t[q], t[q]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { a.cnt[kCntTileJobs] = s_t[0]; a.cnt[kCntTileBytes] = s_t[1]; a.cnt[kCntOtherBytes] = s_t[2]; }
+        return;
+    }
     const uint64_t n_other = min<uint64_t>(a.cnt[kCntOthers], a.others_cap);
     uint64_t base[kStreamClasses];
     uint64_t acc = 0;
 #pragma unroll
     for (uint32_t c = 0; c < kStreamClasses; c++) { base[c] = acc; acc += a.cnt[kCntCls0 + c]; }
     const int lane = threadIdx.x & 63;
-    for (uint64_t i0 = ((uint64_t)blockIdx.x * kT + threadIdx.x) & ~63ull; i0 < n_other; i0 += (uint64_t)gridDim.x * kT) {
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * kT + threadIdx.x) & ~63ull; i0 < n_other; i0 += (uint64_t)(gridDim.x - 1) * kT) {
         const uint64_t i = i0 + lane;
         const uint32_t cls = i < n_other ? a.ocls[i] : 0xffu;
         uint64_t pos = ~0ull;
@@ -340,8 +380,36 @@ __global__ __launch_bounds__(kT) void k_chain_desc(const StreamArgs a, ChainDesc
         d.num_aligned = (last.query_position - first.query_position) + d.n_jobs;       // sum of the parts' read regions (rmap.cpp:292)
     }
     chains[c] = d;
-    key[c] = min(d.n_jobs, 65535u);
-    val[c] = (uint32_t)c;
+    key[c] = d.n_jobs;
+    (void)val;
+}
+
+// Fold order: chains by part count, longest first (the lane-per-chain fold gives a wave 64 chains of similar length).
+// One workgroup: a counting sort over 1024 length buckets in LDS (the order inside a bucket does not matter).
+__global__ __launch_bounds__(1024) void k_fold_order(uint64_t n_chains, const uint32_t *__restrict__ key, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    auto bucket = [](uint32_t k) { return 1023u - min(k, 1023u); };
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint64_t c = tid; c < n_chains; c += 1024) atomicAdd(&hist[bucket(key[c])], 1u);
+    __syncthreads();
+    uint32_t v = hist[tid], incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wv; w++) pre += wsum[w];
+    __syncthreads();
+    hist[tid] = pre + incl - v; // exclusive start of the bucket
+    __syncthreads();
+    for (uint64_t c = tid; c < n_chains; c += 1024) order[atomicAdd(&hist[bucket(key[c])], 1u)] = (uint32_t)c;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -349,27 +417,19 @@ __global__ __launch_bounds__(kT) void k_chain_desc(const StreamArgs a, ChainDesc
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-// LDS scratch: the run table while a tile is laid out, then the sort's histogram and permutation
-struct RunTable {
-    uint64_t ref_start[kStreamMaxRuns];
-    uint32_t read_start[kStreamMaxRuns];
-    uint32_t read_len[kStreamMaxRuns], ref_len[kStreamMaxRuns];   // floats, then rounded up to multiples of 4
-    uint32_t span_off[2 * kStreamMaxRuns + 1];                    // LDS float offset of span 2r (events) and 2r + 1 (reference)
-};
 constexpr uint32_t kSortBins = 512; // bin = kind * 80 + (79 - longer side): 6 kinds x 80
-struct SortTable {
+template <int TT> struct SortTable {
     uint32_t hist[kSortBins];
-    uint16_t perm[kStreamMaxTileJobs];
+    uint16_t perm[kItems * TT];
 };
-union Scratch { RunTable runs; SortTable sort; };
 
 __device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, int kind,
                                                  uint32_t R, bool excl, const unsigned long long *__restrict__ masks, bool act)
 {
     float res = 0.0f;
     const int k = act ? kind : -1;
-    if (__any(k == 0)) {
-        if (k == 0) {
+    if (__any(k == 2)) {
+        if (k == 2) {
             const unsigned long long mask = masks[((N - 1) * 8 + (M - 1)) * (kMaxLaneRadius + 1) + R];
             const uint32_t Nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)N); // sorted by longer side, descending
             if (Nw <= 2) res = micro_job_cols<4, 2>(LA, LB, N, M, mask);
@@ -387,224 +447,240 @@ __device__ __forceinline__ float stream_lane_job(const float *LA, const float *L
             else res = micro_job_cols<8, 8>(LA, LB, N, M, mask);
         }
     }
-#define RAWDTW_LANE_KIND(RR)                                                                                                   \
-    if (__any(k == 2 + RR)) {                                                                                                  \
-        if (k == 2 + RR) {                                                                                                     \
-            const uint32_t N0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)N), M0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)M); \
-            if (__all(N == N0)) {                                                                                              \
-                if (__all(M == M0)) res = lane_dp<RR>(LA, LB, N0, M0);                                                         \
-                else res = lane_dp_sel<RR>(LA, LB, N0, M);                                                                     \
-            } else res = lane_dp_sel<RR>(LA, LB, N, M);                                                                        \
-        }                                                                                                                      \
+    if (__any(k == 0)) { // every other shape, any radius: one generic body, lanes sorted by longer side (descending)
+        if (k == 0) res = lane_dp_gen(LA, LB, N, M, R, (uint32_t)__builtin_amdgcn_readfirstlane((int)N));
     }
-    RAWDTW_LANE_KIND(0)
-    RAWDTW_LANE_KIND(1)
-    RAWDTW_LANE_KIND(2)
-    RAWDTW_LANE_KIND(3)
-#undef RAWDTW_LANE_KIND
     if (act && excl) res = res - dist(LA[N - 1], LB[M - 1]);
     return res;
 }
 
 } // namespace
 
-__global__ __launch_bounds__(kT) void k_stream(const StreamArgs a, const uint32_t others_blocks, const uint32_t lds_floats)
+// Tile queue: one returning atomic on a single word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md),
+// which a batch's ten thousand tiles would reach; eight heads on lines of their own, each dealing every eighth tile.
+// A workgroup starts on the head of its block index and moves on when a head runs dry.
+__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, uint32_t &head, uint32_t n_tiles)
+{
+    if (a.debug & 8u) { // timing experiments: tiles dealt by block index, no queue
+        const uint32_t t = head;
+        head += gridDim.x;
+        return t < n_tiles ? t : 0xffffffffu;
+    }
+    for (uint32_t tries = 0; tries < 8; tries++) {
+        const uint32_t h = (head + tries) & 7u;
+        const uint32_t k = (uint32_t)atomicAdd(&a.cnt[kCntHeads + 16 * h], 1ull);
+        const uint64_t t = (uint64_t)k * 8u + h;
+        if (t < n_tiles) { head = h; return (uint32_t)t; }
+    }
+    return 0xffffffffu;
+}
+
+// TT threads per workgroup (256 or 512): a tile's range holds up to 4 * TT jobs.  More jobs per tile = fuller and more
+// uniform waves after the sort (the lane class's first wave carries the tile's few long jobs) and half as many tiles.
+template <int TT>
+__global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint32_t lds_floats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *win = smem;                                                            // the tile's LDS image
     uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);                    // one record per job of the tile's range
-    Scratch &sc = *reinterpret_cast<Scratch *>(smem + lds_floats + 2 * kStreamMaxTileJobs);
-    __shared__ uint32_t s_tmp[kT / 64];
-    __shared__ uint32_t s_next, s_first_flag;
+    constexpr uint32_t kMaxJobs = kItems * TT;
+    SortTable<TT> &sc = *reinterpret_cast<SortTable<TT> *>(smem + lds_floats + 2 * kMaxJobs);
+    __shared__ uint32_t s_tmp[TT / 64];
+    __shared__ TileInfo s_tile[2];
+    __shared__ uint32_t s_seq;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
 
-    // ---- the side list: wave-cooperative jobs, wave-per-job classes first ----
-    if (blockIdx.x < others_blocks) {
+    // ---- the side list: wave-cooperative jobs dealt over ALL waves of the grid, wave-per-job classes (longest first) to the
+    // first waves: a long job starts at once and runs next to the tiles instead of behind them ----
+    if (!(a.debug & 4u)) {
         uint64_t n_w = 0;
 #pragma unroll
         for (uint32_t c = kClsW0; c < kClsW0 + 4; c++) n_w += a.cnt[kCntCls0 + c];
         const uint64_t n_g16 = a.cnt[kCntCls0 + kClsG16], n_g8 = a.cnt[kCntCls0 + kClsG8];
-        const uint64_t cap = a.others_cap;
-        if (n_w + n_g16 + n_g8 <= cap) { // (otherwise the batch is redone through the job-list path)
+        if (n_w + n_g16 + n_g8 <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
             const uint64_t it_g16 = (n_g16 + 3) / 4, it_g8 = (n_g8 + 7) / 8, items = n_w + it_g16 + it_g8;
-            for (uint64_t it = (uint64_t)blockIdx.x * (kT / 64) + wv; it < items; it += (uint64_t)others_blocks * (kT / 64)) {
-                if (it < n_w) wreg_small_job(a.ojobs[it], lane, a.ev, a.ref, a.out);
+            for (uint64_t it = (uint64_t)blockIdx.x * (TT / 64) + wv; it < items; it += (uint64_t)gridDim.x * (TT / 64)) {
+                if (it < n_w) { if (!(a.debug & 32u)) wreg_small_job(a.ojobs[it], lane, a.ev, a.ref, a.out); }
+                else if (a.debug & 64u) continue;
                 else if (it < n_w + it_g16) grp_wave<16>(a.ojobs + n_w, (uint32_t)n_g16, (uint32_t)(it - n_w), lane, a.ev, a.ref, a.out);
                 else grp_wave<8>(a.ojobs + n_w + n_g16, (uint32_t)n_g8, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
             }
         }
     }
 
-    // ---- tiles: the first (gridDim - others_blocks) tiles are dealt by block index, the rest pulled from the queue ----
+    // ---- tiles, pulled from the queue two ahead: while tile i is computed, tile i + 1's records are already on their way
+    // into registers and tile i + 2's number is being dequeued -- no global round trip sits between two tiles ----
     const uint32_t n_tiles = (uint32_t)min<unsigned long long>(a.cnt[kCntTiles], (unsigned long long)a.tiles_cap);
-    const uint32_t n_static = gridDim.x - others_blocks;
-    uint32_t t;
-    if (blockIdx.x >= others_blocks) t = blockIdx.x - others_blocks;
-    else {
-        if (tid == 0) s_next = n_static + (uint32_t)atomicAdd(&a.cnt[kCntQueue], 1ull);
-        __syncthreads();
-        t = s_next;
-        __syncthreads();
+    // thread 0's queue state: `head`, the resolved number of the next tile, the raw ticket of the one after it
+    uint32_t head = (a.debug & 8u) ? blockIdx.x : (blockIdx.x & 7u), t_next = 0xffffffffu;
+    if (tid == 0) {
+        const uint32_t t0 = next_tile(a, head, n_tiles);
+        t_next = t0 != 0xffffffffu ? next_tile(a, head, n_tiles) : 0xffffffffu;
+        s_tile[0] = t0 != 0xffffffffu ? a.tiles[t0] : TileInfo{};
+        s_seq = 0;
     }
-    while (t < n_tiles) {
-        if (tid == 0) s_next = n_static + (uint32_t)atomicAdd(&a.cnt[kCntQueue], 1ull); // the next tile's number travels meanwhile
-        const uint32_t first = a.tile_first[t];
-        const uint32_t n = a.tile_first[t + 1] - first; // jobs in the tile's range (tile-class or not)
-        if (n > kStreamMaxTileJobs) { // cannot happen with the cost floor; keep the batch safe
-            if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)t);
-            __syncthreads();
-            t = s_next;
-            __syncthreads();
-            continue;
-        }
-        // ---- 1. the range's records (blocked: thread t owns jobs [kItems * t, kItems * t + kItems)) and its runs ----
-        JobRec jr[kItems];
-        uint32_t packed = 0; // low half: tile jobs, high half: run starts (by the chain rule) among this thread's jobs
+    for (uint32_t b = tid; b < kSortBins; b += TT) sc.hist[b] = 0;
+    __syncthreads();
+    uint32_t slot = 0, seq = 1; // seq: tag of the image's chunk marks (stale marks of an earlier tile never match)
+    TileInfo D = s_tile[0];
+    JobRec jr[kItems];
+    uint32_t ce_read = 0, ce_ref = 0; // running sums BEFORE this thread's first job of the tile
+    auto fetch_records = [&](const TileInfo &T, JobRec (&r)[kItems], uint32_t &c_read, uint32_t &c_ref) {
 #pragma unroll
         for (uint32_t k = 0; k < kItems; k++) {
-            const uint32_t i = tid * kItems + k;
-            jr[k] = JobRec{0, 0, 0};
-            if (i < n) jr[k] = a.jrec[first + i];
-            if (jr[k].meta & kMetaTile) packed += 1u + ((jr[k].meta & kMetaStarts) ? 0x10000u : 0u);
+            const uint32_t i = tid * kItems + k; // thread t owns jobs [kItems * t, kItems * t + kItems) of the range
+            r[k] = JobRec{0, 0, 0};
+            if (i < T.n) r[k] = a.jrec[T.first + i];
         }
-        uint32_t total = 0;
-        const uint32_t incl = block_scan_incl(packed, s_tmp, OpAdd(), 0u, &total);
-        uint32_t run = incl - packed; // exclusive counts before this thread's first job
-        const uint32_t n_tile_jobs = total & 0xffffu;
-        // the tile's first tile job opens a run whether or not its chain's run began in the previous tile
-        if (tid == 0) s_first_flag = 0;
-        __syncthreads();
-        uint32_t rid[kItems];
-        bool opens[kItems];
+        const uint32_t i0 = tid * kItems;
+        c_read = 0; c_ref = 0;
+        if (i0 < T.n && T.first + i0 > 0) { const Cum c = a.cum[T.first + i0 - 1]; c_read = c.read; c_ref = c.ref; }
+    };
+    fetch_records(D, jr, ce_read, ce_ref);
+    while (D.n) {
+        // thread 0: the next tile's geometry and the ticket of the one after it -- issued now, consumed at the publish
+        // below (nothing here waits for them)
+        TileInfo D1{};
+        unsigned long long ticket = 0;
+        if (tid == 0 && t_next != 0xffffffffu) {
+            D1 = a.tiles[t_next];
+            if (!(a.debug & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+        }
+        const uint32_t first = D.first, n = D.n;
+        const bool bad = n > kMaxJobs || D.image > lds_floats; // cannot happen with the cost floor and the bracket rule
+        if (bad && tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)first);
+        const uint32_t tag = seq++;
+        // ---- 1. records, chunk marks, histogram: every job's place in the image from its own running sums ----
+        uint32_t bin[kItems], rank[kItems];
         {
-            uint32_t tiles_before = run & 0xffffu, starts_incl = run >> 16;
+            uint32_t c_read = ce_read, c_ref = ce_ref;
 #pragma unroll
             for (uint32_t k = 0; k < kItems; k++) {
-                rid[k] = 0;
-                opens[k] = false;
-                if (jr[k].meta & kMetaTile) {
-                    opens[k] = (jr[k].meta & kMetaStarts) || tiles_before == 0;
-                    if (jr[k].meta & kMetaStarts) starts_incl++;
-                    else if (tiles_before == 0) s_first_flag = 1; // (one thread at most: the tile's first tile job)
-                    rid[k] = starts_incl; // run number + 1 - F, fixed up below
-                    tiles_before++;
+                bin[k] = 0xffffffffu;
+                const Cum d = job_cum(jr[k], a.min_cost8);
+                if ((jr[k].meta & kMetaTile) && !bad) {
+                    const uint32_t i = tid * kItems + k;
+                    const uint32_t N = jr[k].meta & 127u, M = (jr[k].meta >> 7) & 127u, R = (jr[k].meta >> 14) & 3u;
+                    const bool swap = (jr[k].meta >> 17) & 1u, starts = (jr[k].meta >> 18) & 1u;
+                    const uint32_t p_read = image_pos(c_read, jr[k].read_off, starts) - D.base_read;
+                    const uint32_t p_ref = image_pos(c_ref, jr[k].ref_off, starts) - D.base_ref + D.ref_region;
+                    const uint32_t kind = N <= a.micro_max_n ? (N <= 4 ? 2u : 1u) : 0u; // the heavy class first
+                    rec[i] = make_uint2((swap ? p_ref : p_read) | ((swap ? p_read : p_ref) << 16),
+                                        N | (M << 7) | (R << 14) | (((jr[k].meta >> 16) & 1u) << 16) | (kind << 17));
+                    bin[k] = kind * 80u + (79u - N);
+                    rank[k] = atomicAdd(&sc.hist[bin[k]], 1u);
+                    // Marks: every 16-byte chunk the two windows touch gets (arena index - image offset) and the tile's tag:
+                    // the same value for all chunks of a run, and two runs never share a chunk.  A run start also owns the
+                    // (at most one) chunk of slack between the previous run's last chunk and its own first one.
+                    if (!(a.debug & 16u)) {
+#pragma unroll
+                        for (uint32_t w = 0; w < 2; w++) {
+                            const uint32_t P = w ? p_ref : p_read, L = w ? (swap ? N : M) : (swap ? M : N);
+                            const long long delta = (w ? (long long)jr[k].ref_off : (long long)jr[k].read_off) - (long long)P;
+                            const uint4 mark = make_uint4((uint32_t)delta, (uint32_t)((unsigned long long)delta >> 32), 0x5eed0000u ^ tag, tag);
+                            for (uint32_t c = P & ~3u; c < P + L; c += 4u) *reinterpret_cast<uint4 *>(win + c) = mark;
+                            if (starts && i != D.first_tile) {
+                                const uint32_t gap = ((w ? c_ref - D.base_ref + D.ref_region : c_read - D.base_read)) & ~3u;
+                                if (gap < (P & ~3u)) *reinterpret_cast<uint4 *>(win + gap) = make_uint4(0u, 0u, 0u, tag);
+                            }
+                        }
+                    }
+                }
+                c_read += d.read; c_ref += d.ref;
+            }
+        }
+        if (tid == 0) { // publish the next tile; resolve the ticket into the tile after it
+            s_tile[slot ^ 1u] = D1;
+            uint32_t t2 = 0xffffffffu;
+            if (t_next != 0xffffffffu) {
+                if (a.debug & 8u) t2 = next_tile(a, head, n_tiles);
+                else {
+                    const unsigned long long t = ticket * 8ull + head;
+                    t2 = t < n_tiles ? (uint32_t)t : next_tile(a, head, n_tiles); // (this head is dry: try the others)
                 }
             }
+            t_next = t2;
+            s_seq = 0; // the DP's chunk counter
         }
-        __syncthreads();
-        const uint32_t F = s_first_flag;
-        const uint32_t n_runs = (total >> 16) + F;
-        if (n_runs > kStreamMaxRuns) {
-            if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)t);
-            __syncthreads();
-            t = s_next;
-            __syncthreads();
-            continue;
-        }
-        for (uint32_t r = tid; r < n_runs; r += kT) { sc.runs.read_len[r] = 0; sc.runs.ref_len[r] = 0; }
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; k++) {
-            if (!(jr[k].meta & kMetaTile)) continue;
-            rid[k] = rid[k] - 1u + F;
-            if (opens[k]) {
-                sc.runs.read_start[rid[k]] = jr[k].read_off & ~3u;
-                sc.runs.ref_start[rid[k]] = jr[k].ref_off & ~3ull;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; k++) {
-            if (!(jr[k].meta & kMetaTile)) continue;
-            const uint32_t N = jr[k].meta & 127u, M = (jr[k].meta >> 7) & 127u;
-            const bool swap = (jr[k].meta >> 17) & 1u; // the reference window is the longer one
-            const uint32_t n_read = swap ? M : N, n_ref = swap ? N : M;
-            atomicMax(&sc.runs.read_len[rid[k]], jr[k].read_off + n_read - sc.runs.read_start[rid[k]]);
-            atomicMax(&sc.runs.ref_len[rid[k]], (uint32_t)(jr[k].ref_off + n_ref - sc.runs.ref_start[rid[k]]));
-        }
-        __syncthreads();
-        {   // span offsets: one run per thread (kStreamMaxRuns <= kT)
-            uint32_t lr = 0, lf = 0;
-            if ((uint32_t)tid < n_runs) {
-                lr = (sc.runs.read_len[tid] + 3u) & ~3u;
-                lf = (sc.runs.ref_len[tid] + 3u) & ~3u;
-                sc.runs.read_len[tid] = lr; sc.runs.ref_len[tid] = lf;
-            }
-            uint32_t image = 0;
-            const uint32_t end = block_scan_incl(lr + lf, s_tmp, OpAdd(), 0u, &image);
-            if ((uint32_t)tid < n_runs) {
-                sc.runs.span_off[2 * tid] = end - lr - lf;
-                sc.runs.span_off[2 * tid + 1] = end - lf;
-            }
-            if (tid == 0) sc.runs.span_off[2 * n_runs] = image;
-            if (image > lds_floats) { // cannot happen with the bracket rule; keep the batch safe
-                if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)t);
-                __syncthreads();
-                t = s_next;
-                __syncthreads();
-                continue;
-            }
-            if (tid == 0) atomicMax(&a.cnt[kCntLdsMax], (unsigned long long)image);
-        }
-        __syncthreads();
-        // ---- 2. job records: LDS offsets of the two windows, shape, kind ----
-        uint32_t bin[kItems];
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; k++) {
-            bin[k] = 0xffffffffu;
-            if (!(jr[k].meta & kMetaTile)) continue;
-            const uint32_t i = tid * kItems + k;
-            const uint32_t N = jr[k].meta & 127u, M = (jr[k].meta >> 7) & 127u, R = (jr[k].meta >> 14) & 3u;
-            const bool swap = (jr[k].meta >> 17) & 1u;
-            const uint32_t off_read = sc.runs.span_off[2 * rid[k]] + (jr[k].read_off - sc.runs.read_start[rid[k]]);
-            const uint32_t off_ref = sc.runs.span_off[2 * rid[k] + 1] + (uint32_t)(jr[k].ref_off - sc.runs.ref_start[rid[k]]);
-            const uint32_t kind = N <= a.micro_max_n ? (N <= 4 ? 0u : 1u) : 2u + R;
-            rec[i] = make_uint2((swap ? off_ref : off_read) | ((swap ? off_read : off_ref) << 16),
-                                N | (M << 7) | (R << 14) | (((jr[k].meta >> 16) & 1u) << 16) | (kind << 17));
-            bin[k] = kind * 80u + (79u - N);
-        }
-        // ---- 3. stage the spans: one 16-byte chunk per thread and step, the chunk's span by binary search ----
+        __syncthreads(); // marks, records, histogram complete; next tile's geometry visible
+        // the next tile's records: on their way while this tile is staged, sorted and computed
+        const TileInfo Dn = s_tile[slot ^ 1u];
+        JobRec jr_n[kItems];
+        uint32_t cn_read, cn_ref;
+        fetch_records(Dn, jr_n, cn_read, cn_ref);
+        // ---- 2. stage: a flat copy of the marked chunks, 16 bytes per lane, consecutive lanes consecutive chunks; the
+        // histogram's scan runs while the first loads are in flight ----
+        const uint32_t chunks = bad ? 0u : D.image >> 2;
+        uint32_t n_tile_jobs = 0;
         {
-            const uint32_t chunks = sc.runs.span_off[2 * n_runs] >> 2, n_spans = 2 * n_runs;
+            constexpr uint32_t BPT = kSortBins / TT > 0 ? kSortBins / TT : 1; // bins per thread (threads beyond the bins idle)
+            uint32_t h[BPT], sum = 0;
             __builtin_amdgcn_s_setprio(3); // a fresh tile's loads must not queue behind the DP of the older workgroups
-            for (uint32_t q = tid; q < chunks; q += kT) {
-                uint32_t lo = 0, hi = n_spans; // largest s with span_off[s] <= 4q
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sc.runs.span_off[mid] <= 4 * q) lo = mid; else hi = mid;
+            for (uint32_t q0 = 0; q0 < chunks || q0 == 0; q0 += 4 * TT) { // four chunks per thread and round
+                uint32_t ok[4];
+                const float *src[4];
+                float4 v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t q = q0 + tid + u * TT;
+                    ok[u] = 0; src[u] = a.ev;
+                    if (q < chunks && !(a.debug & 2u)) {
+                        const uint4 hd = reinterpret_cast<const uint4 *>(win)[q];
+                        const long long delta = (long long)((unsigned long long)hd.x | ((unsigned long long)hd.y << 32));
+                        ok[u] = (hd.z == (0x5eed0000u ^ tag) && hd.w == tag) ? 1u : 0u;
+                        src[u] = ((4u * q < D.ref_region) ? a.ev : a.ref) + ((long long)(4u * q) + delta);
+                    }
                 }
-                const uint32_t r = lo >> 1, within = 4 * q - sc.runs.span_off[lo];
-                const float *src = (lo & 1u) ? a.ref + sc.runs.ref_start[r] + within : a.ev + sc.runs.read_start[r] + within;
-                reinterpret_cast<float4 *>(win)[q] = *reinterpret_cast<const float4 *>(src);
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++)
+                    if (ok[u]) v[u] = *reinterpret_cast<const float4 *>(src[u]);
+                if (q0 == 0) { // the sort's scan, first half: per-thread bins, wave scan, wave totals
+#pragma unroll
+                    for (uint32_t q = 0; q < BPT; q++) { h[q] = (uint32_t)tid * BPT + q < kSortBins ? sc.hist[tid * BPT + q] : 0u; sum += h[q]; }
+                    uint32_t incl = sum;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                        if (lane >= d) incl += o;
+                    }
+                    if (lane == 63) s_tmp[wv] = incl;
+                    sum = incl - sum; // exclusive inside the wave
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t q = q0 + tid + u * TT;
+                    if (ok[u]) reinterpret_cast<float4 *>(win)[q] = v[u];
+                }
             }
-            __builtin_amdgcn_s_setprio(0);
+            __syncthreads(); // image staged; wave totals written
+            uint32_t pre = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < (uint32_t)TT / 64; w++) {
+                const uint32_t x = s_tmp[w];
+                if (w < wv) pre += x;
+                n_tile_jobs += x;
+            }
+            uint32_t run = pre + sum;
+#pragma unroll
+            for (uint32_t q = 0; q < BPT; q++) { if ((uint32_t)tid * BPT + q < kSortBins) sc.hist[tid * BPT + q] = run; run += h[q]; }
         }
-        __syncthreads(); // the run table is dead, the image and the records are complete
-        // ---- 4. counting sort of the tile jobs by (kind, longer side descending) ----
-        for (uint32_t b = tid; b < kSortBins; b += kT) sc.sort.hist[b] = 0;
-        __syncthreads();
-        uint32_t rank[kItems];
+        __syncthreads(); // bin starts written
 #pragma unroll
         for (uint32_t k = 0; k < kItems; k++)
-            if (bin[k] != 0xffffffffu) rank[k] = atomicAdd(&sc.sort.hist[bin[k]], 1u);
-        __syncthreads();
-        {
-            static_assert(kSortBins == 2 * kT, "two bins per thread");
-            const uint32_t h0 = sc.sort.hist[2 * tid], h1 = sc.sort.hist[2 * tid + 1];
-            const uint32_t end = block_scan_incl(h0 + h1, s_tmp, OpAdd(), 0u, nullptr);
-            sc.sort.hist[2 * tid] = end - h0 - h1;
-            sc.sort.hist[2 * tid + 1] = end - h1;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < kItems; k++)
-            if (bin[k] != 0xffffffffu) sc.sort.perm[sc.sort.hist[bin[k]] + rank[k]] = (uint16_t)(tid * kItems + k);
-        __syncthreads();
-        // ---- 5. the DP: one lane per job, 64 jobs of (nearly) one shape per wave ----
-        for (uint32_t r0 = 0; r0 < n_tile_jobs; r0 += kT) {
-            const uint32_t r = r0 + tid;
+            if (bin[k] != 0xffffffffu) sc.perm[sc.hist[bin[k]] + rank[k]] = (uint16_t)(tid * kItems + k);
+        __syncthreads(); // permutation complete
+        for (uint32_t b = tid; b < kSortBins; b += TT) sc.hist[b] = 0; // (for the next tile; nobody reads it any more)
+        // ---- 3. the DP: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
+        // workgroup finish together whatever the mix ----
+        while (!(a.debug & 1u)) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&s_seq, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c * 64u >= n_tile_jobs) break;
+            const uint32_t r = c * 64u + lane;
             const bool act = r < n_tile_jobs;
-            const uint32_t i = sc.sort.perm[act ? r : n_tile_jobs - 1];
+            const uint32_t i = sc.perm[act ? r : n_tile_jobs - 1];
             const uint2 rc = rec[i];
             const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
             const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, (int)((rc.y >> 17) & 7u), R,
@@ -612,8 +688,11 @@ __global__ __launch_bounds__(kT) void k_stream(const StreamArgs a, const uint32_
             if (act) a.out[first + i] = res;
         }
         __syncthreads();
-        t = s_next;
-        __syncthreads();
+        slot ^= 1u;
+        D = Dn;
+#pragma unroll
+        for (uint32_t k = 0; k < kItems; k++) jr[k] = jr_n[k];
+        ce_read = cn_read; ce_ref = cn_ref;
     }
 }
 
@@ -660,32 +739,39 @@ __global__ __launch_bounds__(kT) void k_events_scatter(const float *__restrict__
 // host-callable drivers
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct CastU64 {
-    __host__ __device__ uint64_t operator()(const uint32_t &x) const { return (uint64_t)x; }
+struct JobCumOf { // the scan's input: what a job adds, from its record
+    uint32_t min_cost8;
+    __host__ __device__ Cum operator()(const JobRec &r) const { return job_cum(r, min_cost8); }
 };
-using CostIter = hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t *>;
+struct CumAdd {
+    __host__ __device__ Cum operator()(const Cum &x, const Cum &y) const { return Cum{x.read + y.read, x.ref + y.ref, x.cost + y.cost}; }
+};
+using CumIter = hipcub::TransformInputIterator<Cum, JobCumOf, const JobRec *>;
 inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 } // namespace
 
 size_t stream_scan_bytes(uint64_t n_jobs)
 {
     size_t b = 0;
-    CostIter it(nullptr, CastU64());
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, it, (uint64_t *)nullptr, (int)n_jobs);
+    CumIter it(nullptr, JobCumOf{0});
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, it, (Cum *)nullptr, CumAdd(), (int)n_jobs);
     return b + 256;
 }
 
 size_t stream_sort_bytes(uint64_t n_chains)
 {
-    size_t b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_chains, 0, 16);
-    return b + 256;
+    (void)n_chains; // (the fold order is a one-workgroup counting sort: no workspace)
+    return 256;
+}
+
+static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
+{
+    return lds_floats * 4u + kItems * (uint32_t)threads * 8u + (uint32_t)(threads == 512 ? sizeof(SortTable<512>) : sizeof(SortTable<256>));
 }
 
 uint32_t stream_lds_bytes(uint32_t lds_floats)
 {
-    return (uint32_t)(lds_floats * 4u + kStreamMaxTileJobs * 8u + sizeof(Scratch));
+    return 0; // (see stream_lds_bytes_t)
 }
 
 // everything rawdtw_batch_create enqueues for a sparse + banded batch: planning of the DTW launch and the chain records
@@ -696,46 +782,45 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     if (a.n_jobs) {
         hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kT), 0, s, a);
         size_t tb = tmp_bytes;
-        CostIter it(a.lds_cost, CastU64());
-        hipError_t e = hipcub::DeviceScan::InclusiveSum(d_tmp, tb, it, a.cum, (int)a.n_jobs, s);
+        CumIter it(a.jrec, JobCumOf{a.min_cost8});
+        hipError_t e = hipcub::DeviceScan::InclusiveScan(d_tmp, tb, it, a.cum, CumAdd(), (int)a.n_jobs, s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_tile_first, dim3(blocks_for((uint64_t)a.tiles_cap + 1)), dim3(kT), 0, s, a);
-        hipLaunchKernelGGL(k_others, dim3(64), dim3(kT), 0, s, a);
+        hipLaunchKernelGGL(k_others, dim3(65), dim3(kT), 0, s, a);
     }
     if (a.n_chains) {
         hipLaunchKernelGGL(k_chain_desc, dim3(blocks_for(a.n_chains)), dim3(kT), 0, s, a, d_chains, d_key, d_val);
-        size_t tb = tmp_bytes;
-        hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tb, d_key, d_key_out, d_val, d_fold_order,
-                                                                    (int)a.n_chains, 0, 16, s);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fold_order, dim3(1), dim3(1024), 0, s, a.n_chains, d_key, d_fold_order);
     }
+    (void)d_key_out;
     return hipGetLastError();
 }
 
-hipError_t stream_run(const StreamArgs &a, uint32_t others_blocks, uint32_t tile_blocks, uint32_t lds_floats, hipStream_t s)
+hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, hipStream_t s)
 {
     if (a.n_jobs == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(&a.cnt[kCntQueue], 0, sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(&a.cnt[kCntHeads], 0, 8 * 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    const uint32_t lds_bytes = stream_lds_bytes(lds_floats);
+    const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_stream<512>) : reinterpret_cast<const void *>(k_stream<256>);
     if (lds_bytes > 64 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_stream, dim3(others_blocks + tile_blocks), dim3(kT), lds_bytes, s, a, others_blocks, lds_floats);
+    if (threads == 512) hipLaunchKernelGGL(k_stream<512>, dim3(blocks), dim3(512), lds_bytes, s, a, lds_floats);
+    else hipLaunchKernelGGL(k_stream<256>, dim3(blocks), dim3(256), lds_bytes, s, a, lds_floats);
     return hipGetLastError();
 }
 
 // workgroups of k_stream one compute unit holds at this LDS size (for the persistent grid)
-int stream_blocks_per_cu(uint32_t lds_floats)
+int stream_blocks_per_cu(uint32_t lds_floats, int threads)
 {
     int n = 0;
-    const uint32_t lds_bytes = stream_lds_bytes(lds_floats);
-    if (lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-        return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(k_stream), kT, lds_bytes) != hipSuccess) return 0;
+    const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_stream<512>) : reinterpret_cast<const void *>(k_stream<256>);
+    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds_bytes) != hipSuccess) return 0;
     return n;
 }
 
