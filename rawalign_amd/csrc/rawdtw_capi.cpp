@@ -77,6 +77,8 @@ struct rawdtw_ctx {
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_stream (256 or 512: 1024 / 2048 jobs per tile)
     int stream_threads_cached = 0;
+    int stream_blocks_per_cu = 0;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
+    int stream_bpc_cached = -1;
     uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
     uint32_t stream_debug = 0;         // StreamArgs::debug
     std::vector<uint32_t> unit_chain_scratch;
@@ -1186,6 +1188,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "sorted_tile_jobs")) { ctx->sorted_tile_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 16), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "device_plan")) { ctx->device_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "device_plan_min_jobs")) { ctx->device_plan_min_jobs = (uint64_t)std::max<int64_t>(value, 0); return RAWDTW_OK; }
+    if (!strcmp(name, "stream_blocks_per_cu")) { ctx->stream_blocks_per_cu = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 16); return RAWDTW_OK; }
     if (!strcmp(name, "stream_threads")) { ctx->stream_threads = value >= 512 ? 512 : 256; return RAWDTW_OK; }
     if (!strcmp(name, "stream_debug")) { ctx->stream_debug = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
@@ -1647,6 +1650,7 @@ struct StreamLayout { // sizes in bytes of one batch's device workspace and pinn
 bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)
 {
     if (!ctx->device_plan || n_jobs < ctx->device_plan_min_jobs || n_jobs == 0 || n_jobs >= (1ull << 31)) return false;
+    if (n_jobs * (uint64_t)(ctx->lane_max_n + 8u) >= (1ull << 32)) return false; // (the regions' running sums are 32-bit halves of one 64-bit sum)
     if (opt->border_constraint != 1 || opt->fill_method == 0) return false; // sparse + banded only
     if (ctx->lane_max_radius < 0 || ctx->sort_n || ctx->sort_r1_n || ctx->sort_r3 || ctx->lane_hi || !ctx->merge_small) return false;
     if (ctx->tile_threads != 256 || ctx->debug_skip_kinds) return false;
@@ -1725,7 +1729,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint64_t n_units = (n_jobs + 1023) / 1024;
     const size_t dev_bytes = al((nc + 1) * 8) * 2 + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) +   // inputs
-                             al(n_jobs * 16) + al(n_jobs * 16) + al(((size_t)a.tiles_cap + 1) * sizeof(TileInfo)) + // per job: record, scan
+                             al(n_jobs * 16) + al(n_jobs * 8) + al(n_jobs * 4) + 2 * al((n_units + 1) * 8) + al(((size_t)a.tiles_cap + 1) * sizeof(TileInfo)) + // per job: record, sums
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) + al(tmp) +
                              al(nc * sizeof(ChainDesc)) + 7 * al(nc * 4) + al(nc) + al(n_jobs * 4) + al((n_units + 1) * 4) + al(n_units * 24);
     const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8) + al((n_units + 1) * 4);
@@ -1738,7 +1742,8 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
-    a.jrec = carve<JobRec>(p, n_jobs); a.cum = carve<Cum>(p, n_jobs);
+    a.jrec = carve<JobRec>(p, n_jobs); a.cpos = carve<uint64_t>(p, n_jobs); a.ccost = carve<uint32_t>(p, n_jobs);
+    a.unit_pos = carve<uint64_t>(p, n_units + 1); a.unit_cost = carve<uint64_t>(p, n_units + 1);
     a.tiles = carve<TileInfo>(p, (uint64_t)a.tiles_cap + 1);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     a.cnt = carve<unsigned long long>(p, kStreamCounters);
@@ -1792,12 +1797,14 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
     // the persistent grid: what the device holds at this LDS size
-    if (ctx->stream_lds != lds_floats || ctx->stream_threads_cached != ctx->stream_threads) {
+    if (ctx->stream_lds != lds_floats || ctx->stream_threads_cached != ctx->stream_threads || ctx->stream_bpc_cached != ctx->stream_blocks_per_cu) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         const int per_cu = stream_blocks_per_cu(lds_floats, ctx->stream_threads);
         if (per_cu <= 0) return fail(ctx, RAWDTW_ERR_DEVICE, "occupancy query failed for the batch kernel");
-        ctx->stream_blocks = (uint32_t)(per_cu * prop.multiProcessorCount);
+        const int use = ctx->stream_blocks_per_cu > 0 ? std::min(per_cu, ctx->stream_blocks_per_cu) : per_cu;
+        ctx->stream_blocks = (uint32_t)(use * prop.multiProcessorCount);
+        ctx->stream_bpc_cached = ctx->stream_blocks_per_cu;
         ctx->stream_lds = lds_floats;
         ctx->stream_threads_cached = ctx->stream_threads;
     }
@@ -2030,7 +2037,19 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         std::vector<TileInfo> ti(n_tiles + 1);
         std::vector<uint32_t> tf(n_tiles + 1);
         if (n_jobs) HIP_TRY(ctx, hipMemcpy(jr.data(), a.jrec, n_jobs * sizeof(JobRec), hipMemcpyDeviceToHost));
-        if (n_jobs) HIP_TRY(ctx, hipMemcpy(cum.data(), a.cum, n_jobs * sizeof(Cum), hipMemcpyDeviceToHost));
+        {
+            const uint64_t n_units = (n_jobs + 1023) / 1024;
+            std::vector<uint64_t> cp(n_jobs), up(n_units + 1), uc(n_units + 1);
+            std::vector<uint32_t> cc(n_jobs);
+            if (n_jobs) HIP_TRY(ctx, hipMemcpy(cp.data(), a.cpos, n_jobs * 8, hipMemcpyDeviceToHost));
+            if (n_jobs) HIP_TRY(ctx, hipMemcpy(cc.data(), a.ccost, n_jobs * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(up.data(), a.unit_pos, (n_units + 1) * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(uc.data(), a.unit_cost, (n_units + 1) * 8, hipMemcpyDeviceToHost));
+            for (uint64_t k = 0; k < n_jobs; k++) { // absolute = the unit's offset + the sum inside the unit
+                const uint64_t pabs = up[k / 1024] + cp[k];
+                cum[k] = Cum{(uint32_t)pabs, (uint32_t)(pabs >> 32), uc[k / 1024] + cc[k]};
+            }
+        }
         HIP_TRY(ctx, hipMemcpy(ti.data(), a.tiles, (n_tiles + 1) * sizeof(TileInfo), hipMemcpyDeviceToHost));
         for (uint64_t t = 0; t <= n_tiles; t++) tf[t] = ti[t].first;
         if (ti[n_tiles].n != 0) e = "no end marker behind the last tile";

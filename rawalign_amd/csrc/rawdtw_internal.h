@@ -130,6 +130,7 @@ __host__ __device__ inline Cum job_cum(const JobRec &r, uint32_t min_cost8)
     c.cost = c8 > min_cost8 ? c8 : min_cost8;
     return c;
 }
+__host__ __device__ inline Cum cum_of(uint64_t packed) { return Cum{(uint32_t)packed, (uint32_t)(packed >> 32), 0ull}; }
 __host__ __device__ inline uint32_t image_pos(uint32_t c_excl, uint64_t arena_off, bool starts)
 {
     return (starts ? c_excl : c_excl - 4u) + (((uint32_t)arena_off - c_excl) & 3u);
@@ -168,7 +169,9 @@ struct StreamArgs {
     const unsigned long long *masks;
     // planning arrays and outputs (device)
     JobRec *jrec;
-    Cum *cum;                    // inclusive scan of job_cum over the jobs
+    uint64_t *cpos;              // inclusive sums of job_cum INSIDE the job's unit of 1024: event floats | reference floats << 32
+    uint32_t *ccost;             // ... and cost
+    uint64_t *unit_pos, *unit_cost; // the sums before each unit (n_units + 1 entries)
     TileInfo *tiles;             // tiles_cap + 1 entries; tiles[n_tiles].n = 0
     unsigned long long *unit_stats; // per k_pre unit: tile jobs, tile bytes, side-list bytes
     DevJob *omix, *ojobs;

@@ -24,7 +24,6 @@
 // persistent, every count lives in a device counter block.  rawdtw_batch_create only enqueues; errors and the rare
 // shapes this path does not take (band wider than 256 offsets) surface in the counters, which rawdtw_batch_fetch reads
 // together with the results.
-#include <hipcub/hipcub.hpp>
 
 #include "rawdtw_dp.h"
 
@@ -170,6 +169,10 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
     // ---- stage 4: geometry, class, record ----
     uint32_t my_tiles = 0;
     unsigned long long my_bytes = 0, my_obytes = 0;
+    uint64_t lpos[kPer];  // running sums over this thread's jobs: event floats | reference floats << 32
+    uint32_t lcost[kPer]; // ... and cost
+    uint64_t run_pos = 0;
+    uint32_t run_cost = 0;
     auto tile_class = [&](const rawdtw_anchor_t &s, const rawdtw_anchor_t &e) { // would the part s -> e be a tile job?
         if (!(e.target_position >= s.target_position && e.query_position >= s.query_position)) return false;
         const uint32_t m = e.target_position - s.target_position + 1, n = e.query_position - s.query_position + 1;
@@ -217,7 +220,14 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             else meta = (cls + 1u) | ((uint32_t)R << 8); // (side list: class and radius travel in the record until the append below)
             my_obytes += 4ull * ((unsigned long long)n + m) + 36ull;
         }
-        a.jrec[j] = JobRec{ref_off, read_off, (meta & kMetaTile) ? meta : 0u};
+        const JobRec rec{ref_off, read_off, (meta & kMetaTile) ? meta : 0u};
+        a.jrec[j] = rec;
+        {
+            const Cum d = job_cum(rec, a.min_cost8);
+            run_pos += (uint64_t)d.read | ((uint64_t)d.ref << 32);
+            run_cost += (uint32_t)d.cost;
+            lpos[k] = run_pos; lcost[k] = run_cost;
+        }
         // the side list: rare (a few jobs per workgroup)
         if (!(meta & kMetaTile) && meta) {
             const uint32_t cls = (meta & 0xffu) - 1u;
@@ -229,6 +239,36 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             S[k] = rawdtw_anchor_t{n, m}; E[k] = rawdtw_anchor_t{(uint32_t)R, excl ? kFlagExcludeLast : 0u};
             SP[k] = rawdtw_anchor_t{read_off, (uint32_t)j}; jo[k] = ref_off;
         } else parts[k] = 0;
+    }
+    // The running sums of the tile layout (rawdtw_internal.h: Cum), local to the unit: a scan over the workgroup's threads;
+    // k_unit_scan turns the units' totals into their offsets.  (No pass over the batch for a global scan.)
+    {
+        __shared__ uint64_t s_wpos[kT / 64];
+        __shared__ uint32_t s_wcost[kT / 64];
+        uint64_t ipos = run_pos;
+        uint32_t icost = run_cost;
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t op = (uint64_t)__shfl_up((long long)ipos, d);
+            const uint32_t oc = (uint32_t)__shfl_up((int)icost, d);
+            if (lane >= d) { ipos += op; icost += oc; }
+        }
+        if (lane == 63) { s_wpos[wv] = ipos; s_wcost[wv] = icost; }
+        __syncthreads();
+        uint64_t ppos = 0, tpos = 0;
+        uint32_t pcost = 0, tcost = 0;
+#pragma unroll
+        for (int w = 0; w < kT / 64; w++) {
+            if (w < wv) { ppos += s_wpos[w]; pcost += s_wcost[w]; }
+            tpos += s_wpos[w]; tcost += s_wcost[w];
+        }
+        const uint64_t epos = ppos + ipos - run_pos;   // sums before this thread's first job, inside the unit
+        const uint32_t ecost = pcost + icost - run_cost;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++)
+            if (have[k]) { a.cpos[jf + k] = epos + lpos[k]; a.ccost[jf + k] = ecost + lcost[k]; }
+        if (tid == 0) { a.unit_pos[blockIdx.x] = tpos; a.unit_cost[blockIdx.x] = (uint64_t)tcost; }
     }
     // totals: per workgroup, then one record per unit (reduced by k_others); the side list's base: one returning atomic per
     // workgroup that has side-list jobs
@@ -262,6 +302,42 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// k_unit_scan: the units' totals -> the sums BEFORE each unit (exclusive, in place; entry n_units = the batch totals).
+// One workgroup: a few thousand entries.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_unit_scan(const StreamArgs a)
+{
+    const uint64_t n_units = (a.n_jobs + kPreUnit - 1) / kPreUnit;
+    __shared__ uint64_t s_p[16], s_c[16];
+    __shared__ uint64_t s_carry[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    __syncthreads();
+    for (uint64_t base = 0; base < n_units; base += 1024) {
+        const uint64_t u = base + tid;
+        const uint64_t vp = u < n_units ? a.unit_pos[u] : 0ull, vc = u < n_units ? a.unit_cost[u] : 0ull;
+        uint64_t ip = vp, ic = vc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t op = (uint64_t)__shfl_up((long long)ip, d), oc = (uint64_t)__shfl_up((long long)ic, d);
+            if (lane >= (uint32_t)d) { ip += op; ic += oc; }
+        }
+        if (lane == 63) { s_p[wv] = ip; s_c[wv] = ic; }
+        __syncthreads();
+        uint64_t pp = s_carry[0], pc = s_carry[1], tp = 0, tc = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wv) { pp += s_p[w]; pc += s_c[w]; }
+            tp += s_p[w]; tc += s_c[w];
+        }
+        if (u < n_units) { a.unit_pos[u] = pp + ip - vp; a.unit_cost[u] = pc + ic - vc; }
+        __syncthreads();
+        if (tid == 0) { s_carry[0] += tp; s_carry[1] += tc; }
+        __syncthreads();
+    }
+    if (tid == 0) { a.unit_pos[n_units] = s_carry[0]; a.unit_cost[n_units] = s_carry[1]; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // k_tile_first: tile k = the jobs whose exclusive running cost lies in [k * width, (k + 1) * width).  Every job has a
 // positive cost, so tile_first[k] = 1 + (first job whose inclusive running cost reaches k * width).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -269,7 +345,9 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kT + threadIdx.x;
     const uint64_t n = a.n_jobs;
-    const uint64_t n_tiles = (n >= 2 ? a.cum[n - 2].cost / a.width8 : 0ull) + 1ull;
+    const uint64_t n_units = (n + kPreUnit - 1) / kPreUnit;
+    auto cost_incl = [&](uint64_t j) { return a.unit_cost[j / kPreUnit] + a.ccost[j]; }; // inclusive running cost of job j
+    const uint64_t n_tiles = (n >= 2 ? cost_incl(n - 2) / a.width8 : 0ull) + 1ull;
     if (k == 0) {
         a.cnt[kCntTiles] = n_tiles;
         if (n_tiles > a.tiles_cap) atomicMin(&a.cnt[kCntOverflow], 0ull);
@@ -279,12 +357,23 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
         if (q == 0) return 0;
         if (q >= n_tiles) return n;
         const uint64_t key = q * a.width8;
-        uint64_t lo = 0, hi = n; // first job whose inclusive cost reaches the key
+        // first job whose inclusive cost reaches the key: the unit first (its end = the next unit's offset), then the job
+        uint64_t lo = 0, hi = n_units;
         while (lo < hi) {
             const uint64_t mid = (lo + hi) >> 1;
-            if (a.cum[mid].cost >= key) hi = mid; else lo = mid + 1;
+            if (a.unit_cost[mid + 1] >= key) hi = mid; else lo = mid + 1;
         }
-        return lo + 1;
+        const uint64_t u = lo < n_units ? lo : n_units - 1, rel = key - a.unit_cost[u];
+        uint64_t jl = u * kPreUnit, jh = jl + kPreUnit < n ? jl + kPreUnit : n;
+        while (jl < jh) {
+            const uint64_t mid = (jl + jh) >> 1;
+            if ((uint64_t)a.ccost[mid] >= rel) jh = mid; else jl = mid + 1;
+        }
+        return jl + 1;
+    };
+    auto pos_before = [&](uint64_t j) -> Cum { // sums before job j
+        if (j == 0) return Cum{0u, 0u, 0ull};
+        return cum_of(a.unit_pos[(j - 1) / kPreUnit] + a.cpos[j - 1]);
     };
     TileInfo t{};
     const uint64_t first = first_of(k), end = first_of(k + 1);
@@ -300,8 +389,8 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
         while (l > f && !(a.jrec[l - 1].meta & kMetaTile)) l--;
         if (f < end) {
             const JobRec rf = a.jrec[f], rl = a.jrec[l - 1];
-            const Cum cf = f ? a.cum[f - 1] : Cum{0u, 0u, 0ull};
-            const Cum cl = l - 1 ? a.cum[l - 2] : Cum{0u, 0u, 0ull};
+            const Cum cf = pos_before(f);
+            const Cum cl = pos_before(l - 1);
             const bool sf = (rf.meta >> 18) & 1u, sl = (rl.meta >> 18) & 1u, swl = (rl.meta >> 17) & 1u;
             const uint32_t Nl = rl.meta & 127u, Ml = (rl.meta >> 7) & 127u;
             t.base_read = image_pos(cf.read, rf.read_off, sf) & ~3u;
@@ -535,7 +624,7 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
         }
         const uint32_t i0 = tid * kItems;
         c_read = 0; c_ref = 0;
-        if (i0 < T.n && T.first + i0 > 0) { const Cum c = a.cum[T.first + i0 - 1]; c_read = c.read; c_ref = c.ref; }
+        if (i0 < T.n && T.first + i0 > 0) { const uint64_t jb = T.first + i0 - 1, c = a.unit_pos[jb / kPreUnit] + a.cpos[jb]; c_read = (uint32_t)c; c_ref = (uint32_t)(c >> 32); }
     };
     fetch_records(D, jr, ce_read, ce_ref);
     while (D.n) {
@@ -739,23 +828,13 @@ __global__ __launch_bounds__(kT) void k_events_scatter(const float *__restrict__
 // host-callable drivers
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct JobCumOf { // the scan's input: what a job adds, from its record
-    uint32_t min_cost8;
-    __host__ __device__ Cum operator()(const JobRec &r) const { return job_cum(r, min_cost8); }
-};
-struct CumAdd {
-    __host__ __device__ Cum operator()(const Cum &x, const Cum &y) const { return Cum{x.read + y.read, x.ref + y.ref, x.cost + y.cost}; }
-};
-using CumIter = hipcub::TransformInputIterator<Cum, JobCumOf, const JobRec *>;
 inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 } // namespace
 
 size_t stream_scan_bytes(uint64_t n_jobs)
 {
-    size_t b = 0;
-    CumIter it(nullptr, JobCumOf{0});
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, it, (Cum *)nullptr, CumAdd(), (int)n_jobs);
-    return b + 256;
+    (void)n_jobs; // (the layout's running sums are made by k_pre per unit and k_unit_scan over the units: no library scan)
+    return 256;
 }
 
 size_t stream_sort_bytes(uint64_t n_chains)
@@ -781,10 +860,7 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     (void)hipGetLastError();
     if (a.n_jobs) {
         hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kT), 0, s, a);
-        size_t tb = tmp_bytes;
-        CumIter it(a.jrec, JobCumOf{a.min_cost8});
-        hipError_t e = hipcub::DeviceScan::InclusiveScan(d_tmp, tb, it, a.cum, CumAdd(), (int)a.n_jobs, s);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_unit_scan, dim3(1), dim3(1024), 0, s, a);
         hipLaunchKernelGGL(k_tile_first, dim3(blocks_for((uint64_t)a.tiles_cap + 1)), dim3(kT), 0, s, a);
         hipLaunchKernelGGL(k_others, dim3(65), dim3(kT), 0, s, a);
     }
