@@ -109,19 +109,17 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
     per_job_1 = (time.perf_counter() - t0) / min(n, 100000)
     runs = []
     out_full = None
-    for threads in sorted({1, min(16, usable), usable}):
-        take = int(min(n, max(50000, seconds * threads * 0.7 / max(per_job_1, 1e-9))))
+    # thread counts: one, 16 (round 1's figure), then doubling up to every core the process may run on
+    counts = sorted({1, min(16, usable), usable} | {t for t in (32, 64, 128) if t < usable})
+    for threads in counts:
+        # one pool of threads works through `reps` passes over a prefix of the job list: about `seconds` of wall time
+        take = int(min(n, max(50000, seconds * 0.7 / max(per_job_1, 1e-9)))) if threads == 1 else n
+        est = per_job_1 * take / max(1.0, min(threads, 64) * 0.6)
+        reps = int(max(1, min(400, round(seconds / max(est, 1e-6)))))
         t0 = time.perf_counter()
-        out = impl.batch_costs(jobs[:take], events, ref_arena, threads)
+        out = impl.batch_costs(jobs[:take], events, ref_arena, threads, reps)
         dt = time.perf_counter() - t0
-        reps = 1
-        while dt * reps < seconds * 0.5 and reps < 64:  # short sample: repeat it
-            t1 = time.perf_counter()
-            impl.batch_costs(jobs[:take], events, ref_arena, threads)
-            dt = min(dt, time.perf_counter() - t1)
-            reps += 1
-        runs.append({"threads": threads, "value": cells * (take / n) / dt / 1e9, "jobs": take, "seconds": round(dt, 3),
-                     "repetitions": reps})
+        runs.append({"threads": threads, "value": cells * (take / n) * reps / dt / 1e9, "jobs": take, "passes": reps, "seconds": round(dt, 3)})
         if out_full is None or take > len(out_full):
             out_full = out
     best = max(runs, key=lambda r: r["value"])
@@ -129,8 +127,9 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
         "value": best["value"], "unit": "GCUPS", "cores": best["threads"], "kind": kind,
         "nproc": nproc, "usable_cores": usable,
         "sample": f"first {best['jobs']} of {n} DTW jobs of one batch of the same workload ({best['jobs'] / n * 100:.0f}% of its "
-                  f"cells, pro-rated by job count), {best['threads']} threads pulling jobs from a shared counter (one task per "
-                  f"job range, as kt_for deals reads: kthread.c:54-72), best of {best['repetitions']} run(s) of {best['seconds']} s",
+                  f"cells, pro-rated by job count), {best['passes']} passes inside one pool of {best['threads']} threads pulling job "
+                  f"ranges from a shared counter (as kt_for deals reads: kthread.c:54-72), {best['seconds']} s wall; the best of "
+                  f"the thread counts tried is reported",
         "by_threads": runs,
     }, out_full
 

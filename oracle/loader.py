@@ -109,6 +109,8 @@ class Oracle:
         ]
         L.orc_batch_costs.restype = None
         L.orc_batch_costs.argtypes = [C.c_void_p, C.c_uint64, f32p, f32p, f32p, C.c_int]
+        L.orc_batch_costs_reps.restype = None
+        L.orc_batch_costs_reps.argtypes = [C.c_void_p, C.c_uint64, f32p, f32p, f32p, C.c_int, C.c_int]
 
     # --- single calls -------------------------------------------------------
     def dtw_global(self, a, b, exclude_last=False) -> np.float32:
@@ -192,11 +194,11 @@ class Oracle:
         k = ln.value
         return np.float32(score), np.float32(cost.value), pi[:k].copy(), pj[:k].copy(), pd[:k].copy()
 
-    def batch_costs(self, jobs, events, ref, nthreads=1) -> np.ndarray:
+    def batch_costs(self, jobs, events, ref, nthreads=1, reps=1) -> np.ndarray:
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         out = np.zeros(len(jobs), np.float32)
-        self.lib.orc_batch_costs(
-            jobs.ctypes.data_as(C.c_void_p), len(jobs), _as_f32(events), _as_f32(ref), out, int(nthreads)
+        self.lib.orc_batch_costs_reps(
+            jobs.ctypes.data_as(C.c_void_p), len(jobs), _as_f32(events), _as_f32(ref), out, int(nthreads), int(reps)
         )
         return out
 
@@ -222,6 +224,8 @@ class RefDTW:
         ]
         L.ref_batch_costs.restype = None
         L.ref_batch_costs.argtypes = [C.c_void_p, C.c_uint64, f32p, f32p, f32p, C.c_int]
+        L.ref_batch_costs_reps.restype = None
+        L.ref_batch_costs_reps.argtypes = [C.c_void_p, C.c_uint64, f32p, f32p, f32p, C.c_int, C.c_int]
 
     @staticmethod
     def available(path: str | None = None) -> bool:
@@ -256,10 +260,10 @@ class RefDTW:
         k = ln.value
         return np.float32(cost), pi[:k].copy(), pj[:k].copy(), pd[:k].copy()
 
-    def batch_costs(self, jobs, events, ref, nthreads=1) -> np.ndarray:
+    def batch_costs(self, jobs, events, ref, nthreads=1, reps=1) -> np.ndarray:
         jobs = np.ascontiguousarray(jobs, dtype=JOB_DTYPE)
         out = np.zeros(len(jobs), np.float32)
-        self.lib.ref_batch_costs(
-            jobs.ctypes.data_as(C.c_void_p), len(jobs), _as_f32(events), _as_f32(ref), out, int(nthreads)
+        self.lib.ref_batch_costs_reps(
+            jobs.ctypes.data_as(C.c_void_p), len(jobs), _as_f32(events), _as_f32(ref), out, int(nthreads), int(reps)
         )
         return out

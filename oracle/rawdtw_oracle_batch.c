@@ -35,6 +35,7 @@ typedef struct {
     float *out;
     uint64_t *next;
     pthread_mutex_t *mu;
+    uint64_t total; /* n_jobs * passes over the list */
 } batch_ctx;
 
 static void *batch_worker(void *p)
@@ -46,9 +47,10 @@ static void *batch_worker(void *p)
         uint64_t s = *c->next;
         *c->next = s + grain;
         pthread_mutex_unlock(c->mu);
-        if (s >= c->n_jobs) break;
-        uint64_t e = s + grain < c->n_jobs ? s + grain : c->n_jobs;
-        for (uint64_t k = s; k < e; k++) {
+        if (s >= c->total) break;
+        uint64_t e = s + grain < c->total ? s + grain : c->total;
+        for (uint64_t q = s; q < e; q++) {
+            const uint64_t k = q % c->n_jobs;
             const orc_job_t *j = &c->jobs[k];
             const float *a = c->events + j->read_off;
             const float *b = c->ref + j->ref_off;
@@ -60,12 +62,13 @@ static void *batch_worker(void *p)
     return NULL;
 }
 
-void orc_batch_costs(const void *jobs, uint64_t n_jobs, const float *events, const float *ref,
-                     float *out, int nthreads)
+/* `reps` passes over the job list inside one pool of threads (bench.py: one pass is too short to time). */
+void orc_batch_costs_reps(const void *jobs, uint64_t n_jobs, const float *events, const float *ref,
+                          float *out, int nthreads, int reps)
 {
     uint64_t next = 0;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    batch_ctx c = {(const orc_job_t *)jobs, n_jobs, events, ref, out, &next, &mu};
+    batch_ctx c = {(const orc_job_t *)jobs, n_jobs, events, ref, out, &next, &mu, n_jobs * (uint64_t)(reps > 1 ? reps : 1)};
     if (nthreads <= 1) {
         batch_worker(&c);
         return;
@@ -74,6 +77,12 @@ void orc_batch_costs(const void *jobs, uint64_t n_jobs, const float *events, con
     for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, batch_worker, &c);
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
     free(th);
+}
+
+void orc_batch_costs(const void *jobs, uint64_t n_jobs, const float *events, const float *ref,
+                     float *out, int nthreads)
+{
+    orc_batch_costs_reps(jobs, n_jobs, events, ref, out, nthreads, 1);
 }
 
 /* One read's candidate chains, already in evaluation order.

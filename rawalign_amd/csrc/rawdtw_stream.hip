@@ -567,7 +567,7 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, uint32_t &hea
 // TT threads per workgroup (256 or 512): a tile's range holds up to 4 * TT jobs.  More jobs per tile = fuller and more
 // uniform waves after the sort (the lane class's first wave carries the tile's few long jobs) and half as many tiles.
 template <int TT>
-__global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint32_t lds_floats)
+__global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamArgs a, const uint32_t lds_floats)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *win = smem;                                                            // the tile's LDS image
@@ -613,20 +613,24 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
     __syncthreads();
     uint32_t slot = 0, seq = 1; // seq: tag of the image's chunk marks (stale marks of an earlier tile never match)
     TileInfo D = s_tile[0];
+    // thread t owns jobs t, t + TT, ... of the tile's range (a tile of 500 jobs keeps every wave busy with two of them; its
+    // records load coalesced); the sums BEFORE each job come from k_pre's running sums: the unit's offset + the job before
     JobRec jr[kItems];
-    uint32_t ce_read = 0, ce_ref = 0; // running sums BEFORE this thread's first job of the tile
-    auto fetch_records = [&](const TileInfo &T, JobRec (&r)[kItems], uint32_t &c_read, uint32_t &c_ref) {
+    uint64_t ce[kItems];
+    auto fetch_records = [&](const TileInfo &T, JobRec (&r)[kItems], uint64_t (&c)[kItems]) {
 #pragma unroll
         for (uint32_t k = 0; k < kItems; k++) {
-            const uint32_t i = tid * kItems + k; // thread t owns jobs [kItems * t, kItems * t + kItems) of the range
+            const uint32_t i = k * TT + tid;
             r[k] = JobRec{0, 0, 0};
-            if (i < T.n) r[k] = a.jrec[T.first + i];
+            c[k] = 0;
+            if (i < T.n) {
+                const uint64_t j = (uint64_t)T.first + i;
+                r[k] = a.jrec[j];
+                if (j > 0) c[k] = a.unit_pos[(j - 1) / kPreUnit] + a.cpos[j - 1];
+            }
         }
-        const uint32_t i0 = tid * kItems;
-        c_read = 0; c_ref = 0;
-        if (i0 < T.n && T.first + i0 > 0) { const uint64_t jb = T.first + i0 - 1, c = a.unit_pos[jb / kPreUnit] + a.cpos[jb]; c_read = (uint32_t)c; c_ref = (uint32_t)(c >> 32); }
     };
-    fetch_records(D, jr, ce_read, ce_ref);
+    fetch_records(D, jr, ce);
     while (D.n) {
         // thread 0: the next tile's geometry and the ticket of the one after it -- issued now, consumed at the publish
         // below (nothing here waits for them)
@@ -642,14 +646,15 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
         const uint32_t tag = seq++;
         // ---- 1. records, chunk marks, histogram: every job's place in the image from its own running sums ----
         uint32_t bin[kItems], rank[kItems];
+#pragma unroll
+        for (uint32_t k = 0; k < kItems; k++) { bin[k] = 0xffffffffu; rank[k] = 0; }
         {
-            uint32_t c_read = ce_read, c_ref = ce_ref;
 #pragma unroll
             for (uint32_t k = 0; k < kItems; k++) {
-                bin[k] = 0xffffffffu;
-                const Cum d = job_cum(jr[k], a.min_cost8);
+                if (k * TT >= n) break; // (uniform: no job of this round exists)
                 if ((jr[k].meta & kMetaTile) && !bad) {
-                    const uint32_t i = tid * kItems + k;
+                    const uint32_t c_read = (uint32_t)ce[k], c_ref = (uint32_t)(ce[k] >> 32);
+                    const uint32_t i = k * TT + tid;
                     const uint32_t N = jr[k].meta & 127u, M = (jr[k].meta >> 7) & 127u, R = (jr[k].meta >> 14) & 3u;
                     const bool swap = (jr[k].meta >> 17) & 1u, starts = (jr[k].meta >> 18) & 1u;
                     const uint32_t p_read = image_pos(c_read, jr[k].read_off, starts) - D.base_read;
@@ -676,7 +681,6 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
                         }
                     }
                 }
-                c_read += d.read; c_ref += d.ref;
             }
         }
         if (tid == 0) { // publish the next tile; resolve the ticket into the tile after it
@@ -696,8 +700,8 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
         // the next tile's records: on their way while this tile is staged, sorted and computed
         const TileInfo Dn = s_tile[slot ^ 1u];
         JobRec jr_n[kItems];
-        uint32_t cn_read, cn_ref;
-        fetch_records(Dn, jr_n, cn_read, cn_ref);
+        uint64_t ce_n[kItems];
+        fetch_records(Dn, jr_n, ce_n);
         // ---- 2. stage: a flat copy of the marked chunks, 16 bytes per lane, consecutive lanes consecutive chunks; the
         // histogram's scan runs while the first loads are in flight ----
         const uint32_t chunks = bad ? 0u : D.image >> 2;
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
         __syncthreads(); // bin starts written
 #pragma unroll
         for (uint32_t k = 0; k < kItems; k++)
-            if (bin[k] != 0xffffffffu) sc.perm[sc.hist[bin[k]] + rank[k]] = (uint16_t)(tid * kItems + k);
+            if (bin[k] != 0xffffffffu) sc.perm[sc.hist[bin[k]] + rank[k]] = (uint16_t)(k * TT + tid);
         __syncthreads(); // permutation complete
         for (uint32_t b = tid; b < kSortBins; b += TT) sc.hist[b] = 0; // (for the next tile; nobody reads it any more)
         // ---- 3. the DP: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
             if (c * 64u >= n_tile_jobs) break;
             const uint32_t r = c * 64u + lane;
             const bool act = r < n_tile_jobs;
-            const uint32_t i = sc.perm[act ? r : n_tile_jobs - 1];
+            const uint32_t i = min((uint32_t)sc.perm[act ? r : n_tile_jobs - 1], n - 1u); // (never past the tile's range, whatever the table holds)
             const uint2 rc = rec[i];
             const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
             const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, (int)((rc.y >> 17) & 7u), R,
@@ -780,8 +784,7 @@ __global__ __launch_bounds__(TT, 4) void k_stream(const StreamArgs a, const uint
         slot ^= 1u;
         D = Dn;
 #pragma unroll
-        for (uint32_t k = 0; k < kItems; k++) jr[k] = jr_n[k];
-        ce_read = cn_read; ce_ref = cn_ref;
+        for (uint32_t k = 0; k < kItems; k++) { jr[k] = jr_n[k]; ce[k] = ce_n[k]; }
     }
 }
 

@@ -8,6 +8,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    """PyTorch bundles its own HIP runtime: in a process that uses both, torch has to initialise first (tests that hand
+    device tensors to the library need it; harmless without a GPU)."""
+    try:
+        import torch
+
+        torch.cuda.is_available()
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

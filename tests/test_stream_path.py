@@ -1,0 +1,218 @@
+"""The sync-free batch path (rawdtw_stream.hip) against the oracle: every shape class the tile kernel and its side list take
+(radii 1..3 with any slant, shorter sides down to 1-2 events, wide bands, bands it declines), its tuning knobs, the
+incremental event upload and the shared / device-resident inputs.  Parts are the DTW sub-problems align_chain issues
+between consecutive anchors (src/rmap.cpp:248-293) through DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+try:  # PyTorch bundles its own HIP runtime: when both live in one process, torch has to come up first
+    import torch
+
+    torch.cuda.is_available()
+except Exception:  # pragma: no cover
+    torch = None
+
+import rawalign_amd as ra
+from rawalign_amd.align import CandidateBatch
+from tests.golden_util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _chains(rng, n_reads, ref_len, shapes):
+    """One read per chain group; every chain's parts draw (dq, dt) from `shapes`(rng) -> anchors end-first."""
+    events, chain_off, anchor_off, anchors, ref_base, read_base = [], [0], [0], [], [], []
+    ev_at = 0
+    for r in range(n_reads):
+        n_chains = int(rng.integers(1, 4))
+        read_len = 0
+        per = []
+        for _ in range(n_chains):
+            parts = int(rng.integers(1, 40))
+            dq, dt = zip(*[shapes(rng) for _ in range(parts)])
+            q = np.concatenate([[int(rng.integers(0, 5))], np.cumsum(dq) + 0]).astype(np.int64)
+            q[1:] += q[0]
+            t0 = int(rng.integers(0, ref_len - int(np.sum(dt)) - 2))
+            t = np.concatenate([[t0], t0 + np.cumsum(dt)]).astype(np.int64)
+            per.append((q, t))
+            read_len = max(read_len, int(q[-1]) + 1)
+        events.append(rng.normal(size=read_len).astype(np.float32))
+        for q, t in per:
+            a = np.zeros(len(q), ra.ANCHOR_DTYPE)
+            a["query_position"] = q[::-1]
+            a["target_position"] = t[::-1]
+            anchors.append(a)
+            anchor_off.append(anchor_off[-1] + len(a))
+            read_base.append(ev_at)
+            ref_base.append(int(rng.integers(0, 2)))  # strand slot, resolved by the caller
+        chain_off.append(len(anchor_off) - 1)
+        ev_at += read_len
+    return (np.concatenate(events), np.array(chain_off, np.uint64), np.array(anchor_off, np.uint64), np.concatenate(anchors),
+            np.array(ref_base), np.array(read_base, np.uint32))
+
+
+def _oracle_check(oracle, cb, ref_arrays, strand_of, score, keep, job_cost, opt):
+    from oracle.loader import OrcOpt
+
+    oopt = OrcOpt(1, 1, opt.dtw_band_radius_frac, opt.dtw_match_bonus, opt.dtw_min_score, 1)
+    j = 0
+    for r in range(cb.n_reads):
+        best = np.float32(0.0)
+        for c in range(int(cb.chain_off[r]), int(cb.chain_off[r + 1])):
+            a = cb.anchors[int(cb.anchor_off[c]):int(cb.anchor_off[c + 1])]
+            arr = ref_arrays[strand_of[c]]
+            ev = cb.events[int(cb.read_base[c]):]
+            parts = len(a) - 1
+            for p in range(parts):  # every part's cost, bit for bit (dtw.cpp:273-520 with rmap.cpp:270,276)
+                s, e = a[parts - p], a[parts - p - 1]
+                n = int(e["query_position"]) - int(s["query_position"]) + 1
+                m = int(e["target_position"]) - int(s["target_position"]) + 1
+                R0 = max(1, int(np.float32(n) * np.float32(opt.dtw_band_radius_frac)))
+                want = oracle.dtw_banded(ev[int(s["query_position"]):int(s["query_position"]) + n],
+                                         arr[int(s["target_position"]):int(s["target_position"]) + m], R0, p != parts - 1)
+                assert bits(job_cost[j]) == bits(want), (r, c, p, n, m, R0, job_cost[j], want)
+                j += 1
+            want_s = oracle.align_chain(a, arr, ev, oopt, float(best))
+            assert bits(score[c]) == bits(want_s), (r, c, score[c], want_s)
+            k = want_s >= np.float32(opt.dtw_min_score)
+            assert bool(keep[c]) == bool(k)
+            if k and want_s > best:
+                best = want_s
+    assert j == len(job_cost)
+
+
+def _tiny(rng):     # the bulk of sparse mode: 2..8 events, slanted or square
+    dq = int(rng.integers(1, 8))
+    return dq, max(1, dq + int(rng.integers(-2, 3)))
+
+
+def _medium(rng):   # radii 1..3, shorter side down to 2, up to the tile class's longest side and a little beyond
+    dq = int(rng.integers(1, 40))
+    return dq, max(1, int(round(dq * rng.uniform(0.3, 2.2))))
+
+
+def _wide(rng):     # side list: 8-lane, 16-lane and wave-per-job classes
+    dq = int(rng.choice([3, 12, 45, 90, 160, 400]))
+    return dq, max(1, int(round(dq * rng.uniform(0.6, 1.6))))
+
+
+@pytest.mark.parametrize("shapes,opts", [
+    (_tiny, {}), (_medium, {}), (_wide, {}),
+    (_medium, {"stream_threads": 512, "tile_lds_floats": 9000}),
+    (_medium, {"tile_lds_floats": 2048}), (_tiny, {"micro_max_n": 0}), (_medium, {"micro_max_n": 4, "lane_max_n": 20}),
+    (_medium, {"lane_max_radius": 1}), (_wide, {"stream_threads": 512}),
+])
+def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
+    rng = np.random.default_rng(hash((shapes.__name__, tuple(sorted(opts)))) & 0xFFFF)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 120, 60000, shapes)
+    strand_of = [1 if s == 0 else 0 for s in slot]  # slot 0 = forward array (strand 1, rmap.cpp:182-188)
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is True  # the sync-free path took the batch, and its records pass the self-check
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+    info = b.info()
+    assert info["n_jobs"] == len(jc) and info["n_lane_jobs"] + info["n_wave_band_jobs"] == len(jc)
+
+
+def test_band_too_wide_for_the_stream_path_is_redone_through_the_job_list(oracle):
+    """A part whose band needs more than 256 offsets: the sync-free path declines the batch at fetch and the job-list
+    path (register-resident wave kernel with more chunks) produces the same answers the oracle gives."""
+    rng = np.random.default_rng(77)
+    ref = [rng.normal(size=40000).astype(np.float32), rng.normal(size=40000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    state = {"k": 0}
+
+    def shapes(r):
+        state["k"] += 1
+        return (3000, 2800) if state["k"] == 17 else _tiny(r)  # n = 3001 -> band_radius 300 (rmap.cpp:276)
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 30, 40000, shapes)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    assert b.verify_plan() is False  # now a job-list batch
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+
+
+def test_incremental_events_shared_reference_and_resident_arrays(oracle):
+    """rawdtw_events_reserve / rawdtw_events_append (a round uploads only the new events, rmap.cpp:554-567),
+    rawdtw_share_reference (one resident arena per GPU) and "resident_arrays" (anchors already on the device): same
+    scores as the plain upload."""
+    if torch is None:
+        pytest.skip("torch not importable")
+    rng = np.random.default_rng(5)
+    ref = [rng.normal(size=40000).astype(np.float32), rng.normal(size=40000).astype(np.float32)]
+    owner = ra.Engine(0)
+    owner.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 200, 40000, _medium)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([owner.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    owner.upload_events(events)
+    b = ra.Batch(owner, opt, cb)
+    b.run()
+    want = b.fetch(with_job_costs=True)
+    # second context: shares the arena, uploads the events in two rounds (a prefix, then every read's last 30 events)
+    eng = ra.Engine(0)
+    lib = eng.lib
+    eng._check(lib.rawdtw_share_reference(eng._ctx, owner._ctx))
+    assert eng.reference_offset(0, 1) == owner.reference_offset(0, 1)
+    starts = np.unique(read_base.astype(np.int64))
+    ends = np.concatenate([starts[1:], [len(events)]])
+    new_len = np.minimum(ends - starts, 30)
+    old = events.copy()
+    for s, e, nl in zip(starts, ends, new_len):
+        old[e - nl:e] = np.float32(7777.0)  # not there yet
+    eng._check(lib.rawdtw_events_reserve(eng._ctx, len(events)))
+    eng._check(lib.rawdtw_upload_events(eng._ctx, old.ctypes.data_as(C.c_void_p), len(old)))
+    seg_src = np.concatenate([[0], np.cumsum(new_len)]).astype(np.uint64)
+    seg_dst = (ends - new_len).astype(np.uint32)
+    new_events = np.concatenate([events[e - nl:e] for e, nl in zip(ends, new_len)]).astype(np.float32)
+    eng._check(lib.rawdtw_events_append(eng._ctx, new_events.ctypes.data_as(C.c_void_p), len(new_events), len(new_len),
+                                        seg_src.ctypes.data_as(C.c_void_p), seg_dst.ctypes.data_as(C.c_void_p)))
+    # ... and takes the three big arrays from device memory
+    eng.set_option("resident_arrays", 1)
+    t_anchors = torch.from_numpy(anchors.view(np.uint8).copy()).cuda()
+    t_ref_base = torch.from_numpy(ref_base.view(np.uint8).copy()).cuda()
+    t_read_base = torch.from_numpy(read_base.view(np.uint8).copy()).cuda()
+    torch.cuda.synchronize()
+    copt = opt.c_struct()
+    h = C.c_void_p()
+    co, ao = np.ascontiguousarray(chain_off, np.uint64), np.ascontiguousarray(anchor_off, np.uint64)
+    eng._check(lib.rawdtw_batch_create(eng._ctx, C.byref(copt), cb.n_reads, co.ctypes.data_as(C.c_void_p), ao.ctypes.data_as(C.c_void_p),
+                                       C.c_void_p(t_anchors.data_ptr()), C.c_void_p(t_ref_base.data_ptr()),
+                                       C.c_void_p(t_read_base.data_ptr()), C.byref(h)))
+    eng._check(lib.rawdtw_batch_run(eng._ctx, h))
+    score = np.zeros(cb.n_chains, np.float32)
+    keep = np.zeros(cb.n_chains, np.uint8)
+    jc = np.zeros(len(want[2]), np.float32)
+    eng._check(lib.rawdtw_batch_fetch(eng._ctx, h, score.ctypes.data_as(C.c_void_p), keep.ctypes.data_as(C.c_void_p), jc.ctypes.data_as(C.c_void_p)))
+    lib.rawdtw_batch_destroy(h)
+    assert np.array_equal(score.view(np.uint32), want[0].view(np.uint32)) and np.array_equal(keep, want[1])
+    assert np.array_equal(jc.view(np.uint32), want[2].view(np.uint32))
+    # out-of-range segment: refused
+    bad_dst = seg_dst.copy(); bad_dst[0] = len(events)
+    assert lib.rawdtw_events_append(eng._ctx, new_events.ctypes.data_as(C.c_void_p), len(new_events), len(new_len),
+                                    seg_src.ctypes.data_as(C.c_void_p), bad_dst.ctypes.data_as(C.c_void_p)) == 4
+    # pinned host memory round trip
+    p = C.c_void_p()
+    assert lib.rawdtw_host_alloc(4096, C.byref(p)) == 0 and p.value
+    assert lib.rawdtw_host_free(p) == 0
