@@ -262,8 +262,13 @@ uint32_t rawdtw_gen_primary_chains(rawdtw_chain_t *chains, uint32_t n_chains,
 /* is_mapped_with_high_confidence (src/rmap.cpp:594-665) over the primary chains, best first. */
 int rawdtw_is_mapped_with_high_confidence(const rawdtw_chain_t *primary, uint32_t n_chains,
                                           const rawdtw_select_opt_t *opt);
-/* find_outlier (src/sequence_until.c:4-18): x[point][dim], n dims, m points. */
+/* find_outlier (src/sequence_until.c:4-18): x[point][dim], n dims, m points.  The first form is the source's
+ * arithmetic (one rounded product and one rounded add per element, in order; equal bit for bit to the reference
+ * file compiled with -ffp-contract=off).  The second is what the reference's default build computes when the
+ * compiler has FMA (GCC -O3 -march=native on AVX2 hosts): same order, but elements past the last full group
+ * of four are accumulated with one fused multiply-add each; equal bit for bit to that build. */
 float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m);
+float rawdtw_find_outlier_contracted(const float *const *x, uint32_t n, uint32_t m);
 
 /* ---- chaining DP of gen_chains (src/rmap.cpp:430-507) and traceback_chains (src/rmap.cpp:130-173) for
  * one (reference sequence, strand): anchors must be sorted by (target_position, query_position) as

@@ -139,6 +139,7 @@ SYMBOLS = {
     "rawdtw_gen_primary_chains": (U32, [VP, U32, C.POINTER(SelectOpt), VP]),
     "rawdtw_is_mapped_with_high_confidence": (I32, [VP, U32, C.POINTER(SelectOpt)]),
     "rawdtw_find_outlier": (F32, [VP, U32, U32]),
+    "rawdtw_find_outlier_contracted": (F32, [VP, U32, U32]),
     "rawdtw_chain_anchors": (I32, [C.POINTER(ChainOpt), VP, U32, C.POINTER(F32), VP, VP, VP, U32, U64]),
     "rawdtw_sort_by_chaining_score": (I32, [VP, U32, VP]),
     "rawdtw_batch_build_jobs": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, U64, C.POINTER(U64)]),

@@ -207,20 +207,36 @@ int rawdtw_is_mapped_with_high_confidence(const rawdtw_chain_t *c, uint32_t n_ch
     return (n_chains == 1 && c[0].n_anchors >= opt->min_chain_anchor) ? 1 : 0; // rmap.cpp:620, 659
 }
 
-float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m)
+// sequence_until.c:5-19.  The source is one rounded product and one rounded add per element, summed in order;
+// `contracted_tail` selects what the reference's own default build (GCC -O3 with FMA available) computes instead:
+// the same in-order sum, but the elements after the last full group of four go through one fused multiply-add each
+// (the vectorised groups keep mul + add; only the scalar remainder loop is contracted).
+static float find_outlier_impl(const float *const *x, uint32_t n, uint32_t m, bool contracted_tail)
 {
     uint32_t outlier = 0;
     float max_dist = 0.0f;
+    const uint32_t n_plain = contracted_tail ? (n & ~3u) : n;
     for (uint32_t i = 0; i < m; i++) {
         float dist = 0.0f;
-        for (uint32_t j = 0; j < n; j++) {
+        for (uint32_t j = 0; j < n_plain; j++) {
             const float d = x[i][j] - x[outlier][j];
-            volatile float sq = d * d; // product rounded, then added: the reference build vectorises this loop
-            dist += sq;                // (mul + add) and fuses only its scalar tail; compared within 1e-6 in tests
+            volatile float sq = d * d; // product rounded, then added
+            dist += sq;
+        }
+        for (uint32_t j = n_plain; j < n; j++) {
+            const float d = x[i][j] - x[outlier][j];
+            dist = std::fmaf(d, d, dist);
         }
         if (dist > max_dist) { max_dist = dist; outlier = i; }
     }
     return max_dist;
+}
+
+float rawdtw_find_outlier(const float *const *x, uint32_t n, uint32_t m) { return find_outlier_impl(x, n, m, false); }
+
+float rawdtw_find_outlier_contracted(const float *const *x, uint32_t n, uint32_t m)
+{
+    return find_outlier_impl(x, n, m, true);
 }
 
 int rawdtw_chain_anchors(const rawdtw_chain_opt_t *opt, const rawdtw_anchor_t *anchors, uint32_t n_anchors,

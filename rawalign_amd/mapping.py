@@ -73,13 +73,15 @@ def is_mapped_with_high_confidence(primary, opt: MapOpt, stop: StopOpt = StopOpt
     return bool(lib.rawdtw_is_mapped_with_high_confidence(rec, len(primary), C.byref(so)))
 
 
-def find_outlier(x) -> np.float32:
-    """src/sequence_until.c:4-18; x[point][dim]."""
+def find_outlier(x, contracted: bool = False) -> np.float32:
+    """src/sequence_until.c:4-18; x[point][dim].  `contracted` selects the arithmetic of the reference's
+    default FMA build (see include/rawdtw.h) instead of the source's."""
     lib = load_library()
     x = np.ascontiguousarray(x, dtype=np.float32)
     m, n = x.shape
     rows = (C.c_void_p * m)(*[x[i].ctypes.data for i in range(m)])
-    return np.float32(lib.rawdtw_find_outlier(rows, n, m))
+    fn = lib.rawdtw_find_outlier_contracted if contracted else lib.rawdtw_find_outlier
+    return np.float32(fn(rows, n, m))
 
 
 def default_chain_opt(e: int = 6) -> ChainOpt:
@@ -215,7 +217,7 @@ class SequenceUntil:
     tmin_reads: int = 500
 
     def __post_init__(self):
-        self.c_estimations = np.zeros(self.n_seq, np.uint64)
+        self.c_estimations = np.zeros(self.n_seq, np.uint32)  # rmap.h:76: uint32_t (wraps like the reference's)
         self.estimations = np.zeros((self.tn_samples, self.n_seq), np.float32)
         self.ab_count = 0
         self.nreads = 0
@@ -228,8 +230,8 @@ class SequenceUntil:
         stop signal fires (p->su_stop = k+1)."""
         if self.stop:
             return True
-        self.c_estimations[ref_id] += np.uint64(fragment_length)
-        self.ab_count += fragment_length
+        self.c_estimations[ref_id] = np.uint32((int(self.c_estimations[ref_id]) + int(fragment_length)) & 0xFFFFFFFF)
+        self.ab_count = (self.ab_count + int(fragment_length)) & 0xFFFFFFFF  # rmap.h:74: uint32_t
         self.nreads += 1
         if self.nreads > self.tmin_reads and self.nreads % self.ttest_freq == 0:
             self.estimations[self.cur] = (self.c_estimations.astype(np.float32) / np.float32(self.ab_count))

@@ -138,15 +138,19 @@ def test_find_outlier_against_compiled_reference(tmp_path):
         assert o == best
     if not os.path.exists(src):
         pytest.skip("no /root/reference here")
-    so = tmp_path / "libsu.so"
-    subprocess.run(["gcc", "-O3", "-march=x86-64-v3", "-shared", "-fPIC", "-I/root/reference/src", "-o", str(so), src],
-                   check=True)
-    lib = C.CDLL(str(so))
-    lib.find_outlier.restype = C.c_float
-    for x, o in zip(xs, ours):
-        rows = (C.c_void_p * len(x))(*[x[i].ctypes.data for i in range(len(x))])
-        ref = lib.find_outlier(rows, x.shape[1], len(x))
-        assert abs(ref - float(o)) <= 1e-6 * max(1.0, abs(ref))  # the reference build fuses part of the loop
+    # the reference's translation unit, built twice from where it lies: with contraction off (the source's
+    # arithmetic) and as its Makefile builds it on an FMA host (-O3, FMA available): both matched bit for bit
+    xs += [rng.random((4, n)).astype(np.float32) for n in (2, 4, 5, 7, 9, 12, 15, 16, 31, 33, 100, 257)]
+    for flags, contracted in ((["-ffp-contract=off", "-march=x86-64-v3"], False), (["-march=x86-64-v3"], True)):
+        so = tmp_path / f"libsu{int(contracted)}.so"
+        subprocess.run(["gcc", "-O3", *flags, "-shared", "-fPIC", "-I/root/reference/src", "-o", str(so), src],
+                       check=True)
+        lib = C.CDLL(str(so))
+        lib.find_outlier.restype = C.c_float
+        for x in xs:
+            rows = (C.c_void_p * len(x))(*[x[i].ctypes.data for i in range(len(x))])
+            ref = np.float32(lib.find_outlier(rows, x.shape[1], len(x)))
+            assert ref == M.find_outlier(x, contracted=contracted), (flags, x.shape)
 
 
 def test_sequence_until_state_machine():

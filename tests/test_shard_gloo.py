@@ -127,3 +127,66 @@ def test_bench_launches_its_own_ranks_dry_run():
     # weak scaling: rank 0's shard is the same in both runs, rank 1 adds its own
     assert l2["totals_over_timed_steps"]["reads"] == 2 * l1["totals_over_timed_steps"]["reads"]
     assert l2["totals_over_timed_steps"]["dtw_jobs"] > l1["totals_over_timed_steps"]["dtw_jobs"]
+
+
+def _su_records(n_reads, n_seq, seed):
+    rng = np.random.default_rng(seed)
+    mapped = rng.random(n_reads) < 0.8
+    probs = np.array([0.5, 0.3, 0.2, 0.0][:n_seq], float)
+    probs = probs / probs.sum()
+    ref_id = rng.choice(n_seq, size=n_reads, p=probs)
+    frag = rng.integers(200, 9000, n_reads)
+    return mapped, ref_id, frag
+
+
+def _su_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from rawalign_amd.mapping import SequenceUntil
+    from rawalign_amd.shard import sequence_until_round, shard_reads
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    su = SequenceUntil(n_seq=3, tmin_reads=40, ttest_freq=10, tn_samples=3, t_threshold=1.5)
+    stops = []
+    for mb in range(3):  # three mini-batches; the state carries over (rmap.cpp:1018-1027 initialises it once)
+        n = 101 + 7 * mb
+        mapped, ref_id, frag = _su_records(n, 3, 100 + mb)
+        lo, hi = shard_reads(n, rank, world)
+        stops.append(sequence_until_round(dist, su, mapped[lo:hi], ref_id[lo:hi], frag[lo:hi], n))
+        if stops[-1]:
+            break
+    q.put((rank, stops, su.c_estimations.tolist(), su.nreads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sequence_until_across_ranks_equals_one_process():
+    """f-3: the stop point of --sequence-until (rmap.cpp:918-944) with a mini-batch's reads sharded over two ranks is the one
+    a single process finds, and every rank holds the same abundance counters."""
+    from rawalign_amd.mapping import SequenceUntil
+    from rawalign_amd.shard import sequence_until_round
+
+    su = SequenceUntil(n_seq=3, tmin_reads=40, ttest_freq=10, tn_samples=3, t_threshold=1.5)
+    want = []
+    for mb in range(3):
+        n = 101 + 7 * mb
+        mapped, ref_id, frag = _su_records(n, 3, 100 + mb)
+        want.append(sequence_until_round(None, su, mapped, ref_id, frag, n))
+        if want[-1]:
+            break
+    assert want[-1] > 0  # the rule fires inside these mini-batches
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_su_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, stops, cest, nreads in got:
+        assert stops == want and cest == su.c_estimations.tolist() and nreads == su.nreads
