@@ -89,8 +89,9 @@ def self_launch(args):
 
 def cpu_baseline(jobs, events, ref_arena, cells, seconds):
     """The same job list on the host cores, through the REFERENCE's own compiled dtw.cpp when oracle/_ref is present
-    ("reference"), else through the oracle's C restatement ("port").  Thread counts: 1, 16, every core the process may
-    run on; each on a bounded sample of whole jobs (cells pro-rated by job count)."""
+    ("reference"), else through the oracle's C restatement ("port").  Thread counts: 1, every core the process may use
+    (affinity mask capped by the cgroup's CPU quota), twice that; each on a bounded sample of whole jobs (cells pro-rated
+    by job count)."""
     from oracle.loader import Oracle, RefDTW, build_oracle
 
     if RefDTW.available():
@@ -101,20 +102,27 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
     n = len(jobs)
     nproc = os.cpu_count() or 1
     try:
-        usable = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        usable = nproc
+        affinity = nproc
+    quota = cgroup_cpu_quota()  # the box gives one GPU's job a share of the host's cores (a CFS quota, not an affinity mask)
+    usable = max(1, min(affinity, int(quota + 0.999))) if quota else affinity
     t0 = time.perf_counter()
     impl.batch_costs(jobs[:100000], events, ref_arena, 1)
     per_job_1 = (time.perf_counter() - t0) / min(n, 100000)
     runs = []
     out_full = None
-    # thread counts: one, 16 (round 1's figure), then doubling up to every core the process may run on
-    counts = sorted({1, min(16, usable), usable} | {t for t in (32, 64, 128) if t < usable})
+    # thread counts: one, every core this process may use, and twice that (SMT / oversubscription check)
+    counts = {1, usable} | ({2 * usable} if 2 * usable <= affinity else set())
+    if quota is None and usable > 16:
+        counts.add(16)  # no quota visible: a one-GPU box's share is 16 cores, so that count is tried as well
+    counts = sorted(counts)
     for threads in counts:
         # one pool of threads works through `reps` passes over a prefix of the job list: about `seconds` of wall time
         take = int(min(n, max(50000, seconds * 0.7 / max(per_job_1, 1e-9)))) if threads == 1 else n
-        est = per_job_1 * take / max(1.0, min(threads, 64) * 0.6)
+        t0 = time.perf_counter()
+        impl.batch_costs(jobs[:take], events, ref_arena, threads, 1)  # calibration pass (also warms the pool's pages)
+        est = time.perf_counter() - t0
         reps = int(max(1, min(400, round(seconds / max(est, 1e-6)))))
         t0 = time.perf_counter()
         out = impl.batch_costs(jobs[:take], events, ref_arena, threads, reps)
@@ -125,13 +133,28 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
     best = max(runs, key=lambda r: r["value"])
     return {
         "value": best["value"], "unit": "GCUPS", "cores": best["threads"], "kind": kind,
-        "nproc": nproc, "usable_cores": usable,
+        "nproc": nproc, "affinity_cores": affinity, "cgroup_cpu_quota": quota, "usable_cores": usable,
         "sample": f"first {best['jobs']} of {n} DTW jobs of one batch of the same workload ({best['jobs'] / n * 100:.0f}% of its "
                   f"cells, pro-rated by job count), {best['passes']} passes inside one pool of {best['threads']} threads pulling job "
                   f"ranges from a shared counter (as kt_for deals reads: kthread.c:54-72), {best['seconds']} s wall; the best of "
                   f"the thread counts tried is reported",
         "by_threads": runs,
     }, out_full
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of CFS quota of this process's cgroup (v2 cpu.max, v1 cpu.cfs_quota_us), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
 
 
 # ---------------------------------------------------------------------------------------------------------------------

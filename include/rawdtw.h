@@ -71,6 +71,9 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
  *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create takes the sync-free path (planning on the device, in LDS)
+ *   "stream_tile_radius" 1..3 (default 2), "stream_threads" 256/512, "stream_blocks_per_cu": the device-planned batch's DTW
+ *   launch -- tiles take radii up to stream_tile_radius, the radii between that and lane_max_radius are scored a lane per
+ *   job from the side list, bucketed by length over the whole batch
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
  *   "time_plan" 0/1: event pair around a batch's planning kernels; "stream_others_blocks": workgroups that start on the wide-band jobs
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
@@ -365,6 +368,11 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
                        float *job_cost);
 /* GPU time of the batch's planning kernels (HIP events; 0 unless the option "time_plan" was set before create) */
 int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
+/* Diagnostics of a device-planned batch (waits for its planning kernels): the planner's counters, in the order of
+ * rawdtw_internal.h's StreamCounter -- 0 first invalid job (~0 none), 1 first tile over a capacity (~0 none), 2 jobs with
+ * a band the side list does not take, 3 tile jobs, 4 their algorithmic bytes, 5 the side list's bytes, 6 side-list jobs,
+ * 7 tiles, 9.. jobs per side-list class.  *n_out = 0 for a batch planned on the host. */
+int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out);
 int rawdtw_batch_destroy(rawdtw_batch *batch);
 
 #ifdef __cplusplus

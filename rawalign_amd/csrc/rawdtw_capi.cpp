@@ -99,6 +99,7 @@ struct rawdtw_ctx {
     uint32_t tile_max_spans = kTileMaxSpans;
     int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
     int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
+    int stream_tile_radius = 2;           // device-planned batches: the tiles' radius limit ("stream_tile_radius")
     // reference arena
     float *d_ref = nullptr;
     uint64_t n_ref = 0;
@@ -1205,6 +1206,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "lane_hi_max_n")) { ctx->lane_hi_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 200); return RAWDTW_OK; }
     if (!strcmp(name, "lane_hi")) { ctx->lane_hi = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_n")) { ctx->lane_max_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), kLaneMaxN); return RAWDTW_OK; }
+    if (!strcmp(name, "stream_tile_radius")) { ctx->stream_tile_radius = value < 1 ? 1 : (value > kMaxLaneRadius ? kMaxLaneRadius : (int)value); return RAWDTW_OK; }
     if (!strcmp(name, "lane_max_radius")) {
         ctx->lane_max_radius = value < 0 ? 0 : (value > kMaxLaneRadius ? kMaxLaneRadius : (int)value);
         return RAWDTW_OK;
@@ -1714,7 +1716,10 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a = StreamArgs{};
     a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
     a.frac = b->opt.band_radius_frac;
-    a.lane_max_radius = ctx->lane_max_radius; a.lane_max_n = ctx->lane_max_n; a.micro_max_n = (uint32_t)ctx->micro_max_n;
+    // tiles take radius <= stream_tile_radius (2: 98 % of a sparse batch's jobs, one short body); the radii between that
+    // and lane_max_radius go to the side list's lane classes
+    a.lane_max_radius = std::min(ctx->lane_max_radius, ctx->stream_tile_radius); a.side_lane_radius = ctx->lane_max_radius;
+    a.lane_max_n = ctx->lane_max_n; a.micro_max_n = (uint32_t)ctx->micro_max_n;
     // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the
     // bracket by at most the largest cost a job can have, so the image needs at most tile_budget floats
     const uint32_t tile_budget = lds_floats - kStreamSlack;
@@ -2212,8 +2217,10 @@ int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint6
     I.n_jobs = b->n_jobs;
     I.cells = c[kCntCells];
     I.algorithmic_bytes = c[kCntTileBytes] + c[kCntOtherBytes];
-    I.n_lane_jobs = c[kCntTileJobs];
-    I.n_wave_band_jobs = c[kCntOthers];
+    unsigned long long side_lane = 0; // the side list's lane-per-job classes count with the tiles' jobs: same body, same class rule
+    for (uint32_t q = kClsL0; q < kClsL0 + kClsLCount; q++) side_lane += c[kCntCls0 + q];
+    I.n_lane_jobs = c[kCntTileJobs] + side_lane;
+    I.n_wave_band_jobs = c[kCntOthers] - side_lane;
     I.n_full_jobs = 0;
     I.workspace_bytes = b->ws_bytes;
     I.n_launches = 1;
@@ -2440,6 +2447,19 @@ int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms)
     if (!batch->stream || !batch->ev_plan[0] || !batch->ev_plan[1]) return RAWDTW_OK;
     HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[1]));
     HIP_TRY(ctx, hipEventElapsedTime(ms, batch->ev_plan[0], batch->ev_plan[1]));
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!ctx || !batch || batch->ctx != ctx || !n_out) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to batch_stream_counters");
+    *n_out = 0;
+    if (!batch->stream) return RAWDTW_OK;
+    const int st = stream_counters(ctx, batch);
+    if (st != RAWDTW_OK) return st;
+    const uint32_t n = (uint32_t)kCntHeads; // (the queue heads behind them are the kernel's scratch)
+    *n_out = n;
+    for (uint32_t i = 0; i < n && i < cap && out; i++) out[i] = batch->h_cnt[i];
     return RAWDTW_OK;
 }
 

@@ -356,7 +356,7 @@ struct GenLane {
     bool prev_adv;
 };
 
-template <bool MASKED>
+template <bool MASKED, bool CLAMP>
 __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const float *LB, const uint32_t N, const uint32_t M,
                                               const int off, const bool sh, const bool r1, const bool r2, const uint32_t col)
 {
@@ -369,7 +369,7 @@ __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const
 #pragma unroll
     for (int p = 0; p < 3; p++) bn[p] = adv ? g.bp[p + 1] : g.bp[p];
     bn[3] = adv ? g.b_next : g.bp[3];
-    g.b_next = LB[g.row + 4 - off];
+    g.b_next = LB[CLAMP ? min(g.row + 4 - off, (int)M - 1) : g.row + 4 - off];
     // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column, b-window of the new row
     float X[4];
     {
@@ -391,7 +391,7 @@ __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const
     }
     // a-window: one step per column
     g.ap[3] = g.ap[2]; g.ap[2] = g.ap[1]; g.ap[1] = g.ap[0]; g.ap[0] = g.a_next;
-    g.a_next = LA[col + 1 + off];
+    g.a_next = LA[CLAMP ? min(col + 1u + (uint32_t)off, N - 1u) : col + 1u + (uint32_t)off];
     // primary antidiagonal (dtw.cpp:416-485)
     {
         const float top1 = (sh && !adv) ? kInf : X[0];                   // o == 0 of an odd radius when the row stays
@@ -421,7 +421,9 @@ __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const
 }
 
 // N, M, R per lane (R in 1..3, N >= M, N >= 2); n_max = the largest N of the wave.  Lanes past their last column keep
-// stepping on values nobody reads.
+// stepping on values nobody reads.  CLAMP: the windows lie in the arenas, not in a tile's image with slack behind it --
+// reads past a window's end go to its last element instead.
+template <bool CLAMP = false>
 __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t R,
                                              const uint32_t n_max)
 {
@@ -444,13 +446,107 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
     }
     g.res = g.d1[off == 1 ? 1 : 2]; // (N == 1 cannot occur here; kept for completeness)
     g.rem = 0; g.row = 0; g.prev_adv = false;
-    g.a_next = LA[1 + off];
-    g.b_next = LB[4 - off];
+    g.a_next = LA[CLAMP ? min(1 + off, iN - 1) : 1 + off];
+    g.b_next = LB[CLAMP ? min(4 - off, iM - 1) : 4 - off];
     uint32_t col = 1;
     // first columns: some lane still has cells above row 0 (or left of column 0) inside its band
-    for (; col < n_max && __any((g.row < off || col < 3u) && col < N); col++) lane_gen_step<true>(g, LA, LB, N, M, off, sh, r1, r2, col);
-    for (; col < n_max; col++) lane_gen_step<false>(g, LA, LB, N, M, off, sh, r1, r2, col);
+    for (; col < n_max && __any((g.row < off || col < 3u) && col < N); col++) lane_gen_step<true, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
+    for (; col < n_max; col++) lane_gen_step<false, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
     return g.res;
+}
+
+// Radii 1 and 2 mixed in a wave -- 98 % of a sparse batch's jobs (radius 1 = square parts, radius 2 = every other part
+// whose read side is under 20 events): the generic body with K = 3 slots and off = 1 for both radii.  Radius 2 has
+// S = 2 secondaries (slots 0, 1) and P = 3 primaries (slots 0..2, no shift); radius 1 has S = 2 and P = 1 at slot 1.
+// Dropped against the 4-slot body: slot 3, d0[2] (read by slot 3 only), the secondaries' low-side mask (a secondary
+// counts only after a row advance, when row >= 1 = off), and the masked copy of the loop -- the one low-side cell left,
+// primary slot 0 = (col + 1, row - 1) while row == 0, is a select in the loop.  X[2] = d1[2] whether or not the row
+// advances: after an advance it is read behind the is_last guard only (left2).
+__device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t R,
+                                             const uint32_t n_max)
+{
+    const bool r1 = R == 1u;
+    const int iM = (int)M;
+    float d00 = kInf, d01 = kInf;                       // the antidiagonal before the latest: slots 0, 1
+    float d10 = kInf, d11 = dist(LA[0], LB[0]), d12 = kInf; // the latest: the corner at the centre slot (dtw.cpp:317-347)
+    float ap0 = LA[1], ap1 = LA[0], ap2 = LA[0];
+    float bp0 = LB[0], bp1 = LB[0], bp2 = LB[iM > 1 ? 1 : 0];
+    float a_next = LA[2], b_next = LB[2];
+    float res = d11;
+    uint32_t rem = 0, row = 0;
+    bool prev_adv = false;
+    for (uint32_t col = 1; col < n_max; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        rem -= adv ? N : 0u;
+        row += adv ? 1u : 0u;
+        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? bp2 : bp1, bn2 = adv ? b_next : bp2;
+        b_next = LB[row + 2];
+        // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
+        const float top0 = r1 ? kInf : d10;                       // is_first (odd radius)
+        const float tl0s = (r1 && !prev_adv) ? kInf : d00;        // previous_increment_center_row
+        const float left1 = r1 ? kInf : d12;                      // is_last (odd radius)
+        const float sec0 = min3f(top0, d11, tl0s) + dist(ap0, bn0);
+        const float sec1 = min3f(d11, left1, d01) + dist(ap1, bn1);
+        const float X0 = adv ? sec0 : d10, X1 = adv ? sec1 : d11;
+        ap2 = ap1; ap1 = ap0; ap0 = a_next;
+        a_next = LA[col + 2];
+        // primary antidiagonal (dtw.cpp:416-485)
+        const float top1 = (r1 && !adv) ? kInf : X0;
+        const float left2 = (!r1 && adv) ? kInf : d12;
+        const float tl0 = adv ? d10 : kInf;
+        const float tl1 = adv ? d11 : tl0s;                       // (odd radius, row stays: d0[0] only after an advance)
+        const float tl2 = adv ? d12 : d01;
+        float pr0 = min3f(kInf, X0, tl0) + dist(ap0, bn0);
+        const float pr1 = min3f(top1, X1, tl1) + dist(ap1, bn1);
+        const float pr2 = min3f(X1, left2, tl2) + dist(ap2, bn2);
+        pr0 = row == 0u ? kInf : pr0;                             // (col + 1, -1): above the matrix
+        d00 = X0; d01 = X1; d10 = pr0; d11 = pr1; d12 = pr2;
+        bp0 = bn0; bp1 = bn1; bp2 = bn2;
+        prev_adv = adv;
+        res = (col == N - 1u) ? d11 : res;
+    }
+    return res;
+}
+
+// Radius 1 in every lane of the wave -- 97 % of a sparse batch's jobs: the body above with R = 1 folded in (sh = 1,
+// off = 1, S = 2 secondaries at slots 0 and 1, one primary at slot 1; slots 2 and 3 drop out).  Per column: the primary
+// cell (col, row), and, when the centre row advances, the two secondaries (col, row - 1) and (col - 1, row) before it.
+// State: prim = d1[1]; x0, x1 = d0[0], d0[1]; x0 always takes the secondary's value: it is read only behind
+// `prev_adv` (is_first / previous_increment_center_row, dtw.cpp:373-375, 392-397), when it is that value.  No low-side
+// mask: slot 0 of a secondary lies above row 0 only when the row did not advance, i.e. when nobody reads it, and slot 1
+// never does.  About 30 instructions per column against 50 for the generic body.
+__device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t n_max)
+{
+    float prim = dist(LA[0], LB[0]); // the corner (dtw.cpp:317-347)
+    float x0 = kInf, x1 = kInf;
+    float ap0 = LA[1], ap1 = LA[0];
+    float bp0 = LB[0], bp1 = LB[0];
+    float a_next = LA[2], b_next = LB[1];
+    float res = prim;
+    uint32_t rem = 0, row = 0;
+    bool prev_adv = false;
+    for (uint32_t col = 1; col < n_max; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        rem -= adv ? N : 0u;
+        row += adv ? 1u : 0u;
+        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? b_next : bp1;
+        b_next = LB[row + 1];
+        const float g = prev_adv ? x0 : kInf;
+        const float sec0 = min3f(kInf, prim, g) + dist(ap0, bn0);   // (col, row - 1): no top (is_first)
+        const float sec1 = min3f(prim, kInf, x1) + dist(ap1, bn1);  // (col - 1, row): no left (is_last)
+        const float X1 = adv ? sec1 : prim;
+        const float top1 = adv ? sec0 : kInf;
+        const float tl1 = adv ? prim : g;
+        ap1 = ap0; ap0 = a_next;
+        a_next = LA[col + 2];
+        const float pr1 = min3f(top1, X1, tl1) + dist(ap1, bn1);    // (col, row)
+        x0 = sec0; x1 = X1; prim = pr1; bp0 = bn0; bp1 = bn1;
+        prev_adv = adv;
+        res = (col == N - 1u) ? prim : res;
+    }
+    return res;
 }
 
 // Micro path for the shapes that dominate sparse mode (longer side <= W, W = 4 or 8): the whole

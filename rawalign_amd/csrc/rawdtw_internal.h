@@ -100,7 +100,14 @@ constexpr uint32_t kMetaStarts = 1u << 18, kMetaTile = 1u << 19;
 constexpr uint32_t kStreamMaxTileJobs = 2048; // jobs in a tile's range, 512-thread workgroups (256-thread: half)
 constexpr uint32_t kStreamSlack = 32;         // LDS floats of a tile's image kept free for region alignment
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
-constexpr uint32_t kStreamClasses = 6, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5;
+constexpr uint32_t kStreamClasses = 14, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5, kClsL0 = 6, kClsLCount = 8;
+// Side-list classes 6..13: jobs the lane-per-job body takes (radius <= side_lane_radius, longer side <= lane_max_n) but the
+// tiles do not (radius > lane_max_radius): scored 64 to a wave straight from the arenas, bucketed by longer side so that
+// a wave's jobs have similar lengths -- over the whole batch there are enough of them to fill waves, inside one tile not.
+__host__ __device__ inline uint32_t side_lane_bucket(uint32_t N)
+{
+    return N >= 65u ? 0u : N >= 49u ? 1u : N >= 41u ? 2u : N >= 33u ? 3u : N >= 29u ? 4u : N >= 25u ? 5u : N >= 21u ? 6u : 7u;
+}
 
 // Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive parts of a chain
 // (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every job
@@ -136,7 +143,7 @@ __host__ __device__ inline uint32_t image_pos(uint32_t c_excl, uint64_t arena_of
     return (starts ? c_excl : c_excl - 4u) + (((uint32_t)arena_off - c_excl) & 3u);
 }
 // One tile: its job range and the geometry of its image (k_tile_first)
-struct TileInfo { uint32_t first, n, base_read, base_ref, ref_region, image, first_tile /* index in the range of its first tile-class job */, pad1; };
+struct alignas(16) TileInfo { uint32_t first, n, base_read, base_ref, ref_region, image, first_tile /* index in the range of its first tile-class job */, pad1; };
 static_assert(sizeof(TileInfo) == 32, "TileInfo is 32 bytes");
 
 enum StreamCounter : int {
@@ -145,15 +152,17 @@ enum StreamCounter : int {
     kCntUnsupported,    // jobs whose band is wider than the side list's kernels take (radius + 1 > 256)
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntOthers, kCntTiles, kCntLdsMax,
     kCntCls0,           // kStreamClasses totals
-    kCntCur0 = kCntCls0 + 6, // kStreamClasses scatter cursors
-    kCntCells = kCntCur0 + 6,
-    kCntHeads = 32,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
+    kCntCur0 = kCntCls0 + 14, // kStreamClasses scatter cursors
+    kCntCells = kCntCur0 + 14,
+    kCntHeads = 48,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
+static_assert(kCntCells < kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
     uint64_t n_jobs, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
     int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
+    int32_t side_lane_radius;    // side-list lane classes: radius in (lane_max_radius, this], longer side <= lane_max_n
     uint32_t lane_max_n, micro_max_n;
     uint32_t min_cost8;          // cost floor in eighths of a float: bounds the jobs of a tile's range
     uint64_t width8;             // bracket width of the tile rule: 8 * (image floats - slack) - the largest cost a job can have

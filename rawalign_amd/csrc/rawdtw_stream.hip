@@ -212,7 +212,8 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
         } else if (ok) {
             const uint32_t K = (uint32_t)R + 1u;
             uint32_t cls;
-            if (K <= 8) cls = kClsG8;
+            if (R >= 1 && R <= a.side_lane_radius && N <= a.lane_max_n) cls = kClsL0 + side_lane_bucket(N);
+            else if (K <= 8) cls = kClsG8;
             else if (K <= 16) cls = kClsG16;
             else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
             else cls = 0xff;
@@ -426,27 +427,30 @@ __global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
         if (threadIdx.x == 0) { a.cnt[kCntTileJobs] = s_t[0]; a.cnt[kCntTileBytes] = s_t[1]; a.cnt[kCntOtherBytes] = s_t[2]; }
         return;
     }
+    // Each workgroup orders one contiguous slice of the unordered list: class counts of the slice in LDS, ONE returning
+    // atomic per class and workgroup for the slice's places (same-address atomics run near 88 per microsecond: a wave-level
+    // scheme spends the kernel there once the list has 10^5 entries), then the scatter through LDS cursors.
     const uint64_t n_other = min<uint64_t>(a.cnt[kCntOthers], a.others_cap);
-    uint64_t base[kStreamClasses];
-    uint64_t acc = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < kStreamClasses; c++) { base[c] = acc; acc += a.cnt[kCntCls0 + c]; }
-    const int lane = threadIdx.x & 63;
-    for (uint64_t i0 = ((uint64_t)blockIdx.x * kT + threadIdx.x) & ~63ull; i0 < n_other; i0 += (uint64_t)(gridDim.x - 1) * kT) {
-        const uint64_t i = i0 + lane;
-        const uint32_t cls = i < n_other ? a.ocls[i] : 0xffu;
-        uint64_t pos = ~0ull;
-#pragma unroll
-        for (uint32_t c = 0; c < kStreamClasses; c++) {
-            const unsigned long long mask = __ballot(cls == c);
-            if (!mask) continue;
-            const int leader = __ffsll((long long)mask) - 1;
-            unsigned long long got = 0;
-            if (lane == leader) got = atomicAdd(&a.cnt[kCntCur0 + c], (unsigned long long)__popcll(mask));
-            got = (unsigned long long)__shfl((long long)got, leader);
-            if (cls == c) pos = base[c] + got + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
-        }
-        if (pos != ~0ull && pos < a.others_cap) a.ojobs[pos] = a.omix[i];
+    const uint64_t groups = gridDim.x - 1, per = (n_other + groups - 1) / groups;
+    const uint64_t lo = min(n_other, (uint64_t)blockIdx.x * per), hi = min(n_other, lo + per);
+    __shared__ uint32_t s_n[kStreamClasses];
+    __shared__ uint64_t s_at[kStreamClasses];
+    if (threadIdx.x < kStreamClasses) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kT) atomicAdd(&s_n[a.ocls[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kStreamClasses) {
+        uint64_t base = 0;
+        for (uint32_t c = 0; c < threadIdx.x; c++) base += a.cnt[kCntCls0 + c];
+        const uint32_t mine = s_n[threadIdx.x];
+        s_at[threadIdx.x] = base + (mine ? atomicAdd(&a.cnt[kCntCur0 + threadIdx.x], (unsigned long long)mine) : 0ull);
+        s_n[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += kT) {
+        const uint32_t cls = a.ocls[i];
+        const uint64_t pos = s_at[cls] + atomicAdd(&s_n[cls], 1u);
+        if (pos < a.others_cap) a.ojobs[pos] = a.omix[i];
     }
 }
 
@@ -506,41 +510,55 @@ __global__ __launch_bounds__(1024) void k_fold_order(uint64_t n_chains, const ui
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kSortBins = 512; // bin = kind * 80 + (79 - longer side): 6 kinds x 80
+constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
 template <int TT> struct SortTable {
     uint32_t hist[kSortBins];
     uint16_t perm[kItems * TT];
 };
 
-__device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, int kind,
-                                                 uint32_t R, bool excl, const unsigned long long *__restrict__ masks, bool act)
+// One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
+// first (none unless "stream_tile_radius" is 3), then the others, both runs by longer side, descending; a wave takes the
+// shortest body that covers its radii.
+__device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
 {
-    float res = 0.0f;
-    const int k = act ? kind : -1;
-    if (__any(k == 2)) {
-        if (k == 2) {
-            const unsigned long long mask = masks[((N - 1) * 8 + (M - 1)) * (kMaxLaneRadius + 1) + R];
-            const uint32_t Nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)N); // sorted by longer side, descending
-            if (Nw <= 2) res = micro_job_cols<4, 2>(LA, LB, N, M, mask);
-            else if (Nw == 3) res = micro_job_cols<4, 3>(LA, LB, N, M, mask);
-            else res = micro_job_cols<4, 4>(LA, LB, N, M, mask);
-        }
+    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u);
+    uint32_t n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)N); // lane 0 leads the wave's first run
+    if (r12) {                                                         // ... and the first lane of radius <= 2 the second
+        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)r12) - 1);
+        n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)N, l));
     }
-    if (__any(k == 1)) {
-        if (k == 1) {
-            const unsigned long long mask = masks[((N - 1) * 8 + (M - 1)) * (kMaxLaneRadius + 1) + R];
-            const uint32_t Nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)N);
-            if (Nw <= 5) res = micro_job_cols<8, 5>(LA, LB, N, M, mask);
-            else if (Nw == 6) res = micro_job_cols<8, 6>(LA, LB, N, M, mask);
-            else if (Nw == 7) res = micro_job_cols<8, 7>(LA, LB, N, M, mask);
-            else res = micro_job_cols<8, 8>(LA, LB, N, M, mask);
-        }
-    }
-    if (__any(k == 0)) { // every other shape, any radius: one generic body, lanes sorted by longer side (descending)
-        if (k == 0) res = lane_dp_gen(LA, LB, N, M, R, (uint32_t)__builtin_amdgcn_readfirstlane((int)N));
-    }
+    float res;
+    if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, M, n_max);
+    else if (~r12 == 0ull) res = lane_dp_r12(LA, LB, N, M, R, n_max);
+    else res = lane_dp_gen(LA, LB, N, M, R, n_max);
     if (act && excl) res = res - dist(LA[N - 1], LB[M - 1]);
     return res;
+}
+
+// 64 jobs of the side list's lane classes: one lane per job, operands straight from the arenas (the jobs of a wave come
+// from all over the batch: nothing to stage together; they are 2 % of a sparse batch's jobs)
+__device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
+                                                 const float *__restrict__ ev, const float *__restrict__ ref, float *__restrict__ out)
+{
+    const uint32_t idx = wave * 64u + (uint32_t)lane;
+    const bool have = idx < count;
+    const DevJob jb = jobs[have ? idx : count - 1u];
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        const uint32_t tn = N; N = M; M = tn;
+    }
+    uint32_t n_max = N;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
+    n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
+    float res = lane_dp_gen<true>(A, B, N, M, (uint32_t)jb.R, n_max);
+    if (have) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
 }
 
 } // namespace
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
     uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);                    // one record per job of the tile's range
     constexpr uint32_t kMaxJobs = kItems * TT;
     SortTable<TT> &sc = *reinterpret_cast<SortTable<TT> *>(smem + lds_floats + 2 * kMaxJobs);
-    __shared__ uint32_t s_tmp[TT / 64];
+    __shared__ uint32_t s_tmp[2];
     __shared__ TileInfo s_tile[2];
     __shared__ uint32_t s_seq;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -587,13 +605,29 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
 #pragma unroll
         for (uint32_t c = kClsW0; c < kClsW0 + 4; c++) n_w += a.cnt[kCntCls0 + c];
         const uint64_t n_g16 = a.cnt[kCntCls0 + kClsG16], n_g8 = a.cnt[kCntCls0 + kClsG8];
-        if (n_w + n_g16 + n_g8 <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
-            const uint64_t it_g16 = (n_g16 + 3) / 4, it_g8 = (n_g8 + 7) / 8, items = n_w + it_g16 + it_g8;
+        uint64_t n_l = 0;
+#pragma unroll
+        for (uint32_t c = kClsL0; c < kClsL0 + kClsLCount; c++) n_l += a.cnt[kCntCls0 + c];
+        if (n_w + n_g16 + n_g8 + n_l <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
+            // item order = list order: wave-per-job (longest first), 16-lane groups, 8-lane groups, lane-per-job (by length)
+            const uint64_t it_g16 = (n_g16 + 3) / 4, it_g8 = (n_g8 + 7) / 8, it_l = (n_l + 63) / 64, items = n_w + it_g16 + it_g8 + it_l;
             for (uint64_t it = (uint64_t)blockIdx.x * (TT / 64) + wv; it < items; it += (uint64_t)gridDim.x * (TT / 64)) {
-                if (it < n_w) { if (!(a.debug & 32u)) wreg_small_job(a.ojobs[it], lane, a.ev, a.ref, a.out); }
+                if (it < n_w) {
+                    if (a.debug & 32u) continue;
+                    // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its
+                    // SIMD with the waves around it -- it goes first in the issue order
+                    const DevJob jb = a.ojobs[it];
+                    const uint32_t len = max(jb.n, jb.m);
+                    if (len >= 256u) __builtin_amdgcn_s_setprio(3);
+                    else if (len >= 96u) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(1);
+                    wreg_small_job(jb, lane, a.ev, a.ref, a.out);
+                    __builtin_amdgcn_s_setprio(0);
+                }
                 else if (a.debug & 64u) continue;
                 else if (it < n_w + it_g16) grp_wave<16>(a.ojobs + n_w, (uint32_t)n_g16, (uint32_t)(it - n_w), lane, a.ev, a.ref, a.out);
-                else grp_wave<8>(a.ojobs + n_w + n_g16, (uint32_t)n_g8, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
+                else if (it < n_w + it_g16 + it_g8) grp_wave<8>(a.ojobs + n_w + n_g16, (uint32_t)n_g8, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
+                else lane_global_wave(a.ojobs + n_w + n_g16 + n_g8, (uint32_t)n_l, (uint32_t)(it - n_w - it_g16 - it_g8), lane, a.ev, a.ref, a.out);
             }
         }
     }
@@ -634,10 +668,12 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
     while (D.n) {
         // thread 0: the next tile's geometry and the ticket of the one after it -- issued now, consumed at the publish
         // below (nothing here waits for them)
-        TileInfo D1{};
+        uint4 d1_lo = make_uint4(0, 0, 0, 0), d1_hi = d1_lo; // (a TileInfo as two 16-byte halves: stays in registers)
         unsigned long long ticket = 0;
         if (tid == 0 && t_next != 0xffffffffu) {
-            D1 = a.tiles[t_next];
+            const uint4 *tp = reinterpret_cast<const uint4 *>(a.tiles + t_next);
+            d1_lo = tp[0];
+            d1_hi = tp[1];
             if (!(a.debug & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
         }
         const uint32_t first = D.first, n = D.n;
@@ -659,10 +695,9 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
                     const bool swap = (jr[k].meta >> 17) & 1u, starts = (jr[k].meta >> 18) & 1u;
                     const uint32_t p_read = image_pos(c_read, jr[k].read_off, starts) - D.base_read;
                     const uint32_t p_ref = image_pos(c_ref, jr[k].ref_off, starts) - D.base_ref + D.ref_region;
-                    const uint32_t kind = N <= a.micro_max_n ? (N <= 4 ? 2u : 1u) : 0u; // the heavy class first
                     rec[i] = make_uint2((swap ? p_ref : p_read) | ((swap ? p_read : p_ref) << 16),
-                                        N | (M << 7) | (R << 14) | (((jr[k].meta >> 16) & 1u) << 16) | (kind << 17));
-                    bin[k] = kind * 80u + (79u - N);
+                                        N | (M << 7) | (R << 14) | (((jr[k].meta >> 16) & 1u) << 16));
+                    bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
                     rank[k] = atomicAdd(&sc.hist[bin[k]], 1u);
                     // Marks: every 16-byte chunk the two windows touch gets (arena index - image offset) and the tile's tag:
                     // the same value for all chunks of a run, and two runs never share a chunk.  A run start also owns the
@@ -684,7 +719,9 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
             }
         }
         if (tid == 0) { // publish the next tile; resolve the ticket into the tile after it
-            s_tile[slot ^ 1u] = D1;
+            uint4 *sp = reinterpret_cast<uint4 *>(&s_tile[slot ^ 1u]);
+            sp[0] = d1_lo;
+            sp[1] = d1_hi;
             uint32_t t2 = 0xffffffffu;
             if (t_next != 0xffffffffu) {
                 if (a.debug & 8u) t2 = next_tile(a, head, n_tiles);
@@ -703,13 +740,25 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
         uint64_t ce_n[kItems];
         fetch_records(Dn, jr_n, ce_n);
         // ---- 2. stage: a flat copy of the marked chunks, 16 bytes per lane, consecutive lanes consecutive chunks; the
-        // histogram's scan runs while the first loads are in flight ----
+        // histogram's scan is the first wave's, ahead of its share of the copy ----
         const uint32_t chunks = bad ? 0u : D.image >> 2;
-        uint32_t n_tile_jobs = 0;
         {
-            constexpr uint32_t BPT = kSortBins / TT > 0 ? kSortBins / TT : 1; // bins per thread (threads beyond the bins idle)
-            uint32_t h[BPT], sum = 0;
-            __builtin_amdgcn_s_setprio(3); // a fresh tile's loads must not queue behind the DP of the older workgroups
+            __builtin_amdgcn_s_setprio(2); // a fresh tile's loads must not queue behind the DP of the older workgroups
+            if (wv == 0) {
+                // the sort's scan, by the first wave alone (the others are already staging): three bins per lane, the bins'
+                // first places back into the table, the tile's job count next to it
+                const uint32_t h0 = sc.hist[3 * lane], h1 = sc.hist[3 * lane + 1], h2 = sc.hist[3 * lane + 2];
+                const uint32_t sum = h0 + h1 + h2;
+                uint32_t incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += o;
+                }
+                const uint32_t ex = incl - sum;
+                sc.hist[3 * lane] = ex; sc.hist[3 * lane + 1] = ex + h0; sc.hist[3 * lane + 2] = ex + h0 + h1;
+                if (lane == 63) s_tmp[0] = incl;
+            }
             for (uint32_t q0 = 0; q0 < chunks || q0 == 0; q0 += 4 * TT) { // four chunks per thread and round
                 uint32_t ok[4];
                 const float *src[4];
@@ -726,39 +775,17 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++)
-                    if (ok[u]) v[u] = *reinterpret_cast<const float4 *>(src[u]);
-                if (q0 == 0) { // the sort's scan, first half: per-thread bins, wave scan, wave totals
-#pragma unroll
-                    for (uint32_t q = 0; q < BPT; q++) { h[q] = (uint32_t)tid * BPT + q < kSortBins ? sc.hist[tid * BPT + q] : 0u; sum += h[q]; }
-                    uint32_t incl = sum;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-                        if (lane >= d) incl += o;
-                    }
-                    if (lane == 63) s_tmp[wv] = incl;
-                    sum = incl - sum; // exclusive inside the wave
-                }
+                for (uint32_t u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4 *>(src[u]); // (idle lanes read ev[0..3])
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) {
                     const uint32_t q = q0 + tid + u * TT;
                     if (ok[u]) reinterpret_cast<float4 *>(win)[q] = v[u];
                 }
             }
-            __syncthreads(); // image staged; wave totals written
-            uint32_t pre = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < (uint32_t)TT / 64; w++) {
-                const uint32_t x = s_tmp[w];
-                if (w < wv) pre += x;
-                n_tile_jobs += x;
-            }
-            uint32_t run = pre + sum;
-#pragma unroll
-            for (uint32_t q = 0; q < BPT; q++) { if ((uint32_t)tid * BPT + q < kSortBins) sc.hist[tid * BPT + q] = run; run += h[q]; }
+            __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads(); // bin starts written
+        __syncthreads(); // image staged; bin starts and job count written
+        const uint32_t n_tile_jobs = s_tmp[0];
 #pragma unroll
         for (uint32_t k = 0; k < kItems; k++)
             if (bin[k] != 0xffffffffu) sc.perm[sc.hist[bin[k]] + rank[k]] = (uint16_t)(k * TT + tid);
@@ -776,8 +803,7 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
             const uint32_t i = min((uint32_t)sc.perm[act ? r : n_tile_jobs - 1], n - 1u); // (never past the tile's range, whatever the table holds)
             const uint2 rc = rec[i];
             const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
-            const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, (int)((rc.y >> 17) & 7u), R,
-                                              (rc.y >> 16) & 1u, a.masks, act);
+            const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
             if (act) a.out[first + i] = res;
         }
         __syncthreads();

@@ -35,6 +35,11 @@ for cfg in configs:
     ms = b.run_reps(20, timed=True)
     pm = C.c_float()
     eng.lib.rawdtw_batch_plan_ms(eng._ctx, b._h, C.byref(pm))
+    cnt = (C.c_uint64 * 32)()
+    ncnt = C.c_uint32()
+    eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 32, C.byref(ncnt))
+    if cfg == configs[0]:
+        print("counters: tile jobs %d  tiles %d  side list %d  classes %s" % (cnt[3], cnt[7], cnt[6], list(cnt[9:15])), flush=True)
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
                                                                    ["%.4f" % m[2] for m in ms]), flush=True)
     b.close()
