@@ -319,25 +319,33 @@ def main():
         engines[sl]._check(lib.rawdtw_batch_collect(engines[sl]._ctx, handles[sl], vp(ms), vp(kind), 8, C.byref(nl), C.byref(nr)))
         sink.append(ms[:nl.value].copy())
 
-    def pipeline(K, pcie, timed_launches=None):
+    host_s = {"fetch": 0.0, "create": 0.0, "run": 0.0, "steps": 0}
+
+    def pipeline(K, pcie, timed_launches=None, host=None):
         """K steps, every one a fresh batch; context k % slots; a context's previous batch is fetched before its next."""
         for e in engines:
             e.set_option("resident_arrays", 0 if pcie else 1)
+        pc = time.perf_counter
         for k in range(K):
             sl = k % slots
             d, e = B[sl], engines[sl]
+            t0 = pc()
             if live[sl]:
                 if timed_launches is not None:
                     collect(sl, timed_launches)
                 fetch_destroy(sl)
+            t1 = pc()
             if pcie:  # the round's new events: one H2D of the packed chunk events + a scatter into the per-read arrays
                 e._check(lib.rawdtw_events_append(e._ctx, vp(d["new_events"]), len(d["new_events"]), d["n_reads"],
                                                   vp(d["seg_src"]), vp(d["seg_dst"])))
             create(sl, not pcie)
+            t2 = pc()
             if timed_launches is None:
                 e._check(lib.rawdtw_batch_run(e._ctx, handles[sl]))
             else:  # HIP event pair around every launch, read when the context comes round again
                 e._check(lib.rawdtw_batch_enqueue(e._ctx, handles[sl], 1))
+            if host is not None:
+                host["fetch"] += t1 - t0; host["create"] += t2 - t1; host["run"] += pc() - t2; host["steps"] += 1
         for sl in range(slots):
             if live[sl]:
                 if timed_launches is not None:
@@ -367,7 +375,7 @@ def main():
     # ---- warm-up (workspace pools, code objects), then the three timed loops ----
     pipeline(max(args.warmup, slots), pcie=False)
     pipeline(slots, pcie=True)
-    t_fresh = repeat_region(lambda: pipeline(K, pcie=False))
+    t_fresh = repeat_region(lambda: pipeline(K, pcie=False, host=host_s))
     t_pcie = repeat_region(lambda: pipeline(K, pcie=True))
     # host cost of one create call, steady state (inputs resident / from pinned host memory)
     create_ms = {}
@@ -478,6 +486,9 @@ def main():
                                       "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory"},
             "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / K * 1e3, "repeats": len(r_replay),
                               "note": "launches of pre-planned resident batches only (round 1's headline)"},
+            "host_ms_per_step": {k: round(host_s[k] / max(host_s["steps"], 1) * 1e3, 4) for k in ("fetch", "create", "run")} | {
+                "note": "host wall time inside the three calls of one step of the timed fresh-batch loop: `fetch` includes "
+                        "waiting for the context's previous batch (the only blocking call); `create` + `run` only enqueue"},
             "batch_create_ms": {"steady": create_ms["resident"], "from_pinned_host": create_ms["from_host"],
                                 "note": "host wall time of one rawdtw_batch_create call, steady state: it only enqueues (no "
                                         "synchronisation, no allocation); `planning_gpu_ms` is what its kernels cost the device",

@@ -716,67 +716,76 @@ __device__ __forceinline__ void wreg_body(const DevJob &jb, const int lane, cons
     }
 }
 
-// The same wave-per-job scheme without per-cell validity (see lane_dp_gen for the argument: slots outside an
-// antidiagonal's extent and cells beyond the matrix on the high side are never read by a cell inside it, except through
-// the reference's guarded reads; cells beyond the matrix on the LOW side exist only in a job's first columns, which take
-// the masked copy of the step).  Two buffers (d1 = latest antidiagonal, d0 = the one before), control flow scalar: the
-// job is the wave's, so `adv` is uniform.  About half the instructions of wreg_body per antidiagonal -- it is the
-// longest wide-band job of a batch that decides when the batch's DTW launch ends.
+// The wave-per-job scheme without per-cell validity (see lane_dp_gen for the argument: slots outside an antidiagonal's
+// extent and cells beyond the matrix on the high side are never read by a cell inside it, except through the reference's
+// guarded reads; cells beyond the matrix on the LOW side exist only in a job's first columns, which take the masked copy
+// of the step).  Two buffers (d1 = latest antidiagonal, d0 = the one before), control flow scalar: the job is the wave's,
+// so `adv` is uniform.
+// Layout: BLOCKED -- lane l holds the physical slots l*C .. l*C + C-1 in its C registers.  A neighbour at p-1 / p+1 is a
+// register of the same lane except at the block's edge: ONE DPP wave shift per direction and buffer, whatever C is, and
+// no v_readlane carry between registers (the strided layout p = c*64 + lane of wreg_body needs C shifts and C-1 carries
+// for each, every carry a VALU -> SALU -> VALU round trip in the column's dependent chain).  It is the longest
+// wide-band job of a batch that decides when the batch's DTW launch ends, and that job has a band of 65..128 slots.
+// Guards: none in the step.  Invariant instead: a slot outside its antidiagonal's extent (secondaries: p < S; primaries:
+// SH <= p < SH + P) holds 1e10 -- one select per antidiagonal on a loop-invariant lane mask.  Every guarded read of the
+// reference (is_first, is_last, previous_increment_center_row: dtw.cpp:373-375, 392-397, 428-441, 461-473) is a read of
+// such a slot, or of the slot before slot 0 (the shift's fill), and yields 1e10 there:
+//   secondary p reads d1[p], d1[p+1] (the primary before it) and d0[p]: odd radius -- primaries live at 1..R, so d1[0]
+//   (is_first) and d1[R+1] (is_last, p = S-1) are outside, and d0[0] is outside exactly when d0 is a primary, i.e. when
+//   the row did not advance the column before; even radius -- all inside;
+//   primary p after a secondary reads X[p-1], X[p], d1[p]: even radius, p = P-1 = S reads X[S], outside (is_last);
+//   primary p without one reads d1[p-1], d1[p], d0[p-1]: at p = SH these are slot SH-1 of primaries (outside: slot 0 of
+//   an odd radius, the fill of an even one) -- d0[0] of an odd radius again inside exactly after an advance.
 template <int C, bool MASKED>
 __device__ __forceinline__ void wreg_gen_step(float (&d0)[C], float (&d1)[C], float (&ap)[C], float (&bp)[C], const bool adv,
-                                              const bool prev_adv, const float fresh_a, const float fresh_b, const int lane,
-                                              const int SH, const int S, const int P, const int off, const int row, const int col)
+                                              const float fresh_a, const float fresh_b, const bool (&in_sec)[C],
+                                              const bool (&in_prim)[C], const int lane, const int off, const int row, const int col)
 {
+    const int p0 = lane * C;
     float X[C];
     if (adv) {
-        // b-window: every lane takes its right neighbour's value
+        // b-window: every slot takes its right neighbour's value (the last physical slot the fresh one)
+        {
+            const float in = wave_shl1(bp[0], fresh_b);
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const float fill = (c + 1 < C) ? read_lane(bp[c + 1 < C ? c + 1 : c], 0) : fresh_b;
-            bp[c] = wave_shl1(bp[c], fill);
+            for (int c = 0; c + 1 < C; c++) bp[c] = bp[c + 1];
+            bp[C - 1] = in;
         }
         // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
+        const float d1_up = wave_shl1(d1[0], kInf); // the next lane's first slot
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const int p = c * 64 + lane;
-            const float fill = (c + 1 < C) ? read_lane(d1[c + 1 < C ? c + 1 : c], 0) : kInf;
-            float left = wave_shl1(d1[c], fill), top = d1[c], tl = d0[c];
-            if (SH) {
-                if (p == 0) { top = kInf; if (!prev_adv) tl = kInf; }
-                if (p == S - 1) left = kInf;
-            }
-            float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
-            if (MASKED && (p < off - row || p > col - 1 + off)) v = kInf;
-            X[c] = v;
+            const float left = (c + 1 < C) ? d1[c + 1 < C ? c + 1 : c] : d1_up;
+            float v = min3f(d1[c], left, d0[c]) + dist(ap[c], bp[c]);
+            bool keep = in_sec[c];
+            if (MASKED) keep = keep && !(p0 + c < off - row || p0 + c > col - 1 + off);
+            X[c] = keep ? v : kInf;
         }
     } else {
 #pragma unroll
         for (int c = 0; c < C; c++) X[c] = d1[c];
     }
-    // a-window: every lane takes its left neighbour's value
+    // a-window: every slot takes its left neighbour's value (slot 0 the fresh one)
+    {
+        const float in = wave_shr1(ap[C - 1], fresh_a);
 #pragma unroll
-    for (int c = C - 1; c >= 0; c--) {
-        const float fill = (c > 0) ? read_lane(ap[c > 0 ? c - 1 : 0], 63) : fresh_a;
-        ap[c] = wave_shr1(ap[c], fill);
+        for (int c = C - 1; c > 0; c--) ap[c] = ap[c - 1];
+        ap[0] = in;
     }
-    // primary antidiagonal (dtw.cpp:416-485)
+    // primary antidiagonal (dtw.cpp:416-485): after a secondary (top, left, diagonal) = (X[p-1], X[p], d1[p]); otherwise
+    // X is the primary before this one and they are (X[p-1], X[p], d0[p-1])
+    const float X_dn = wave_shr1(X[C - 1], kInf); // the previous lane's last slot
+    float d0_dn = kInf;
+    if (!adv) d0_dn = wave_shr1(d0[C - 1], kInf);
     float pr[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const int p = c * 64 + lane;
-        const float f1 = (c > 0) ? read_lane(X[c > 0 ? c - 1 : 0], 63) : kInf;
-        float top = wave_shr1(X[c], f1), left = X[c], tl;
-        if (adv) {
-            tl = d1[c];
-            if (!SH && p == P - 1) left = kInf;
-        } else {
-            const float f0 = (c > 0) ? read_lane(d0[c > 0 ? c - 1 : 0], 63) : kInf;
-            tl = wave_shr1(d0[c], f0);
-            if (p == SH) { top = kInf; if (!SH || !prev_adv) tl = kInf; }
-        }
-        float v = min3f(top, left, tl) + dist(ap[c], bp[c]);
-        if (MASKED && p < off - row) v = kInf;
-        pr[c] = v;
+        const float top = c > 0 ? X[c > 0 ? c - 1 : 0] : X_dn;
+        const float tl = adv ? d1[c] : (c > 0 ? d0[c > 0 ? c - 1 : 0] : d0_dn);
+        float v = min3f(top, X[c], tl) + dist(ap[c], bp[c]);
+        bool keep = in_prim[c];
+        if (MASKED) keep = keep && !(p0 + c < off - row);
+        pr[c] = keep ? v : kInf;
     }
 #pragma unroll
     for (int c = 0; c < C; c++) { d0[c] = X[c]; d1[c] = pr[c]; }
@@ -802,44 +811,61 @@ __device__ __forceinline__ void wreg_gen(const DevJob &jb, const int lane, const
     auto ldA = [&](int i) { return A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; };
     auto ldB = [&](int i) { return B[i < 0 ? 0 : (i >= iM ? iM - 1 : i)]; };
     float d0[C], d1[C], ap[C], bp[C];
+    bool in_sec[C], in_prim[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        const int p = c * 64 + lane;
+        const int p = lane * C + c;
         d0[c] = kInf; d1[c] = kInf;
         ap[c] = ldA(off - p);
         bp[c] = ldB(p - off);
         if (p == off) d1[c] = dist(A[0], B[0]); // the corner (dtw.cpp:317-347)
+        in_sec[c] = p < S;
+        in_prim[c] = p >= SH && p < SH + P;
     }
-    // fresh-value chunks: column col needs A[col + off]; the r-th row advance needs B[b0 + r - 1]
+    // fresh-value chunks, 64 values a lane each, read by cursor: column col needs A[col + off] = A[a0 + col - 1]; the r-th
+    // row advance needs B[b0 + r - 1].  A chunk is replaced right after its last value went out (the one after it is
+    // already in registers; the load issued here is for the chunk after that).
     const int a0 = off + 1, b0 = 64 * C - off;
     float acur = ldA(a0 + lane), anxt = ldA(a0 + 64 + lane);
     float bcur = ldB(b0 + lane), bnxt = ldB(b0 + 64 + lane);
+    uint32_t ca = 0, cb = 0;
     int row = 0;
-    uint32_t rem = 0;
-    bool prev_adv = false;
-    for (uint32_t col = 1; col < N; col++) {
+    uint32_t rem = 0, col = 1;
+    auto next_a = [&]() {
+        const float v = read_lane(acur, (int)ca);
+        if (++ca == 64u) { ca = 0; acur = anxt; anxt = ldA(a0 + (int)col + 64 + lane); }
+        return v;
+    };
+    auto next_b = [&]() { // (row already counts this advance)
+        const float v = read_lane(bcur, (int)cb);
+        if (++cb == 64u) { cb = 0; bcur = bnxt; bnxt = ldB(b0 + row + 64 + lane); }
+        return v;
+    };
+    // first columns: cells above row 0 or left of column 0 exist while row < off or col - 1 + off < K - 1
+    for (; col < N && (row < off || (int)col < K - off + 1); col++) {
         rem += M;
         const bool adv = rem >= N;
-        const uint32_t ca = (col - 1) & 63u;
-        if (ca == 0 && col > 1) { acur = anxt; anxt = ldA(a0 + (int)(col - 1) + 64 + lane); }
-        const float fresh_a = read_lane(acur, (int)ca);
+        const float fresh_a = next_a();
         float fresh_b = 0.0f;
-        if (adv) {
-            rem -= N;
-            row++;
-            const uint32_t cb = (uint32_t)(row - 1) & 63u;
-            if (cb == 0 && row > 1) { bcur = bnxt; bnxt = ldB(b0 + (row - 1) + 64 + lane); }
-            fresh_b = read_lane(bcur, (int)cb);
+        if (adv) { rem -= N; row++; fresh_b = next_b(); }
+        wreg_gen_step<C, true>(d0, d1, ap, bp, adv, fresh_a, fresh_b, in_sec, in_prim, lane, off, row, (int)col);
+    }
+    // the rest: one uniform branch per column (did the centre row advance?), nothing else
+    for (; col < N; col++) {
+        rem += M;
+        const float fresh_a = next_a();
+        if (rem >= N) {
+            rem -= N; row++;
+            const float fresh_b = next_b();
+            wreg_gen_step<C, false>(d0, d1, ap, bp, true, fresh_a, fresh_b, in_sec, in_prim, lane, off, row, (int)col);
+        } else {
+            wreg_gen_step<C, false>(d0, d1, ap, bp, false, fresh_a, 0.0f, in_sec, in_prim, lane, off, row, (int)col);
         }
-        // cells above row 0 or left of column 0 exist while row < off or col - 1 + off < K - 1
-        if (row < off || (int)col < K - off + 1) wreg_gen_step<C, true>(d0, d1, ap, bp, adv, prev_adv, fresh_a, fresh_b, lane, SH, S, P, off, row, (int)col);
-        else wreg_gen_step<C, false>(d0, d1, ap, bp, adv, prev_adv, fresh_a, fresh_b, lane, SH, S, P, off, row, (int)col);
-        prev_adv = adv;
     }
     float res = 0.0f; // dtw.cpp:506-512: the centre of the last primary
 #pragma unroll
     for (int c = 0; c < C; c++)
-        if ((off >> 6) == c) res = read_lane(d1[c], off & 63);
+        if (off % C == c) res = read_lane(d1[c], off / C);
     if (lane == 0) {
         if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
         out[jb.aux] = res;

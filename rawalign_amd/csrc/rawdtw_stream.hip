@@ -804,9 +804,19 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
             const uint2 rc = rec[i];
             const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
             const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
-            if (act) a.out[first + i] = res;
+            if (act) rec[i].x = __float_as_uint(res); // (the job's record is done with; its slot carries the result out)
         }
         __syncthreads();
+        // results out in job order, 256 bytes a wave: the sorted order would scatter every wave's 64 results over the tile's
+        // range (one memory write request per job).  Thread t reads back the slots of the jobs t, t + TT, ... -- the same
+        // slots it fills with the next tile's records afterwards, so no barrier stands between the two.
+        if (!bad && !(a.debug & 1u)) {
+#pragma unroll
+            for (uint32_t k = 0; k < kItems; k++) {
+                const uint32_t i = k * TT + tid;
+                if (i < n && (jr[k].meta & kMetaTile)) a.out[first + i] = __uint_as_float(rec[i].x);
+            }
+        }
         slot ^= 1u;
         D = Dn;
 #pragma unroll
