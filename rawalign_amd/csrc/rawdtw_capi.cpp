@@ -1723,7 +1723,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the
     // bracket by at most the largest cost a job can have, so the image needs at most tile_budget floats
     const uint32_t tile_budget = lds_floats - kStreamSlack;
-    const uint32_t max_tile_jobs = 4u * (uint32_t)ctx->stream_threads;
+    const uint32_t max_tile_jobs = kStreamItems * (uint32_t)ctx->stream_threads;
     a.min_cost8 = (8u * tile_budget + max_tile_jobs - 1) / max_tile_jobs;
     const uint64_t worst8 = std::max<uint64_t>(8ull * (2ull * a.lane_max_n + 12ull), a.min_cost8);
     a.width8 = 8ull * tile_budget - worst8;

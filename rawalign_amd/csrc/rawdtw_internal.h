@@ -97,7 +97,8 @@ struct FullAux {
 struct JobRec { uint64_t ref_off; uint32_t read_off; uint32_t meta; };
 static_assert(sizeof(JobRec) == 16, "JobRec is 16 bytes");
 constexpr uint32_t kMetaStarts = 1u << 18, kMetaTile = 1u << 19;
-constexpr uint32_t kStreamMaxTileJobs = 2048; // jobs in a tile's range, 512-thread workgroups (256-thread: half)
+constexpr uint32_t kStreamItems = 4;          // jobs per thread in a tile's prologue: a tile's range holds kStreamItems * threads jobs
+constexpr uint32_t kStreamMaxTileJobs = kStreamItems * 512; // ... of 512-thread workgroups (256-thread: half)
 constexpr uint32_t kStreamSlack = 32;         // LDS floats of a tile's image kept free for region alignment
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
 constexpr uint32_t kStreamClasses = 14, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5, kClsL0 = 6, kClsLCount = 8;

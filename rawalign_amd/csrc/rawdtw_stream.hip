@@ -33,14 +33,23 @@ namespace {
 
 constexpr int kT = 256;                 // threads per workgroup, everywhere in this file
 constexpr uint32_t kPreUnit = 1024;     // jobs per k_pre workgroup
-constexpr uint32_t kItems = 4;          // jobs per thread in the tile prologue (blocked): a tile's range holds 4 * threads jobs
+constexpr uint32_t kItems = kStreamItems; // jobs per thread in the tile prologue (strided)
 static_assert(kStreamMaxTileJobs == kItems * 512, "tile job capacity of the 512-thread instance");
 
 __device__ __forceinline__ int d_slanted_radius(uint32_t n, uint32_t m, int r0)
 {
     const uint32_t N = n > m ? n : m, M = n > m ? m : n;
-    const uint32_t extra = ((N - M) * (uint32_t)r0 + N - 1u) / N; // dtw.cpp:298-300, unsigned 32-bit
-    return r0 + (int)extra;
+    const uint32_t x = (N - M) * (uint32_t)r0 + N - 1u; // dtw.cpp:298-300, unsigned 32-bit: extra = x / N
+    uint32_t q;
+    if (N < (1u << 11) && (uint32_t)r0 < (1u << 11)) {
+        // x < 2^23 is exact in a float and the quotient is below 2^12: the product with the hardware reciprocal (1 ulp)
+        // is within 2^-10 of it, so the truncation is the quotient or one beside it -- one remainder check settles it
+        // (an integer division is some 25 instructions, three of them per job)
+        q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)N));
+        const int r = (int)x - (int)(q * N);
+        q = r < 0 ? q - 1u : (r >= (int)N ? q + 1u : q);
+    } else q = x / N;
+    return r0 + (int)q;
 }
 
 // exact size of the band's cell set (same walk as the kernels; reporting only)
@@ -110,6 +119,10 @@ struct OpMax { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { re
 // its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs and
 // every stage below issues the loads of all of them before anything waits, and nothing in the job path crosses a
 // workgroup barrier.
+// Register budget: 102 VGPRs (allocated 104).  In a pipeline of batches this kernel shares the SIMDs with the k_stream
+// waves (96 VGPRs) of the batches before it, and with 104 any mix of the two keeps five waves on a SIMD (4 x 104 + 96 =
+// 512).  A variant that evaluated the class rule of the neighbouring parts once per thread (6 instead of 12 radius
+// computations, -20 % VALU) needed 116 and made the whole pipeline 10 % SLOWER, every kernel in it included.
 __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 {
     constexpr uint32_t kPer = kPreUnit / kT;
@@ -273,13 +286,15 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
     }
     // totals: per workgroup, then one record per unit (reduced by k_others); the side list's base: one returning atomic per
     // workgroup that has side-list jobs
-    for (int off = 32; off > 0; off >>= 1) {
-        my_tiles += __shfl_down((int)my_tiles, off);
-        my_bytes += __shfl_down(my_bytes, off);
-        my_obytes += __shfl_down(my_obytes, off);
-    }
-    if ((tid & 63) == 0) {
-        atomicAdd(&s_stats[0], (unsigned long long)my_tiles); atomicAdd(&s_stats[1], my_bytes); atomicAdd(&s_stats[2], my_obytes);
+    {
+        // tile jobs (<= 4 a thread) and their bytes (< 2^12 a thread) share one 32-bit word through the wave's reduction;
+        // the side list's bytes are rare and unbounded: an atomic of their own from the threads that have any
+        uint32_t packed = my_tiles | ((uint32_t)my_bytes << 10);
+        for (int off = 32; off > 0; off >>= 1) packed += (uint32_t)__shfl_down((int)packed, off);
+        if ((tid & 63) == 0) {
+            atomicAdd(&s_stats[0], (unsigned long long)(packed & 1023u)); atomicAdd(&s_stats[1], (unsigned long long)(packed >> 10));
+        }
+        if (my_obytes) atomicAdd(&s_stats[2], my_obytes);
     }
     __syncthreads();
     if (tid == 0) s_obase = s_ocnt ? (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt) : 0u;
