@@ -67,6 +67,7 @@ struct rawdtw_ctx {
     bool full_wg = true; // full-matrix jobs with >= 3 strips: four waves per job, pipelined strips
     bool lane_hi = false; // radii 4..8 on the second tile-kernel instance (else on k_band_wreg<1>)
     uint32_t tile_lds_floats = kTileLdsFloats, tile_max_jobs = kTileMaxJobs;
+    bool tile_lds_set = false;                  // "tile_lds_floats" was given: it also sizes the device-planned batches' tiles
     uint32_t lane_max_n = kLaneMaxN;
     uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
     uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
@@ -77,7 +78,7 @@ struct rawdtw_ctx {
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_stream (256 or 512: 1024 / 2048 jobs per tile)
     int stream_threads_cached = 0;
-    int stream_blocks_per_cu = 0;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
+    int stream_blocks_per_cu = 4;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
     int stream_bpc_cached = -1;
     uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
     uint32_t stream_debug = 0;         // StreamArgs::debug
@@ -1179,7 +1180,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name) return RAWDTW_ERR_INVALID;
     if (!strcmp(name, "serial_launches")) { ctx->serial_launches = value != 0; return RAWDTW_OK; }
-    if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); return RAWDTW_OK; }
+    if (!strcmp(name, "tile_lds_floats")) { ctx->tile_lds_floats = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1024), 40000); ctx->tile_lds_set = true; return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
@@ -1649,6 +1650,12 @@ struct StreamLayout { // sizes in bytes of one batch's device workspace and pinn
     uint32_t tiles_cap = 0;
 };
 
+// LDS image of a device-planned batch's tiles, in floats.  With four workgroups a CU (stream_blocks_per_cu) a SIMD keeps
+// 128 registers free beside the DTW launch's waves -- room for a wave of the next batches' planning kernels or of the
+// batch before's fold -- and the LDS that a fifth workgroup would take goes into larger tiles (fewer tiles, fuller sorted
+// waves).  Measured on the bench pipeline (4 batches in flight): 5 x 4800 floats 425 GCUPS, 4 x 7200 453, 3 x 6400 450.
+static uint32_t stream_tile_floats(const rawdtw_ctx *ctx) { return ctx->tile_lds_set ? ctx->tile_lds_floats : kStreamTileFloats; }
+
 bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)
 {
     if (!ctx->device_plan || n_jobs < ctx->device_plan_min_jobs || n_jobs == 0 || n_jobs >= (1ull << 31)) return false;
@@ -1657,7 +1664,7 @@ bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint6
     if (ctx->lane_max_radius < 0 || ctx->sort_n || ctx->sort_r1_n || ctx->sort_r3 || ctx->lane_hi || !ctx->merge_small) return false;
     if (ctx->tile_threads != 256 || ctx->debug_skip_kinds) return false;
     const uint32_t worst_job = 2u * ctx->lane_max_n + 12u;
-    return ctx->tile_lds_floats >= 4u * worst_job + kStreamSlack && ctx->tile_lds_floats <= 16384u;
+    return stream_tile_floats(ctx) >= 4u * worst_job + kStreamSlack && stream_tile_floats(ctx) <= 16384u;
 }
 
 int ws_acquire(rawdtw_ctx *ctx, size_t dev_bytes, size_t host_bytes, StreamWs *out)
@@ -1711,7 +1718,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
                         const uint64_t *job_off_host, uint64_t n_jobs)
 {
     const uint64_t nc = b->n_chains, nr = b->n_reads, na = anchor_off[nc];
-    const uint32_t lds_floats = ctx->tile_lds_floats;
+    const uint32_t lds_floats = stream_tile_floats(ctx);
     StreamArgs &a = b->sa;
     a = StreamArgs{};
     a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;

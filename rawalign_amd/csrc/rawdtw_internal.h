@@ -68,7 +68,8 @@ constexpr int kMaxLaneRadius = 3;      // lane-per-job DP is instantiated for R 
 constexpr int kMaxLaneRadiusHi = 8;    // second tile-kernel instance: radii kMaxLaneRadius+1 .. 8
 constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is at most this
 // tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
-constexpr uint32_t kTileLdsFloats = 4800;  // job-list tile kernel: 8 workgroups per CU; k_stream: 5 (image + records + sort table = 32 KB)
+constexpr uint32_t kTileLdsFloats = 4800;  // job-list tile kernel: 8 workgroups per CU
+constexpr uint32_t kStreamTileFloats = 7200; // k_stream: 4 workgroups per CU (image + records + sort table = 40 KB)
 constexpr uint32_t kTileMaxJobs = 1024;
 constexpr uint32_t kTileHiLdsFloats = 14336, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;
