@@ -123,11 +123,18 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
         t0 = time.perf_counter()
         impl.batch_costs(jobs[:take], events, ref_arena, threads, 1)  # calibration pass (also warms the pool's pages)
         est = time.perf_counter() - t0
-        reps = int(max(1, min(400, round(seconds / max(est, 1e-6)))))
-        t0 = time.perf_counter()
-        out = impl.batch_costs(jobs[:take], events, ref_arena, threads, reps)
-        dt = time.perf_counter() - t0
-        runs.append({"threads": threads, "value": cells * (take / n) * reps / dt / 1e9, "jobs": take, "passes": reps, "seconds": round(dt, 3)})
+        # the box's cores are shared with other tenants: three shorter measurements, the best one counts
+        tries = 1 if threads == 1 else 3
+        reps = int(max(1, min(400, round(seconds / tries / max(est, 1e-6)))))
+        best_dt, out = None, None
+        for _ in range(tries):
+            t0 = time.perf_counter()
+            out = impl.batch_costs(jobs[:take], events, ref_arena, threads, reps)
+            dt = time.perf_counter() - t0
+            best_dt = dt if best_dt is None else min(best_dt, dt)
+        dt = best_dt
+        runs.append({"threads": threads, "value": cells * (take / n) * reps / dt / 1e9, "jobs": take, "passes": reps, "seconds": round(dt, 3),
+                     "tries": tries})
         if out_full is None or take > len(out_full):
             out_full = out
     best = max(runs, key=lambda r: r["value"])
@@ -136,8 +143,8 @@ def cpu_baseline(jobs, events, ref_arena, cells, seconds):
         "nproc": nproc, "affinity_cores": affinity, "cgroup_cpu_quota": quota, "usable_cores": usable,
         "sample": f"first {best['jobs']} of {n} DTW jobs of one batch of the same workload ({best['jobs'] / n * 100:.0f}% of its "
                   f"cells, pro-rated by job count), {best['passes']} passes inside one pool of {best['threads']} threads pulling job "
-                  f"ranges from a shared counter (as kt_for deals reads: kthread.c:54-72), {best['seconds']} s wall; the best of "
-                  f"the thread counts tried is reported",
+                  f"ranges from a shared counter (as kt_for deals reads: kthread.c:54-72), {best['seconds']} s wall (best of "
+                  f"{best['tries']} such measurements: the host's cores are shared); the best of the thread counts tried is reported",
         "by_threads": runs,
     }, out_full
 

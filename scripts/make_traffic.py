@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""profiles/traffic_r01.json from a PMC summary (scripts/pmc_summary.py output): HBM bytes per launch of the
-dominant kernel = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KB."""
+"""profiles/traffic_rNN.json from a PMC summary (scripts/pmc_summary.py output): HBM bytes per launch of the dominant
+kernel = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KB.
+Usage: make_traffic.py <summary.json> <kernel substring> <reads> <source note>"""
 import json, sys
 summary, kernel, reads = sys.argv[1], sys.argv[2], int(sys.argv[3])
+note = sys.argv[4] if len(sys.argv) > 4 else ""
 d = json.load(open(summary))
 k = next(x for x in d if kernel in x)
 f, w = d[k]["FETCH_SIZE"], d[k]["WRITE_SIZE"]
@@ -10,5 +12,5 @@ json.dump({"workload": "ecoli_k12_4.6Mb_r9.4_sparse_banded0.10", "reads": reads,
            "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
            "correction": "gfx950: FETCH_SIZE x2 (128-byte requests tallied at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as is",
            "hbm_bytes_per_launch": int(f * 2 * 1024 + w * 1024),
-           "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-                     "serialised launches, scripts/pmc_profile.sh)"}, sys.stdout, indent=1)
+           "source": note or "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over scripts/stream_probe.py "
+                             "(one bench batch, every launch alone on the chip): scripts/pmc_r02.sh"}, sys.stdout, indent=1)
