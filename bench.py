@@ -327,6 +327,7 @@ def main():
         sink.append(ms[:nl.value].copy())
 
     host_s = {"fetch": 0.0, "create": 0.0, "run": 0.0, "steps": 0}
+    issued = {"dtw": 0}  # DTW launches (k_stream dispatches) issued by this process so far: locates a pass in a kernel trace
 
     def pipeline(K, pcie, timed_launches=None, host=None):
         """K steps, every one a fresh batch; context k % slots; a context's previous batch is fetched before its next."""
@@ -351,6 +352,7 @@ def main():
                 e._check(lib.rawdtw_batch_run(e._ctx, handles[sl]))
             else:  # HIP event pair around every launch, read when the context comes round again
                 e._check(lib.rawdtw_batch_enqueue(e._ctx, handles[sl], 1))
+            issued["dtw"] += 1
             if host is not None:
                 host["fetch"] += t1 - t0; host["create"] += t2 - t1; host["run"] += pc() - t2; host["steps"] += 1
         for sl in range(slots):
@@ -395,13 +397,16 @@ def main():
             create(0, not pc)
             ts.append((time.perf_counter() - t0) * 1e3)
             engines[0]._check(lib.rawdtw_batch_run(engines[0]._ctx, handles[0]))
+            issued["dtw"] += 1
             fetch_destroy(0)
         create_ms[mode] = round(float(np.median(ts)), 4)
     # launch durations inside the pipeline (HIP events on the context's stream), and the planning kernels' GPU time
     launches_in_pipeline = []
     for e in engines:
         e.set_option("time_plan", 1)
+    timed_pass_first = issued["dtw"]
     pipeline(max(K, 2 * slots), pcie=False, timed_launches=launches_in_pipeline)
+    timed_pass_count = issued["dtw"] - timed_pass_first
     plan_ms = []
     for sl in range(slots):
         create(sl, True)
@@ -509,6 +514,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_stream", "launch_ms": dms,
                          "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": infos[0]["n_jobs"],
+                         "launch_window": {"first_dispatch": timed_pass_first, "count": timed_pass_count,
+                                           "note": "launch_ms is over these k_stream dispatches of the process (0-based, in issue "
+                                                   "order); scripts/trace_window.py averages the same ones in a rocprofv3 kernel trace"},
                          "note": "launch_ms = mean HIP-event bracket of the batch's one DTW launch inside the fresh-batch pipeline "
                                  "(recorded on the launch's own stream), where it shares the chip with the other contexts' "
                                  "planning and DTW launches; `alone` = the same launch repeated on an idle chip",

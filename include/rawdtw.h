@@ -58,6 +58,7 @@ typedef struct rawdtw_plan rawdtw_plan;
 int rawdtw_abi_version(void);
 int rawdtw_device_count(int *count);
 int rawdtw_create(int device_ordinal, rawdtw_ctx **out);
+/* Destroy a context's plans and batches before the context: they hold pointers into its pools. */
 int rawdtw_destroy(rawdtw_ctx *ctx);
 const char *rawdtw_last_error(const rawdtw_ctx *ctx);
 const char *rawdtw_status_string(int status);

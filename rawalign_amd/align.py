@@ -244,6 +244,7 @@ class Batch:
         engine._check(engine.lib.rawdtw_batch_create(engine._ctx, C.byref(self._copt), cb.n_reads, _ptr(a[0]),
                                                      _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), C.byref(h)))
         self._h = h
+        engine._children.add(self)
 
     def info(self) -> dict:
         from ._lib import PlanInfo
@@ -347,7 +348,8 @@ class Batch:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            self.engine.lib.rawdtw_batch_destroy(self._h)
+            if self.engine._ctx is not None:  # (a context that is gone took its pools with it: nothing left to hand back)
+                self.engine.lib.rawdtw_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1654,7 +1654,7 @@ struct StreamLayout { // sizes in bytes of one batch's device workspace and pinn
 // 128 registers free beside the DTW launch's waves -- room for a wave of the next batches' planning kernels or of the
 // batch before's fold -- and the LDS that a fifth workgroup would take goes into larger tiles (fewer tiles, fuller sorted
 // waves).  Measured on the bench pipeline (4 batches in flight): 5 x 4800 floats 425 GCUPS, 4 x 7200 453, 3 x 6400 450.
-static uint32_t stream_tile_floats(const rawdtw_ctx *ctx) { return ctx->tile_lds_set ? ctx->tile_lds_floats : kStreamTileFloats; }
+static uint32_t stream_tile_floats(const rawdtw_ctx *ctx) { return (ctx->tile_lds_set ? ctx->tile_lds_floats : kStreamTileFloats) & ~3u; } // (16-byte multiples: the records and the sort table sit behind the image)
 
 bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)
 {

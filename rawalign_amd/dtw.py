@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -75,6 +76,7 @@ class Plan:
         self.engine = engine
         self._h = handle
         self.n_jobs = n_jobs
+        engine._children.add(self)
 
     def info(self) -> dict:
         pi = PlanInfo()
@@ -102,7 +104,8 @@ class Plan:
 
     def close(self):
         if self._h is not None:
-            self.engine.lib.rawdtw_plan_destroy(self._h)
+            if self.engine._ctx is not None:  # (see Batch.close)
+                self.engine.lib.rawdtw_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -127,6 +130,9 @@ class Engine:
         self._ctx = ctx
         self.device = device
         self._keep = []  # arrays / tensors the context points at
+        # plans and batches of this context: they must be destroyed before it (include/rawdtw.h), also when the garbage
+        # collector finalises an unreachable engine and its batches in an order of its own choosing
+        self._children = weakref.WeakSet()
 
     # -- plumbing ---------------------------------------------------------------
     def _check(self, st: int):
@@ -136,6 +142,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_ctx", None) is not None:
+            for child in list(self._children):
+                child.close()
             self.lib.rawdtw_destroy(self._ctx)
             self._ctx = None
 

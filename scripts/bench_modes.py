@@ -82,7 +82,7 @@ def main():
         out.update({"jobs": len(jobs), "cells": cells, "seconds_end_to_end": dt, "GCUPS_end_to_end": cells / dt / 1e9,
                     "path_elements": int(sum(len(r) for r in res)),
                     "direction_bytes": int(cells // 4)})
-    print(json.dumps(out))
+    print(json.dumps(out, default=lambda o: o.tolist() if hasattr(o, "tolist") else float(o)))
 
 
 if __name__ == "__main__":
