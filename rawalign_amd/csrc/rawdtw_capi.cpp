@@ -2225,7 +2225,7 @@ int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint6
     I.cells = c[kCntCells];
     I.algorithmic_bytes = c[kCntTileBytes] + c[kCntOtherBytes];
     unsigned long long side_lane = 0; // the side list's lane-per-job classes count with the tiles' jobs: same body, same class rule
-    for (uint32_t q = kClsL0; q < kClsL0 + kClsLCount; q++) side_lane += c[kCntCls0 + q];
+    for (uint32_t q = kClsL0; q < kClsL0 + kClsLCount; q++) side_lane += c[kCntCls0 + q]; // (the 8-slot lane classes stay with the wide bands)
     I.n_lane_jobs = c[kCntTileJobs] + side_lane;
     I.n_wave_band_jobs = c[kCntOthers] - side_lane;
     I.n_full_jobs = 0;

@@ -455,6 +455,109 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
     return g.res;
 }
 
+// One lane per job for bands of up to 8 slots (radius <= 7), any radius mix in a wave: the scheme of wreg_gen_step with
+// the band's slots in the lane's own registers instead of across lanes.  Physical slot p of a secondary antidiagonal is
+// cell (col - 1 + off - p, row - off + p), of a primary (col + off - p, row - off + p); primaries live at slots SH ..
+// SH + P - 1, secondaries at 0 .. S - 1 (dtw.cpp:301-303, 459, 479).  No guards: a slot outside its antidiagonal's extent
+// holds 1e10 (one select per slot on a lane-constant flag), which is what every guarded read of the reference yields
+// (argument at wreg_gen_step); no per-cell validity on the high side (lane_dp_gen); the low side in a masked copy of
+// the step for the first columns.  The row advance is per lane: selects, not branches (X = adv ? secondary : previous
+// primary).  Operand reads are clamped into the windows: they come from the arenas, not from a tile's image.
+// ~130 VALU per column for 64 jobs, against ~75 per column for the 8 jobs of grp_wave<8>.
+struct K8Lane {
+    float d0[8], d1[8], ap[8], bp[8];
+    float a_next, b_next; // the operands the next column / the next row advance bring in: loaded one column ahead
+    uint32_t rem;
+    int row;
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void lane_k8_step(K8Lane &g, const float *A, const float *B, const uint32_t N, const uint32_t M,
+                                             const int off, const bool (&in_sec)[8], const bool (&in_prim)[8], const uint32_t col)
+{
+    g.rem += M;
+    const bool adv = g.rem >= N;
+    g.rem -= adv ? N : 0u;
+    g.row += adv ? 1 : 0;
+    // b-window: every slot takes its right neighbour's value when the row advances (b_next is a function of the row alone)
+    float bn[8];
+#pragma unroll
+    for (int p = 0; p < 7; p++) bn[p] = adv ? g.bp[p + 1] : g.bp[p];
+    bn[7] = adv ? g.b_next : g.bp[7];
+    g.b_next = B[min(max(g.row - off + 8, 0), (int)M - 1)];
+    // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column; counts only after an advance
+    float X[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const float left = p < 7 ? g.d1[p < 7 ? p + 1 : p] : kInf;
+        float v = min3f(g.d1[p], left, g.d0[p]) + dist(g.ap[p], bn[p]);
+        bool keep = in_sec[p];
+        if (MASKED) keep = keep && !(p < off - g.row || p > (int)col - 1 + off);
+        v = keep ? v : kInf;
+        X[p] = adv ? v : g.d1[p];
+    }
+    // a-window: every slot takes its left neighbour's value
+#pragma unroll
+    for (int p = 7; p > 0; p--) g.ap[p] = g.ap[p - 1];
+    g.ap[0] = g.a_next;
+    g.a_next = A[min(col + 1u + (uint32_t)off, N - 1u)];
+    // primary antidiagonal (dtw.cpp:416-485): after a secondary (top, left, diagonal) = (X[p-1], X[p], d1[p]); otherwise X is
+    // the primary before this one and they are (X[p-1], X[p], d0[p-1])
+    float pr[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const float top = p > 0 ? X[p > 0 ? p - 1 : 0] : kInf;
+        const float tl_stay = p > 0 ? g.d0[p > 0 ? p - 1 : 0] : kInf;
+        const float tl = adv ? g.d1[p] : tl_stay;
+        float v = min3f(top, X[p], tl) + dist(g.ap[p], bn[p]);
+        bool keep = in_prim[p];
+        if (MASKED) keep = keep && !(p < off - g.row);
+        pr[p] = keep ? v : kInf;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p++) { g.d0[p] = X[p]; g.d1[p] = pr[p]; g.bp[p] = bn[p]; }
+}
+
+// N >= M (the caller swaps), R in 1..7; n_max = the largest N of the wave.
+__device__ __forceinline__ float lane_dp_k8(const float *A, const float *B, const uint32_t N, const uint32_t M, const int R,
+                                            const uint32_t n_max)
+{
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int SH = P > S ? 0 : 1;
+    const int off = P / 2 + SH, K = P > S ? P : S;
+    const int iN = (int)N, iM = (int)M;
+    K8Lane g;
+    bool in_sec[8], in_prim[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        g.d0[p] = kInf; g.d1[p] = kInf;
+        g.ap[p] = A[min(max(off - p, 0), iN - 1)];
+        g.bp[p] = B[min(max(p - off, 0), iM - 1)];
+        in_sec[p] = p < S;
+        in_prim[p] = p >= SH && p < SH + P;
+    }
+    const float corner = dist(A[0], B[0]); // dtw.cpp:317-347, at the centre slot
+#pragma unroll
+    for (int p = 1; p <= 4; p++) g.d1[p] = (p == off) ? corner : kInf;
+    g.rem = 0; g.row = 0;
+    g.a_next = A[min(1 + off, iN - 1)];      // column 1 brings in A[1 + off]
+    g.b_next = B[min(max(8 - off, 0), iM - 1)]; // the first advance brings in B[1 - off + 7]
+    float res = corner;
+    auto centre = [&]() { return off == 1 ? g.d1[1] : off == 2 ? g.d1[2] : off == 3 ? g.d1[3] : g.d1[4]; }; // dtw.cpp:506-512
+    uint32_t col = 1;
+    // first columns: cells above row 0 or left of column 0 exist while row < off or col - 1 + off < K - 1
+    for (; col < n_max && __any((g.row < off || (int)col < K - off + 1) && col < N); col++) {
+        lane_k8_step<true>(g, A, B, N, M, off, in_sec, in_prim, col);
+        res = (col == N - 1u) ? centre() : res;
+    }
+    for (; col < n_max; col++) {
+        lane_k8_step<false>(g, A, B, N, M, off, in_sec, in_prim, col);
+        res = (col == N - 1u) ? centre() : res;
+    }
+    return res;
+}
+
 // Radii 1 and 2 mixed in a wave -- 98 % of a sparse batch's jobs (radius 1 = square parts, radius 2 = every other part
 // whose read side is under 20 events): the generic body with K = 3 slots and off = 1 for both radii.  Radius 2 has
 // S = 2 secondaries (slots 0, 1) and P = 3 primaries (slots 0..2, no shift); radius 1 has S = 2 and P = 1 at slot 1.

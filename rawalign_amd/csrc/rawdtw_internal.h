@@ -102,8 +102,11 @@ constexpr uint32_t kStreamItems = 4;          // jobs per thread in a tile's pro
 constexpr uint32_t kStreamMaxTileJobs = kStreamItems * 512; // ... of 512-thread workgroups (256-thread: half)
 constexpr uint32_t kStreamSlack = 32;         // LDS floats of a tile's image kept free for region alignment
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
-constexpr uint32_t kStreamClasses = 14, kClsW0 = 0, kClsG16 = 4, kClsG8 = 5, kClsL0 = 6, kClsLCount = 8;
-// Side-list classes 6..13: jobs the lane-per-job body takes (radius <= side_lane_radius, longer side <= lane_max_n) but the
+constexpr uint32_t kStreamClasses = 21, kClsW0 = 0, kClsG16 = 4, kClsL0 = 5, kClsLCount = 8, kClsM0 = 13, kClsMCount = 8;
+// Side-list classes 13..20: bands of up to 8 slots (radius <= 7) that are not in the classes below: one lane per job too
+// (lane_dp_k8), same length buckets -- as eight-lane groups (grp_wave<8>) they were a third of the DTW launch's arithmetic
+// for 0.4 % of its jobs.
+// Side-list classes 5..12: jobs the lane-per-job body takes (radius <= side_lane_radius, longer side <= lane_max_n) but the
 // tiles do not (radius > lane_max_radius): scored 64 to a wave straight from the arenas, bucketed by longer side so that
 // a wave's jobs have similar lengths -- over the whole batch there are enough of them to fill waves, inside one tile not.
 __host__ __device__ inline uint32_t side_lane_bucket(uint32_t N)
@@ -154,9 +157,9 @@ enum StreamCounter : int {
     kCntUnsupported,    // jobs whose band is wider than the side list's kernels take (radius + 1 > 256)
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntOthers, kCntTiles, kCntLdsMax,
     kCntCls0,           // kStreamClasses totals
-    kCntCur0 = kCntCls0 + 14, // kStreamClasses scatter cursors
-    kCntCells = kCntCur0 + 14,
-    kCntHeads = 48,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
+    kCntCur0 = kCntCls0 + 21, // kStreamClasses scatter cursors
+    kCntCells = kCntCur0 + 21,
+    kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
 static_assert(kCntCells < kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             const uint32_t K = (uint32_t)R + 1u;
             uint32_t cls;
             if (R >= 1 && R <= a.side_lane_radius && N <= a.lane_max_n) cls = kClsL0 + side_lane_bucket(N);
-            else if (K <= 8) cls = kClsG8;
+            else if (K <= 8) cls = kClsM0 + side_lane_bucket(N);
             else if (K <= 16) cls = kClsG16;
             else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
             else cls = 0xff;
@@ -552,6 +552,7 @@ __device__ __forceinline__ float stream_lane_job(const float *LA, const float *L
 
 // 64 jobs of the side list's lane classes: one lane per job, operands straight from the arenas (the jobs of a wave come
 // from all over the batch: nothing to stage together; they are 2 % of a sparse batch's jobs)
+template <int SLOTS>
 __device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
                                                  const float *__restrict__ ev, const float *__restrict__ ref, float *__restrict__ out)
 {
@@ -569,7 +570,7 @@ __device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
     n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
-    float res = lane_dp_gen<true>(A, B, N, M, (uint32_t)jb.R, n_max);
+    float res = SLOTS == 4 ? lane_dp_gen<true>(A, B, N, M, (uint32_t)jb.R, n_max) : lane_dp_k8(A, B, N, M, jb.R, n_max);
     if (have) {
         if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
         out[jb.aux] = res;
@@ -619,13 +620,15 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
         uint64_t n_w = 0;
 #pragma unroll
         for (uint32_t c = kClsW0; c < kClsW0 + 4; c++) n_w += a.cnt[kCntCls0 + c];
-        const uint64_t n_g16 = a.cnt[kCntCls0 + kClsG16], n_g8 = a.cnt[kCntCls0 + kClsG8];
-        uint64_t n_l = 0;
+        const uint64_t n_g16 = a.cnt[kCntCls0 + kClsG16];
+        uint64_t n_l = 0, n_m = 0;
 #pragma unroll
         for (uint32_t c = kClsL0; c < kClsL0 + kClsLCount; c++) n_l += a.cnt[kCntCls0 + c];
-        if (n_w + n_g16 + n_g8 + n_l <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
-            // item order = list order: wave-per-job (longest first), 16-lane groups, 8-lane groups, lane-per-job (by length)
-            const uint64_t it_g16 = (n_g16 + 3) / 4, it_g8 = (n_g8 + 7) / 8, it_l = (n_l + 63) / 64, items = n_w + it_g16 + it_g8 + it_l;
+#pragma unroll
+        for (uint32_t c = kClsM0; c < kClsM0 + kClsMCount; c++) n_m += a.cnt[kCntCls0 + c];
+        if (n_w + n_g16 + n_l + n_m <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
+            // item order = list order: wave-per-job (longest first), 16-lane groups, lane-per-job (4 slots, then 8; by length)
+            const uint64_t it_g16 = (n_g16 + 3) / 4, it_l = (n_l + 63) / 64, it_m = (n_m + 63) / 64, items = n_w + it_g16 + it_l + it_m;
             for (uint64_t it = (uint64_t)blockIdx.x * (TT / 64) + wv; it < items; it += (uint64_t)gridDim.x * (TT / 64)) {
                 if (it < n_w) {
                     if (a.debug & 32u) continue;
@@ -641,8 +644,8 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
                 }
                 else if (a.debug & 64u) continue;
                 else if (it < n_w + it_g16) grp_wave<16>(a.ojobs + n_w, (uint32_t)n_g16, (uint32_t)(it - n_w), lane, a.ev, a.ref, a.out);
-                else if (it < n_w + it_g16 + it_g8) grp_wave<8>(a.ojobs + n_w + n_g16, (uint32_t)n_g8, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
-                else lane_global_wave(a.ojobs + n_w + n_g16 + n_g8, (uint32_t)n_l, (uint32_t)(it - n_w - it_g16 - it_g8), lane, a.ev, a.ref, a.out);
+                else if (it < n_w + it_g16 + it_l) lane_global_wave<4>(a.ojobs + n_w + n_g16, (uint32_t)n_l, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
+                else lane_global_wave<8>(a.ojobs + n_w + n_g16 + n_l, (uint32_t)n_m, (uint32_t)(it - n_w - it_g16 - it_l), lane, a.ev, a.ref, a.out);
             }
         }
     }
