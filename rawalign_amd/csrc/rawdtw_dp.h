@@ -466,7 +466,6 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
 // ~130 VALU per column for 64 jobs, against ~75 per column for the 8 jobs of grp_wave<8>.
 struct K8Lane {
     float d0[8], d1[8], ap[8], bp[8];
-    float a_next, b_next; // the operands the next column / the next row advance bring in: loaded one column ahead
     uint32_t rem;
     int row;
 };
@@ -479,12 +478,14 @@ __device__ __forceinline__ void lane_k8_step(K8Lane &g, const float *A, const fl
     const bool adv = g.rem >= N;
     g.rem -= adv ? N : 0u;
     g.row += adv ? 1 : 0;
-    // b-window: every slot takes its right neighbour's value when the row advances (b_next is a function of the row alone)
+    // b-window: every slot takes its right neighbour's value when the row advances.  (The fresh operands are loaded where
+    // they are used: one column ahead costs two more registers, which this body -- the kernel's widest -- does not have
+    // without spilling; its waves are few and run beside the tiles.)
+    const float fresh_b = B[min(max(g.row - off + 7, 0), (int)M - 1)];
     float bn[8];
 #pragma unroll
     for (int p = 0; p < 7; p++) bn[p] = adv ? g.bp[p + 1] : g.bp[p];
-    bn[7] = adv ? g.b_next : g.bp[7];
-    g.b_next = B[min(max(g.row - off + 8, 0), (int)M - 1)];
+    bn[7] = adv ? fresh_b : g.bp[7];
     // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column; counts only after an advance
     float X[8];
 #pragma unroll
@@ -497,10 +498,10 @@ __device__ __forceinline__ void lane_k8_step(K8Lane &g, const float *A, const fl
         X[p] = adv ? v : g.d1[p];
     }
     // a-window: every slot takes its left neighbour's value
+    const float fresh_a = A[min(col + (uint32_t)off, N - 1u)];
 #pragma unroll
     for (int p = 7; p > 0; p--) g.ap[p] = g.ap[p - 1];
-    g.ap[0] = g.a_next;
-    g.a_next = A[min(col + 1u + (uint32_t)off, N - 1u)];
+    g.ap[0] = fresh_a;
     // primary antidiagonal (dtw.cpp:416-485): after a secondary (top, left, diagonal) = (X[p-1], X[p], d1[p]); otherwise X is
     // the primary before this one and they are (X[p-1], X[p], d0[p-1])
     float pr[8];
@@ -541,8 +542,6 @@ __device__ __forceinline__ float lane_dp_k8(const float *A, const float *B, cons
 #pragma unroll
     for (int p = 1; p <= 4; p++) g.d1[p] = (p == off) ? corner : kInf;
     g.rem = 0; g.row = 0;
-    g.a_next = A[min(1 + off, iN - 1)];      // column 1 brings in A[1 + off]
-    g.b_next = B[min(max(8 - off, 0), iM - 1)]; // the first advance brings in B[1 - off + 7]
     float res = corner;
     auto centre = [&]() { return off == 1 ? g.d1[1] : off == 2 ? g.d1[2] : off == 3 ? g.d1[3] : g.d1[4]; }; // dtw.cpp:506-512
     uint32_t col = 1;
