@@ -4,20 +4,24 @@
 // of DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520) that align_chain (src/rmap.cpp:238-300) issues.
 //
 // Round 1 planned a batch in eleven launches with two host round trips and wrote 16-byte tile records for every job to
-// HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here:
+// HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here a batch is
+// six launches (k_pre, k_mid, k_tile_first, k_stream, fold, select), none of which the host waits for:
 //
-//   k_pre          one thread per job: the job's windows from its chain's anchors (rmap.cpp:251-254, 270, 276), the
-//                  slant-corrected radius (dtw.cpp:298-300) and its class.  Writes one 16-byte record per job (arena
-//                  offsets + packed shape); the rare jobs the lane-per-job DP does not take (radius > 3 or longer
-//                  side > 73) are appended to a side list as full job records.
-//   scan           ONE hipcub scan of (event floats, reference floats, cost) per job (rawdtw_internal.h: Cum): it fixes
-//                  every job's place in its tile's LDS image in closed form and cuts the batch into tiles
-//   k_tile_first   one binary search per tile boundary
-//   k_others       the side list ordered by class and length (wave-per-job first, longest first)
-//   k_stream       ONE persistent launch per batch: every wave first takes its share of the side list's wave-cooperative
-//                  jobs, then workgroups pull tiles from an eight-headed queue.  Per tile: each lane turns its jobs'
-//                  scan values into LDS offsets and copies the jobs' own new elements (16-byte chunks of the arenas are
-//                  16-byte chunks of the image); a counting sort by (kind, longer side) in LDS; the lane-per-job DP of
+//   k_pre          1024 jobs per workgroup, four consecutive jobs per thread: a job's windows from its chain's anchors
+//                  (rmap.cpp:251-254, 270, 276), the slant-corrected radius (dtw.cpp:298-300) and its class.  Writes one
+//                  16-byte record per job (arena offsets + packed shape) and the running sums of the tile layout INSIDE
+//                  the workgroup's unit (rawdtw_internal.h: Cum); the jobs the tiles do not take (radius > 2, longer side
+//                  > 73) are appended to a side list as full job records.
+//   k_mid          the roles between k_pre and k_tile_first in one launch: workgroup 0 scans the units' totals (a job's
+//                  place in its tile's LDS image is then a closed form of its own sums); workgroup 1 sorts the chains by
+//                  part count for the fold; 65 workgroups put the side list into class order (wave-per-job first, longest
+//                  first) and add up the statistics; the rest write the fold's chain records
+//   k_tile_first   one thread per tile: the first job of cost bracket k by a two-level binary search (unit, then job), the
+//                  image's exact region bounds
+//   k_stream       ONE persistent launch per batch: every wave first takes its share of the side list's items, then
+//                  workgroups pull tiles from an eight-headed queue.  Per tile: each thread turns its jobs' running sums
+//                  into LDS offsets and marks the image's 16-byte chunks with their source; a flat, coalesced copy of the
+//                  marked chunks; a counting sort by (radius class, longer side) in LDS; the lane-per-job DP of
 //                  rawdtw_dp.h.  Nothing about a tile is ever written to HBM.
 //
 // No step needs a number on the host: grids are sized by the job count (known from the anchor offsets) or are
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 // k_unit_scan: the units' totals -> the sums BEFORE each unit (exclusive, in place; entry n_units = the batch totals).
 // One workgroup: a few thousand entries.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_unit_scan(const StreamArgs a)
+__device__ __forceinline__ void unit_scan_body(const StreamArgs &a)
 {
     const uint64_t n_units = (a.n_jobs + kPreUnit - 1) / kPreUnit;
     __shared__ uint64_t s_p[16], s_c[16];
@@ -424,12 +428,13 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 // k_others: the side list in class order (wave-per-job classes first, longest first; then 16-lane groups, 8-lane groups)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
+template <int NT>
+__device__ __forceinline__ void others_body(const StreamArgs &a, const uint32_t group, const uint32_t groups_all)
 {
-    if (blockIdx.x == gridDim.x - 1) { // the last workgroup adds up k_pre's per-unit totals instead (a few thousand records)
+    if (group == groups_all - 1) { // the last workgroup adds up k_pre's per-unit totals instead (a few thousand records)
         const uint64_t n_units = (a.n_jobs + kPreUnit - 1) / kPreUnit;
         unsigned long long t[3] = {0, 0, 0};
-        for (uint64_t u = threadIdx.x; u < n_units; u += kT)
+        for (uint64_t u = threadIdx.x; u < n_units; u += NT)
             for (int q = 0; q < 3; q++) t[q] += a.unit_stats[3 * u + q];
         __shared__ unsigned long long s_t[3];
         if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
@@ -446,13 +451,13 @@ __global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
     // atomic per class and workgroup for the slice's places (same-address atomics run near 88 per microsecond: a wave-level
     // scheme spends the kernel there once the list has 10^5 entries), then the scatter through LDS cursors.
     const uint64_t n_other = min<uint64_t>(a.cnt[kCntOthers], a.others_cap);
-    const uint64_t groups = gridDim.x - 1, per = (n_other + groups - 1) / groups;
-    const uint64_t lo = min(n_other, (uint64_t)blockIdx.x * per), hi = min(n_other, lo + per);
+    const uint64_t groups = groups_all - 1, per = (n_other + groups - 1) / groups;
+    const uint64_t lo = min(n_other, (uint64_t)group * per), hi = min(n_other, lo + per);
     __shared__ uint32_t s_n[kStreamClasses];
     __shared__ uint64_t s_at[kStreamClasses];
     if (threadIdx.x < kStreamClasses) s_n[threadIdx.x] = 0;
     __syncthreads();
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kT) atomicAdd(&s_n[a.ocls[i]], 1u);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += NT) atomicAdd(&s_n[a.ocls[i]], 1u);
     __syncthreads();
     if (threadIdx.x < kStreamClasses) {
         uint64_t base = 0;
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
         s_n[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += kT) {
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += NT) {
         const uint32_t cls = a.ocls[i];
         const uint64_t pos = s_at[cls] + atomicAdd(&s_n[cls], 1u);
         if (pos < a.others_cap) a.ojobs[pos] = a.omix[i];
@@ -472,10 +477,8 @@ __global__ __launch_bounds__(kT) void k_others(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 // chain records for the fold (ChainDesc) and the key of the fold order (part count, clamped)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void k_chain_desc(const StreamArgs a, ChainDesc *__restrict__ chains,
-                                                   uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+__device__ __forceinline__ void chain_desc_body(const StreamArgs &a, ChainDesc *__restrict__ chains, const uint64_t c)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * kT + threadIdx.x;
     if (c >= a.n_chains) return;
     const uint64_t a0 = a.anchor_off[c], a1 = a.anchor_off[c + 1];
     ChainDesc d;
@@ -488,21 +491,20 @@ __global__ __launch_bounds__(kT) void k_chain_desc(const StreamArgs a, ChainDesc
         d.num_aligned = (last.query_position - first.query_position) + d.n_jobs;       // sum of the parts' read regions (rmap.cpp:292)
     }
     chains[c] = d;
-    key[c] = d.n_jobs;
-    (void)val;
 }
 
 // Fold order: chains by part count, longest first (the lane-per-chain fold gives a wave 64 chains of similar length).
 // One workgroup: a counting sort over 1024 length buckets in LDS (the order inside a bucket does not matter).
-__global__ __launch_bounds__(1024) void k_fold_order(uint64_t n_chains, const uint32_t *__restrict__ key, uint32_t *__restrict__ order)
+__device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const uint64_t *__restrict__ job_off, uint32_t *__restrict__ order)
 {
+    auto key_of = [&](uint64_t c) { return (uint32_t)min<uint64_t>(job_off[c + 1] - job_off[c], 0xffffffffull); }; // a chain's part count
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     auto bucket = [](uint32_t k) { return 1023u - min(k, 1023u); };
     hist[tid] = 0;
     __syncthreads();
-    for (uint64_t c = tid; c < n_chains; c += 1024) atomicAdd(&hist[bucket(key[c])], 1u);
+    for (uint64_t c = tid; c < n_chains; c += 1024) atomicAdd(&hist[bucket(key_of(c))], 1u);
     __syncthreads();
     uint32_t v = hist[tid], incl = v;
 #pragma unroll
@@ -517,7 +519,24 @@ __global__ __launch_bounds__(1024) void k_fold_order(uint64_t n_chains, const ui
     __syncthreads();
     hist[tid] = pre + incl - v; // exclusive start of the bucket
     __syncthreads();
-    for (uint64_t c = tid; c < n_chains; c += 1024) order[atomicAdd(&hist[bucket(key[c])], 1u)] = (uint32_t)c;
+    for (uint64_t c = tid; c < n_chains; c += 1024) order[atomicAdd(&hist[bucket(key_of(c))], 1u)] = (uint32_t)c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_mid: everything between k_pre and k_tile_first as the roles of ONE launch -- they are independent of each other and
+// each is a latency chain of one or a few workgroups: workgroup 0 scans the units' totals, workgroup 1 sorts the chains
+// for the fold, the next kMidOthers + 1 order the side list (the last of them adds up the per-unit statistics), the rest
+// write the chain records.  (As four launches they were 60 us of mostly idle chip in a batch's critical path, and three
+// more launches for the host to issue.)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kMidOthers = 64;
+__global__ __launch_bounds__(1024) void k_mid(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+{
+    const uint32_t b = blockIdx.x;
+    if (b == 0) { if (a.n_jobs) unit_scan_body(a); }
+    else if (b == 1) { if (a.n_chains) fold_order_body(a.n_chains, a.job_off, order); }
+    else if (b < 2 + kMidOthers + 1) { if (a.n_jobs) others_body<1024>(a, b - 2, kMidOthers + 1); }
+    else chain_desc_body(a, chains, (uint64_t)(b - (2 + kMidOthers + 1)) * 1024 + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -917,15 +936,11 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     (void)hipGetLastError();
     if (a.n_jobs) {
         hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kT), 0, s, a);
-        hipLaunchKernelGGL(k_unit_scan, dim3(1), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(k_tile_first, dim3(blocks_for((uint64_t)a.tiles_cap + 1)), dim3(kT), 0, s, a);
-        hipLaunchKernelGGL(k_others, dim3(65), dim3(kT), 0, s, a);
     }
-    if (a.n_chains) {
-        hipLaunchKernelGGL(k_chain_desc, dim3(blocks_for(a.n_chains)), dim3(kT), 0, s, a, d_chains, d_key, d_val);
-        hipLaunchKernelGGL(k_fold_order, dim3(1), dim3(1024), 0, s, a.n_chains, d_key, d_fold_order);
-    }
-    (void)d_key_out;
+    if (a.n_jobs || a.n_chains)
+        hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + 1023) / 1024)), dim3(1024), 0, s, a, d_chains, d_fold_order);
+    if (a.n_jobs) hipLaunchKernelGGL(k_tile_first, dim3(blocks_for((uint64_t)a.tiles_cap + 1)), dim3(kT), 0, s, a);
+    (void)d_key; (void)d_val; (void)d_key_out;
     return hipGetLastError();
 }
 
