@@ -171,6 +171,7 @@ struct rawdtw_batch {
     int stream_threads = 256;
     unsigned long long *h_cnt = nullptr; // pinned landing zone of the counter block
     bool cnt_valid = false, cells_counted = false;
+    uint32_t stream_runs = 0;                // DTW launches issued for this batch (the tile queue needs a reset from the second on)
     bool dirty = false;                  // work enqueued since the last host synchronisation
     size_t ws_bytes = 0;
     hipEvent_t ev_plan[2] = {nullptr, nullptr};
@@ -1749,7 +1750,14 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (st != RAWDTW_OK) return st;
     if ((st = ensure_masks(ctx)) != RAWDTW_OK) return st;
     char *p = b->ws.d;
-    uint64_t *d_job_off = carve<uint64_t>(p, nc + 1), *d_anchor_off = carve<uint64_t>(p, nc + 1);
+    // what the library itself uploads per batch sits in one piece, on the device and in the pinned block alike (one copy):
+    // the counters' initial values, the chains' job offsets, the units' first chains
+    char *d_pack = p;
+    a.cnt = carve<unsigned long long>(p, kStreamCounters);
+    uint64_t *d_job_off = carve<uint64_t>(p, nc + 1);
+    uint32_t *d_unit_chain = carve<uint32_t>(p, n_units + 1);
+    const size_t pack_bytes = (size_t)(p - d_pack);
+    uint64_t *d_anchor_off = carve<uint64_t>(p, nc + 1);
     rawdtw_anchor_t *d_anchors = carve<rawdtw_anchor_t>(p, na);
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
@@ -1758,7 +1766,6 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.unit_pos = carve<uint64_t>(p, n_units + 1); a.unit_cost = carve<uint64_t>(p, n_units + 1);
     a.tiles = carve<TileInfo>(p, (uint64_t)a.tiles_cap + 1);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
-    a.cnt = carve<unsigned long long>(p, kStreamCounters);
     void *d_tmp = carve<char>(p, tmp);
     b->d_chains = carve<ChainDesc>(p, nc);
     uint32_t *d_key = carve<uint32_t>(p, nc), *d_val = carve<uint32_t>(p, nc), *d_key_out = carve<uint32_t>(p, nc);
@@ -1766,7 +1773,6 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
     b->d_keep = carve<uint8_t>(p, nc);
     a.out = carve<float>(p, n_jobs);
-    uint32_t *d_unit_chain = carve<uint32_t>(p, n_units + 1);
     a.unit_chain = d_unit_chain;
     a.unit_stats = carve<unsigned long long>(p, 3 * n_units);
     a.debug = ctx->stream_debug;
@@ -1774,8 +1780,9 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
     a.ev = ctx->d_ev; a.ref = ctx->d_ref; a.masks = ctx->d_masks;
     char *hp = b->ws.h;
-    uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
+    char *h_pack = hp;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
+    uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
     uint32_t *h_unit_chain = carve<uint32_t>(hp, n_units + 1);
     memcpy(h_job_off, job_off_host, (nc + 1) * 8);
     {   // unit u (jobs [1024 u, 1024 u + 1024)) starts inside chain unit_chain[u]: one merge walk over the chains
@@ -1795,9 +1802,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         if (!b->ev_plan[0]) { HIP_TRY(ctx, hipEventCreate(&b->ev_plan[0])); HIP_TRY(ctx, hipEventCreate(&b->ev_plan[1])); }
         HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_job_off, h_job_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_unit_chain, h_unit_chain, (n_units + 1) * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pack, h_pack, pack_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     if (!b->in_resident) {
         HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
@@ -2262,7 +2267,7 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
     if (batch->stream) {
         if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) {
-            hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, ctx->stream);
+            hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, batch->stream_runs++ > 0, ctx->stream);
             if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
         }
         if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;

@@ -199,7 +199,7 @@ uint32_t stream_lds_bytes(uint32_t lds_floats);
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key, uint32_t *d_val, uint32_t *d_key_out,
                        uint32_t *d_fold_order, void *d_tmp, size_t tmp_bytes, hipStream_t s);
-hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, hipStream_t s);
+hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
 hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);
 hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,
                                  uint32_t n_seg, hipStream_t s);

@@ -944,11 +944,12 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     return hipGetLastError();
 }
 
-hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, hipStream_t s)
+// reset_queue: the batch has run before (the tile queue's heads start at zero with the counters' initial values)
+hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s)
 {
     if (a.n_jobs == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(&a.cnt[kCntHeads], 0, 8 * 16 * sizeof(unsigned long long), s);
+    hipError_t e = reset_queue ? hipMemsetAsync(&a.cnt[kCntHeads], 0, 8 * 16 * sizeof(unsigned long long), s) : hipSuccess;
     if (e != hipSuccess) return e;
     const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
     const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_stream<512>) : reinterpret_cast<const void *>(k_stream<256>);
