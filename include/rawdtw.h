@@ -77,7 +77,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   lane_max_radius are scored a lane per job from the side list, bucketed by length over the whole batch; its tiles'
  *   LDS image is 7200 floats unless "tile_lds_floats" is given
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
- *   "time_plan" 0/1: event pair around a batch's planning kernels; "stream_others_blocks": workgroups that start on the wide-band jobs
+ *   "time_plan" 0/1: event pair around a batch's planning kernels
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
  *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
  *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)

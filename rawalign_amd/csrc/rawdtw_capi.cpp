@@ -80,7 +80,6 @@ struct rawdtw_ctx {
     int stream_threads_cached = 0;
     int stream_blocks_per_cu = 4;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
     int stream_bpc_cached = -1;
-    uint32_t stream_others_blocks = 32;         // ... of which this many start on the side list
     uint32_t stream_debug = 0;         // StreamArgs::debug
     std::vector<uint32_t> unit_chain_scratch;
     bool resident_arrays = false;      // rawdtw_batch_create: anchors / ref_base / read_base are DEVICE pointers (used in place)
@@ -1196,7 +1195,6 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "stream_debug")) { ctx->stream_debug = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
-    if (!strcmp(name, "stream_others_blocks")) { ctx->stream_others_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1024); return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }

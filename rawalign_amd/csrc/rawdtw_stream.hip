@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
         } else parts[k] = 0;
     }
     // The running sums of the tile layout (rawdtw_internal.h: Cum), local to the unit: a scan over the workgroup's threads;
-    // k_unit_scan turns the units' totals into their offsets.  (No pass over the batch for a global scan.)
+    // k_mid's first workgroup turns the units' totals into their offsets.  (No pass over the batch for a global scan.)
     {
         __shared__ uint64_t s_wpos[kT / 64];
         __shared__ uint32_t s_wcost[kT / 64];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             if (have[k]) { a.cpos[jf + k] = epos + lpos[k]; a.ccost[jf + k] = ecost + lcost[k]; }
         if (tid == 0) { a.unit_pos[blockIdx.x] = tpos; a.unit_cost[blockIdx.x] = (uint64_t)tcost; }
     }
-    // totals: per workgroup, then one record per unit (reduced by k_others); the side list's base: one returning atomic per
+    // totals: per workgroup, then one record per unit (reduced by k_mid); the side list's base: one returning atomic per
     // workgroup that has side-list jobs
     {
         // tile jobs (<= 4 a thread) and their bytes (< 2^12 a thread) share one 32-bit word through the wave's reduction;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_unit_scan: the units' totals -> the sums BEFORE each unit (exclusive, in place; entry n_units = the batch totals).
+// unit scan (a role of k_mid): the units' totals -> the sums BEFORE each unit (exclusive, in place; entry n_units = the batch totals).
 // One workgroup: a few thousand entries.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void unit_scan_body(const StreamArgs &a)
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_others: the side list in class order (wave-per-job classes first, longest first; then 16-lane groups, 8-lane groups)
+// side list in class order (a role of k_mid): wave-per-job classes first, longest first; then 16-lane groups, the lane classes
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void others_body(const StreamArgs &a, const uint32_t group, const uint32_t groups_all)
@@ -909,7 +909,7 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 
 size_t stream_scan_bytes(uint64_t n_jobs)
 {
-    (void)n_jobs; // (the layout's running sums are made by k_pre per unit and k_unit_scan over the units: no library scan)
+    (void)n_jobs; // (the layout's running sums are made by k_pre per unit and k_mid over the units: no library scan)
     return 256;
 }
 
