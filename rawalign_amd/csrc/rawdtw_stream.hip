@@ -648,7 +648,13 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
         if (n_w + n_g16 + n_l + n_m <= a.others_cap) { // (otherwise the batch is redone through the job-list path)
             // item order = list order: wave-per-job (longest first), 16-lane groups, lane-per-job (4 slots, then 8; by length)
             const uint64_t it_g16 = (n_g16 + 3) / 4, it_l = (n_l + 63) / 64, it_m = (n_m + 63) / 64, items = n_w + it_g16 + it_l + it_m;
-            for (uint64_t it = (uint64_t)blockIdx.x * (TT / 64) + wv; it < items; it += (uint64_t)gridDim.x * (TT / 64)) {
+            // The waves that draw the long items (a wave-per-job or 16-lane item: 30..150 us) take the short ones as well, in
+            // further rounds: their workgroups start on tiles late anyway, and every other workgroup starts at once.
+            // (debug 2048: all waves of the grid share the items, one round.)
+            const uint32_t all_waves = gridDim.x * (TT / 64), widx = blockIdx.x * (TT / 64) + wv;
+            const uint32_t side_waves = (a.debug & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
+            const uint32_t n_items = (uint32_t)min<uint64_t>(items, 0xffffffffull); // (the list's capacity is a quarter of the jobs)
+            for (uint32_t it = widx < side_waves ? widx : n_items; it < n_items; it += side_waves) {
                 if (it < n_w) {
                     if (a.debug & 32u) continue;
                     // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its
