@@ -103,6 +103,9 @@ def test_cross_chunk_memoisation_is_exact_and_saves_work(oracle):
         b, rb_ = mapper.map_reads(seeds, list(range(40)), memo, opt, never)
         assert a == b and ra_ == rb_ and ra_ > 1
         assert memo.jobs_reused > 0 and memo.jobs_scored < plain.jobs_scored
+        # ... and against the oracle's sequential loop under the same stop rule (not only against the plain device path)
+        c, rc_ = mapper.map_reads(seeds, list(range(40)), OracleScorer(oracle, ref), opt, never)
+        assert c == b and rc_ == rb_
 
 
 def test_cigar_and_log_scores_flags_oracle_path(oracle):
