@@ -79,7 +79,8 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
  *   "time_plan" 0/1: event pair around a batch's planning kernels
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
- *   "fold_mode" 0/1/2: chain fold as a wave per chain, or a lane per chain with 16 / 32 parts per round (default 2)
+ *   "fold_mode" 0/1/2/3: chain fold as a wave per chain, a lane per chain with 16 / 32 parts per round, or (default 3) a lane
+ *   per chain plus a wave for each chain of at least "fold_long_parts" (768) parts
  *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)
  * The environment variable RAWDTW_OPTS="name=value,..." applies options at rawdtw_create. */
 int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);

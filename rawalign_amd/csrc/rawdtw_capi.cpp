@@ -94,7 +94,8 @@ struct rawdtw_ctx {
     void *h_pinned = nullptr;  // pinned host staging (traceback paths), grow-only
     size_t pinned_bytes = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
-    int fold_mode = 2; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work)
+    int fold_mode = 3; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work), 3: lanes + a wave for each long chain
+    uint32_t fold_long_parts = 768; // fold_mode 3: chains of at least this many parts are folded a wave each
     int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
     uint32_t tile_max_spans = kTileMaxSpans;
     int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
@@ -1196,7 +1197,8 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
-    if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
+    if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3); return RAWDTW_OK; }
+    if (!strcmp(name, "fold_long_parts")) { ctx->fold_long_parts = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 30); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_spans")) { ctx->tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 4096); return RAWDTW_OK; }
     if (!strcmp(name, "full_wg")) { ctx->full_wg = value != 0; return RAWDTW_OK; }
@@ -2245,7 +2247,7 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
     const float *job_cost = b->stream ? b->sa.out : b->plan->d_cost;
     if (which == 0)
         e = launch_chain_fold(ctx->fold_mode, b->d_chains, b->d_fold_order, b->n_chains, job_cost, b->opt.match_bonus, b->opt.fused_score,
-                              b->d_full, b->d_gate, ctx->stream);
+                              b->d_full, b->d_gate, ctx->fold_long_parts, ctx->stream);
     else
         e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
                                b->d_keep, ctx->stream);

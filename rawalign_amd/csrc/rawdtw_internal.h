@@ -224,7 +224,8 @@ hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux
                                hipStream_t s);
 
 hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
-                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, hipStream_t s);
+                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, uint32_t long_parts,
+                             hipStream_t s);
 hipError_t launch_read_select(const uint64_t *chain_off, uint64_t n_reads, const float *full_score,
                               const float *att_last, float min_score, float *score, uint8_t *keep,
                               hipStream_t s);

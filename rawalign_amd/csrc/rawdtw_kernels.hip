@@ -595,22 +595,14 @@ __global__ __launch_bounds__(256) void k_tb_finish(const DevJob *__restrict__ jo
 // read.  All arithmetic is fp32 in the reference's order; the final score is a single fma when the
 // reference build contracts it.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict__ chains,
-                                                    const uint32_t *__restrict__ order, uint64_t n_chains,
-                                                    const float *__restrict__ job_cost, float bonus,
-                                                    int fused, float *__restrict__ full_score,
-                                                    float *__restrict__ att_last)
-{
-    // One wave per chain (`order`: longest chains first, so the long folds start first).  The part
-    // costs are fetched 64 at a time (coalesced, next chunk in flight while the current one is folded);
-    // the fp32 fold itself is inherently sequential and runs on wave-uniform values taken out of the
-    // chunk with v_readlane.  (A lane-per-chain variant was slower: ~40 k chains are too few lanes.)
-    const uint64_t t = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (t >= n_chains) return;
-    const uint32_t c = order[t];
-    const ChainDesc d = chains[c];
-    float attainable = (float)d.span * bonus; // rmap.cpp:205,246
+// One wave per chain.  The part costs are fetched 64 at a time (coalesced, next chunk in flight while the current one is
+// folded); the fp32 fold itself is inherently sequential and runs on wave-uniform values taken out of the chunk with
+// v_readlane: two instructions a part, but no memory round trip per 32 parts as in the lane-per-chain form -- the form for
+// the few chains long enough to bound the launch.
+__device__ __forceinline__ void fold_wave_body(const uint32_t c, const ChainDesc d, const int lane, const float *__restrict__ job_cost,
+                                               const float bonus, const int fused, float *__restrict__ full_score,
+                                               float *__restrict__ att_last)
+{    float attainable = (float)d.span * bonus; // rmap.cpp:205,246
     float cost = 0.0f;
     const float *jc = job_cost + d.job_first;
     // all parts but the last: cost += sub; attainable -= sub (two independent fp32 chains)
@@ -649,23 +641,31 @@ __global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict_
     }
 }
 
+
+__global__ __launch_bounds__(256) void k_chain_fold(const ChainDesc *__restrict__ chains,
+                                                    const uint32_t *__restrict__ order, uint64_t n_chains,
+                                                    const float *__restrict__ job_cost, float bonus,
+                                                    int fused, float *__restrict__ full_score,
+                                                    float *__restrict__ att_last)
+{
+    // (`order`: longest chains first, so the long folds start first)
+    const uint64_t t = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (t >= n_chains) return;
+    const uint32_t c = order[t];
+    fold_wave_body(c, chains[c], threadIdx.x & 63, job_cost, bonus, fused, full_score, att_last);
+}
+
 // Lane-per-chain fold: 64 chains per wave (`order`: longest first, so a wave's chains have similar lengths), each
 // lane adds its own chain's part costs in order.  One packed add per 64 parts instead of a v_readlane + add per
 // part: ~30x less VALU work than k_chain_fold, which matters once several batches share the chip (the DTW kernels
 // are VALU-bound).  Each lane streams 4 bytes at a time through its own cache lines; U parts are fetched one
 // round ahead so that a round costs one memory round trip.
 template <int U>
-__global__ __launch_bounds__(64) void k_chain_fold_lane(const ChainDesc *__restrict__ chains,
-                                                        const uint32_t *__restrict__ order, uint64_t n_chains,
-                                                        const float *__restrict__ job_cost, float bonus, int fused,
-                                                        float *__restrict__ full_score, float *__restrict__ att_last)
+__device__ __forceinline__ void fold_lane_body(const bool act, const uint32_t c, ChainDesc d, const float *__restrict__ job_cost,
+                                               const float bonus, const int fused, float *__restrict__ full_score,
+                                               float *__restrict__ att_last)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    const bool act = t < n_chains;
-    const uint32_t c = act ? order[t] : 0u;
-    ChainDesc d = chains[act ? c : order[0]];
-    if (!act) d.n_jobs = 0;
-    const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0; // all parts but the last: cost += sub; attainable -= sub
+    if (!act) d.n_jobs = 0;    const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0; // all parts but the last: cost += sub; attainable -= sub
     const float *jc = job_cost + d.job_first;
     v2f acc = {0.0f, (float)d.span * bonus}; // {cost, attainable}  (rmap.cpp:205,246)
     float nx[U];
@@ -692,6 +692,44 @@ __global__ __launch_bounds__(64) void k_chain_fold_lane(const ChainDesc *__restr
     }
 }
 
+template <int U>
+__global__ __launch_bounds__(64) void k_chain_fold_lane(const ChainDesc *__restrict__ chains,
+                                                        const uint32_t *__restrict__ order, uint64_t n_chains,
+                                                        const float *__restrict__ job_cost, float bonus, int fused,
+                                                        float *__restrict__ full_score, float *__restrict__ att_last)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    const bool act = t < n_chains;
+    const uint32_t c = act ? order[t] : 0u;
+    fold_lane_body<U>(act, c, chains[act ? c : order[0]], job_cost, bonus, fused, full_score, att_last);
+}
+
+// Both forms in one launch of one-wave workgroups (`order`: longest chains first): the first `long_waves` take the entries
+// order[0 .. long_waves) a wave each -- those of at least `long_parts` parts; a shorter one is left alone -- and the others
+// take every entry a lane each, idling on the chains the waves took.  The lane form alone ends with its longest chain
+// (one memory round trip per 32 parts: 43 rounds for the bench batch's 1373 parts); a thousand chains of 768+ parts cost
+// the wave form 2 M instructions and leave the lanes 24 rounds.  (One wave per workgroup: the lane form's scattered loads
+// are bound by a CU's texture path -- four such waves on one CU took twice as long.)
+__global__ __launch_bounds__(64) void k_chain_fold_hybrid(const ChainDesc *__restrict__ chains, const uint32_t *__restrict__ order,
+                                                          uint64_t n_chains, const float *__restrict__ job_cost, float bonus, int fused,
+                                                          float *__restrict__ full_score, float *__restrict__ att_last,
+                                                          uint32_t long_parts, uint32_t long_waves)
+{
+    if (blockIdx.x < long_waves) {
+        const uint32_t c = order[blockIdx.x]; // (long_waves <= n_chains)
+        const ChainDesc d = chains[c];
+        if (d.n_jobs < long_parts) return;
+        fold_wave_body(c, d, threadIdx.x, job_cost, bonus, fused, full_score, att_last);
+        return;
+    }
+    const uint64_t t = (uint64_t)(blockIdx.x - long_waves) * 64u + threadIdx.x;
+    bool act = t < n_chains;
+    const uint32_t c = act ? order[t] : 0u;
+    const ChainDesc d = chains[act ? c : order[0]];
+    if (t < long_waves && d.n_jobs >= long_parts) act = false; // (a wave has it)
+    fold_lane_body<32>(act, c, d, job_cost, bonus, fused, full_score, att_last);
+}
+
 __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict__ chain_off, uint64_t n_reads,
                                                      const float *__restrict__ full_score,
                                                      const float *__restrict__ att_last, float min_score,
@@ -713,10 +751,15 @@ __global__ __launch_bounds__(256) void k_read_select(const uint64_t *__restrict_
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
-                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, hipStream_t s)
+                             const float *job_cost, float bonus, int fused, float *full_score, float *att_last, uint32_t long_parts,
+                             hipStream_t s)
 {
     if (n_chains == 0) return hipSuccess;
-    if (mode == 1)
+    if (mode == 3) {
+        const uint32_t long_waves = (uint32_t)std::min<uint64_t>(n_chains, 4096); // at most this many chains a wave each
+        hipLaunchKernelGGL(k_chain_fold_hybrid, dim3(long_waves + (uint32_t)((n_chains + 63) / 64)), dim3(64), 0, s, chains, order,
+                           n_chains, job_cost, bonus, fused, full_score, att_last, long_parts, long_waves);
+    } else if (mode == 1)
         hipLaunchKernelGGL(k_chain_fold_lane<16>, dim3((uint32_t)((n_chains + 63) / 64)), dim3(64), 0, s, chains, order,
                            n_chains, job_cost, bonus, fused, full_score, att_last);
     else if (mode == 2)
