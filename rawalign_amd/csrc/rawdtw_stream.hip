@@ -35,7 +35,14 @@ namespace rawdtw {
 
 namespace {
 
-constexpr int kT = 256;                 // threads per workgroup, everywhere in this file
+constexpr int kT = 256;                 // threads per workgroup, everywhere in this file but k_pre
+#ifndef PRE_THREADS
+#define PRE_THREADS 512
+#endif
+#ifndef PRE_WAVES
+#define PRE_WAVES 4
+#endif
+constexpr int kPreT = PRE_THREADS;      // k_pre: 1024 jobs per workgroup, kPreUnit / kPreT consecutive jobs per thread
 constexpr uint32_t kPreUnit = 1024;     // jobs per k_pre workgroup
 constexpr uint32_t kItems = kStreamItems; // jobs per thread in the tile prologue (strided)
 static_assert(kStreamMaxTileJobs == kItems * 512, "tile job capacity of the 512-thread instance");
@@ -123,13 +130,14 @@ struct OpMax { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { re
 // its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs and
 // every stage below issues the loads of all of them before anything waits, and nothing in the job path crosses a
 // workgroup barrier.
-// Register budget: 102 VGPRs (allocated 104).  In a pipeline of batches this kernel shares the SIMDs with the k_stream
-// waves (96 VGPRs) of the batches before it, and with 104 any mix of the two keeps five waves on a SIMD (4 x 104 + 96 =
-// 512).  A variant that evaluated the class rule of the neighbouring parts once per thread (6 instead of 12 radius
+// Register budget: 63 VGPRs with two jobs per thread (512 threads a workgroup).  In a pipeline of batches this kernel shares
+// the SIMDs with the k_stream waves (96 VGPRs, four a SIMD) of the batches before it: what it needs decides how many of its
+// waves fit beside them.  With four jobs per thread it took 102 (104 allocated: one wave beside four of k_stream's); a
+// variant of that which evaluated the class rule of the neighbouring parts once per thread (6 instead of 12 radius
 // computations, -20 % VALU) needed 116 and made the whole pipeline 10 % SLOWER, every kernel in it included.
-__global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
+__global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
 {
-    constexpr uint32_t kPer = kPreUnit / kT;
+    constexpr uint32_t kPer = kPreUnit / kPreT;
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses];
     __shared__ unsigned long long s_stats[3]; // tile jobs, tile bytes, side-list bytes
     const int tid = threadIdx.x;
@@ -255,14 +263,14 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             // so stage it in the side list's own staging slot right away: the slot index is fixed, only the base is not
             P[k] = slot; parts[k] = cls | 0x80000000u;
             S[k] = rawdtw_anchor_t{n, m}; E[k] = rawdtw_anchor_t{(uint32_t)R, excl ? kFlagExcludeLast : 0u};
-            SP[k] = rawdtw_anchor_t{read_off, (uint32_t)j}; jo[k] = ref_off;
+            SP[k] = rawdtw_anchor_t{read_off, (uint32_t)j};
         } else parts[k] = 0;
     }
     // The running sums of the tile layout (rawdtw_internal.h: Cum), local to the unit: a scan over the workgroup's threads;
     // k_mid's first workgroup turns the units' totals into their offsets.  (No pass over the batch for a global scan.)
     {
-        __shared__ uint64_t s_wpos[kT / 64];
-        __shared__ uint32_t s_wcost[kT / 64];
+        __shared__ uint64_t s_wpos[kPreT / 64];
+        __shared__ uint32_t s_wcost[kPreT / 64];
         uint64_t ipos = run_pos;
         uint32_t icost = run_cost;
         const int lane = tid & 63, wv = tid >> 6;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
         uint64_t ppos = 0, tpos = 0;
         uint32_t pcost = 0, tcost = 0;
 #pragma unroll
-        for (int w = 0; w < kT / 64; w++) {
+        for (int w = 0; w < kPreT / 64; w++) {
             if (w < wv) { ppos += s_wpos[w]; pcost += s_wcost[w]; }
             tpos += s_wpos[w]; tcost += s_wcost[w];
         }
@@ -313,7 +321,8 @@ __global__ __launch_bounds__(kT) void k_pre(const StreamArgs a)
             const uint64_t q = base + P[k];
             if (q < a.others_cap) { // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
                 DevJob d;
-                d.ref_off = jo[k]; d.read_off = SP[k].target_position; d.n = S[k].target_position; d.m = S[k].query_position;
+                d.ref_off = a.jrec[jf + k].ref_off; // (this thread's own record, re-read: a rare path, and two registers less in the common one)
+                d.read_off = SP[k].target_position; d.n = S[k].target_position; d.m = S[k].query_position;
                 d.R = (int32_t)E[k].target_position; d.flags = E[k].query_position; d.aux = SP[k].query_position;
                 a.omix[q] = d; a.ocls[q] = (uint8_t)(parts[k] & 0xffu);
             }
@@ -941,7 +950,7 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
 {
     (void)hipGetLastError();
     if (a.n_jobs) {
-        hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kT), 0, s, a);
+        hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kPreT), 0, s, a);
     }
     if (a.n_jobs || a.n_chains)
         hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + 1023) / 1024)), dim3(1024), 0, s, a, d_chains, d_fold_order);
