@@ -7,7 +7,7 @@
 // HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here a batch is
 // six launches (k_pre, k_mid, k_tile_first, k_stream, fold, select), none of which the host waits for:
 //
-//   k_pre          1024 jobs per workgroup, four consecutive jobs per thread: a job's windows from its chain's anchors
+//   k_pre          1024 jobs per workgroup, two consecutive jobs per thread: a job's windows from its chain's anchors
 //                  (rmap.cpp:251-254, 270, 276), the slant-corrected radius (dtw.cpp:298-300) and its class.  Writes one
 //                  16-byte record per job (arena offsets + packed shape) and the running sums of the tile layout INSIDE
 //                  the workgroup's unit (rawdtw_internal.h: Cum); the jobs the tiles do not take (radius > 2, longer side
