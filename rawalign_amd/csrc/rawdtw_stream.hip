@@ -370,9 +370,10 @@ __device__ __forceinline__ void unit_scan_body(const StreamArgs &a)
 // k_tile_first: tile k = the jobs whose exclusive running cost lies in [k * width, (k + 1) * width).  Every job has a
 // positive cost, so tile_first[k] = 1 + (first job whose inclusive running cost reaches k * width).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kT) void k_tile_first(const StreamArgs a)
+// (one-wave workgroups: every thread chases ~25 dependent, scattered loads -- spread over as many CUs as there are waves)
+__global__ __launch_bounds__(64) void k_tile_first(const StreamArgs a)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * kT + threadIdx.x;
+    const uint64_t k = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     const uint64_t n = a.n_jobs;
     const uint64_t n_units = (n + kPreUnit - 1) / kPreUnit;
     auto cost_incl = [&](uint64_t j) { return a.unit_cost[j / kPreUnit] + a.ccost[j]; }; // inclusive running cost of job j
@@ -954,7 +955,7 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     }
     if (a.n_jobs || a.n_chains)
         hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + 1023) / 1024)), dim3(1024), 0, s, a, d_chains, d_fold_order);
-    if (a.n_jobs) hipLaunchKernelGGL(k_tile_first, dim3(blocks_for((uint64_t)a.tiles_cap + 1)), dim3(kT), 0, s, a);
+    if (a.n_jobs) hipLaunchKernelGGL(k_tile_first, dim3((uint32_t)(((uint64_t)a.tiles_cap + 1 + 63) / 64)), dim3(64), 0, s, a);
     (void)d_key; (void)d_val; (void)d_key_out;
     return hipGetLastError();
 }
