@@ -7,7 +7,7 @@
 // HBM, which the DTW kernel then read back: 0.6 ms of GPU time and 4 ms of host time per 0.15 ms of DTW.  Here a batch is
 // six launches (k_pre, k_mid, k_tile_first, k_stream, fold, select), none of which the host waits for:
 //
-//   k_pre          1024 jobs per workgroup, two consecutive jobs per thread: a job's windows from its chain's anchors
+//   k_pre          1024 jobs per workgroup, four consecutive jobs per thread: a job's windows from its chain's anchors
 //                  (rmap.cpp:251-254, 270, 276), the slant-corrected radius (dtw.cpp:298-300) and its class.  Writes one
 //                  16-byte record per job (arena offsets + packed shape) and the running sums of the tile layout INSIDE
 //                  the workgroup's unit (rawdtw_internal.h: Cum); the jobs the tiles do not take (radius > 2, longer side
@@ -37,7 +37,7 @@ namespace {
 
 constexpr int kT = 256;                 // threads per workgroup, everywhere in this file but k_pre
 #ifndef PRE_THREADS
-#define PRE_THREADS 512
+#define PRE_THREADS 256
 #endif
 #ifndef PRE_WAVES
 #define PRE_WAVES 4
@@ -130,11 +130,11 @@ struct OpMax { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { re
 // its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs and
 // every stage below issues the loads of all of them before anything waits, and nothing in the job path crosses a
 // workgroup barrier.
-// Register budget: 63 VGPRs with two jobs per thread (512 threads a workgroup).  In a pipeline of batches this kernel shares
-// the SIMDs with the k_stream waves (96 VGPRs, four a SIMD) of the batches before it: what it needs decides how many of its
-// waves fit beside them.  With four jobs per thread it took 102 (104 allocated: one wave beside four of k_stream's); a
-// variant of that which evaluated the class rule of the neighbouring parts once per thread (6 instead of 12 radius
-// computations, -20 % VALU) needed 116 and made the whole pipeline 10 % SLOWER, every kernel in it included.
+// Register budget: 97 VGPRs (104 allocated) with four jobs per thread (256 threads a workgroup; PRE_THREADS=512: two jobs,
+// fewer registers, 15 % more instructions, same throughput).  In a pipeline of batches this kernel shares the SIMDs with
+// the k_stream waves (96 VGPRs, four a SIMD) of the batches before it, and what it needs decides how many of its waves
+// fit beside them: at 116 registers (the first version of the class-rule reuse below, before the side list's record
+// stopped being parked in registers) the whole pipeline ran 10 % SLOWER, every kernel in it included; at 104 it is level.
 __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
 {
     constexpr uint32_t kPer = kPreUnit / kPreT;
@@ -205,31 +205,53 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
         r = r > 1 ? r : 1;
         return d_slanted_radius(n, m, r) <= a.lane_max_radius && max(n, m) <= a.lane_max_n; // (r >= 1)
     };
+    // the class rule of every job of the thread first: consecutive jobs are consecutive parts of one chain (or the chain
+    // ends), so the part before job k and the part after it are the thread's own jobs k - 1 and k + 1 -- only the part
+    // before the first job and the one after the last need a rule evaluation of their own (6 instead of 12 a thread)
+    bool tc[kPer], okk[kPer];
+    int Rk[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        const rawdtw_anchor_t s = S[k], e = E[k];
+        const bool asc = have[k] && e.target_position >= s.target_position && e.query_position >= s.query_position;
+        const uint32_t m = e.target_position - s.target_position + 1, n = e.query_position - s.query_position + 1;
+        int r0 = (int)((float)n * a.frac); // rmap.cpp:276, fp32 product
+        r0 = r0 > 1 ? r0 : 1;
+        Rk[k] = asc ? d_slanted_radius(n, m, r0) : 0;
+        tc[k] = asc && Rk[k] <= a.lane_max_radius && max(n, m) <= a.lane_max_n; // (= tile_class(s, e))
+        okk[k] = asc && !((uint64_t)qb[k] + s.query_position + n > a.n_ev || rb[k] + s.target_position + m > a.n_ref ||
+                          n >= 0x7fffffffu || m >= 0x7fffffffu);
+    }
+    bool prev_tc[kPer], next_tc[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; k++) {
+        if (k == 0) prev_tc[k] = have[0] && P[0] > 0 && tile_class(SP[0], S[0]);
+        else prev_tc[k] = have[k] && c[k] == c[k - 1] && tc[k - 1]; // (another chain: job k is its first part)
+        if (k + 1 < kPer) next_tc[k] = have[k + 1 < kPer ? k + 1 : k] && c[k + 1 < kPer ? k + 1 : k] == c[k] && tc[k + 1 < kPer ? k + 1 : k];
+        else next_tc[k] = have[k] && P[k] + 1 < parts[k] && tile_class(E[k], EN[k]);
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kPer; k++) {
         if (!have[k]) continue;
         const uint64_t j = jf + k;
         const rawdtw_anchor_t s = S[k], e = E[k];
-        bool ok = e.target_position >= s.target_position && e.query_position >= s.query_position;
+        const bool ok = okk[k];
         const uint64_t ref_off = rb[k] + s.target_position;
         const uint32_t read_off = qb[k] + s.query_position;
         const uint32_t m = e.target_position - s.target_position + 1;
         const uint32_t n = e.query_position - s.query_position + 1;
-        if ((uint64_t)qb[k] + s.query_position + n > a.n_ev || ref_off + m > a.n_ref || n >= 0x7fffffffu || m >= 0x7fffffffu) ok = false;
         const bool excl = P[k] != parts[k] - 1; // rmap.cpp:270
-        int r0 = (int)((float)n * a.frac); // rmap.cpp:276, fp32 product
-        r0 = r0 > 1 ? r0 : 1;
-        const int R = ok ? d_slanted_radius(n, m, r0) : 0;
+        const int R = ok ? Rk[k] : 0;
         const uint32_t N = n > m ? n : m, M = n > m ? m : n;
-        const bool tile = ok && R >= 1 && R <= a.lane_max_radius && N <= a.lane_max_n; // (radius 0 cannot come from rmap.cpp:276)
+        const bool tile = ok && R >= 1 && tc[k]; // (radius 0 cannot come from rmap.cpp:276)
         uint32_t meta = 0;
         if (!ok) atomicMin(&a.cnt[kCntBad], (unsigned long long)j);
         if (tile) {
             // a tile job continues its chain's run when the part before it is a tile job too (consecutive parts share their
             // anchor element: the run is one contiguous piece of each arena), and ends the run when the part after it is
             // not one: the run's end is then padded to a 16-byte boundary, so that two runs never share a chunk of the image
-            const bool starts = !(P[k] > 0 && tile_class(SP[k], s));
-            const bool ends = !(P[k] + 1 < parts[k] && tile_class(e, EN[k]));
+            const bool starts = !prev_tc[k];
+            const bool ends = !next_tc[k];
             meta = N | (M << 7) | ((uint32_t)R << 14) | ((excl ? 1u : 0u) << 16) | ((n < m ? 1u : 0u) << 17) |
                    ((starts ? 1u : 0u) << 18) | kMetaTile | (ends ? kMetaEnds : 0u);
             my_tiles++;
