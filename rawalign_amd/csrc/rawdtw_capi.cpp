@@ -1727,7 +1727,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // tiles take radius <= stream_tile_radius (2: 98 % of a sparse batch's jobs, one short body); the radii between that
     // and lane_max_radius go to the side list's lane classes
     a.lane_max_radius = std::min(ctx->lane_max_radius, ctx->stream_tile_radius); a.side_lane_radius = ctx->lane_max_radius;
-    a.lane_max_n = ctx->lane_max_n; a.micro_max_n = (uint32_t)ctx->micro_max_n;
+    a.lane_max_n = ctx->lane_max_n;
     // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the
     // bracket by at most the largest cost a job can have, so the image needs at most tile_budget floats
     const uint32_t tile_budget = lds_floats - kStreamSlack;
@@ -1738,13 +1738,12 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // every bracket holds at most width8 / min_cost8 + 1 jobs: with the floor above that is below kStreamMaxTileJobs
     a.tiles_cap = (uint32_t)std::min<uint64_t>(n_jobs * worst8 / a.width8 + 2, 0x7fffffffull);
     a.others_cap = std::min<uint64_t>(n_jobs, n_jobs / 4 + 4096);
-    const size_t tmp = std::max(stream_scan_bytes(n_jobs), stream_sort_bytes(nc));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint64_t n_units = (n_jobs + 1023) / 1024;
     const size_t dev_bytes = al((nc + 1) * 8) * 2 + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) +   // inputs
                              al(n_jobs * 16) + al(n_jobs * 8) + al(n_jobs * 4) + 2 * al((n_units + 1) * 8) + al(((size_t)a.tiles_cap + 1) * sizeof(TileInfo)) + // per job: record, sums
-                             2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) + al(tmp) +
-                             al(nc * sizeof(ChainDesc)) + 7 * al(nc * 4) + al(nc) + al(n_jobs * 4) + al((n_units + 1) * 4) + al(n_units * 24);
+                             2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) +
+                             al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(n_jobs * 4) + al((n_units + 1) * 4) + al(n_units * 24);
     const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8) + al((n_units + 1) * 4);
     int st = ws_acquire(ctx, dev_bytes, host_bytes, &b->ws);
     if (st != RAWDTW_OK) return st;
@@ -1766,9 +1765,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.unit_pos = carve<uint64_t>(p, n_units + 1); a.unit_cost = carve<uint64_t>(p, n_units + 1);
     a.tiles = carve<TileInfo>(p, (uint64_t)a.tiles_cap + 1);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
-    void *d_tmp = carve<char>(p, tmp);
     b->d_chains = carve<ChainDesc>(p, nc);
-    uint32_t *d_key = carve<uint32_t>(p, nc), *d_val = carve<uint32_t>(p, nc), *d_key_out = carve<uint32_t>(p, nc);
     b->d_fold_order = carve<uint32_t>(p, nc);
     b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
     b->d_keep = carve<uint8_t>(p, nc);
@@ -1778,7 +1775,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.debug = ctx->stream_debug;
     a.job_off = d_job_off; a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
     if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
-    a.ev = ctx->d_ev; a.ref = ctx->d_ref; a.masks = ctx->d_masks;
+    a.ev = ctx->d_ev; a.ref = ctx->d_ref;
     char *hp = b->ws.h;
     char *h_pack = hp;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
@@ -1810,7 +1807,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
-    hipError_t e = stream_plan(a, b->d_chains, d_key, d_val, d_key_out, b->d_fold_order, d_tmp, tmp, s);
+    hipError_t e = stream_plan(a, b->d_chains, b->d_fold_order, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
     // the persistent grid: what the device holds at this LDS size

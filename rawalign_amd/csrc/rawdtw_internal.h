@@ -168,7 +168,7 @@ struct StreamArgs {
     float frac;                  // dtw_band_radius_frac
     int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
     int32_t side_lane_radius;    // side-list lane classes: radius in (lane_max_radius, this], longer side <= lane_max_n
-    uint32_t lane_max_n, micro_max_n;
+    uint32_t lane_max_n;
     uint32_t min_cost8;          // cost floor in eighths of a float: bounds the jobs of a tile's range
     uint64_t width8;             // bracket width of the tile rule: 8 * (image floats - slack) - the largest cost a job can have
     uint32_t tiles_cap;
@@ -180,7 +180,6 @@ struct StreamArgs {
     const uint64_t *ref_base;
     const uint32_t *read_base;
     const float *ev, *ref;
-    const unsigned long long *masks;
     // planning arrays and outputs (device)
     JobRec *jrec;
     uint64_t *cpos;              // inclusive sums of job_cum INSIDE the job's unit of 1024: event floats | reference floats << 32
@@ -193,12 +192,9 @@ struct StreamArgs {
     unsigned long long *cnt;
     float *out;
 };
-size_t stream_scan_bytes(uint64_t n_jobs);
-size_t stream_sort_bytes(uint64_t n_chains);
 uint32_t stream_lds_bytes(uint32_t lds_floats);
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
-hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key, uint32_t *d_val, uint32_t *d_key_out,
-                       uint32_t *d_fold_order, void *d_tmp, size_t tmp_bytes, hipStream_t s);
+hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
 hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);
 hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,

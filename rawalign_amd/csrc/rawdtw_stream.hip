@@ -945,18 +945,6 @@ namespace {
 inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 } // namespace
 
-size_t stream_scan_bytes(uint64_t n_jobs)
-{
-    (void)n_jobs; // (the layout's running sums are made by k_pre per unit and k_mid over the units: no library scan)
-    return 256;
-}
-
-size_t stream_sort_bytes(uint64_t n_chains)
-{
-    (void)n_chains; // (the fold order is a one-workgroup counting sort: no workspace)
-    return 256;
-}
-
 static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
 {
     return lds_floats * 4u + kItems * (uint32_t)threads * 8u + (uint32_t)(threads == 512 ? sizeof(SortTable<512>) : sizeof(SortTable<256>));
@@ -968,8 +956,7 @@ uint32_t stream_lds_bytes(uint32_t lds_floats)
 }
 
 // everything rawdtw_batch_create enqueues for a sparse + banded batch: planning of the DTW launch and the chain records
-hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key, uint32_t *d_val, uint32_t *d_key_out,
-                       uint32_t *d_fold_order, void *d_tmp, size_t tmp_bytes, hipStream_t s)
+hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s)
 {
     (void)hipGetLastError();
     if (a.n_jobs) {
@@ -978,7 +965,6 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_key
     if (a.n_jobs || a.n_chains)
         hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + 1023) / 1024)), dim3(1024), 0, s, a, d_chains, d_fold_order);
     if (a.n_jobs) hipLaunchKernelGGL(k_tile_first, dim3((uint32_t)(((uint64_t)a.tiles_cap + 1 + 63) / 64)), dim3(64), 0, s, a);
-    (void)d_key; (void)d_val; (void)d_key_out;
     return hipGetLastError();
 }
 
