@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -90,7 +91,8 @@ unsigned bits(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin [--pipeline steps]\n"); return 1; }
+    const int pipeline_steps = (argc >= 4 && !strcmp(argv[2], "--pipeline")) ? atoi(argv[3]) : 0;
     Blob b;
     if (!load(argv[1], b)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
     const bool evaluate = b.flag & 0x2, cigar = b.flag & 0x4, log_scores = b.flag & 0x8; // roptions.h:13-15
@@ -136,6 +138,49 @@ int main(int argc, char **argv)
         CHECK(rawdtw_batch_run(dtw, batch));
         CHECK(rawdtw_batch_fetch(dtw, batch, score.data(), keep.data(), nullptr));
         CHECK(rawdtw_batch_destroy(batch));
+    }
+
+    // ---- the same round as a pipeline ("The calls are asynchronous"): one context per pipeline
+    // worker sharing the resident reference, the batch's arrays in page-locked memory, create + run enqueued for step k
+    // while the steps before it are still on the device, fetch only when a worker's slot comes round again ----
+    if (pipeline_steps > 0 && (evaluate || log_scores)) {
+        const int W = 4;
+        rawdtw_ctx *wctx[W] = {nullptr, nullptr, nullptr, nullptr};
+        rawdtw_batch *wb[W] = {nullptr, nullptr, nullptr, nullptr};
+        void *pin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const size_t bytes[5] = {(b.n_reads + 1) * 8, (n_chains + 1) * 8, anchors.size() * sizeof(rawdtw_anchor_t), n_chains * 8, n_chains * 4};
+        const void *src[5] = {b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(), read_base.data()};
+        for (int k = 0; k < 5; k++) {
+            CHECK(rawdtw_host_alloc(bytes[k] ? bytes[k] : 8, &pin[k]));
+            memcpy(pin[k], src[k], bytes[k]);
+        }
+        for (int w = 0; w < W; w++) {
+            if (rawdtw_create(0, &wctx[w]) != RAWDTW_OK) { fprintf(stderr, "no device\n"); return 3; }
+            CHECK(rawdtw_share_reference(wctx[w], dtw));
+            CHECK(rawdtw_upload_events(wctx[w], b.events.data(), b.events.size()));
+        }
+        std::vector<float> s2(n_chains);
+        std::vector<uint8_t> k2(n_chains);
+        int bad = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int step = 0; step < pipeline_steps + W; step++) {
+            const int w = step % W;
+            if (wb[w]) {
+                if (rawdtw_batch_fetch(wctx[w], wb[w], s2.data(), k2.data(), nullptr) != RAWDTW_OK) { fprintf(stderr, "%s\n", rawdtw_last_error(wctx[w])); return 2; }
+                rawdtw_batch_destroy(wb[w]);
+                wb[w] = nullptr;
+                if (memcmp(s2.data(), score.data(), n_chains * 4) || memcmp(k2.data(), keep.data(), n_chains)) bad++;
+            }
+            if (step < pipeline_steps) {
+                if (rawdtw_batch_create(wctx[w], &b.opt, b.n_reads, (const uint64_t *)pin[0], (const uint64_t *)pin[1], (const rawdtw_anchor_t *)pin[2],
+                                        (const uint64_t *)pin[3], (const uint32_t *)pin[4], &wb[w]) != RAWDTW_OK ||
+                    rawdtw_batch_run(wctx[w], wb[w]) != RAWDTW_OK) { fprintf(stderr, "%s\n", rawdtw_last_error(wctx[w])); return 2; }
+            }
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("pipeline steps=%d mismatches=%d ms_per_step=%.4f\n", pipeline_steps, bad, ms / pipeline_steps);
+        for (int w = 0; w < W; w++) rawdtw_destroy(wctx[w]);
+        for (int k = 0; k < 5; k++) rawdtw_host_free(pin[k]);
     }
 
     // ---- per read: post_alignment_chains, primary chains, MAPQ, stop rule, tags ----

@@ -184,3 +184,23 @@ def test_cpp_shim_matches_oracle(oracle, tmp_path, border, fill, flag):
         assert "log chaining_score=" in text
     if flag == 0x8:  # log-scores alone: nothing is filtered, every chain stays a candidate (rmap.cpp:525)
         assert sum(int(ln.split("nc=")[1].split(" ")[0]) for ln in got if ln.startswith("read")) > 0
+
+
+@pytest.mark.gpu
+def test_cpp_shim_pipeline_of_four_contexts(oracle, tmp_path):
+    """INTEGRATION.md section 4 as a compiled program: four contexts sharing the resident reference, the batch's arrays in
+    page-locked memory, create + run enqueued ahead and fetch one slot behind; every step's scores and keeps must equal
+    the single-batch result (which the cases above pin to the oracle), and the per-read lines must still match it."""
+    exe = _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
+    ref, cb, cseq, cstr, cscore = _make_case(57, 60)
+    opt = ra.MapOpt()
+    blob = os.path.join(str(tmp_path), "batch.bin")
+    _write_blob(blob, ref, cb, cseq, cstr, cscore, opt, 0x2)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([exe, blob, "--pipeline", "24"], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr
+    got = run.stdout.rstrip("\n").split("\n")
+    pipe = [ln for ln in got if ln.startswith("pipeline ")]
+    assert len(pipe) == 1 and "steps=24 mismatches=0 " in pipe[0], pipe
+    rest = [ln for ln in got if not ln.startswith("pipeline ")]
+    assert rest == _expected_lines(oracle, ref, cb, cseq, cstr, cscore, opt, 0x2)
