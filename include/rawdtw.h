@@ -72,7 +72,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
  *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create takes the sync-free path (planning on the device, in LDS)
- *   "stream_tile_radius" 1..3 (default 2), "stream_threads" 256/512, "stream_blocks_per_cu" (default 4; 0 = as many as
+ *   "stream_tile_radius" 1..3 (default 3), "stream_threads" 256/512, "stream_blocks_per_cu" (default 4; 0 = as many as
  *   fit): the device-planned batch's DTW launch -- tiles take radii up to stream_tile_radius, the radii between that and
  *   lane_max_radius are scored a lane per job from the side list, bucketed by length over the whole batch; its tiles'
  *   LDS image is 7200 floats unless "tile_lds_floats" is given

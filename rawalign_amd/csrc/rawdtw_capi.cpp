@@ -100,7 +100,7 @@ struct rawdtw_ctx {
     uint32_t tile_max_spans = kTileMaxSpans;
     int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
     int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
-    int stream_tile_radius = 2;           // device-planned batches: the tiles' radius limit ("stream_tile_radius")
+    int stream_tile_radius = 3;           // device-planned batches: the tiles' radius limit ("stream_tile_radius")
     // reference arena
     float *d_ref = nullptr;
     uint64_t n_ref = 0;
@@ -1724,8 +1724,8 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a = StreamArgs{};
     a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
     a.frac = b->opt.band_radius_frac;
-    // tiles take radius <= stream_tile_radius (2: 98 % of a sparse batch's jobs, one short body); the radii between that
-    // and lane_max_radius go to the side list's lane classes
+    // tiles take radius <= stream_tile_radius; the radii between that and lane_max_radius (none by default) go to the side
+    // list's lane classes
     a.lane_max_radius = std::min(ctx->lane_max_radius, ctx->stream_tile_radius); a.side_lane_radius = ctx->lane_max_radius;
     a.lane_max_n = ctx->lane_max_n;
     // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the

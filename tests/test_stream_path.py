@@ -103,6 +103,8 @@ def _wide(rng):     # side list: 8-lane, 16-lane and wave-per-job classes
     (_medium, {"stream_threads": 512, "tile_lds_floats": 9000}),
     (_medium, {"tile_lds_floats": 2048}), (_tiny, {"micro_max_n": 0}), (_medium, {"micro_max_n": 4, "lane_max_n": 20}),
     (_medium, {"lane_max_radius": 1}), (_wide, {"stream_threads": 512}),
+    # tiles of radius <= 2 / <= 1: the wider lane radii go to the side list's lane classes (lane_global_wave, lane_dp_r12)
+    (_medium, {"stream_tile_radius": 2}), (_medium, {"stream_tile_radius": 1}), (_wide, {"stream_tile_radius": 2}),
 ])
 def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
     rng = np.random.default_rng(hash((shapes.__name__, tuple(sorted(opts)))) & 0xFFFF)
