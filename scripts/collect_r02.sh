@@ -11,7 +11,7 @@ cp $OUT/pmc/summary.json $OUT/r02_pmc_summary.json
 python3 scripts/make_traffic.py $OUT/pmc/summary.json "k_stream<256>" 16384 > $OUT/traffic_r02.json
 # attribution of the DTW launch's instructions: stream_debug masks (4 no side list, 1 no DP, 2 no staging, 16 no marks)
 CFGS="stream_debug=0 stream_debug=4 stream_debug=5 stream_debug=7 stream_debug=23" bash scripts/pmc_debug_masks.sh > $OUT/r02_pmc_attribution.txt 2>&1
-python scripts/stream_probe.py 16384 "" stream_debug=4 stream_debug=32 stream_debug=96 stream_tile_radius=3 stream_blocks_per_cu=5,tile_lds_floats=4800 > $OUT/r02_stream_probe.txt 2>&1
+python scripts/stream_probe.py 16384 "" stream_debug=4 stream_debug=32 stream_debug=96 stream_tile_radius=2 stream_blocks_per_cu=5,tile_lds_floats=4800 > $OUT/r02_stream_probe.txt 2>&1
 python scripts/wreg_probe.py > $OUT/r02_wreg_probe.txt 2>&1
 bash scripts/sensitivity.sh $OUT/sens > $OUT/sens_top.txt; cp $OUT/sens/summary.json $OUT/r02_sensitivity.json
 mkdir -p $OUT/r02_modes
