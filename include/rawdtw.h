@@ -75,7 +75,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "stream_tile_radius" 1..3 (default 3), "stream_threads" 256/512, "stream_blocks_per_cu" (default 4; 0 = as many as
  *   fit): the device-planned batch's DTW launch -- tiles take radii up to stream_tile_radius, the radii between that and
  *   lane_max_radius are scored a lane per job from the side list, bucketed by length over the whole batch; its tiles'
- *   LDS image is 7200 floats unless "tile_lds_floats" is given
+ *   LDS image is 7000 floats unless "tile_lds_floats" is given
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
  *   "time_plan" 0/1: event pair around a batch's planning kernels
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)

@@ -1654,7 +1654,9 @@ struct StreamLayout { // sizes in bytes of one batch's device workspace and pinn
 // LDS image of a device-planned batch's tiles, in floats.  With four workgroups a CU (stream_blocks_per_cu) a SIMD keeps
 // 128 registers free beside the DTW launch's waves -- room for a wave of the next batches' planning kernels or of the
 // batch before's fold -- and the LDS that a fifth workgroup would take goes into larger tiles (fewer tiles, fuller sorted
-// waves).  Measured on the bench pipeline (4 batches in flight): 5 x 4800 floats 425 GCUPS, 4 x 7200 453, 3 x 6400 450.
+// waves).  Measured on the bench pipeline (4 batches in flight): 5 x 4800 floats 425 GCUPS, 4 x 7200 453, 3 x 6400 450;
+// later, with k_pre's chain table in LDS (2 KB a workgroup): 4 x 7200 508, 4 x 7000 524, 4 x 6800 523, 4 x 6000 511 -- the planning
+// kernels of the batches behind need LDS beside the four resident workgroups.
 static uint32_t stream_tile_floats(const rawdtw_ctx *ctx) { return (ctx->tile_lds_set ? ctx->tile_lds_floats : kStreamTileFloats) & ~3u; } // (16-byte multiples: the records and the sort table sit behind the image)
 
 bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)

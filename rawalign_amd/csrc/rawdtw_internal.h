@@ -69,7 +69,8 @@ constexpr int kMaxLaneRadiusHi = 8;    // second tile-kernel instance: radii kMa
 constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is at most this
 // tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
 constexpr uint32_t kTileLdsFloats = 4800;  // job-list tile kernel: 8 workgroups per CU
-constexpr uint32_t kStreamTileFloats = 7200; // k_stream: 4 workgroups per CU (image + records + sort table = 40 KB)
+constexpr uint32_t kStreamTileFloats = 7000; // k_stream: 4 workgroups per CU (image + records + sort table = 39 KB: ~7 KB of the
+                                             // CU's 160 KB stay free for the planning kernels of the batches behind it)
 constexpr uint32_t kTileMaxJobs = 1024;
 constexpr uint32_t kTileHiLdsFloats = 14336, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;

@@ -44,6 +44,7 @@ constexpr int kT = 256;                 // threads per workgroup, everywhere in 
 #endif
 constexpr int kPreT = PRE_THREADS;      // k_pre: 1024 jobs per workgroup, kPreUnit / kPreT consecutive jobs per thread
 constexpr uint32_t kPreUnit = 1024;     // jobs per k_pre workgroup
+constexpr uint32_t kPreChains = 64;     // chain entries of a unit k_pre keeps in LDS (1.8 KB)
 constexpr uint32_t kItems = kStreamItems; // jobs per thread in the tile prologue (strided)
 static_assert(kStreamMaxTileJobs == kItems * 512, "tile job capacity of the 512-thread instance");
 
@@ -149,32 +150,52 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
     // first job (the host tabulates the unit -> chain map while it counts the jobs; the table ends with n_chains - 1)
     const uint64_t c_lo = a.unit_chain[blockIdx.x], c_hi = a.unit_chain[blockIdx.x + 1];
     const uint64_t jf = j0 + (uint64_t)tid * kPer; // this thread's first job
-    // ---- stage 1: the chain of the thread's first job (last chain c in [c_lo, c_hi] with job_off[c] <= jf; the step count
-    // is the same for the whole workgroup), then of the following jobs (usually the same chain) ----
-    uint64_t c[kPer];
-    {
-        uint64_t lo = c_lo, hi = c_hi; // invariant: job_off[lo] <= jf, answer in [lo, hi]
-        for (uint64_t span = c_hi - c_lo; span > 0; span >>= 1) {
-            const uint64_t mid = lo + ((hi - lo + 1) >> 1);
-            if (hi > lo) { if (a.job_off[mid] <= jf) lo = mid; else hi = mid - 1; }
-        }
-        // chains without jobs share their successor's offset: the search lands on the LAST of them, which owns the job
-        c[0] = lo;
-    }
+    // ---- stages 1 + 2: each job's chain and the chain's offsets.  A unit spans few chains (a chain has one job per part:
+    // some 130 in the bench batch), so the workgroup loads the offsets of chains c_lo .. c_hi + 1 into LDS in ONE round trip
+    // and every thread searches there: the job path then has three dependent trips to memory (unit -> chains, the
+    // chains' offsets, the anchors) instead of a dozen (binary search, one probe per further job, offsets, anchors).
+    // Units of more than kPreChains - 2 chains (batches of very short chains) search the arrays in memory instead. ----
+    __shared__ uint64_t s_jo[kPreChains], s_ao[kPreChains], s_rb[kPreChains];
+    __shared__ uint32_t s_qb[kPreChains];
+    const uint32_t span = (uint32_t)min<uint64_t>(c_hi - c_lo, 0xfffffff0ull);
+    uint32_t ce[kPer]; // the job's chain, counted from c_lo
     bool have[kPer];
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; k++) {
-        have[k] = jf + k < a.n_jobs;
-        if (k) c[k] = c[k - 1];
-        if (have[k]) while (a.job_off[c[k] + 1] <= jf + k) c[k]++;
-    }
-    // ---- stage 2: the chains' offsets ----
     uint64_t jo[kPer], a0[kPer], a1[kPer], rb[kPer];
     uint32_t qb[kPer];
 #pragma unroll
-    for (uint32_t k = 0; k < kPer; k++) {
-        const uint64_t cc = have[k] ? c[k] : c_lo;
-        jo[k] = a.job_off[cc]; a0[k] = a.anchor_off[cc]; a1[k] = a.anchor_off[cc + 1]; rb[k] = a.ref_base[cc]; qb[k] = a.read_base[cc];
+    for (uint32_t k = 0; k < kPer; k++) have[k] = jf + k < a.n_jobs;
+    if (span + 2u <= kPreChains) {
+        if ((uint32_t)tid < span + 2u) { s_jo[tid] = a.job_off[c_lo + tid]; s_ao[tid] = a.anchor_off[c_lo + tid]; }
+        if ((uint32_t)tid <= span) { s_rb[tid] = a.ref_base[c_lo + tid]; s_qb[tid] = a.read_base[c_lo + tid]; }
+        __syncthreads();
+        // the last entry e <= span with job_off <= jf (chains without jobs share their successor's offset: the LAST of them
+        // owns the job), by doubling steps
+        uint32_t e = 0;
+        for (uint32_t step = kPreChains / 2; step > 0; step >>= 1)
+            if (e + step <= span && s_jo[e + step] <= jf) e += step;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            if (have[k]) while (s_jo[e + 1] <= jf + k) e++; // (job_off[c_hi + 1] is beyond the unit: e stays <= span)
+            ce[k] = e;
+            jo[k] = s_jo[e]; a0[k] = s_ao[e]; a1[k] = s_ao[e + 1]; rb[k] = s_rb[e]; qb[k] = s_qb[e];
+        }
+    } else {
+        uint64_t c;
+        {
+            uint64_t lo = c_lo, hi = c_hi; // invariant: job_off[lo] <= jf, answer in [lo, hi]
+            for (uint64_t sp = c_hi - c_lo; sp > 0; sp >>= 1) {
+                const uint64_t mid = lo + ((hi - lo + 1) >> 1);
+                if (hi > lo) { if (a.job_off[mid] <= jf) lo = mid; else hi = mid - 1; }
+            }
+            c = lo;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; k++) {
+            if (have[k]) while (a.job_off[c + 1] <= jf + k) c++;
+            ce[k] = (uint32_t)(c - c_lo);
+            const uint64_t cc = have[k] ? c : c_lo;
+            jo[k] = a.job_off[cc]; a0[k] = a.anchor_off[cc]; a1[k] = a.anchor_off[cc + 1]; rb[k] = a.ref_base[cc]; qb[k] = a.read_base[cc];
+        }
     }
     // ---- stage 3: the anchors: this part's (s, e), the end of the part before (sp) and of the part after (en) ----
     rawdtw_anchor_t S[kPer], E[kPer], SP[kPer], EN[kPer];
@@ -226,8 +247,8 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
 #pragma unroll
     for (uint32_t k = 0; k < kPer; k++) {
         if (k == 0) prev_tc[k] = have[0] && P[0] > 0 && tile_class(SP[0], S[0]);
-        else prev_tc[k] = have[k] && c[k] == c[k - 1] && tc[k - 1]; // (another chain: job k is its first part)
-        if (k + 1 < kPer) next_tc[k] = have[k + 1 < kPer ? k + 1 : k] && c[k + 1 < kPer ? k + 1 : k] == c[k] && tc[k + 1 < kPer ? k + 1 : k];
+        else prev_tc[k] = have[k] && ce[k] == ce[k - 1] && tc[k - 1]; // (another chain: job k is its first part)
+        if (k + 1 < kPer) next_tc[k] = have[k + 1 < kPer ? k + 1 : k] && ce[k + 1 < kPer ? k + 1 : k] == ce[k] && tc[k + 1 < kPer ? k + 1 : k];
         else next_tc[k] = have[k] && P[k] + 1 < parts[k] && tile_class(E[k], EN[k]);
     }
 #pragma unroll
@@ -356,18 +377,28 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
 // unit scan (a role of k_mid): the units' totals -> the sums BEFORE each unit (exclusive, in place; entry n_units = the batch totals).
 // One workgroup: a few thousand entries.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
 __device__ __forceinline__ void unit_scan_body(const StreamArgs &a)
 {
+    constexpr uint32_t kU = 8; // consecutive units per thread and round (NT * kU units a round: two or three rounds a bench batch)
     const uint64_t n_units = (a.n_jobs + kPreUnit - 1) / kPreUnit;
-    __shared__ uint64_t s_p[16], s_c[16];
+    __shared__ uint64_t s_p[NT / 64], s_c[NT / 64];
     __shared__ uint64_t s_carry[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     if (tid == 0) { s_carry[0] = 0; s_carry[1] = 0; }
     __syncthreads();
-    for (uint64_t base = 0; base < n_units; base += 1024) {
-        const uint64_t u = base + tid;
-        const uint64_t vp = u < n_units ? a.unit_pos[u] : 0ull, vc = u < n_units ? a.unit_cost[u] : 0ull;
-        uint64_t ip = vp, ic = vc;
+    for (uint64_t base = 0; base < n_units; base += (uint64_t)NT * kU) {
+        const uint64_t u0 = base + (uint64_t)tid * kU;
+        uint64_t vp[kU], vc[kU];
+#pragma unroll
+        for (uint32_t q = 0; q < kU; q++) {
+            vp[q] = u0 + q < n_units ? a.unit_pos[u0 + q] : 0ull;
+            vc[q] = u0 + q < n_units ? a.unit_cost[u0 + q] : 0ull;
+        }
+        uint64_t tp = 0, tc = 0; // this thread's units
+#pragma unroll
+        for (uint32_t q = 0; q < kU; q++) { tp += vp[q]; tc += vc[q]; }
+        uint64_t ip = tp, ic = tc;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t op = (uint64_t)__shfl_up((long long)ip, d), oc = (uint64_t)__shfl_up((long long)ic, d);
@@ -375,14 +406,19 @@ __device__ __forceinline__ void unit_scan_body(const StreamArgs &a)
         }
         if (lane == 63) { s_p[wv] = ip; s_c[wv] = ic; }
         __syncthreads();
-        uint64_t pp = s_carry[0], pc = s_carry[1], tp = 0, tc = 0;
-        for (uint32_t w = 0; w < 16; w++) {
+        uint64_t pp = s_carry[0] + ip - tp, pc = s_carry[1] + ic - tc, ap = 0, ac = 0; // sums before this thread's first unit
+#pragma unroll
+        for (uint32_t w = 0; w < NT / 64; w++) {
             if (w < wv) { pp += s_p[w]; pc += s_c[w]; }
-            tp += s_p[w]; tc += s_c[w];
+            ap += s_p[w]; ac += s_c[w];
         }
-        if (u < n_units) { a.unit_pos[u] = pp + ip - vp; a.unit_cost[u] = pc + ic - vc; }
+#pragma unroll
+        for (uint32_t q = 0; q < kU; q++) {
+            if (u0 + q < n_units) { a.unit_pos[u0 + q] = pp; a.unit_cost[u0 + q] = pc; }
+            pp += vp[q]; pc += vc[q];
+        }
         __syncthreads();
-        if (tid == 0) { s_carry[0] += tp; s_carry[1] += tc; }
+        if (tid == 0) { s_carry[0] += ap; s_carry[1] += ac; }
         __syncthreads();
     }
     if (tid == 0) { a.unit_pos[n_units] = s_carry[0]; a.unit_cost[n_units] = s_carry[1]; }
@@ -527,18 +563,39 @@ __device__ __forceinline__ void chain_desc_body(const StreamArgs &a, ChainDesc *
 
 // Fold order: chains by part count, longest first (the lane-per-chain fold gives a wave 64 chains of similar length).
 // One workgroup: a counting sort over 1024 length buckets in LDS (the order inside a bucket does not matter).
+template <int NT>
 __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const uint64_t *__restrict__ job_off, uint32_t *__restrict__ order)
 {
-    auto key_of = [&](uint64_t c) { return (uint32_t)min<uint64_t>(job_off[c + 1] - job_off[c], 0xffffffffull); }; // a chain's part count
-    __shared__ uint32_t hist[1024];
-    __shared__ uint32_t wsum[16];
+    constexpr uint32_t kBins = 1024, kB = kBins / NT; // consecutive buckets per thread in the scan
+    constexpr uint32_t kC = 4;                        // chains per thread and round: their offsets are all requested before any is used
+    __shared__ uint32_t hist[kBins];
+    __shared__ uint32_t wsum[NT / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    auto bucket = [](uint32_t k) { return 1023u - min(k, 1023u); };
-    hist[tid] = 0;
+    auto bucket = [](uint64_t parts) { return 1023u - (uint32_t)min<uint64_t>(parts, 1023ull); }; // a chain's part count, clamped
+    auto keys = [&](uint64_t c0, uint32_t (&b)[kC]) { // buckets of chains c0 + q * NT
+        uint64_t lo[kC], hi[kC];
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++) {
+            const uint64_t c = min(c0 + (uint64_t)q * NT, n_chains - 1);
+            lo[q] = job_off[c]; hi[q] = job_off[c + 1];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++) b[q] = bucket(hi[q] - lo[q]);
+    };
+    for (uint32_t i = tid; i < kBins; i += NT) hist[i] = 0;
     __syncthreads();
-    for (uint64_t c = tid; c < n_chains; c += 1024) atomicAdd(&hist[bucket(key_of(c))], 1u);
+    for (uint64_t c0 = tid; c0 < n_chains; c0 += (uint64_t)NT * kC) {
+        uint32_t b[kC];
+        keys(c0, b);
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++)
+            if (c0 + (uint64_t)q * NT < n_chains) atomicAdd(&hist[b[q]], 1u);
+    }
     __syncthreads();
-    uint32_t v = hist[tid], incl = v;
+    uint32_t v[kB], mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kB; q++) { v[q] = hist[tid * kB + q]; mine += v[q]; }
+    uint32_t incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
@@ -546,12 +603,18 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
     }
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    uint32_t pre = 0;
-    for (uint32_t w = 0; w < wv; w++) pre += wsum[w];
+    uint32_t at = incl - mine;
+    for (uint32_t w = 0; w < wv; w++) at += wsum[w];
+#pragma unroll
+    for (uint32_t q = 0; q < kB; q++) { hist[tid * kB + q] = at; at += v[q]; } // exclusive start of the bucket
     __syncthreads();
-    hist[tid] = pre + incl - v; // exclusive start of the bucket
-    __syncthreads();
-    for (uint64_t c = tid; c < n_chains; c += 1024) order[atomicAdd(&hist[bucket(key_of(c))], 1u)] = (uint32_t)c;
+    for (uint64_t c0 = tid; c0 < n_chains; c0 += (uint64_t)NT * kC) {
+        uint32_t b[kC];
+        keys(c0, b);
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++)
+            if (c0 + (uint64_t)q * NT < n_chains) order[atomicAdd(&hist[b[q]], 1u)] = (uint32_t)(c0 + (uint64_t)q * NT);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -562,13 +625,17 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
 // more launches for the host to issue.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMidOthers = 64;
-__global__ __launch_bounds__(1024) void k_mid(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+#ifndef MID_THREADS
+#define MID_THREADS 1024
+#endif
+constexpr int kMidT = MID_THREADS;
+__global__ __launch_bounds__(kMidT) void k_mid(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x;
-    if (b == 0) { if (a.n_jobs) unit_scan_body(a); }
-    else if (b == 1) { if (a.n_chains) fold_order_body(a.n_chains, a.job_off, order); }
-    else if (b < 2 + kMidOthers + 1) { if (a.n_jobs) others_body<1024>(a, b - 2, kMidOthers + 1); }
-    else chain_desc_body(a, chains, (uint64_t)(b - (2 + kMidOthers + 1)) * 1024 + threadIdx.x);
+    if (b == 0) { if (a.n_jobs) unit_scan_body<kMidT>(a); }
+    else if (b == 1) { if (a.n_chains) fold_order_body<kMidT>(a.n_chains, a.job_off, order); }
+    else if (b < 2 + kMidOthers + 1) { if (a.n_jobs) others_body<kMidT>(a, b - 2, kMidOthers + 1); }
+    else chain_desc_body(a, chains, (uint64_t)(b - (2 + kMidOthers + 1)) * kMidT + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -683,10 +750,13 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
             // The waves that draw the long items (a wave-per-job or 16-lane item: 30..150 us) take the short ones as well, in
             // further rounds: their workgroups start on tiles late anyway, and every other workgroup starts at once.
             // (debug 2048: all waves of the grid share the items, one round.)
-            const uint32_t all_waves = gridDim.x * (TT / 64), widx = blockIdx.x * (TT / 64) + wv;
+            const uint32_t all_waves = gridDim.x * (TT / 64), widx = __builtin_amdgcn_readfirstlane(blockIdx.x * (TT / 64) + wv);
             const uint32_t side_waves = (a.debug & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
             const uint32_t n_items = (uint32_t)min<uint64_t>(items, 0xffffffffull); // (the list's capacity is a quarter of the jobs)
-            for (uint32_t it = widx < side_waves ? widx : n_items; it < n_items; it += side_waves) {
+            // dealt like a snake: the wave that drew the longest item of a round draws the shortest of the next
+            // (item r * S + w in even rounds, r * S + S - 1 - w in odd ones: the stride alternates between 2S - 1 - 2w and 1 + 2w)
+            for (uint32_t it = widx < side_waves ? widx : n_items, step = (a.debug & 4096u) ? side_waves : 2u * side_waves - 1u - 2u * widx; it < n_items;
+                 it += step, step = 2u * side_waves - step) {
                 if (it < n_w) {
                     if (a.debug & 32u) continue;
                     // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its
@@ -963,7 +1033,7 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
         hipLaunchKernelGGL(k_pre, dim3((uint32_t)((a.n_jobs + kPreUnit - 1) / kPreUnit)), dim3(kPreT), 0, s, a);
     }
     if (a.n_jobs || a.n_chains)
-        hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + 1023) / 1024)), dim3(1024), 0, s, a, d_chains, d_fold_order);
+        hipLaunchKernelGGL(k_mid, dim3(2 + kMidOthers + 1 + (uint32_t)((a.n_chains + kMidT - 1) / kMidT)), dim3(kMidT), 0, s, a, d_chains, d_fold_order);
     if (a.n_jobs) hipLaunchKernelGGL(k_tile_first, dim3((uint32_t)(((uint64_t)a.tiles_cap + 1 + 63) / 64)), dim3(64), 0, s, a);
     return hipGetLastError();
 }

@@ -21,7 +21,7 @@ from tests.golden_util import bits
 pytestmark = pytest.mark.gpu
 
 
-def _chains(rng, n_reads, ref_len, shapes):
+def _chains(rng, n_reads, ref_len, shapes, parts_range=(1, 40)):
     """One read per chain group; every chain's parts draw (dq, dt) from `shapes`(rng) -> anchors end-first."""
     events, chain_off, anchor_off, anchors, ref_base, read_base = [], [0], [0], [], [], []
     ev_at = 0
@@ -30,7 +30,7 @@ def _chains(rng, n_reads, ref_len, shapes):
         read_len = 0
         per = []
         for _ in range(n_chains):
-            parts = int(rng.integers(1, 40))
+            parts = int(rng.integers(*parts_range))
             dq, dt = zip(*[shapes(rng) for _ in range(parts)])
             q = np.concatenate([[int(rng.integers(0, 5))], np.cumsum(dq) + 0]).astype(np.int64)
             q[1:] += q[0]
@@ -126,6 +126,27 @@ def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
     _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
     info = b.info()
     assert info["n_jobs"] == len(jc) and info["n_lane_jobs"] + info["n_wave_band_jobs"] == len(jc)
+
+
+@pytest.mark.parametrize("n_reads,parts_range", [(900, (1, 4)), (12, (300, 500)), (200, (1, 120))])
+def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
+    """k_pre finds a job's chain in LDS when its unit of 1024 jobs spans at most 62 chains and in memory otherwise:
+    batches of very short chains (hundreds a unit), very long ones (a chain over several units) and a mix."""
+    rng = np.random.default_rng(n_reads)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, n_reads, 60000, _tiny, parts_range)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is True
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
 
 
 def test_band_too_wide_for_the_stream_path_is_redone_through_the_job_list(oracle):
