@@ -173,7 +173,9 @@ struct StreamArgs {
     uint32_t min_cost8;          // cost floor in eighths of a float: bounds the jobs of a tile's range
     uint64_t width8;             // bracket width of the tile rule: 8 * (image floats - slack) - the largest cost a job can have
     uint32_t tiles_cap;
-    uint32_t debug;              // timing experiments only (results wrong): 1 no DP, 2 no staging, 4 no side list
+    uint32_t debug;              // timing experiments only (results wrong below 128 except 8): 1 no DP, 2 no staging, 4 no side
+                                 // list, 16 no marks, 32 no wave-per-job items, 64 no group / lane items; 8 tiles without the
+                                 // ticket queue, 2048 side items over all waves, 4096 side items dealt straight (not alternating)
     // inputs (device)
     const uint32_t *unit_chain;  // per k_pre unit of 1024 jobs: the chain its first job belongs to (n_units + 1 entries)
     const uint64_t *job_off, *anchor_off;

@@ -127,11 +127,11 @@ struct OpMax { __device__ uint32_t operator()(uint32_t a, uint32_t b) const { re
 // ---------------------------------------------------------------------------------------------------------------------
 // k_pre
 // ---------------------------------------------------------------------------------------------------------------------
-// Latency is what this kernel costs (its arithmetic is ~20 M wave instructions, its traffic ~120 MB): every job needs
-// its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs and
-// every stage below issues the loads of all of them before anything waits, and nothing in the job path crosses a
-// workgroup barrier.
-// Register budget: 97 VGPRs (104 allocated) with four jobs per thread (256 threads a workgroup; PRE_THREADS=512: two jobs,
+// Latency is what this kernel costs (its arithmetic is ~19 M wave instructions, its traffic ~190 MB): every job needs
+// its chain, the chain's offsets, then four anchors -- dependent loads.  So each thread takes kPer CONSECUTIVE jobs,
+// every stage below issues the loads of all of them before anything waits, and the chains' offsets come from a table
+// the workgroup loads into LDS once (the one barrier of the job path).
+// Register budget: 99 VGPRs (104 allocated) with four jobs per thread (256 threads a workgroup; PRE_THREADS=512: two jobs,
 // fewer registers, 15 % more instructions, same throughput).  In a pipeline of batches this kernel shares the SIMDs with
 // the k_stream waves (96 VGPRs, four a SIMD) of the batches before it, and what it needs decides how many of its waves
 // fit beside them: at 116 registers (the first version of the class-rule reuse below, before the side list's record
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
             SP[k] = rawdtw_anchor_t{read_off, (uint32_t)j};
         } else parts[k] = 0;
     }
+    unsigned long long obase = 0; // (thread 0) the side list's base for this workgroup's jobs
     // The running sums of the tile layout (rawdtw_internal.h: Cum), local to the unit: a scan over the workgroup's threads;
     // k_mid's first workgroup turns the units' totals into their offsets.  (No pass over the batch for a global scan.)
     {
@@ -325,6 +326,10 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
         }
         if (lane == 63) { s_wpos[wv] = ipos; s_wcost[wv] = icost; }
         __syncthreads();
+        // (every thread is through its jobs: the side list's count is final.  Its base is one returning atomic on one word
+        // per workgroup -- the workgroups of a round arrive together and the word takes ~88 a microsecond -- so it is
+        // issued here and waited for at the end, behind the sums' stores)
+        if (tid == 0 && s_ocnt) obase = atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
         uint64_t ppos = 0, tpos = 0;
         uint32_t pcost = 0, tcost = 0;
 #pragma unroll
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
         if (my_obytes) atomicAdd(&s_stats[2], my_obytes);
     }
     __syncthreads();
-    if (tid == 0) s_obase = s_ocnt ? (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt) : 0u;
+    if (tid == 0) s_obase = (uint32_t)obase;
     if (tid < 3) a.unit_stats[3ull * blockIdx.x + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     __syncthreads();
