@@ -1484,14 +1484,13 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
     if (const char *e = getenv("RAWDTW_TB_WORKSPACE_MB")) budget = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;
     uint64_t begin = 0;
     while (begin < n_jobs) {
-        uint64_t end = begin, bytes = 0, path_elems = 0;
+        uint64_t end = begin, bytes = 0;
         while (end < n_jobs) {
             const rawdtw_job_t &j = jobs[end];
             if (j.n == 0 || j.m == 0) return fail(ctx, RAWDTW_ERR_INVALID, "zero-length traceback job");
             const uint64_t b = dir_bytes_for(j.n, j.m, full_rpl(std::min(j.n, j.m))) + 256;
             if (end > begin && bytes + b > budget) break;
             bytes += b;
-            path_elems += (uint64_t)j.n + j.m - 1;
             end++;
         }
         const uint64_t cnt = end - begin;

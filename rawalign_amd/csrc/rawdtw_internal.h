@@ -195,7 +195,6 @@ struct StreamArgs {
     unsigned long long *cnt;
     float *out;
 };
-uint32_t stream_lds_bytes(uint32_t lds_floats);
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);

@@ -1025,11 +1025,6 @@ static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
     return lds_floats * 4u + kItems * (uint32_t)threads * 8u + (uint32_t)(threads == 512 ? sizeof(SortTable<512>) : sizeof(SortTable<256>));
 }
 
-uint32_t stream_lds_bytes(uint32_t lds_floats)
-{
-    return 0; // (see stream_lds_bytes_t)
-}
-
 // everything rawdtw_batch_create enqueues for a sparse + banded batch: planning of the DTW launch and the chain records
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s)
 {
