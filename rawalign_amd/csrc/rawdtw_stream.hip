@@ -858,7 +858,13 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_stream(const StreamAr
                             const uint32_t P = w ? p_ref : p_read, L = w ? (swap ? N : M) : (swap ? M : N);
                             const long long delta = (w ? (long long)jr[k].ref_off : (long long)jr[k].read_off) - (long long)P;
                             const uint4 mark = make_uint4((uint32_t)delta, (uint32_t)((unsigned long long)delta >> 32), 0x5eed0000u ^ tag, tag);
-                            for (uint32_t c = P & ~3u; c < P + L; c += 4u) *reinterpret_cast<uint4 *>(win + c) = mark;
+                            // (a window of up to nine floats -- most of a sparse batch's -- lies in three chunks: those
+                            // without a loop, whose trip count would be the wave's longest window's)
+                            const uint32_t c0 = P & ~3u, ce_ = P + L;
+                            *reinterpret_cast<uint4 *>(win + c0) = mark;
+                            if (c0 + 4u < ce_) *reinterpret_cast<uint4 *>(win + c0 + 4u) = mark;
+                            if (c0 + 8u < ce_) *reinterpret_cast<uint4 *>(win + c0 + 8u) = mark;
+                            for (uint32_t c = c0 + 12u; c < ce_; c += 4u) *reinterpret_cast<uint4 *>(win + c) = mark;
                             if (starts && i != D.first_tile) {
                                 const uint32_t gap = ((w ? c_ref - D.base_ref + D.ref_region : c_read - D.base_read)) & ~3u;
                                 if (gap < (P & ~3u)) *reinterpret_cast<uint4 *>(win + gap) = make_uint4(0u, 0u, 0u, tag);
