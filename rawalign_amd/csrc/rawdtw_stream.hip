@@ -219,12 +219,22 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
     uint32_t lcost[kPer]; // ... and cost
     uint64_t run_pos = 0;
     uint32_t run_cost = 0;
+    // Tile class without the division of dtw.cpp:298-300: with d = N - M the radius is R = r0 + ceil(d r0 / N), so
+    //     R <= Rm  <=>  r0 <= Rm and d r0 <= (Rm - r0) N,
+    // and for a tile job (Rm <= 3 and r0 >= 1: the ceiling is 0, 1 or 2)  R = r0 + (d r0 > 0) + (d r0 > N).
+    // (32-bit products: N <= lane_max_n < 128 and r0 <= 3 wherever the result counts.)  The side list's jobs -- one in two
+    // hundred -- get their radius from d_slanted_radius.
+    auto shape_class = [&](const uint32_t n, const uint32_t m, int &R) {
+        int r0 = (int)((float)n * a.frac); // rmap.cpp:276, fp32 product
+        r0 = r0 > 1 ? r0 : 1;
+        const uint32_t N = n > m ? n : m, dr = (N - (n > m ? m : n)) * (uint32_t)r0;
+        R = r0 + (dr > 0u ? 1 : 0) + (dr > N ? 1 : 0);
+        return N <= a.lane_max_n && r0 <= a.lane_max_radius && dr <= (uint32_t)(a.lane_max_radius - r0) * N;
+    };
     auto tile_class = [&](const rawdtw_anchor_t &s, const rawdtw_anchor_t &e) { // would the part s -> e be a tile job?
-        if (!(e.target_position >= s.target_position && e.query_position >= s.query_position)) return false;
-        const uint32_t m = e.target_position - s.target_position + 1, n = e.query_position - s.query_position + 1;
-        int r = (int)((float)n * a.frac);
-        r = r > 1 ? r : 1;
-        return d_slanted_radius(n, m, r) <= a.lane_max_radius && max(n, m) <= a.lane_max_n; // (r >= 1)
+        int R;
+        return e.target_position >= s.target_position && e.query_position >= s.query_position &&
+               shape_class(e.query_position - s.query_position + 1, e.target_position - s.target_position + 1, R);
     };
     // the class rule of every job of the thread first: consecutive jobs are consecutive parts of one chain (or the chain
     // ends), so the part before job k and the part after it are the thread's own jobs k - 1 and k + 1 -- only the part
@@ -236,10 +246,12 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
         const rawdtw_anchor_t s = S[k], e = E[k];
         const bool asc = have[k] && e.target_position >= s.target_position && e.query_position >= s.query_position;
         const uint32_t m = e.target_position - s.target_position + 1, n = e.query_position - s.query_position + 1;
-        int r0 = (int)((float)n * a.frac); // rmap.cpp:276, fp32 product
-        r0 = r0 > 1 ? r0 : 1;
-        Rk[k] = asc ? d_slanted_radius(n, m, r0) : 0;
-        tc[k] = asc && Rk[k] <= a.lane_max_radius && max(n, m) <= a.lane_max_n; // (= tile_class(s, e))
+        tc[k] = shape_class(n, m, Rk[k]) && asc;
+        if (asc && !tc[k]) { // the side list's jobs: the radius by the reference's formula
+            int r0 = (int)((float)n * a.frac);
+            r0 = r0 > 1 ? r0 : 1;
+            Rk[k] = d_slanted_radius(n, m, r0);
+        }
         okk[k] = asc && !((uint64_t)qb[k] + s.query_position + n > a.n_ev || rb[k] + s.target_position + m > a.n_ref ||
                           n >= 0x7fffffffu || m >= 0x7fffffffu);
     }
@@ -262,9 +274,9 @@ __global__ __launch_bounds__(kPreT, PRE_WAVES) void k_pre(const StreamArgs a)
         const uint32_t m = e.target_position - s.target_position + 1;
         const uint32_t n = e.query_position - s.query_position + 1;
         const bool excl = P[k] != parts[k] - 1; // rmap.cpp:270
-        const int R = ok ? Rk[k] : 0;
+        const int R = Rk[k];
         const uint32_t N = n > m ? n : m, M = n > m ? m : n;
-        const bool tile = ok && R >= 1 && tc[k]; // (radius 0 cannot come from rmap.cpp:276)
+        const bool tile = ok && tc[k]; // (its radius is >= 1: rmap.cpp:276)
         uint32_t meta = 0;
         if (!ok) atomicMin(&a.cnt[kCntBad], (unsigned long long)j);
         if (tile) {
