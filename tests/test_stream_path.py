@@ -31,7 +31,7 @@ def _chains(rng, n_reads, ref_len, shapes, parts_range=(1, 40)):
         per = []
         for _ in range(n_chains):
             parts = int(rng.integers(*parts_range))
-            dq, dt = zip(*[shapes(rng) for _ in range(parts)])
+            dq, dt = zip(*[shapes(rng) for _ in range(parts)]) if parts else ((), ())
             q = np.concatenate([[int(rng.integers(0, 5))], np.cumsum(dq) + 0]).astype(np.int64)
             q[1:] += q[0]
             t0 = int(rng.integers(0, ref_len - int(np.sum(dt)) - 2))
@@ -128,10 +128,11 @@ def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
     assert info["n_jobs"] == len(jc) and info["n_lane_jobs"] + info["n_wave_band_jobs"] == len(jc)
 
 
-@pytest.mark.parametrize("n_reads,parts_range", [(900, (1, 4)), (12, (300, 500)), (200, (1, 120))])
+@pytest.mark.parametrize("n_reads,parts_range", [(900, (1, 4)), (12, (300, 500)), (200, (1, 120)), (700, (0, 3))])
 def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
     """k_pre finds a job's chain in LDS when its unit of 1024 jobs spans at most 62 chains and in memory otherwise:
-    batches of very short chains (hundreds a unit), very long ones (a chain over several units) and a mix."""
+    batches of very short chains (hundreds a unit), very long ones (a chain over several units), a mix, and chains of a
+    single anchor (no part, no job: rmap.cpp:251 does not enter its loop) between the others."""
     rng = np.random.default_rng(n_reads)
     ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
     eng = ra.Engine(0)
