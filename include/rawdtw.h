@@ -94,7 +94,8 @@ int rawdtw_stream(rawdtw_ctx *ctx, void **stream);
 int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const *fwd,
                             const float *const *rev, const uint32_t *len);
 int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uint64_t *off);
-/* Adopt a device-resident arena instead (caller keeps ownership; 16-byte aligned). */
+/* Adopt a device-resident arena instead (caller keeps ownership; 16-byte aligned, and readable up to the next multiple
+ * of four floats: the kernels copy whole 16-byte pieces of it). */
 int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats);
 /* Several contexts on one device (one per pipeline worker, rmap.cpp:1033) share ONE resident copy: `ctx` adopts the
  * arena and the sequence table of `owner`, which keeps ownership and must outlive it. */
@@ -118,6 +119,7 @@ int rawdtw_index_close(rawdtw_index *idx);
 /* ---- read events: the `a` operand (p->events[read].values, rmap.cpp:517) of all
  * reads of a batch, concatenated by the caller. ---- */
 int rawdtw_upload_events(rawdtw_ctx *ctx, const float *h_events, uint64_t n_floats);
+/* (a caller's device array: 16-byte aligned, readable up to the next multiple of four floats) */
 int rawdtw_set_events_device(rawdtw_ctx *ctx, const float *d_events, uint64_t n_floats);
 /* Incremental form.  A read's event array only grows (ri_map_frag appends each chunk's events, rmap.cpp:554-567), so a
  * mapper that keeps one slot per read in the arena uploads only the round's NEW events: reserve grows the arena to
