@@ -154,6 +154,34 @@ def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
     _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
 
 
+@pytest.mark.parametrize("ref_len,tail", [(60001, 0), (60003, 0), (60002, 1)])
+def test_windows_that_end_with_the_arenas(oracle, ref_len, tail):
+    """The last part of the last chain ends on the last reference element and the last event (arena lengths that are
+    not multiples of four: the staging copies whole 16-byte pieces), `tail` elements short of it in the second case."""
+    rng = np.random.default_rng(ref_len)
+    ref = [rng.normal(size=ref_len).astype(np.float32), rng.normal(size=ref_len).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 40, ref_len, _tiny)
+    # the event array ends with the last read's last used event already (_chains); move the last read's chains to the end
+    # of their strand arrays
+    for c in range(int(chain_off[-2]), int(chain_off[-1])):
+        a = anchors[int(anchor_off[c]):int(anchor_off[c + 1])]
+        a["target_position"] += np.uint32(ref_len - 1 - tail - int(a["target_position"].max()))
+    if tail:
+        events = np.concatenate([events, rng.normal(size=tail).astype(np.float32)])
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is True
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+
+
 def test_band_too_wide_for_the_stream_path_is_redone_through_the_job_list(oracle):
     """A part whose band needs more than 256 offsets: the sync-free path declines the batch at fetch and the job-list
     path (register-resident wave kernel with more chunks) produces the same answers the oracle gives."""
