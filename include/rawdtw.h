@@ -58,7 +58,10 @@ typedef struct rawdtw_plan rawdtw_plan;
 int rawdtw_abi_version(void);
 int rawdtw_device_count(int *count);
 int rawdtw_create(int device_ordinal, rawdtw_ctx **out);
-/* Destroy a context's plans and batches before the context: they hold pointers into its pools. */
+/* Teardown order is free.  rawdtw_destroy waits for the context's stream, then detaches every plan and batch still alive
+ * on it: their device memory and pooled workspaces are released there and then, and rawdtw_plan_destroy /
+ * rawdtw_batch_destroy called afterwards only delete the host records (every other entry point refuses a detached
+ * batch with RAWDTW_ERR_INVALID).  tests/abi/host_shim.cpp --teardown exercises exactly this. */
 int rawdtw_destroy(rawdtw_ctx *ctx);
 const char *rawdtw_last_error(const rawdtw_ctx *ctx);
 const char *rawdtw_status_string(int status);
@@ -98,7 +101,9 @@ int rawdtw_reference_offset(const rawdtw_ctx *ctx, uint32_t seq, int strand, uin
  * of four floats: the kernels copy whole 16-byte pieces of it). */
 int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_floats);
 /* Several contexts on one device (one per pipeline worker, rmap.cpp:1033) share ONE resident copy: `ctx` adopts the
- * arena and the sequence table of `owner`, which keeps ownership and must outlive it. */
+ * arena and the sequence table of `owner`.  An arena the library allocated (rawdtw_upload_reference, rawdtw_index_upload)
+ * is reference-counted: it lives until the last context using it uploads another reference or is destroyed, so the
+ * owner may go first.  An arena adopted with rawdtw_set_reference_device stays the caller's to keep alive. */
 int rawdtw_share_reference(rawdtw_ctx *ctx, const rawdtw_ctx *owner);
 
 /* ---- index file reader: the part of ri_idx_load (src/rawindex.cpp:317-377) the DTW path needs --
@@ -334,7 +339,9 @@ int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const u
  * once the context's workspace pool is warm.  Consequences for the caller: the five arrays must stay valid and
  * unchanged until rawdtw_batch_fetch has returned (or the batch is destroyed); an invalid batch (anchors not ascending,
  * a window outside the arenas) is reported by rawdtw_batch_fetch with the status and message rawdtw_plan_create would
- * give.  Other modes (global border constraint, full fill) and "device_plan"=0 plan on the host inside create. */
+ * give.  Other modes (global border constraint, full fill) and "device_plan"=0 plan on the host inside create.
+ * The arenas may be re-uploaded or grown between create and run (every run reads the context's current arrays); a run
+ * after an arena SHRANK below the size the batch was planned against returns RAWDTW_ERR_INVALID. */
 typedef struct rawdtw_batch rawdtw_batch;
 int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads,
                         const uint64_t *chain_off, const uint64_t *anchor_off,

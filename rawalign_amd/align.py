@@ -348,8 +348,7 @@ class Batch:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            if self.engine._ctx is not None:  # (a context that is gone took its pools with it: nothing left to hand back)
-                self.engine.lib.rawdtw_batch_destroy(self._h)
+            self.engine.lib.rawdtw_batch_destroy(self._h)  # (safe in any order: rawdtw_destroy detaches live batches)
             self._h = None
 
     def __del__(self):

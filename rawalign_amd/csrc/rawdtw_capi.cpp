@@ -4,6 +4,7 @@
 // There is NO CPU fallback in here: every scoring entry point runs the HIP kernels or
 // returns an error status.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -47,6 +48,12 @@ template <typename T> struct RawVec {
 struct StreamWs {
     char *d = nullptr; size_t d_bytes = 0;
     char *h = nullptr; size_t h_bytes = 0;
+};
+
+// a reference arena the library allocated, alive while any context uses it
+struct RefHold {
+    float *d = nullptr;
+    std::atomic<int> refs{1};
 };
 
 struct rawdtw_ctx {
@@ -101,10 +108,16 @@ struct rawdtw_ctx {
     int plan_threads = 0; // planner threads (0: from the job count and the machine, at most 16)
     int lane_max_radius = kMaxLaneRadius; // radii above this go to the register-resident wave kernel (RAWDTW_LANE_MAX_R)
     int stream_tile_radius = 3;           // device-planned batches: the tiles' radius limit ("stream_tile_radius")
-    // reference arena
+    // reference arena.  An arena the library allocated (rawdtw_upload_reference, rawdtw_index_upload) is held through a
+    // counted RefHold, shared by every context that adopted it with rawdtw_share_reference: it is freed when the last of
+    // them lets go, so the owner may upload another reference or be destroyed while sharers still run on the old one.
     float *d_ref = nullptr;
     uint64_t n_ref = 0;
-    bool own_ref = false;
+    struct RefHold *ref_hold = nullptr; // null: no arena, or the caller's own device memory (rawdtw_set_reference_device)
+    // plans and batches created on this context and not destroyed yet: rawdtw_destroy detaches them (frees their device
+    // memory, clears their back pointer), after which rawdtw_plan_destroy / rawdtw_batch_destroy only delete the host record
+    std::vector<rawdtw_plan *> live_plans;
+    std::vector<rawdtw_batch *> live_batches;
     std::vector<uint64_t> ref_off; // 2*n_seq entries: [seq*2 + 0] = forward (strand 1), [seq*2 + 1] = reverse
     std::vector<uint32_t> ref_len;
     // event arena
@@ -288,6 +301,21 @@ inline uint64_t dir_bytes_for(uint32_t n, uint32_t m, int rpl)
     const uint64_t strips = (NY + 64ull * rpl - 1) / (64ull * rpl);
     const uint64_t spb = rpl == 8 ? 8 : 16; // steps per 16-byte block (k_full_wave)
     return strips * (((uint64_t)NX + 63 + spb - 1) / spb) * 64 * 16;
+}
+
+// let go of the context's reference arena (the allocation dies with its last user)
+void drop_reference(rawdtw_ctx *ctx)
+{
+    if (RefHold *h = ctx->ref_hold) {
+        if (h->refs.fetch_sub(1) == 1) { if (h->d) (void)hipFree(h->d); delete h; }
+    }
+    ctx->ref_hold = nullptr; ctx->d_ref = nullptr; ctx->n_ref = 0;
+}
+
+template <typename T> void unregister(std::vector<T *> &v, T *x)
+{
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i] == x) { v[i] = v.back(); v.pop_back(); return; }
 }
 
 template <typename T> int dev_alloc(rawdtw_ctx *ctx, T **p, uint64_t count)
@@ -897,6 +925,7 @@ int build_plan(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs, bool 
         st = RAWDTW_ERR_OOM; err = "host allocation failed";
     }
     if (st != RAWDTW_OK) { delete pl; return fail(ctx, st, err); }
+    ctx->live_plans.push_back(pl);
 
     const uint64_t n_dev_jobs = n_jobs - pl->n_tile_jobs;
     if ((st = dev_alloc(ctx, &pl->d_jobs, n_dev_jobs)) != RAWDTW_OK ||
@@ -1145,18 +1174,35 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
     return RAWDTW_OK;
 }
 
+static void batch_detach(rawdtw_ctx *ctx, rawdtw_batch *b);
+static void plan_release_device(rawdtw_plan *plan);
+
 int rawdtw_destroy(rawdtw_ctx *ctx)
 {
     if (!ctx) return RAWDTW_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    // Plans and batches that outlive their context (a caller tearing down in the "wrong" order): their device memory and
+    // pooled workspaces go now, their back pointers are cleared, and the later *_destroy calls only delete host records.
+    while (!ctx->live_batches.empty()) {
+        rawdtw_batch *b = ctx->live_batches.back();
+        ctx->live_batches.pop_back();
+        batch_detach(ctx, b);
+        b->ctx = nullptr;
+    }
+    while (!ctx->live_plans.empty()) {
+        rawdtw_plan *pl = ctx->live_plans.back();
+        ctx->live_plans.pop_back();
+        plan_release_device(pl);
+        pl->ctx = nullptr;
+    }
     for (int k = 0; k < rawdtw_ctx::kSide; k++) {
         if (ctx->side[k]) { (void)hipStreamSynchronize(ctx->side[k]); (void)hipStreamDestroy(ctx->side[k]); }
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    drop_reference(ctx);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
     for (StreamWs &w : ctx->ws_free) { if (w.d) (void)hipFree(w.d); if (w.h) (void)hipHostFree(w.h); }
     if (ctx->d_masks) (void)hipFree(ctx->d_masks);
@@ -1228,8 +1274,7 @@ int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const 
 {
     if (!ctx || (n_seq && (!fwd || !rev || !len))) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
-    ctx->d_ref = nullptr; ctx->own_ref = true; ctx->n_ref = 0;
+    drop_reference(ctx);
     ctx->ref_off.assign(2ull * n_seq, 0);
     ctx->ref_len.assign(len, len + n_seq);
     uint64_t total = 0;
@@ -1240,6 +1285,9 @@ int rawdtw_upload_reference(rawdtw_ctx *ctx, uint32_t n_seq, const float *const 
     }
     int st = dev_alloc(ctx, &ctx->d_ref, std::max<uint64_t>(total, 4));
     if (st != RAWDTW_OK) return st;
+    ctx->ref_hold = new (std::nothrow) RefHold;
+    if (!ctx->ref_hold) { (void)hipFree(ctx->d_ref); ctx->d_ref = nullptr; return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    ctx->ref_hold->d = ctx->d_ref;
     ctx->n_ref = total;
     for (uint32_t s = 0; s < n_seq; s++) {
         if (len[s] == 0) continue;
@@ -1264,10 +1312,9 @@ int rawdtw_set_reference_device(rawdtw_ctx *ctx, const float *d_ref, uint64_t n_
 {
     if (!ctx || (!d_ref && n_floats)) return fail(ctx, RAWDTW_ERR_INVALID, "null reference arena");
     if (((uintptr_t)d_ref & 15u) != 0) return fail(ctx, RAWDTW_ERR_INVALID, "reference arena must be 16-byte aligned");
-    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
+    drop_reference(ctx);
     ctx->d_ref = const_cast<float *>(d_ref);
     ctx->n_ref = n_floats;
-    ctx->own_ref = false;
     ctx->ref_off.clear();
     ctx->ref_len.clear();
     return RAWDTW_OK;
@@ -1277,8 +1324,9 @@ int rawdtw_share_reference(rawdtw_ctx *ctx, const rawdtw_ctx *owner)
 {
     if (!ctx || !owner || ctx == owner) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to share_reference");
     if (ctx->device != owner->device) return fail(ctx, RAWDTW_ERR_INVALID, "contexts on different devices cannot share an arena");
-    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
-    ctx->d_ref = owner->d_ref; ctx->n_ref = owner->n_ref; ctx->own_ref = false;
+    drop_reference(ctx);
+    if (owner->ref_hold) { owner->ref_hold->refs.fetch_add(1); ctx->ref_hold = owner->ref_hold; } // (else: the caller's memory, its to keep alive)
+    ctx->d_ref = owner->d_ref; ctx->n_ref = owner->n_ref;
     ctx->ref_off = owner->ref_off; ctx->ref_len = owner->ref_len;
     return RAWDTW_OK;
 }
@@ -1428,19 +1476,24 @@ int rawdtw_plan_device_costs(const rawdtw_plan *plan, const float **d_cost, cons
     return RAWDTW_OK;
 }
 
+// a plan's device arrays (the host record stays: rawdtw_plan_info still answers)
+static void plan_release_device(rawdtw_plan *plan)
+{
+    auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
+    drop(plan->d_jobs); drop(plan->d_aux); drop(plan->d_tiles); drop(plan->d_spans); drop(plan->d_tjobs);
+    drop(plan->d_masks); drop(plan->d_cost); drop(plan->d_bnd);
+    if (plan->d_dir && !plan->dir_borrowed) (void)hipFree(plan->d_dir);
+    plan->d_dir = nullptr;
+}
+
 int rawdtw_plan_destroy(rawdtw_plan *plan)
 {
     if (!plan) return RAWDTW_OK;
-    if (plan->ctx) (void)hipSetDevice(plan->ctx->device);
-    if (plan->d_jobs) (void)hipFree(plan->d_jobs);
-    if (plan->d_aux) (void)hipFree(plan->d_aux);
-    if (plan->d_tiles) (void)hipFree(plan->d_tiles);
-    if (plan->d_spans) (void)hipFree(plan->d_spans);
-    if (plan->d_tjobs) (void)hipFree(plan->d_tjobs);
-    if (plan->d_masks) (void)hipFree(plan->d_masks);
-    if (plan->d_cost) (void)hipFree(plan->d_cost);
-    if (plan->d_bnd) (void)hipFree(plan->d_bnd);
-    if (plan->d_dir && !plan->dir_borrowed) (void)hipFree(plan->d_dir);
+    if (rawdtw_ctx *ctx = plan->ctx) { // (null: rawdtw_destroy came first and took the device arrays with it)
+        (void)hipSetDevice(ctx->device);
+        plan_release_device(plan);
+        unregister(ctx->live_plans, plan);
+    }
     delete plan;
     return RAWDTW_OK;
 }
@@ -1587,16 +1640,16 @@ static int single_call(rawdtw_ctx *ctx, const float *a, uint32_t n, const float 
     if (!ctx || !a || !b || !cost) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     if (n == 0 || m == 0 || radius < RAWDTW_FULL) return fail(ctx, RAWDTW_ERR_INVALID, "zero length or negative radius");
     // b goes to a private reference arena for the duration of the call
-    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; bool saved_own = ctx->own_ref;
+    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; // (the hold on the context's own arena stays)
     float *d_b = nullptr;
     int st = dev_alloc(ctx, &d_b, ((uint64_t)m + 3) & ~3ull);
     if (st != RAWDTW_OK) return st;
     hipError_t e = hipMemcpyAsync(d_b, b, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(ctx, e, "operand upload"); }
-    ctx->d_ref = d_b; ctx->n_ref = m; ctx->own_ref = false;
+    ctx->d_ref = d_b; ctx->n_ref = m;
     rawdtw_job_t j{0, 0, n, m, radius, excl ? 1u : 0u, 0};
     st = rawdtw_score_batch(ctx, &j, 1, a, n, cost);
-    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n; ctx->own_ref = saved_own;
+    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n;
     (void)hipFree(d_b);
     return st;
 }
@@ -1620,17 +1673,17 @@ int rawdtw_dtw_global_tb(rawdtw_ctx *ctx, const float *a, uint32_t n, const floa
     if (!ctx || !a || !b || !cost || !path_len || !path_i || !path_j || !path_d)
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     if (n == 0 || m == 0) return fail(ctx, RAWDTW_ERR_INVALID, "zero length (dtw.cpp:596 asserts)");
-    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; bool saved_own = ctx->own_ref;
+    const float *saved_ref = ctx->d_ref; uint64_t saved_n = ctx->n_ref; // (the hold on the context's own arena stays)
     float *d_b = nullptr;
     int st = dev_alloc(ctx, &d_b, ((uint64_t)m + 3) & ~3ull);
     if (st != RAWDTW_OK) return st;
     hipError_t e = hipMemcpyAsync(d_b, b, (size_t)m * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(d_b); return hip_fail(ctx, e, "operand upload"); }
-    ctx->d_ref = d_b; ctx->n_ref = m; ctx->own_ref = false;
+    ctx->d_ref = d_b; ctx->n_ref = m;
     rawdtw_job_t j{0, 0, n, m, RAWDTW_FULL, exclude_last ? 1u : 0u, 0};
     uint64_t off = 0;
     st = rawdtw_traceback_batch(ctx, &j, 1, a, n, cost, &off, path_len, path_i, path_j, path_d);
-    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n; ctx->own_ref = saved_own;
+    ctx->d_ref = const_cast<float *>(saved_ref); ctx->n_ref = saved_n;
     (void)hipFree(d_b);
     return st;
 }
@@ -2007,6 +2060,7 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
     if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
     b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
+    ctx->live_batches.push_back(b);
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
     b->in_resident = ctx->resident_arrays;
     if (stream_eligible(ctx, opt, n_jobs))
@@ -2263,6 +2317,12 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
     int st = RAWDTW_OK;
     batch->dirty = true;
     if (batch->stream) {
+        // The arenas may have been re-uploaded, grown or swapped since the batch was planned (rawdtw_upload_events,
+        // rawdtw_events_reserve, rawdtw_upload_reference ... free and reallocate them): the launch reads the context's
+        // CURRENT arrays, and the windows -- checked against the sizes at planning time -- must still lie inside them.
+        if (ctx->n_ev < batch->sa.n_ev || ctx->n_ref < batch->sa.n_ref)
+            return fail(ctx, RAWDTW_ERR_INVALID, "an arena shrank after the batch was created: create the batch again");
+        batch->sa.ev = ctx->d_ev; batch->sa.ref = ctx->d_ref;
         if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) {
             hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, batch->stream_runs++ > 0, ctx->stream);
@@ -2473,16 +2533,26 @@ int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t 
     return RAWDTW_OK;
 }
 
+// everything of a batch that lives on the device or in its context's pools; `ctx` = the batch's context
+static void batch_detach(rawdtw_ctx *ctx, rawdtw_batch *b)
+{
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev_plan) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    b->ev.clear(); b->ev_runs = 0;
+    batch_release_device(b); // (also destroys the job-list plan, which unregisters itself)
+    ws_release(ctx, b->ws);
+    b->stream = false;       // neither form left: every entry point but destroy refuses the batch (batch_dead)
+}
+
 int rawdtw_batch_destroy(rawdtw_batch *b)
 {
     if (!b) return RAWDTW_OK;
-    rawdtw_ctx *ctx = b->ctx;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    if (ctx && b->dirty) (void)hipStreamSynchronize(ctx->stream); // its workspace goes back to the pool
-    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : b->ev_plan) if (e) (void)hipEventDestroy(e);
-    batch_release_device(b);
-    if (ctx) ws_release(ctx, b->ws);
+    if (rawdtw_ctx *ctx = b->ctx) { // (null: rawdtw_destroy came first and took the device side with it)
+        (void)hipSetDevice(ctx->device);
+        if (b->dirty) (void)hipStreamSynchronize(ctx->stream); // its workspace goes back to the pool
+        batch_detach(ctx, b);
+        unregister(ctx->live_batches, b);
+    }
     delete b;
     return RAWDTW_OK;
 }
@@ -2621,8 +2691,7 @@ int rawdtw_index_upload(rawdtw_ctx *ctx, const rawdtw_index *idx)
     if (!ctx || !idx) return RAWDTW_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n_seq = (uint32_t)idx->lens.size();
-    if (ctx->own_ref && ctx->d_ref) (void)hipFree(ctx->d_ref);
-    ctx->d_ref = nullptr; ctx->own_ref = true; ctx->n_ref = 0;
+    drop_reference(ctx);
     ctx->ref_off.assign(2ull * n_seq, 0);
     ctx->ref_len = idx->lens;
     uint64_t total = 0;
@@ -2632,6 +2701,9 @@ int rawdtw_index_upload(rawdtw_ctx *ctx, const rawdtw_index *idx)
     }
     int st = dev_alloc(ctx, &ctx->d_ref, std::max<uint64_t>(total, 4));
     if (st != RAWDTW_OK) return st;
+    ctx->ref_hold = new (std::nothrow) RefHold;
+    if (!ctx->ref_hold) { (void)hipFree(ctx->d_ref); ctx->d_ref = nullptr; return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+    ctx->ref_hold->d = ctx->d_ref;
     ctx->n_ref = total;
     FILE *f = fopen(idx->path.c_str(), "rb");
     if (!f) return fail(ctx, RAWDTW_ERR_INVALID, "cannot reopen index file");

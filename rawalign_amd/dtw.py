@@ -104,8 +104,7 @@ class Plan:
 
     def close(self):
         if self._h is not None:
-            if self.engine._ctx is not None:  # (see Batch.close)
-                self.engine.lib.rawdtw_plan_destroy(self._h)
+            self.engine.lib.rawdtw_plan_destroy(self._h)  # (safe in any order: rawdtw_destroy detaches live plans)
             self._h = None
 
     def __del__(self):
@@ -130,8 +129,8 @@ class Engine:
         self._ctx = ctx
         self.device = device
         self._keep = []  # arrays / tensors the context points at
-        # plans and batches of this context: they must be destroyed before it (include/rawdtw.h), also when the garbage
-        # collector finalises an unreachable engine and its batches in an order of its own choosing
+        # plans and batches of this context: closed with it, so that their device memory goes back at a known point (the
+        # C ABI itself tolerates any order: rawdtw_destroy detaches what is still alive)
         self._children = weakref.WeakSet()
 
     # -- plumbing ---------------------------------------------------------------

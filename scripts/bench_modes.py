@@ -37,7 +37,7 @@ def main():
     cb, sinfo = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=args.reads, max_chunks=args.max_chunks),
                                            seed=77)
     eng.upload_events(cb.events)
-    out = {"mode": args.mode, "reads": args.reads, **sinfo}
+    out = {"mode": args.mode, "reads": args.reads, **{k: v for k, v in sinfo.items() if k != "ev_off"}}
     if args.mode in ("global_full", "global_banded"):
         opt = ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0 if args.mode == "global_full" else 1)
         batch = ra.Batch(eng, opt, cb)

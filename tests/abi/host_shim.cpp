@@ -91,8 +91,9 @@ unsigned bits(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin [--pipeline steps]\n"); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin [--pipeline steps | --teardown]\n"); return 1; }
     const int pipeline_steps = (argc >= 4 && !strcmp(argv[2], "--pipeline")) ? atoi(argv[3]) : 0;
+    const bool teardown = argc >= 3 && !strcmp(argv[2], "--teardown");
     Blob b;
     if (!load(argv[1], b)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
     const bool evaluate = b.flag & 0x2, cigar = b.flag & 0x4, log_scores = b.flag & 0x8; // roptions.h:13-15
@@ -181,6 +182,65 @@ int main(int argc, char **argv)
         printf("pipeline steps=%d mismatches=%d ms_per_step=%.4f\n", pipeline_steps, bad, ms / pipeline_steps);
         for (int w = 0; w < W; w++) rawdtw_destroy(wctx[w]);
         for (int k = 0; k < 5; k++) rawdtw_host_free(pin[k]);
+    }
+
+    // ---- teardown in the "wrong" order (include/rawdtw.h, lifetime): a context destroyed before its batch and its plan,
+    // the owner of a shared reference before the sharer, an event arena re-uploaded between create and run.  A C++ host
+    // tears down by scope exit, not by the library's preferred order: none of it may touch freed memory. ----
+    if (teardown && (evaluate || log_scores)) {
+        rawdtw_ctx *own = nullptr, *shr = nullptr;
+        if (rawdtw_create(0, &own) != RAWDTW_OK || rawdtw_create(0, &shr) != RAWDTW_OK) { fprintf(stderr, "no device\n"); return 3; }
+        int bad = 0;
+        std::vector<float> s2(n_chains);
+        std::vector<uint8_t> k2(n_chains);
+        auto same = [&]() { return !memcmp(s2.data(), score.data(), n_chains * 4) && !memcmp(k2.data(), keep.data(), n_chains); };
+#define TD(call) do { int st_ = (call); if (st_ != RAWDTW_OK) { fprintf(stderr, "%s -> %d\n", #call, st_); return 2; } } while (0)
+        TD(rawdtw_upload_reference(own, n_seq, fwd.data(), rev.data(), len.data()));
+        TD(rawdtw_share_reference(shr, own));
+        TD(rawdtw_upload_events(own, b.events.data(), b.events.size()));
+        TD(rawdtw_upload_events(shr, b.events.data(), b.events.size()));
+        rawdtw_batch *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
+        TD(rawdtw_batch_create(own, &b.opt, b.n_reads, b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), &b1));
+        TD(rawdtw_batch_run(own, b1));
+        TD(rawdtw_batch_fetch(own, b1, s2.data(), k2.data(), nullptr));
+        bad += !same();
+        TD(rawdtw_batch_create(shr, &b.opt, b.n_reads, b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), &b2));
+        std::vector<uint64_t> job_off(n_chains + 1);
+        uint64_t nj = 0;
+        TD(rawdtw_batch_build_jobs(&b.opt, n_chains, anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), job_off.data(), nullptr, 0, &nj));
+        std::vector<rawdtw_job_t> jobs(nj);
+        TD(rawdtw_batch_build_jobs(&b.opt, n_chains, anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), job_off.data(), jobs.data(), nj, &nj));
+        rawdtw_plan *pl = nullptr;
+        TD(rawdtw_plan_create(own, jobs.data(), nj, &pl));
+        TD(rawdtw_destroy(own)); // the owner goes first: b1 and pl are detached, the arena lives on for `shr`
+        rawdtw_plan_info_t info;
+        if (rawdtw_batch_info(b1, &info, nullptr) == RAWDTW_OK) bad++; // a detached batch is refused, not dereferenced
+        TD(rawdtw_plan_info(pl, &info));                                // (a plan's host record still answers)
+        bad += info.n_jobs != nj;
+        TD(rawdtw_batch_run(shr, b2));
+        TD(rawdtw_batch_fetch(shr, b2, s2.data(), k2.data(), nullptr));
+        bad += !same();
+        // a batch created before its context's event arena is re-uploaded into a new, larger allocation
+        TD(rawdtw_batch_create(shr, &b.opt, b.n_reads, b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), &b3));
+        std::vector<float> grown(b.events);
+        grown.resize(2 * b.events.size() + 4096, 0.0f);
+        TD(rawdtw_upload_events(shr, grown.data(), grown.size()));
+        TD(rawdtw_batch_run(shr, b3));
+        TD(rawdtw_batch_fetch(shr, b3, s2.data(), k2.data(), nullptr));
+        bad += !same();
+        // ... and one whose arena shrank under it is refused
+        rawdtw_batch *b4 = nullptr;
+        TD(rawdtw_batch_create(shr, &b.opt, b.n_reads, b.chain_off.data(), anchor_off.data(), anchors.data(), ref_base.data(), read_base.data(), &b4));
+        TD(rawdtw_upload_events(shr, b.events.data(), b.events.size() / 2));
+        if (rawdtw_batch_run(shr, b4) != RAWDTW_ERR_INVALID) bad++;
+        TD(rawdtw_destroy(shr)); // again the context first ...
+        TD(rawdtw_batch_destroy(b4));
+        TD(rawdtw_batch_destroy(b3));
+        TD(rawdtw_batch_destroy(b2));
+        TD(rawdtw_batch_destroy(b1));
+        TD(rawdtw_plan_destroy(pl));
+#undef TD
+        printf("teardown mismatches=%d\n", bad);
     }
 
     // ---- per read: post_alignment_chains, primary chains, MAPQ, stop rule, tags ----

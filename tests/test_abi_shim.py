@@ -204,3 +204,24 @@ def test_cpp_shim_pipeline_of_four_contexts(oracle, tmp_path):
     assert len(pipe) == 1 and "steps=24 mismatches=0 " in pipe[0], pipe
     rest = [ln for ln in got if not ln.startswith("pipeline ")]
     assert rest == _expected_lines(oracle, ref, cb, cseq, cstr, cscore, opt, 0x2)
+
+
+@pytest.mark.gpu
+def test_cpp_shim_teardown_in_any_order(oracle, tmp_path):
+    """include/rawdtw.h, lifetime: a context destroyed BEFORE its batches and plans detaches them (their later destroy calls
+    only delete host records); a shared reference arena outlives its first owner; a batch created before its context's
+    event arena moved to a new allocation runs on the new one, and one whose arena shrank is refused.  The C++ host
+    tears down by scope exit, so the C ABI itself has to be safe here (round 2 recorded a host segfault in this shape)."""
+    exe = _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
+    ref, cb, cseq, cstr, cscore = _make_case(63, 40)
+    opt = ra.MapOpt()
+    blob = os.path.join(str(tmp_path), "batch.bin")
+    _write_blob(blob, ref, cb, cseq, cstr, cscore, opt, 0x2)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([exe, blob, "--teardown"], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr
+    got = run.stdout.rstrip("\n").split("\n")
+    td = [ln for ln in got if ln.startswith("teardown ")]
+    assert td == ["teardown mismatches=0"], (td, run.stderr)
+    rest = [ln for ln in got if not ln.startswith("teardown ")]
+    assert rest == _expected_lines(oracle, ref, cb, cseq, cstr, cscore, opt, 0x2)

@@ -13,7 +13,7 @@ except Exception:  # pragma: no cover - torch is optional for these tests
 import rawalign_amd as ra
 from rawalign_amd.dtw import JOB_DTYPE
 from tests.golden_util import bits
-from tests.util import assert_bits_equal, default_radius, make_arena_jobs, oracle_costs
+from tests.util import assert_bits_equal, default_radius, make_arena_jobs, oracle_costs, planner_options
 
 pytestmark = pytest.mark.gpu
 
@@ -364,14 +364,12 @@ def test_human_scale_reference_offsets(engine, oracle):
     engine.upload_events(events)
     res = {}
     for dev in (0, 1):
-        engine.set_option("device_plan", dev)
-        engine.set_option("device_plan_min_jobs", 0)
-        b = ra.Batch(engine, ra.MapOpt(), cb)
-        assert b.verify_plan() == bool(dev)
-        b.run()
-        res[dev] = b.fetch(with_job_costs=True)
-        b.close()
-    engine.set_option("device_plan_min_jobs", 65536)
+        with planner_options(engine, device_plan=dev, device_plan_min_jobs=0):
+            b = ra.Batch(engine, ra.MapOpt(), cb)
+            assert b.verify_plan() == bool(dev)
+            b.run()
+            res[dev] = b.fetch(with_job_costs=True)
+            b.close()
     for x, y in zip(res[0], res[1]):
         assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
     assert len(res[0][2]) > 1000
@@ -470,51 +468,48 @@ def test_batch_edge_cases(engine, oracle, device_plan):
     align_chain returns 0*bonus - 0, which fails dtw_min_score) -- through the job list and through the sync-free path."""
     from rawalign_amd.align import CandidateBatch
 
-    engine.set_option("device_plan", device_plan)
-    engine.set_option("device_plan_min_jobs", 0)
-    rng = np.random.default_rng(2)
-    refsig = rng.normal(size=3000).astype(np.float32)
-    engine.upload_reference([refsig], [refsig[::-1].copy()])
-    events = rng.normal(size=500).astype(np.float32)
-    engine.upload_events(events)
-    base = engine.reference_offset(0, 1)
-    # no chains at all
-    cb0 = CandidateBatch(events, np.zeros(4, np.uint64), np.zeros(1, np.uint64), np.zeros(0, ra.ANCHOR_DTYPE),
-                         np.zeros(0, np.uint64), np.zeros(0, np.uint32))
-    b0 = ra.Batch(engine, ra.MapOpt(), cb0)
-    b0.run()
-    s0, k0 = b0.fetch()
-    assert len(s0) == 0 and len(k0) == 0
-    # read 0: nothing; read 1: a single-anchor chain and a real chain; read 2: nothing
-    a1 = np.zeros(1, ra.ANCHOR_DTYPE); a1[0] = (100, 7)
-    q = np.array([5, 12, 30, 31, 60]); t = np.array([200, 206, 221, 223, 250])
-    a2 = np.zeros(5, ra.ANCHOR_DTYPE); a2["query_position"] = q[::-1]; a2["target_position"] = t[::-1]
-    ev2 = events.copy()
-    ev2[5:61] = refsig[200:256]
-    engine.upload_events(ev2)
-    cb = CandidateBatch(ev2, np.array([0, 0, 2, 2], np.uint64), np.array([0, 1, 6], np.uint64),
-                        np.concatenate([a1, a2]), np.array([base, base], np.uint64), np.zeros(2, np.uint32))
-    b = ra.Batch(engine, ra.MapOpt(dtw_min_score=5.0), cb)
-    b.run()
-    score, keep = b.fetch()
-    assert score[0] == 0.0 and keep[0] == 0
-    from oracle.loader import OrcOpt
+    with planner_options(engine, device_plan=device_plan, device_plan_min_jobs=0):
+        rng = np.random.default_rng(2)
+        refsig = rng.normal(size=3000).astype(np.float32)
+        engine.upload_reference([refsig], [refsig[::-1].copy()])
+        events = rng.normal(size=500).astype(np.float32)
+        engine.upload_events(events)
+        base = engine.reference_offset(0, 1)
+        # no chains at all
+        cb0 = CandidateBatch(events, np.zeros(4, np.uint64), np.zeros(1, np.uint64), np.zeros(0, ra.ANCHOR_DTYPE),
+                             np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+        b0 = ra.Batch(engine, ra.MapOpt(), cb0)
+        b0.run()
+        s0, k0 = b0.fetch()
+        assert len(s0) == 0 and len(k0) == 0
+        # read 0: nothing; read 1: a single-anchor chain and a real chain; read 2: nothing
+        a1 = np.zeros(1, ra.ANCHOR_DTYPE); a1[0] = (100, 7)
+        q = np.array([5, 12, 30, 31, 60]); t = np.array([200, 206, 221, 223, 250])
+        a2 = np.zeros(5, ra.ANCHOR_DTYPE); a2["query_position"] = q[::-1]; a2["target_position"] = t[::-1]
+        ev2 = events.copy()
+        ev2[5:61] = refsig[200:256]
+        engine.upload_events(ev2)
+        cb = CandidateBatch(ev2, np.array([0, 0, 2, 2], np.uint64), np.array([0, 1, 6], np.uint64),
+                            np.concatenate([a1, a2]), np.array([base, base], np.uint64), np.zeros(2, np.uint32))
+        b = ra.Batch(engine, ra.MapOpt(dtw_min_score=5.0), cb)
+        b.run()
+        score, keep = b.fetch()
+        assert score[0] == 0.0 and keep[0] == 0
+        from oracle.loader import OrcOpt
 
-    want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
-    assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
-    assert b.verify_plan() == bool(device_plan)
-    # anchors that do not ascend (a chain the mapper could never produce): both paths refuse the batch, with the
-    # host planner's wording (the sync-free path hands such batches over to it)
-    bad = a2.copy(); bad["query_position"][1] = 200
-    cbb = CandidateBatch(ev2, np.array([0, 1], np.uint64), np.array([0, 5], np.uint64), bad, np.array([base], np.uint64),
-                         np.zeros(1, np.uint32))
-    with pytest.raises(ra.RawDTWError) as e:   # (the sync-free path reports it when the results are fetched)
-        bb = ra.Batch(engine, ra.MapOpt(), cbb)
-        bb.run()
-        bb.fetch()
-    assert "job " in str(e.value)
-    engine.set_option("device_plan", 1)
-    engine.set_option("device_plan_min_jobs", 0)
+        want = oracle.align_chain(a2, refsig, ev2, OrcOpt(1, 1, 0.10, 0.4, 5.0, 1), 0.0)
+        assert bits(score[1]) == bits(want) and bool(keep[1]) == bool(want >= np.float32(5.0))
+        assert b.verify_plan() == bool(device_plan)
+        # anchors that do not ascend (a chain the mapper could never produce): both paths refuse the batch, with the
+        # host planner's wording (the sync-free path hands such batches over to it)
+        bad = a2.copy(); bad["query_position"][1] = 200
+        cbb = CandidateBatch(ev2, np.array([0, 1], np.uint64), np.array([0, 5], np.uint64), bad, np.array([base], np.uint64),
+                             np.zeros(1, np.uint32))
+        with pytest.raises(ra.RawDTWError) as e:   # (the sync-free path reports it when the results are fetched)
+            bb = ra.Batch(engine, ra.MapOpt(), cbb)
+            bb.run()
+            bb.fetch()
+        assert "job " in str(e.value)
 
 
 @pytest.mark.gpu

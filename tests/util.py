@@ -82,3 +82,21 @@ class OracleScorer:
         chain.alignment_score = float(sc)
         chain.dtw_result = DtwResult(np.float32(cost), pi, pj, pd)
         return chain
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def planner_options(engine, **opts):
+    """Set planner options on a (possibly shared) engine for the duration of a block and put the library's defaults
+    back afterwards, whatever happens inside: later tests on a module-scoped engine then take the default
+    (device-planned) path instead of whatever the previous test left behind."""
+    defaults = {"device_plan": 1, "device_plan_min_jobs": 0}
+    try:
+        for k, v in opts.items():
+            engine.set_option(k, v)
+        yield engine
+    finally:
+        for k in opts:
+            engine.set_option(k, defaults[k])
