@@ -81,14 +81,12 @@ struct rawdtw_ctx {
     bool device_plan = true;  // rawdtw_batch_create takes the sync-free stream path (rawdtw_stream.hip) for sparse + banded batches
     uint64_t device_plan_min_jobs = 0; // smaller batches go through the job list
     std::vector<StreamWs> ws_free;     // workspaces of destroyed batches, reused by the next ones (no hipMalloc in the steady state)
-    unsigned long long *d_masks = nullptr; // band bitmasks of the micro shapes (stream path)
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_stream (256 or 512: 1024 / 2048 jobs per tile)
     int stream_threads_cached = 0;
     int stream_blocks_per_cu = 4;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
     int stream_bpc_cached = -1;
     uint32_t stream_debug = 0;         // StreamArgs::debug
-    std::vector<uint32_t> unit_chain_scratch;
     bool resident_arrays = false;      // rawdtw_batch_create: anchors / ref_base / read_base are DEVICE pointers (used in place)
     bool time_plan = false;            // record an event pair around a batch's planning kernels (rawdtw_batch_plan_ms)
     std::vector<uint64_t> job_off_scratch;
@@ -167,7 +165,8 @@ struct rawdtw_batch {
     rawdtw_ctx *ctx = nullptr;
     rawdtw_plan *plan = nullptr;   // job-list path
     rawdtw_align_opt_t opt{};
-    uint64_t n_reads = 0, n_chains = 0, n_jobs = 0;
+    uint64_t n_reads = 0, n_chains = 0, n_jobs = 0; // (n_jobs of a sync-free batch: counted on first use, see batch_count_jobs)
+    bool jobs_counted = false;
     ChainDesc *d_chains = nullptr;
     uint64_t *d_chain_off = nullptr;
     uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
@@ -1205,7 +1204,6 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     drop_reference(ctx);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
     for (StreamWs &w : ctx->ws_free) { if (w.d) (void)hipFree(w.d); if (w.h) (void)hipHostFree(w.h); }
-    if (ctx->d_masks) (void)hipFree(ctx->d_masks);
     if (ctx->d_append) (void)hipFree(ctx->d_append);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->d_tb_dir) (void)hipFree(ctx->d_tb_dir);
@@ -1711,15 +1709,15 @@ struct StreamLayout { // sizes in bytes of one batch's device workspace and pinn
 // kernels of the batches behind need LDS beside the four resident workgroups.
 static uint32_t stream_tile_floats(const rawdtw_ctx *ctx) { return (ctx->tile_lds_set ? ctx->tile_lds_floats : kStreamTileFloats) & ~3u; } // (16-byte multiples: the records and the sort table sit behind the image)
 
-bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_jobs)
+bool stream_eligible(const rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_anchors)
 {
-    if (!ctx->device_plan || n_jobs < ctx->device_plan_min_jobs || n_jobs == 0 || n_jobs >= (1ull << 31)) return false;
-    if (n_jobs * (uint64_t)(ctx->lane_max_n + 8u) >= (1ull << 32)) return false; // (the regions' running sums are 32-bit halves of one 64-bit sum)
+    // (the job-list path takes batches below "device_plan_min_jobs" anchors: a chain of n anchors has n - 1 jobs)
+    if (!ctx->device_plan || n_anchors < ctx->device_plan_min_jobs || n_anchors == 0 || n_anchors >= (1ull << 31)) return false;
     if (opt->border_constraint != 1 || opt->fill_method == 0) return false; // sparse + banded only
     if (ctx->lane_max_radius < 0 || ctx->sort_n || ctx->sort_r1_n || ctx->sort_r3 || ctx->lane_hi || !ctx->merge_small) return false;
     if (ctx->tile_threads != 256 || ctx->debug_skip_kinds) return false;
-    const uint32_t worst_job = 2u * ctx->lane_max_n + 12u;
-    return stream_tile_floats(ctx) >= 4u * worst_job + kStreamSlack && stream_tile_floats(ctx) <= 16384u;
+    const uint32_t worst_part = 2u * ctx->lane_max_n + 16u; // image floats of the largest tile-class part alone
+    return stream_tile_floats(ctx) >= 2u * worst_part && stream_tile_floats(ctx) <= 16384u;
 }
 
 int ws_acquire(rawdtw_ctx *ctx, size_t dev_bytes, size_t host_bytes, StreamWs *out)
@@ -1758,94 +1756,54 @@ void ws_release(rawdtw_ctx *ctx, StreamWs &w)
     w = StreamWs{};
 }
 
-int ensure_masks(rawdtw_ctx *ctx)
-{
-    if (ctx->d_masks) return RAWDTW_OK;
-    const std::vector<unsigned long long> &m = micro_masks();
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_masks), m.size() * 8));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_masks, m.data(), m.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    return RAWDTW_OK;
-}
-
-// the stream path: everything rawdtw_batch_create does for a sparse + banded batch
+// the stream path: everything rawdtw_batch_create does for a sparse + banded batch -- O(1) host work: a workspace from the
+// pool, five copies and three launches enqueued
 int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
-                        const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base,
-                        const uint64_t *job_off_host, uint64_t n_jobs)
+                        const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base)
 {
     const uint64_t nc = b->n_chains, nr = b->n_reads, na = anchor_off[nc];
     const uint32_t lds_floats = stream_tile_floats(ctx);
     StreamArgs &a = b->sa;
     a = StreamArgs{};
-    a.n_jobs = n_jobs; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
+    a.n_anchors = na; a.n_chains = nc; a.n_reads = nr; a.n_ev = ctx->n_ev; a.n_ref = ctx->n_ref;
     a.frac = b->opt.band_radius_frac;
     // tiles take radius <= stream_tile_radius; the radii between that and lane_max_radius (none by default) go to the side
     // list's lane classes
     a.lane_max_radius = std::min(ctx->lane_max_radius, ctx->stream_tile_radius); a.side_lane_radius = ctx->lane_max_radius;
     a.lane_max_n = ctx->lane_max_n;
-    // tile rule (rawdtw_internal.h: Cum): a tile's jobs start inside one bracket of `width8`; its last job may end past the
-    // bracket by at most the largest cost a job can have, so the image needs at most tile_budget floats
-    const uint32_t tile_budget = lds_floats - kStreamSlack;
-    const uint32_t max_tile_jobs = kStreamItems * (uint32_t)ctx->stream_threads;
-    a.min_cost8 = (8u * tile_budget + max_tile_jobs - 1) / max_tile_jobs;
-    const uint64_t worst8 = std::max<uint64_t>(8ull * (2ull * a.lane_max_n + 12ull), a.min_cost8);
-    a.width8 = 8ull * tile_budget - worst8;
-    // every bracket holds at most width8 / min_cost8 + 1 jobs: with the floor above that is below kStreamMaxTileJobs
-    a.tiles_cap = (uint32_t)std::min<uint64_t>(n_jobs * worst8 / a.width8 + 2, 0x7fffffffull);
-    a.others_cap = std::min<uint64_t>(n_jobs, n_jobs / 4 + 4096);
+    a.tile_anchors = (uint32_t)ctx->stream_threads * kStreamItems;
+    a.n_tiles = (uint32_t)((na + a.tile_anchors - 1) / a.tile_anchors);
+    a.others_cap = std::min<uint64_t>(na, na / 4 + 4096);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const uint64_t n_units = (n_jobs + 1023) / 1024;
-    const size_t dev_bytes = al((nc + 1) * 8) * 2 + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) +   // inputs
-                             al(n_jobs * 16) + al(n_jobs * 8) + al(n_jobs * 4) + 2 * al((n_units + 1) * 8) + al(((size_t)a.tiles_cap + 1) * sizeof(TileInfo)) + // per job: record, sums
-                             2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) + al(kStreamCounters * 8) +
-                             al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(n_jobs * 4) + al((n_units + 1) * 4) + al(n_units * 24);
-    const size_t host_bytes = al((nc + 1) * 8) + al(kStreamCounters * 8) + al((n_units + 1) * 4);
+    const size_t dev_bytes = al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
+                             al((size_t)a.n_tiles * 4) + al((size_t)a.n_tiles * 24) +                                           // per tile
+                             2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
+                             al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
+    const size_t host_bytes = al(kStreamCounters * 8);
     int st = ws_acquire(ctx, dev_bytes, host_bytes, &b->ws);
     if (st != RAWDTW_OK) return st;
-    if ((st = ensure_masks(ctx)) != RAWDTW_OK) return st;
     char *p = b->ws.d;
-    // what the library itself uploads per batch sits in one piece, on the device and in the pinned block alike (one copy):
-    // the counters' initial values, the chains' job offsets, the units' first chains
-    char *d_pack = p;
     a.cnt = carve<unsigned long long>(p, kStreamCounters);
-    uint64_t *d_job_off = carve<uint64_t>(p, nc + 1);
-    uint32_t *d_unit_chain = carve<uint32_t>(p, n_units + 1);
-    const size_t pack_bytes = (size_t)(p - d_pack);
     uint64_t *d_anchor_off = carve<uint64_t>(p, nc + 1);
     rawdtw_anchor_t *d_anchors = carve<rawdtw_anchor_t>(p, na);
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
-    a.jrec = carve<JobRec>(p, n_jobs); a.cpos = carve<uint64_t>(p, n_jobs); a.ccost = carve<uint32_t>(p, n_jobs);
-    a.unit_pos = carve<uint64_t>(p, n_units + 1); a.unit_cost = carve<uint64_t>(p, n_units + 1);
-    a.tiles = carve<TileInfo>(p, (uint64_t)a.tiles_cap + 1);
+    a.tile_chain = carve<uint32_t>(p, a.n_tiles);
+    a.tile_stats = carve<unsigned long long>(p, 3ull * a.n_tiles);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     b->d_chains = carve<ChainDesc>(p, nc);
     b->d_fold_order = carve<uint32_t>(p, nc);
     b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
     b->d_keep = carve<uint8_t>(p, nc);
-    a.out = carve<float>(p, n_jobs);
-    a.unit_chain = d_unit_chain;
-    a.unit_stats = carve<unsigned long long>(p, 3 * n_units);
+    a.out = carve<float>(p, na);
     a.debug = ctx->stream_debug;
-    a.job_off = d_job_off; a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
+    a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
     if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
     a.ev = ctx->d_ev; a.ref = ctx->d_ref;
     char *hp = b->ws.h;
-    char *h_pack = hp;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
-    uint64_t *h_job_off = carve<uint64_t>(hp, nc + 1);
-    uint32_t *h_unit_chain = carve<uint32_t>(hp, n_units + 1);
-    memcpy(h_job_off, job_off_host, (nc + 1) * 8);
-    {   // unit u (jobs [1024 u, 1024 u + 1024)) starts inside chain unit_chain[u]: one merge walk over the chains
-        uint64_t c = 0;
-        for (uint64_t u = 0; u < n_units; u++) {
-            const uint64_t j0 = u * 1024;
-            while (job_off_host[c + 1] <= j0) c++;
-            h_unit_chain[u] = (uint32_t)c;
-        }
-        h_unit_chain[n_units] = (uint32_t)(nc ? nc - 1 : 0);
-    }
-    unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the same pinned block
+    unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the pinned block
     for (int i = 0; i < kStreamCounters; i++) h_init[i] = 0;
     h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
     hipStream_t s = ctx->stream;
@@ -1853,7 +1811,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         if (!b->ev_plan[0]) { HIP_TRY(ctx, hipEventCreate(&b->ev_plan[0])); HIP_TRY(ctx, hipEventCreate(&b->ev_plan[1])); }
         HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(d_pack, h_pack, pack_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     if (!b->in_resident) {
         HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
@@ -1879,11 +1837,25 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->stream = true;
     b->stream_lds = lds_floats;
     b->stream_threads = ctx->stream_threads;
-    b->n_jobs = n_jobs;
+    b->n_jobs = 0; b->jobs_counted = false;
     b->cnt_valid = false;
     b->dirty = true;
     b->ws_bytes = dev_bytes;
     return RAWDTW_OK;
+}
+
+// DTW jobs of a sync-free batch (align_chain issues n_anchors - 1 per chain, rmap.cpp:248): counted from the caller's
+// chain offsets the first time somebody asks -- rawdtw_batch_create itself does not walk the chains
+void batch_count_jobs(rawdtw_batch *b)
+{
+    if (b->jobs_counted || !b->stream) return;
+    uint64_t n = 0;
+    for (uint64_t c = 0; c < b->n_chains; c++) {
+        const uint64_t k = b->in_anchor_off[c + 1] - b->in_anchor_off[c];
+        n += k ? k - 1 : 0;
+    }
+    b->n_jobs = n;
+    b->jobs_counted = true;
 }
 
 // "resident_arrays": bring the three device-resident arrays to the host (the job-list path reads them there)
@@ -1916,7 +1888,7 @@ int batch_create_joblist(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain
         ChainDesc &d = desc[c];
         d.job_first = job_off[c];
         d.n_jobs = (uint32_t)(job_off[c + 1] - job_off[c]);
-        d.reserved = 0;
+        d.descending = 0;
         if (a1 == a0) { d.span = 0; d.num_aligned = 0; continue; }
         const rawdtw_anchor_t &first = anchors[a1 - 1], &last = anchors[a0];
         d.span = last.query_position - first.query_position + 1; // rmap.cpp:202,245
@@ -2025,7 +1997,7 @@ int stream_fallback(rawdtw_ctx *ctx, rawdtw_batch *b)
     st = rawdtw_batch_build_jobs(&b->opt, nc, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base,
                                      job_off.data(), nullptr, 0, &n_jobs);
     if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
-    b->stream = false;
+    b->stream = false; b->jobs_counted = true; // (batch_create_joblist sets n_jobs)
     ws_release(ctx, b->ws);
     b->d_chains = nullptr; b->d_chain_off = nullptr; b->d_fold_order = nullptr;
     b->d_full = b->d_gate = b->d_score = nullptr; b->d_keep = nullptr;
@@ -2051,22 +2023,23 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
         return fail(ctx, RAWDTW_ERR_INVALID, "invalid border constraint (rmap.cpp:301-304)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t n_chains = chain_off[n_reads];
-    std::vector<uint64_t> &job_off = ctx->job_off_scratch; // (a context is not re-entrant)
-    job_off.resize(n_chains + 1);
-    uint64_t n_jobs = 0;
-    int st = rawdtw_batch_build_jobs(opt, n_chains, anchor_off, anchors, ref_base, read_base, job_off.data(), nullptr,
-                                     0, &n_jobs);
-    if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
+    int st = RAWDTW_OK;
     rawdtw_batch *b = new (std::nothrow) rawdtw_batch;
     if (!b) return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed");
     b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
     ctx->live_batches.push_back(b);
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
     b->in_resident = ctx->resident_arrays;
-    if (stream_eligible(ctx, opt, n_jobs))
-        st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base, job_off.data(), n_jobs);
+    if (stream_eligible(ctx, opt, anchor_off[n_chains]))
+        st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base);
     else {
         st = materialise_host_arrays(ctx, b);
+        std::vector<uint64_t> &job_off = ctx->job_off_scratch; // (a context is not re-entrant)
+        job_off.resize(n_chains + 1);
+        uint64_t n_jobs = 0;
+        if (st == RAWDTW_OK && rawdtw_batch_build_jobs(opt, n_chains, anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off.data(),
+                                                        nullptr, 0, &n_jobs) != RAWDTW_OK)
+            st = fail(ctx, RAWDTW_ERR_INVALID, "job counting failed");
         if (st == RAWDTW_OK)
             st = batch_create_joblist(ctx, b, chain_off, anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
     }
@@ -2082,14 +2055,17 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
     say("");
     if (!ctx || !batch || batch->ctx != ctx || (n_jobs && !jobs) || batch_dead(batch)) return RAWDTW_ERR_INVALID;
     if (device_planned) *device_planned = batch->stream ? 1 : 0;
+    batch_count_jobs(const_cast<rawdtw_batch *>(batch));
     if (n_jobs != batch->n_jobs) { say("job count differs from the batch's"); return RAWDTW_ERR_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     auto S = [](uint64_t v) { return std::to_string(v); };
     std::string e;
     if (batch->stream) {
-        // the records k_stream reads: every job's windows, shape, radius and class; the tiles partition the jobs and every
-        // tile's LDS image, job count and run count stay inside the kernel's capacities
+        // What the scan left behind for the DTW launch, against the job list the host builds from the same chains
+        // (rawdtw_batch_build_jobs): every tile's first chain; every job either of the tile class by the class rule (then
+        // k_runs derives it from its anchors: tests/test_stream_path.py pins its costs part by part) or in the side list
+        // exactly once with the job's windows, shape, slanted radius and flag; the statistics.
         rawdtw_batch *mb = const_cast<rawdtw_batch *>(batch);
         int st = stream_counters(ctx, mb);
         if (st != RAWDTW_OK) return st;
@@ -2100,115 +2076,46 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
             say("the stream path declined this batch (it is redone through the job list at fetch)");
             return RAWDTW_OK;
         }
-        std::vector<JobRec> jr(n_jobs);
-        std::vector<Cum> cum(n_jobs);
-        const uint64_t n_tiles = cnt[kCntTiles];
-        std::vector<TileInfo> ti(n_tiles + 1);
-        std::vector<uint32_t> tf(n_tiles + 1);
-        if (n_jobs) HIP_TRY(ctx, hipMemcpy(jr.data(), a.jrec, n_jobs * sizeof(JobRec), hipMemcpyDeviceToHost));
+        const uint64_t nc = batch->n_chains, na = a.n_anchors;
+        const uint64_t *aoff = batch->in_anchor_off;
+        std::vector<uint32_t> tc(a.n_tiles);
+        if (a.n_tiles) HIP_TRY(ctx, hipMemcpy(tc.data(), a.tile_chain, (size_t)a.n_tiles * 4, hipMemcpyDeviceToHost));
         {
-            const uint64_t n_units = (n_jobs + 1023) / 1024;
-            std::vector<uint64_t> cp(n_jobs), up(n_units + 1), uc(n_units + 1);
-            std::vector<uint32_t> cc(n_jobs);
-            if (n_jobs) HIP_TRY(ctx, hipMemcpy(cp.data(), a.cpos, n_jobs * 8, hipMemcpyDeviceToHost));
-            if (n_jobs) HIP_TRY(ctx, hipMemcpy(cc.data(), a.ccost, n_jobs * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(up.data(), a.unit_pos, (n_units + 1) * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(uc.data(), a.unit_cost, (n_units + 1) * 8, hipMemcpyDeviceToHost));
-            for (uint64_t k = 0; k < n_jobs; k++) { // absolute = the unit's offset + the sum inside the unit
-                const uint64_t pabs = up[k / 1024] + cp[k];
-                cum[k] = Cum{(uint32_t)pabs, (uint32_t)(pabs >> 32), uc[k / 1024] + cc[k]};
+            uint64_t c = 0;
+            for (uint64_t t = 0; t < a.n_tiles && e.empty(); t++) {
+                const uint64_t x = t * a.tile_anchors;
+                while (c + 1 < nc && aoff[c + 1] <= x) c++;
+                if (tc[t] != c) e = "tile " + S(t) + ": first chain " + S(tc[t]) + ", expected " + S(c);
             }
         }
-        HIP_TRY(ctx, hipMemcpy(ti.data(), a.tiles, (n_tiles + 1) * sizeof(TileInfo), hipMemcpyDeviceToHost));
-        for (uint64_t t = 0; t <= n_tiles; t++) tf[t] = ti[t].first;
-        if (ti[n_tiles].n != 0) e = "no end marker behind the last tile";
         const uint64_t n_other = cnt[kCntOthers];
         std::vector<DevJob> oj(n_other);
         if (n_other) HIP_TRY(ctx, hipMemcpy(oj.data(), a.ojobs, n_other * sizeof(DevJob), hipMemcpyDeviceToHost));
-        uint64_t tile_jobs = 0;
+        // job k of chain c's part p lives at anchor index a1 - 2 - p
+        std::vector<uint64_t> slot_job(na, ~0ull);
+        {
+            uint64_t k = 0;
+            for (uint64_t c = 0; c < nc; c++) {
+                const uint64_t a0 = aoff[c], a1 = aoff[c + 1];
+                for (uint64_t pidx = 0; a1 > a0 && pidx + 1 < a1 - a0; pidx++) slot_job[a1 - 2 - pidx] = k++;
+            }
+            if (k != n_jobs) e = "job count";
+        }
+        uint64_t tile_jobs = 0, tile_bytes = 0, other_bytes = 0;
         std::vector<uint8_t> is_tile(n_jobs, 0);
-        Cum run{0u, 0u, 0ull};
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++) {
             const rawdtw_job_t &j = jobs[k];
             const int R = slanted_radius(j.n, j.m, j.band_radius);
-            const uint32_t N = std::max(j.n, j.m), M = std::min(j.n, j.m);
-            const bool tile = R <= a.lane_max_radius && N <= a.lane_max_n;
-            if (jr[k].ref_off != j.ref_off || jr[k].read_off != j.read_off) e = "job " + S(k) + ": window offsets";
-            else if (((jr[k].meta & kMetaTile) != 0) != tile) e = "job " + S(k) + ": class";
-            else if (tile && ((jr[k].meta & 127u) != N || ((jr[k].meta >> 7) & 127u) != M || ((jr[k].meta >> 14) & 3u) != (uint32_t)R ||
-                              (((jr[k].meta >> 16) & 1u) != 0) != (j.exclude_last != 0) || (((jr[k].meta >> 17) & 1u) != 0) != (j.n < j.m)))
-                e = "job " + S(k) + ": shape, radius or flags";
-            const Cum d = job_cum(jr[k], a.min_cost8);
-            run = Cum{run.read + d.read, run.ref + d.ref, run.cost + d.cost};
-            if (e.empty() && (cum[k].read != run.read || cum[k].ref != run.ref || cum[k].cost != run.cost)) e = "job " + S(k) + ": running sums";
-            is_tile[k] = tile;
-            tile_jobs += tile;
-        }
-        if (e.empty() && tile_jobs != cnt[kCntTileJobs]) e = "tile job count";
-        if (e.empty() && (tf[0] != 0 || tf[n_tiles] != n_jobs)) e = "tiles do not cover the jobs";
-        // every tile: its range fits the record capacity; every job's windows lie inside the image at a place congruent to
-        // the arena offset; a continuing part starts on its predecessor's last element; distinct runs do not overlap
-        for (uint64_t t = 0; t < n_tiles && e.empty(); t++) {
-            if (tf[t + 1] <= tf[t]) { e = "tile " + S(t) + ": empty or boundaries not ascending"; break; }
-            const uint64_t first = tf[t], n = tf[t + 1] - tf[t];
-            if (n > 4u * (uint32_t)batch->stream_threads) { e = "tile " + S(t) + ": too many jobs"; break; }
-            // geometry as k_tile_first fixes it: from the first tile-class job's first chunk to the last one's last element
-            uint64_t f = first, l = first + n;
-            while (f < first + n && !is_tile[f]) f++;
-            while (l > f && !is_tile[l - 1]) l--;
-            if (f == first + n) {
-                if (ti[t].image != 0 || ti[t].first_tile != n) e = "tile " + S(t) + ": geometry of a tile without tile-class jobs";
-                continue;
-            }
-            auto pos_of = [&](uint64_t k, bool ref) -> uint64_t {
-                const Cum ce = k ? cum[k - 1] : Cum{0u, 0u, 0ull};
-                const bool st = (jr[k].meta & kMetaStarts) != 0;
-                return ref ? image_pos(ce.ref, jobs[k].ref_off, st) : image_pos(ce.read, jobs[k].read_off, st);
-            };
-            const uint32_t base_read = (uint32_t)pos_of(f, false) & ~3u, base_ref = (uint32_t)pos_of(f, true) & ~3u;
-            const uint32_t read_end = (uint32_t)pos_of(l - 1, false) + jobs[l - 1].n, ref_end = (uint32_t)pos_of(l - 1, true) + jobs[l - 1].m;
-            const uint32_t ref_region = (read_end - base_read + 3u) & ~3u, image = ref_region + ((ref_end - base_ref + 3u) & ~3u);
-            if (image > batch->stream_lds) { e = "tile " + S(t) + ": image of " + S(image) + " floats over the LDS budget"; break; }
-            if (ti[t].n != n || ti[t].base_read != base_read || ti[t].base_ref != base_ref || ti[t].ref_region != ref_region ||
-                ti[t].image != image || ti[t].first_tile != f - first) {
-                e = "tile " + S(t) + ": geometry record"; break;
-            }
-            // every job's windows lie inside the image at a place congruent to the arena offset; a continuing part starts on
-            // its predecessor's last element; runs do not share a 16-byte chunk; and every chunk of the image is owned by a
-            // job's window or is the one chunk of slack in front of a run start (the kernel has no clearing pass)
-            std::vector<uint8_t> owned(image / 4, 0);
-            uint64_t prev_end_read = 0, prev_end_ref = 0;
-            bool seen = false;
-            for (uint64_t k = first; k < first + n && e.empty(); k++) {
-                if (!is_tile[k]) continue;
-                const rawdtw_job_t &j = jobs[k];
-                const Cum ce = k ? cum[k - 1] : Cum{0u, 0u, 0ull};
-                const bool starts = (jr[k].meta & kMetaStarts) != 0;
-                const uint64_t pr = pos_of(k, false), pf = pos_of(k, true);
-                if (pr < base_read || pf < base_ref || pr - base_read + j.n > ref_region || pf - base_ref + ref_region + j.m > image)
-                    e = "job " + S(k) + ": window outside its tile's image";
-                else if (((pr ^ j.read_off) & 3u) || ((pf ^ j.ref_off) & 3u)) e = "job " + S(k) + ": image position not congruent to the arena offset";
-                else if (seen && !starts && (pr + 1 != prev_end_read || pf + 1 != prev_end_ref)) e = "job " + S(k) + ": continues a run it does not touch";
-                else if (seen && starts && (pr / 4 < (prev_end_read + 3) / 4 || pf / 4 < (prev_end_ref + 3) / 4)) e = "job " + S(k) + ": run shares a 16-byte chunk with the run before it";
-                if (!e.empty()) break;
-                for (uint64_t c4 = (pr - base_read) / 4; c4 * 4 < pr - base_read + j.n; c4++) owned[c4] = 1;
-                for (uint64_t c4 = (pf - base_ref + ref_region) / 4; c4 * 4 < pf - base_ref + ref_region + j.m; c4++) owned[c4] = 1;
-                if (starts && k != f) {
-                    const uint64_t g0 = (ce.read - base_read) / 4, g1 = (ce.ref - base_ref + ref_region) / 4;
-                    if (g0 < (pr - base_read) / 4) owned[g0] = 1;
-                    if (g1 < (pf - base_ref + ref_region) / 4) owned[g1] = 1;
-                }
-                prev_end_read = pr + j.n; prev_end_ref = pf + j.m;
-                seen = true;
-            }
-            for (size_t q = 0; q < owned.size() && e.empty(); q++)
-                if (!owned[q]) e = "tile " + S(t) + ": chunk " + S(q) + " of the image belongs to no job";
+            const uint32_t N = std::max(j.n, j.m);
+            is_tile[k] = R <= a.lane_max_radius && N <= a.lane_max_n;
+            tile_jobs += is_tile[k];
+            (is_tile[k] ? tile_bytes : other_bytes) += 4ull * ((uint64_t)j.n + j.m) + 36ull;
         }
         std::vector<uint8_t> oseen(n_jobs, 0);
         for (uint64_t q = 0; q < n_other && e.empty(); q++) {
             const DevJob &d = oj[q];
-            const uint32_t k = d.aux;
-            if (k >= n_jobs || oseen[k] || is_tile[k]) e = "side-list job " + S(k) + " duplicated or of the tile class";
+            const uint64_t k = d.aux < na ? slot_job[d.aux] : ~0ull;
+            if (k == ~0ull || oseen[k] || is_tile[k]) e = "side-list entry " + S(q) + " (anchor " + S(d.aux) + ") duplicated, of the tile class or no job at all";
             else if (d.n != jobs[k].n || d.m != jobs[k].m || d.ref_off != jobs[k].ref_off || d.read_off != jobs[k].read_off ||
                      d.R != slanted_radius(d.n, d.m, jobs[k].band_radius) || ((d.flags & kFlagExcludeLast) != 0) != (jobs[k].exclude_last != 0))
                 e = "side-list record of job " + S(k) + " differs from the job";
@@ -2216,6 +2123,13 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         }
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
             if (!is_tile[k] && !oseen[k]) e = "job " + S(k) + " is in no launch";
+        if (e.empty()) {
+            HIP_TRY(ctx, stream_sum_stats(a, ctx->stream));
+            unsigned long long st3[3];
+            HIP_TRY(ctx, hipMemcpyAsync(st3, a.cnt + kCntTileJobs, 24, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (st3[0] != tile_jobs || st3[1] != tile_bytes || st3[2] != other_bytes) e = "tile statistics";
+        }
         say(e);
         return e.empty() ? RAWDTW_OK : RAWDTW_ERR_DEVICE + 100;
     }
@@ -2272,10 +2186,12 @@ int rawdtw_batch_info(const rawdtw_batch *batch, rawdtw_plan_info_t *info, uint6
     }
     if (!b->cells_counted) {
         HIP_TRY(ctx, stream_count_cells(b->sa, b->sa.cnt + kCntCells, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(&b->h_cnt[kCntCells], b->sa.cnt + kCntCells, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, stream_sum_stats(b->sa, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&b->h_cnt[kCntCells], b->sa.cnt + kCntCells, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         b->cells_counted = true;
     }
+    batch_count_jobs(b);
     const unsigned long long *c = b->h_cnt;
     rawdtw_plan_info_t I{};
     I.n_jobs = b->n_jobs;
@@ -2428,6 +2344,7 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
     if (i >= nl) {
         if (kind) *kind = i == nl ? kKindChainFold : kKindReadSelect;
         if (param) *param = 0;
+        batch_count_jobs(const_cast<rawdtw_batch *>(batch));
         if (n_jobs) *n_jobs = i == nl ? batch->n_chains : batch->n_reads;
         // fold: one 4-byte cost per job + a 24-byte descriptor and two 4-byte results per chain;
         // select: 8 bytes read and 5 written per chain
@@ -2443,11 +2360,17 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
             rawdtw_batch *b = const_cast<rawdtw_batch *>(batch);
             int st = stream_counters(b->ctx, b);
             if (st != RAWDTW_OK) return st;
+            if (!b->cells_counted) {
+                if (stream_sum_stats(b->sa, b->ctx->stream) != hipSuccess ||
+                    hipMemcpyAsync(&b->h_cnt[kCntTileJobs], b->sa.cnt + kCntTileJobs, 3 * 8, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(b->ctx->stream) != hipSuccess) return RAWDTW_ERR_DEVICE;
+            }
             I.algorithmic_bytes = b->h_cnt[kCntTileBytes] + b->h_cnt[kCntOtherBytes];
         }
         if (batch->stream) { // (rawdtw_batch_info may have moved the batch to the job-list path)
             if (kind) *kind = kKindBandMerged;
             if (param) *param = (int32_t)batch->stream_lds;
+            batch_count_jobs(const_cast<rawdtw_batch *>(batch));
             if (n_jobs) *n_jobs = batch->n_jobs;
             if (algorithmic_bytes) *algorithmic_bytes = I.algorithmic_bytes;
             if (cells) *cells = I.cells;
@@ -2495,7 +2418,12 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
             if (score) HIP_TRY(ctx, hipMemcpyAsync(score, batch->d_score, batch->n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (keep) HIP_TRY(ctx, hipMemcpyAsync(keep, batch->d_keep, batch->n_chains, hipMemcpyDeviceToHost, ctx->stream));
         }
-        if (job_cost && batch->n_jobs)
+        // (a sync-free batch keeps one cost per ANCHOR: the part that ends there; they are put into job order below)
+        std::vector<float> per_anchor;
+        if (job_cost && batch->stream && batch->sa.n_anchors) {
+            try { per_anchor.resize(batch->sa.n_anchors); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+            HIP_TRY(ctx, hipMemcpyAsync(per_anchor.data(), d_cost, batch->sa.n_anchors * 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else if (job_cost && !batch->stream && batch->n_jobs)
             HIP_TRY(ctx, hipMemcpyAsync(job_cost, d_cost, batch->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (batch->stream && !batch->cnt_valid)
             HIP_TRY(ctx, hipMemcpyAsync(batch->h_cnt, batch->sa.cnt, kStreamCounters * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2503,7 +2431,17 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
         batch->dirty = false;
         if (!batch->stream) return RAWDTW_OK;
         batch->cnt_valid = true;
-        if (!stream_declined(batch)) return RAWDTW_OK;
+        if (!stream_declined(batch)) {
+            if (job_cost) { // chain c's part p (rmap.cpp:248-293) ends at anchor a1 - 2 - p
+                const uint64_t *aoff = batch->in_anchor_off;
+                uint64_t k = 0;
+                for (uint64_t c = 0; c < batch->n_chains; c++) {
+                    const uint64_t a0 = aoff[c], a1 = aoff[c + 1];
+                    for (uint64_t pidx = 0; a1 > a0 && pidx + 1 < a1 - a0; pidx++) job_cost[k++] = per_anchor[a1 - 2 - pidx];
+                }
+            }
+            return RAWDTW_OK;
+        }
         int st = stream_fallback(ctx, batch); // invalid anchors (the job-list path words the error) or a shape it does not take
         if (st != RAWDTW_OK) return st;
     }

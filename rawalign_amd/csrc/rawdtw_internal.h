@@ -58,7 +58,7 @@ struct ChainDesc {
     uint32_t n_jobs;      // 1 (global) or n_anchors-1 (sparse)
     uint32_t span;        // read events between the chain's first and last anchor, inclusive (rmap.cpp:245)
     uint32_t num_aligned; // sum of the parts' read_region_size (rmap.cpp:236,292)
-    uint32_t reserved;
+    uint32_t descending;  // 1: the chain's part p is job_cost[job_first - p] (sync-free batches: costs are stored per anchor)
 };
 static_assert(sizeof(ChainDesc) == 24, "ChainDesc must stay 24 bytes");
 
@@ -92,16 +92,19 @@ struct FullAux {
     uint64_t dir_off; // byte offset of the packed direction buffer (traceback jobs)
 };
 
-// ---- sync-free candidate batches (rawdtw_stream.hip) ----
-// One record per job of the batch, job order: the windows' arena offsets and, for the jobs the lane-per-job DP takes,
-// the packed shape: bits 0-6 longer side, 7-13 shorter side, 14-15 radius after the slant correction (dtw.cpp:298-300),
-// 16 exclude_last_element, 17 swap (the reference window is the longer one, dtw.cpp:284-292), 18 run start, 19 tile class.
-struct JobRec { uint64_t ref_off; uint32_t read_off; uint32_t meta; };
-static_assert(sizeof(JobRec) == 16, "JobRec is 16 bytes");
-constexpr uint32_t kMetaStarts = 1u << 18, kMetaTile = 1u << 19;
-constexpr uint32_t kStreamItems = 4;          // jobs per thread in a tile's prologue: a tile's range holds kStreamItems * threads jobs
-constexpr uint32_t kStreamMaxTileJobs = kStreamItems * 512; // ... of 512-thread workgroups (256-thread: half)
-constexpr uint32_t kStreamSlack = 32;         // LDS floats of a tile's image kept free for region alignment
+// ---- sync-free candidate batches (rawdtw_runs.hip) ----
+// A candidate batch is scored straight from the caller's anchor lists: nothing is written per job but its cost.
+//
+//   tile      a fixed range of kTileAnchors consecutive entries of anchors[]; its DTW jobs are the parts that END at one
+//             of its anchors (part i runs from anchors[i + 1] to anchors[i]: rmap.cpp:251-254 stores chains end-first).
+//             Everything about a tile -- its chains, the parts' windows, radii and classes, the layout of its LDS
+//             image -- is derived inside the DTW launch from those anchors and the chains' offsets.
+//   out[i]    the cost of part i (one float per anchor; the slot of a chain's first entry stays unused).  A chain's
+//             parts p = 0 .. n - 2 in the reference's order are out[a1 - 2 - p]: the fold walks it downwards.
+//   side list parts the lane-per-job bodies do not take (radius > lane_max_radius or longer side > lane_max_n), found
+//             by k_scan ahead of the DTW launch and scored there first, wave-cooperatively, longest first.
+constexpr uint32_t kStreamItems = 2;          // anchors (= candidate parts) per thread of a tile
+constexpr uint32_t kStreamMaxSeg = 32;        // runs of one pass over a tile's image (more: the tile takes another pass)
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
 constexpr uint32_t kStreamClasses = 21, kClsW0 = 0, kClsG16 = 4, kClsL0 = 5, kClsLCount = 8, kClsM0 = 13, kClsMCount = 8;
 // Side-list classes 13..20: bands of up to 8 slots (radius <= 7) that are not in the classes below: one lane per job too
@@ -115,90 +118,49 @@ __host__ __device__ inline uint32_t side_lane_bucket(uint32_t N)
     return N >= 65u ? 0u : N >= 49u ? 1u : N >= 41u ? 2u : N >= 33u ? 3u : N >= 29u ? 4u : N >= 25u ? 5u : N >= 21u ? 6u : 7u;
 }
 
-// Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive parts of a chain
-// (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every job
-// adds `read` / `ref` floats to the regions: a run start its whole window plus 3 floats of slack, a continuing part its
-// window minus the shared first element, and a run's last part the padding that rounds the run's END up to a 16-byte
-// boundary of the arena.  With c = the running sum BEFORE the job (a global exclusive scan) the job's window starts at
-//     start:       c + ((off - c) & 3)            continuing:  c - 4 + ((off - c) & 3)
-// (off = the window's arena offset): a closed form of the job's own scan value that is congruent to the arena offset
-// modulo 4 -- 16-byte chunks of the image are 16-byte chunks of the arena -- consistent along a run, and such that two
-// runs never share a chunk.  So a tile is staged by a flat, fully coalesced copy of chunks, with no per-tile run
-// table and no per-tile scan.  `cost` (eighths of a float, with a floor that bounds the jobs of a tile) cuts the batch
-// into tiles: tile k = the jobs whose exclusive cost lies in [k w, (k + 1) w).
-constexpr uint32_t kMetaEnds = 1u << 20; // the run's last part (the next part of the chain is not a tile job)
-struct Cum { uint32_t read, ref; uint64_t cost; };
-static_assert(sizeof(Cum) == 16, "Cum is 16 bytes");
-__host__ __device__ inline Cum job_cum(const JobRec &r, uint32_t min_cost8)
-{
-    Cum c{0u, 0u, (uint64_t)min_cost8};
-    const uint32_t meta = r.meta;
-    if (!(meta & kMetaTile)) return c;
-    const uint32_t N = meta & 127u, M = (meta >> 7) & 127u;
-    const bool swap = (meta >> 17) & 1u, starts = (meta >> 18) & 1u, ends = (meta >> 20) & 1u;
-    const uint32_t n_read = swap ? M : N, n_ref = swap ? N : M;
-    c.read = (starts ? n_read + 3u : n_read - 1u) + (ends ? (0u - (r.read_off + n_read)) & 3u : 0u);
-    c.ref = (starts ? n_ref + 3u : n_ref - 1u) + (ends ? (0u - ((uint32_t)r.ref_off + n_ref)) & 3u : 0u);
-    const uint32_t c8 = 8u * (c.read + c.ref);
-    c.cost = c8 > min_cost8 ? c8 : min_cost8;
-    return c;
-}
-__host__ __device__ inline Cum cum_of(uint64_t packed) { return Cum{(uint32_t)packed, (uint32_t)(packed >> 32), 0ull}; }
-__host__ __device__ inline uint32_t image_pos(uint32_t c_excl, uint64_t arena_off, bool starts)
-{
-    return (starts ? c_excl : c_excl - 4u) + (((uint32_t)arena_off - c_excl) & 3u);
-}
-// One tile: its job range and the geometry of its image (k_tile_first)
-struct alignas(16) TileInfo { uint32_t first, n, base_read, base_ref, ref_region, image, first_tile /* index in the range of its first tile-class job */, pad1; };
-static_assert(sizeof(TileInfo) == 32, "TileInfo is 32 bytes");
-
 enum StreamCounter : int {
-    kCntBad = 0,        // min: first job with invalid anchors or a window outside the arenas (~0 = none)
-    kCntOverflow,       // min: a tile over one of the kernel's capacities (~0 = none): never with a correct planner
-    kCntUnsupported,    // jobs whose band is wider than the side list's kernels take (radius + 1 > 256)
-    kCntTileJobs, kCntTileBytes, kCntOtherBytes, kCntOthers, kCntTiles, kCntLdsMax,
+    kCntBad = 0,        // min: first anchor index whose part is invalid (anchors not ascending, window outside an arena); ~0 = none
+    kCntOverflow,       // min: a tile over one of the kernel's capacities (~0 = none): never with a correct kernel
+    kCntUnsupported,    // parts whose band is wider than the side list's kernels take (radius + 1 > 256), chains without anchors
+    kCntOthers,         // side-list entries appended
     kCntCls0,           // kStreamClasses totals
     kCntCur0 = kCntCls0 + 21, // kStreamClasses scatter cursors
     kCntCells = kCntCur0 + 21,
+    kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
-static_assert(kCntCells < kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
+static_assert(kCntOtherBytes < kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
-    uint64_t n_jobs, n_chains, n_reads, n_ev, n_ref, others_cap;
+    uint64_t n_anchors, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
     int32_t lane_max_radius;     // tile class: radius <= this and longer side <= lane_max_n
     int32_t side_lane_radius;    // side-list lane classes: radius in (lane_max_radius, this], longer side <= lane_max_n
     uint32_t lane_max_n;
-    uint32_t min_cost8;          // cost floor in eighths of a float: bounds the jobs of a tile's range
-    uint64_t width8;             // bracket width of the tile rule: 8 * (image floats - slack) - the largest cost a job can have
-    uint32_t tiles_cap;
+    uint32_t n_tiles;            // ceil(n_anchors / tile_anchors)
+    uint32_t tile_anchors;       // threads * kStreamItems of the DTW launch
     uint32_t debug;              // timing experiments only (results wrong below 128 except 8): 1 no DP, 2 no staging, 4 no side
-                                 // list, 16 no marks, 32 no wave-per-job items, 64 no group / lane items; 8 tiles without the
-                                 // ticket queue, 2048 side items over all waves, 4096 side items dealt straight (not alternating)
+                                 // list, 32 no wave-per-job items, 64 no group / lane items; 8 tiles without the ticket queue,
+                                 // 2048 side items over all waves, 4096 side items dealt straight (not alternating)
     // inputs (device)
-    const uint32_t *unit_chain;  // per k_pre unit of 1024 jobs: the chain its first job belongs to (n_units + 1 entries)
-    const uint64_t *job_off, *anchor_off;
+    const uint64_t *anchor_off;
     const rawdtw_anchor_t *anchors;
     const uint64_t *ref_base;
     const uint32_t *read_base;
     const float *ev, *ref;
-    // planning arrays and outputs (device)
-    JobRec *jrec;
-    uint64_t *cpos;              // inclusive sums of job_cum INSIDE the job's unit of 1024: event floats | reference floats << 32
-    uint32_t *ccost;             // ... and cost
-    uint64_t *unit_pos, *unit_cost; // the sums before each unit (n_units + 1 entries)
-    TileInfo *tiles;             // tiles_cap + 1 entries; tiles[n_tiles].n = 0
-    unsigned long long *unit_stats; // per k_pre unit: tile jobs, tile bytes, side-list bytes
+    // workspace and outputs (device)
+    uint32_t *tile_chain;        // per tile: the chain its first anchor belongs to (n_tiles entries, written by k_scan)
+    unsigned long long *tile_stats; // per scan unit (8192 anchors): tile-class parts, their algorithmic bytes, the side list's bytes
     DevJob *omix, *ojobs;
     uint8_t *ocls;
     unsigned long long *cnt;
-    float *out;
+    float *out;                  // n_anchors entries
 };
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
 hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);
+hipError_t stream_sum_stats(const StreamArgs &a, hipStream_t s);
 hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,
                                  uint32_t n_seg, hipStream_t s);
 

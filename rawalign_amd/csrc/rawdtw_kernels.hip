@@ -602,16 +602,18 @@ __global__ __launch_bounds__(256) void k_tb_finish(const DevJob *__restrict__ jo
 __device__ __forceinline__ void fold_wave_body(const uint32_t c, const ChainDesc d, const int lane, const float *__restrict__ job_cost,
                                                const float bonus, const int fused, float *__restrict__ full_score,
                                                float *__restrict__ att_last)
-{    float attainable = (float)d.span * bonus; // rmap.cpp:205,246
+{
+    float attainable = (float)d.span * bonus; // rmap.cpp:205,246
     float cost = 0.0f;
     const float *jc = job_cost + d.job_first;
+    const long long dir = d.descending ? -1 : 1; // part p is jc[dir * p]
     // all parts but the last: cost += sub; attainable -= sub (two independent fp32 chains)
     const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0;
     uint32_t base = 0;
-    float nxt = ((uint32_t)lane < d.n_jobs) ? jc[lane] : 0.0f;
+    float nxt = ((uint32_t)lane < d.n_jobs) ? jc[dir * lane] : 0.0f;
     for (; base + 64 <= body; base += 64) {
         const float chunk = nxt;
-        nxt = (base + 64 + (uint32_t)lane < d.n_jobs) ? jc[base + 64 + lane] : 0.0f;
+        nxt = (base + 64 + (uint32_t)lane < d.n_jobs) ? jc[dir * (long long)(base + 64 + lane)] : 0.0f;
         v2f acc = {cost, attainable};
 #pragma unroll
         for (int k = 0; k < 64; k++) {
@@ -667,22 +669,23 @@ __device__ __forceinline__ void fold_lane_body(const bool act, const uint32_t c,
 {
     if (!act) d.n_jobs = 0;    const uint32_t body = d.n_jobs ? d.n_jobs - 1 : 0; // all parts but the last: cost += sub; attainable -= sub
     const float *jc = job_cost + d.job_first;
+    const long long dir = d.descending ? -1 : 1; // part p is jc[dir * p]
     v2f acc = {0.0f, (float)d.span * bonus}; // {cost, attainable}  (rmap.cpp:205,246)
     float nx[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) nx[u] = ((uint32_t)u < body) ? jc[u] : 0.0f;
+    for (int u = 0; u < U; u++) nx[u] = ((uint32_t)u < body) ? jc[dir * u] : 0.0f;
     for (uint32_t k = 0; __any(k < body); k += U) {
         float cur[U];
 #pragma unroll
         for (int u = 0; u < U; u++) cur[u] = nx[u];
 #pragma unroll
-        for (int u = 0; u < U; u++) nx[u] = (k + U + (uint32_t)u < body) ? jc[k + U + u] : 0.0f;
+        for (int u = 0; u < U; u++) nx[u] = (k + U + (uint32_t)u < body) ? jc[dir * (long long)(k + U + u)] : 0.0f;
 #pragma unroll
         for (int u = 0; u < U; u++) acc += v2f{cur[u], -cur[u]}; // x + 0 and x - 0 are exact: finished chains idle
     }
     float cost = acc.x;
     const float gate = d.n_jobs ? acc.y : __builtin_inff(); // tested before the last (or only) DTW call; none: no check
-    if (d.n_jobs) cost += jc[d.n_jobs - 1];                 // the last part only adds to the cost (rmap.cpp:279-280)
+    if (d.n_jobs) cost += jc[dir * (long long)(d.n_jobs - 1)]; // the last part only adds to the cost (rmap.cpp:279-280)
     float score;
     if (fused) score = __builtin_fmaf((float)d.num_aligned, bonus, -cost);
     else { const float prod = (float)d.num_aligned * bonus; score = prod - cost; }

@@ -1,0 +1,1066 @@
+// rawdtw_runs.hip -- the sync-free candidate-batch pipeline (rawdtw_batch_create/run for sparse + banded batches).
+//
+// What it replaces: the DTW block of gen_chains (src/rmap.cpp:509-530) for every read of a mini-batch, i.e. all the calls
+// of DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520) that align_chain (src/rmap.cpp:238-300) issues.
+//
+// Round 2 planned a batch JOB BY JOB: a planning kernel wrote a 16-byte record and two running sums for every DTW job to
+// HBM (143 MB a batch), a scan and a search kernel cut them into tiles, and the DTW launch read all of it back and marked
+// every 16-byte chunk of its LDS image job by job.  But a chain's consecutive parts are ONE contiguous piece of each arena
+// (part p runs from anchors[parts - p] to anchors[parts - p - 1], rmap.cpp:248-293: it starts on the element the part
+// before it ends on), and the anchors' positions ARE the running sums of the window lengths.  So here the unit is a run:
+//
+//   k_scan     one workgroup per 8192 anchors: finds the range's first chain (a 64-way search of the chains' offsets by
+//              one wave), checks every part's anchors, and appends the parts the lane-per-job bodies do not take
+//              (radius > 3, longer side > 73: one part in two hundred) to a side list.  Its other workgroups write the
+//              fold's chain records and sort the chains by part count.  Writes 4 bytes per TILE (its first chain).
+//   k_side     the side list into class order (wave-per-job first, longest first), as before
+//   k_runs     ONE persistent launch per batch: every wave first takes its share of the side list's items, then
+//              workgroups pull tiles from an eight-headed queue.  Per tile: load the range's anchors (coalesced, each
+//              once), derive every part's windows, radius (rmap.cpp:276, dtw.cpp:298-300) and class in registers, lay
+//              the runs out in the LDS image with one workgroup scan, stage each run's two windows with plain coalesced
+//              16-byte copies, sort the parts by (radius class, longer side) in LDS, score them a lane each
+//              (rawdtw_dp.h).  The cost of part i goes to out[i].  Nothing else about a job or a tile touches HBM.
+//
+// No step needs a number on the host: grids are sized by the anchor count or are persistent, every count lives in a
+// device counter block.  rawdtw_batch_create only enqueues; errors and the rare shapes this path does not take (band wider
+// than 256 offsets, chains without anchors) surface in the counters, which rawdtw_batch_fetch reads together with the
+// results and which make k_runs leave at once.
+
+#include "rawdtw_dp.h"
+
+namespace rawdtw {
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ int d_slanted_radius(uint32_t n, uint32_t m, int r0)
+{
+    const uint32_t N = n > m ? n : m, M = n > m ? m : n;
+    const uint32_t x = (N - M) * (uint32_t)r0 + N - 1u; // dtw.cpp:298-300, unsigned 32-bit: extra = x / N
+    uint32_t q;
+    if (N < (1u << 11) && (uint32_t)r0 < (1u << 11)) {
+        // x < 2^23 is exact in a float and the quotient is below 2^12: the product with the hardware reciprocal (1 ulp)
+        // is within 2^-10 of it, so the truncation is the quotient or one beside it -- one remainder check settles it
+        // (an integer division is some 25 instructions)
+        q = (uint32_t)((float)x * __builtin_amdgcn_rcpf((float)N));
+        const int r = (int)x - (int)(q * N);
+        q = r < 0 ? q - 1u : (r >= (int)N ? q + 1u : q);
+    } else q = x / N;
+    return r0 + (int)q;
+}
+
+// exact size of the band's cell set (same walk as the kernels; reporting only)
+__device__ uint32_t d_banded_cells(uint32_t n, uint32_t m, int R)
+{
+    const uint32_t N = n > m ? n : m, M = n > m ? m : n;
+    const int P = R + ((R % 2 == 0) ? 1 : 0), S = R + ((R % 2 == 1) ? 1 : 0);
+    uint32_t cells = 1;
+    int row = 0;
+    uint32_t rem = 0;
+    for (uint32_t col = 1; col < N; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        if (adv) { rem -= N; row++; }
+        for (int pass = adv ? 0 : 1; pass < 2; pass++) {
+            const int len = pass == 0 ? S : P;
+            const int si = pass == 0 ? (int)col + S / 2 - 1 : (int)col + P / 2;
+            const int sj = pass == 0 ? row - S / 2 : row - P / 2;
+            int lo = 0, hi = len;
+            lo = max(lo, si - (int)N + 1);
+            lo = max(lo, -sj);
+            hi = min(hi, si + 1);
+            hi = min(hi, (int)M - sj);
+            if (hi > lo) cells += (uint32_t)(hi - lo);
+        }
+    }
+    return cells;
+}
+
+// One candidate part: the DTW job between two consecutive anchors of a chain (rmap.cpp:251-254, 270, 276), its shape and
+// class.  `s` = the anchor the part starts on, `e` = the one it ends on (s lies one entry BEHIND e in the end-first list).
+struct Part {
+    uint32_t n, m;   // read events, reference signals in the window (rmap.cpp:255-262)
+    int R;           // band radius after the slant correction (dtw.cpp:298-300)
+    bool asc;        // the anchors ascend (a chain the mapper could produce)
+    bool tile;       // the lane-per-job bodies take it
+};
+
+__device__ __forceinline__ Part classify(const StreamArgs &a, const rawdtw_anchor_t s, const rawdtw_anchor_t e)
+{
+    Part p;
+    p.asc = e.target_position >= s.target_position && e.query_position >= s.query_position;
+    p.m = e.target_position - s.target_position + 1;
+    p.n = e.query_position - s.query_position + 1;
+    int r0 = (int)((float)p.n * a.frac); // rmap.cpp:276, fp32 product
+    r0 = r0 > 1 ? r0 : 1;
+    // Tile class without the division of dtw.cpp:298-300: with d = N - M the radius is R = r0 + ceil(d r0 / N), so
+    //     R <= Rm  <=>  r0 <= Rm and d r0 <= (Rm - r0) N,
+    // and for a tile part (Rm <= 3 and r0 >= 1: the ceiling is 0, 1 or 2)  R = r0 + (d r0 > 0) + (d r0 > N).
+    // (32-bit products: N <= lane_max_n < 128 and r0 <= 3 wherever the result counts.)
+    const uint32_t N = p.n > p.m ? p.n : p.m, dr = (N - (p.n > p.m ? p.m : p.n)) * (uint32_t)r0;
+    p.R = r0 + (dr > 0u ? 1 : 0) + (dr > N ? 1 : 0);
+    p.tile = p.asc && p.n < 0x7fffffffu && p.m < 0x7fffffffu && N <= a.lane_max_n && r0 <= a.lane_max_radius &&
+             dr <= (uint32_t)(a.lane_max_radius - r0) * N;
+    return p;
+}
+
+// The chain that owns anchor x: the LAST chain c with anchor_off[c] <= x (chains without anchors share their successor's
+// offset).  A 64-way search by one wave: three rounds for 2^18 chains.  All lanes return the chain.
+__device__ __forceinline__ uint64_t find_chain(const uint64_t *__restrict__ anchor_off, uint64_t n_chains, uint64_t x, int lane)
+{
+    uint64_t lo = 0, hi = n_chains; // invariant: anchor_off[lo] <= x, answer in [lo, hi)
+    while (hi - lo > 1) {
+        const uint64_t step = (hi - lo + 63) / 64;
+        const uint64_t p = lo + (uint64_t)lane * step;
+        const bool le = p < hi && anchor_off[p] <= x;
+        const int cnt = __popcll(__ballot(le)); // the probes are ascending: the predicate is true on a prefix (lane 0 always)
+        const uint64_t nlo = lo + (uint64_t)(cnt - 1) * step;
+        hi = min(hi, nlo + step);
+        lo = nlo;
+    }
+    return lo;
+}
+
+// bit p of a tile's chain-start mask: anchor (tile base + p) is the first entry of a chain (bit AT may be set as well:
+// the anchor behind the tile's last; the end of the anchor list counts as a chain start)
+__device__ __forceinline__ bool mask_bit(const uint32_t *mask, uint32_t p) { return (mask[p >> 5] >> (p & 31u)) & 1u; }
+
+// Marks the chain starts inside [base, base + AT] in `mask` (zeroed by the caller, LDS) from the chains' offsets,
+// starting at chain c0 = the chain that owns anchor `base`.  Chains are few per tile (a handful in a sparse batch): one
+// round of loads; tiles of very short chains take more.  Ends with the workgroup synchronised and the mask complete.
+// Returns false when a chain without anchors was seen (the popcount-based chain lookup would be off: the batch is redone
+// through the job list).
+template <int NT>
+__device__ __forceinline__ bool mark_chain_starts(const StreamArgs &a, uint64_t c0, uint64_t base, uint32_t at, uint32_t *mask)
+{
+    bool ok = true;
+    for (uint64_t c = c0 + threadIdx.x;; c += NT) {
+        uint64_t s = ~0ull;
+        if (c <= a.n_chains) {
+            s = a.anchor_off[c];
+            if (s >= base && s <= base + at) atomicOr(&mask[(uint32_t)(s - base) >> 5], 1u << ((uint32_t)(s - base) & 31u));
+            if (c < a.n_chains && s < base + at && a.anchor_off[c + 1] == s) ok = false; // (c0 itself owns an anchor)
+        }
+        // the round's last thread tells whether chains starting inside the tile may be left
+        if (!__syncthreads_or(threadIdx.x == NT - 1 && c < a.n_chains && s < base + at)) break;
+    }
+    return ok;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fold support: chain records (ChainDesc) and the fold order
+// ---------------------------------------------------------------------------------------------------------------------
+// Also the one bounds check a batch needs: a chain's parts tile the span between its first and last anchor, so when the
+// anchors ascend (checked part by part in k_scan) every window lies inside the arenas iff the chain's span does.
+__device__ __forceinline__ void chain_desc_body(const StreamArgs &a, ChainDesc *__restrict__ chains, const uint64_t c)
+{
+    if (c >= a.n_chains) return;
+    const uint64_t a0 = a.anchor_off[c], a1 = a.anchor_off[c + 1];
+    ChainDesc d;
+    d.job_first = a1 >= 2 ? a1 - 2 : 0;                      // part p = out[a1 - 2 - p]
+    d.n_jobs = a1 > a0 ? (uint32_t)(a1 - a0 - 1) : 0u;
+    d.descending = 1; d.span = 0; d.num_aligned = 0;
+    if (a1 > a0) {
+        const rawdtw_anchor_t first = a.anchors[a1 - 1], last = a.anchors[a0];
+        d.span = last.query_position - first.query_position + 1;                     // rmap.cpp:245
+        d.num_aligned = (last.query_position - first.query_position) + d.n_jobs;       // sum of the parts' read regions (rmap.cpp:292)
+        if (d.n_jobs && ((uint64_t)a.read_base[c] + last.query_position + 1ull > a.n_ev || a.ref_base[c] + last.target_position + 1ull > a.n_ref))
+            atomicMin(&a.cnt[kCntBad], (unsigned long long)a0);
+    } else atomicAdd(&a.cnt[kCntUnsupported], 1ull); // a chain without anchors: align_chain would read anchors[-1]
+    chains[c] = d;
+}
+
+// Fold order: chains by part count, longest first (the lane-per-chain fold gives a wave 64 chains of similar length).
+// One workgroup: a counting sort over 1024 length buckets in LDS (the order inside a bucket does not matter).
+template <int NT>
+__device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const uint64_t *__restrict__ anchor_off, uint32_t *__restrict__ order)
+{
+    constexpr uint32_t kBins = 1024, kB = kBins / NT; // consecutive buckets per thread in the scan
+    constexpr uint32_t kC = 4;                        // chains per thread and round: their offsets are all requested before any is used
+    __shared__ uint32_t hist[kBins];
+    __shared__ uint32_t wsum[NT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    auto bucket = [](uint64_t anchors) { return 1023u - (uint32_t)min<uint64_t>(anchors ? anchors - 1 : 0, 1023ull); }; // a chain's part count, clamped
+    auto keys = [&](uint64_t c0, uint32_t (&b)[kC]) { // buckets of chains c0 + q * NT
+        uint64_t lo[kC], hi[kC];
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++) {
+            const uint64_t c = min(c0 + (uint64_t)q * NT, n_chains - 1);
+            lo[q] = anchor_off[c]; hi[q] = anchor_off[c + 1];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++) b[q] = bucket(hi[q] - lo[q]);
+    };
+    for (uint32_t i = tid; i < kBins; i += NT) hist[i] = 0;
+    __syncthreads();
+    for (uint64_t c0 = tid; c0 < n_chains; c0 += (uint64_t)NT * kC) {
+        uint32_t b[kC];
+        keys(c0, b);
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++)
+            if (c0 + (uint64_t)q * NT < n_chains) atomicAdd(&hist[b[q]], 1u);
+    }
+    __syncthreads();
+    uint32_t v[kB], mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kB; q++) { v[q] = hist[tid * kB + q]; mine += v[q]; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t at = incl - mine;
+    for (uint32_t w = 0; w < wv; w++) at += wsum[w];
+#pragma unroll
+    for (uint32_t q = 0; q < kB; q++) { hist[tid * kB + q] = at; at += v[q]; } // exclusive start of the bucket
+    __syncthreads();
+    for (uint64_t c0 = tid; c0 < n_chains; c0 += (uint64_t)NT * kC) {
+        uint32_t b[kC];
+        keys(c0, b);
+#pragma unroll
+        for (uint32_t q = 0; q < kC; q++)
+            if (c0 + (uint64_t)q * NT < n_chains) order[atomicAdd(&hist[b[q]], 1u)] = (uint32_t)(c0 + (uint64_t)q * NT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_scan: the pass over the anchor list ahead of the DTW launch.  Roles by workgroup: [0, n_tiles) one tile each,
+// n_tiles the fold order, the rest the chain records.
+// ---------------------------------------------------------------------------------------------------------------------
+// A scan unit = kScanUnit consecutive anchors = a whole number of tiles, one 1024-thread workgroup, eight consecutive
+// anchors a thread (forward order: the part of anchor i runs from anchors[i + 1] to anchors[i]).  It writes the first
+// chain of each of its tiles (4 bytes a tile), three statistics, and -- for the one part in two hundred the tiles do not
+// take -- a side-list record.  Units are large because every unit ends with one returning atomic per side-list class on
+// a counter the whole grid shares: such a word takes ~88 atomics a microsecond, and at one workgroup per TILE (ten
+// thousand a batch) the launch spent 150 of its 176 us queueing there.
+constexpr uint32_t kScanUnit = 8192, kScanT = 1024, kScanKI = kScanUnit / kScanT;
+__device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32_t unit)
+{
+    constexpr int NT = (int)kScanT, KI = (int)kScanKI;
+    constexpr uint32_t AT = kScanUnit, kWords = AT / 32 + 1;
+    __shared__ uint32_t s_mask[kWords], s_pre[kWords];
+    __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses];
+    __shared__ unsigned long long s_stats[3];
+    __shared__ uint64_t s_c0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint64_t base = (uint64_t)unit * AT;
+    for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
+    if (tid == 0) s_ocnt = 0;
+    if (tid < 3) s_stats[tid] = 0;
+    if (tid < (int)kStreamClasses) s_cls[tid] = 0;
+    // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
+    // last part), requested before the chain search waits for anything
+    const uint64_t i0 = base + (uint64_t)tid * KI;
+    rawdtw_anchor_t an[KI + 1];
+#pragma unroll
+    for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
+    if (tid < 64) {
+        const uint64_t c = find_chain(a.anchor_off, a.n_chains, base, lane);
+        if (tid == 0) s_c0 = c;
+    }
+    __syncthreads();
+    const uint64_t c0 = s_c0;
+    if (!mark_chain_starts<NT>(a, c0, base, AT, s_mask)) atomicAdd(&a.cnt[kCntUnsupported], 1ull);
+    {   // chain starts before each word of the mask: an exclusive scan over the mask's words, one word a thread
+        static_assert(kWords <= (uint32_t)NT, "one mask word a thread");
+        __shared__ uint32_t s_wsum[NT / 64];
+        const uint32_t pc = (uint32_t)tid < kWords ? __popc(s_mask[tid]) : 0u;
+        uint32_t incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int w = 0; w < (tid >> 6); w++) pre += s_wsum[w];
+        if ((uint32_t)tid < kWords) s_pre[tid] = pre + incl - pc;
+    }
+    __syncthreads();
+    // the chain of the anchor at position p of the unit: c0 + the chain starts in positions 1 .. p
+    auto chain_at = [&](uint32_t p) {
+        return c0 + (s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u));
+    };
+    {   // every tile's first chain
+        const uint32_t tiles_per_unit = AT / a.tile_anchors;
+        const uint64_t t = (uint64_t)unit * tiles_per_unit + (uint32_t)tid;
+        if ((uint32_t)tid < tiles_per_unit && t < a.n_tiles) a.tile_chain[t] = (uint32_t)chain_at((uint32_t)tid * a.tile_anchors);
+    }
+    uint32_t my_tiles = 0, my_bytes = 0;
+    unsigned long long my_obytes = 0;
+    uint32_t o_slot[KI], o_cls[KI];
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        o_cls[k] = 0xffffffffu; o_slot[k] = 0;
+        const uint32_t p = (uint32_t)tid * KI + k; // position in the unit
+        const uint64_t i = base + p;
+        if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
+        const Part pt = classify(a, an[k + 1], an[k]);
+        if (!pt.asc || pt.n >= 0x7fffffffu || pt.m >= 0x7fffffffu) { atomicMin(&a.cnt[kCntBad], (unsigned long long)i); continue; }
+        if (pt.tile) { my_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
+        // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
+        int r0 = (int)((float)pt.n * a.frac);
+        r0 = r0 > 1 ? r0 : 1;
+        const int R = d_slanted_radius(pt.n, pt.m, r0);
+        const uint32_t N = pt.n > pt.m ? pt.n : pt.m, K = (uint32_t)R + 1u;
+        uint32_t cls;
+        if (R >= 1 && R <= a.side_lane_radius && N <= a.lane_max_n) cls = kClsL0 + side_lane_bucket(N);
+        else if (K <= 8) cls = kClsM0 + side_lane_bucket(N);
+        else if (K <= 16) cls = kClsG16;
+        else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
+        else { atomicAdd(&a.cnt[kCntUnsupported], 1ull); continue; }
+        my_obytes += 4ull * ((unsigned long long)pt.n + pt.m) + 36ull;
+        o_cls[k] = cls | ((uint32_t)R << 8);
+        o_slot[k] = atomicAdd(&s_ocnt, 1u);
+        atomicAdd(&s_cls[cls], 1u);
+    }
+    {   // statistics: tile parts (<= KI a thread) and their bytes (< 2^13 a thread) through one wave reduction
+        unsigned long long packed = (unsigned long long)my_tiles | ((unsigned long long)my_bytes << 20);
+        for (int off = 32; off > 0; off >>= 1) packed += __shfl_down(packed, off);
+        if (lane == 0) { atomicAdd(&s_stats[0], packed & 0xfffffull); atomicAdd(&s_stats[1], packed >> 20); }
+        if (my_obytes) atomicAdd(&s_stats[2], my_obytes);
+    }
+    __syncthreads();
+    if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
+    if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
+    if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
+    __syncthreads();
+    if (s_ocnt) {
+        const uint64_t obase = s_obase;
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            if (o_cls[k] == 0xffffffffu) continue;
+            const uint64_t q = obase + o_slot[k];
+            if (q >= a.others_cap) continue; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
+            const uint32_t p = (uint32_t)tid * KI + k;
+            const uint64_t c = chain_at(p);
+            const rawdtw_anchor_t s = an[k + 1], e = an[k];
+            DevJob d;
+            d.ref_off = a.ref_base[c] + s.target_position;
+            d.read_off = a.read_base[c] + s.query_position;
+            d.n = e.query_position - s.query_position + 1;
+            d.m = e.target_position - s.target_position + 1;
+            d.R = (int32_t)(o_cls[k] >> 8);
+            d.flags = mask_bit(s_mask, p) ? 0u : kFlagExcludeLast; // rmap.cpp:270: every part but the chain's last (= its first entry)
+            d.aux = (uint32_t)(base + p);
+            a.omix[q] = d; a.ocls[q] = (uint8_t)(o_cls[k] & 0xffu);
+        }
+    }
+}
+
+// grid: [0, n_units) the scan units, n_units the fold order, the rest the chain records
+__global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+{
+    const uint32_t b = blockIdx.x, n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit);
+    if (b < n_units) scan_unit_body(a, b);
+    else if (b == n_units) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    else chain_desc_body(a, chains, (uint64_t)(b - n_units - 1) * kScanT + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_side: the side list in class order: wave-per-job classes first, longest first; then 16-lane groups, the lane classes
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSideGroups = 64;
+__global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
+{
+    constexpr int NT = 1024;
+    const uint32_t group = blockIdx.x;
+    // Each workgroup orders one contiguous slice of the unordered list: class counts of the slice in LDS, ONE returning
+    // atomic per class and workgroup for the slice's places (same-address atomics run near 88 per microsecond: a wave-level
+    // scheme spends the kernel there once the list has 10^5 entries), then the scatter through LDS cursors.
+    const uint64_t n_other = min<uint64_t>(a.cnt[kCntOthers], a.others_cap);
+    const uint64_t per = (n_other + kSideGroups - 1) / kSideGroups;
+    const uint64_t lo = min(n_other, (uint64_t)group * per), hi = min(n_other, lo + per);
+    if (lo >= hi) return;
+    __shared__ uint32_t s_n[kStreamClasses];
+    __shared__ uint64_t s_at[kStreamClasses];
+    if (threadIdx.x < kStreamClasses) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += NT) atomicAdd(&s_n[a.ocls[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kStreamClasses) {
+        uint64_t base = 0;
+        for (uint32_t c = 0; c < threadIdx.x; c++) base += a.cnt[kCntCls0 + c];
+        const uint32_t mine = s_n[threadIdx.x];
+        s_at[threadIdx.x] = base + (mine ? atomicAdd(&a.cnt[kCntCur0 + threadIdx.x], (unsigned long long)mine) : 0ull);
+        s_n[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += NT) {
+        const uint32_t cls = a.ocls[i];
+        const uint64_t pos = s_at[cls] + atomicAdd(&s_n[cls], 1u);
+        if (pos < a.others_cap) a.ojobs[pos] = a.omix[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_runs: the batch's one DTW launch
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
+
+// One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
+// first, then the others, both runs by longer side, descending; a wave takes the shortest body that covers its radii.
+__device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
+{
+    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u);
+    uint32_t n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)N); // lane 0 leads the wave's first run
+    if (r12) {                                                         // ... and the first lane of radius <= 2 the second
+        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)r12) - 1);
+        n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)N, l));
+    }
+    float res;
+    if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, M, n_max);
+    else if (~r12 == 0ull) res = lane_dp_r12(LA, LB, N, M, R, n_max);
+    else res = lane_dp_gen(LA, LB, N, M, R, n_max);
+    if (act && excl) res = res - dist(LA[N - 1], LB[M - 1]);
+    return res;
+}
+
+// 64 jobs of the side list's lane classes: one lane per job, operands straight from the arenas (the jobs of a wave come
+// from all over the batch: nothing to stage together)
+template <int SLOTS>
+__device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs, uint32_t count, uint32_t wave, int lane,
+                                                 const float *__restrict__ ev, const float *__restrict__ ref, float *__restrict__ out)
+{
+    const uint32_t idx = wave * 64u + (uint32_t)lane;
+    const bool have = idx < count;
+    const DevJob jb = jobs[have ? idx : count - 1u];
+    const float *A = ev + jb.read_off;
+    const float *B = ref + jb.ref_off;
+    uint32_t N = jb.n, M = jb.m;
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        const uint32_t tn = N; N = M; M = tn;
+    }
+    uint32_t n_max = N;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, d));
+    n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
+    float res = SLOTS == 4 ? lane_dp_gen<true>(A, B, N, M, (uint32_t)jb.R, n_max) : lane_dp_k8(A, B, N, M, jb.R, n_max);
+    if (have) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
+}
+
+// Tile queue: one returning atomic on a single word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md),
+// which a batch's ten thousand tiles would reach; eight heads on lines of their own, each dealing every eighth tile.
+// A workgroup starts on the head of its block index and moves on when a head runs dry.
+__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, uint32_t &head, uint32_t n_tiles)
+{
+    if (a.debug & 8u) { // timing experiments: tiles dealt by block index, no queue
+        const uint32_t t = head;
+        head += gridDim.x;
+        return t < n_tiles ? t : 0xffffffffu;
+    }
+    for (uint32_t tries = 0; tries < 8; tries++) {
+        const uint32_t h = (head + tries) & 7u;
+        const uint32_t k = (uint32_t)atomicAdd(&a.cnt[kCntHeads + 16 * h], 1ull);
+        const uint64_t t = (uint64_t)k * 8u + h;
+        if (t < n_tiles) { head = h; return (uint32_t)t; }
+    }
+    return 0xffffffffu;
+}
+
+// A tile's items in the order the image is laid out in: item u is the part that ends at anchor (tile end - 1 - u), so that
+// along a chain (stored end-first) u ascends with the positions -- a run's first part is the one with the lowest addresses,
+// and the scan that places the runs meets it first.
+//
+// Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive tile-class parts of a
+// chain (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every
+// part adds floats to the two regions' running sums: a run's first part its whole window plus 3 floats of slack, a
+// continuing part its window minus the shared first element, a run's last part 3 more (the run's END rounded up to a
+// 16-byte boundary never reaches the next run).  With c = the running sum BEFORE a run's first part the run starts at
+//     c + ((off - c) & 3)                 (off = the window's arena offset),
+// congruent to the arena offset modulo 4 -- 16-byte chunks of the image are 16-byte chunks of the arena -- and a part's
+// window starts at (its start anchor's position + D), D = the run's image start minus its first position.  So a tile is
+// staged by copying each run's chunk range, fully coalesced, and two runs never share a chunk.
+struct RunTab {
+    uint32_t lo[2][kStreamMaxSeg];    // first float of the run's first 16-byte chunk in the image [arena: 0 events, 1 reference]
+    uint32_t end[2][kStreamMaxSeg];   // the run's last position + 1 (query / target coordinates)
+    int32_t D[2][kStreamMaxSeg];      // image index = position + D
+    long long src[2][kStreamMaxSeg];  // arena index = image index + src (a multiple of 4)
+};
+
+} // namespace
+
+// TT threads per workgroup (256 or 512), KI = kStreamItems anchors a thread: tiles of AT = TT * KI anchors.
+//
+// Nothing a tile needs from memory is waited for at its start: while tile i is computed, tile i + 1's anchors and the
+// offsets and bases of its first chains come in by LDS-DMA (issued behind tile i's staging, landed before its last barrier),
+// wave 0 turns the offsets into the next tile's chain-start mask, and tile i + 2's number is being dequeued.
+//
+// A tile whose image does not fit the LDS budget (long parts: rare) takes several passes; a pass does everything from
+// the anchors again (they stay in LDS until the tile's last pass) and carries nothing over but its first item and the
+// three sums before it, so the common single-pass tile keeps no state alive across its DP.
+template <int TT>
+__global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
+{
+    constexpr int KI = (int)kStreamItems;
+    constexpr uint32_t AT = TT * KI, kWords = AT / 32 + 1, kWaves = TT / 64, kCT = 32;
+    static_assert(kWords <= 64, "one mask word a lane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *win = smem;                                                   // the tile's LDS image
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);           // one record per item
+    uint16_t *perm = reinterpret_cast<uint16_t *>(rec + AT);             // sorted order -> item
+    uint32_t *hist = reinterpret_cast<uint32_t *>(perm + AT);            // kSortBins
+    uint2 *anc = reinterpret_cast<uint2 *>(hist + kSortBins);            // AT + 2 anchors: the tile's, the entry behind its last, one of padding
+    __shared__ uint32_t s_mask[kWords], s_pre[kWords];
+    __shared__ uint32_t s_wtot[2][kWaves][3];  // the waves' scan totals, by parity
+    __shared__ RunTab s_run;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ct_off[2 * kCT]; // anchor_off[c0 .. c0 + kCT) as dword pairs
+    __shared__ __attribute__((aligned(16))) uint32_t s_ct_rb[2 * kCT];  // ref_base[c0 .. c0 + kCT)
+    __shared__ __attribute__((aligned(16))) uint32_t s_ct_qb[kCT];      // read_base[c0 .. c0 + kCT)
+    __shared__ uint32_t s_tile[2];
+    __shared__ uint32_t s_c0, s_more;          // the tile's first chain; chains beyond the table may start inside the tile
+    __shared__ uint32_t s_seq, s_njobs;
+    __shared__ uint32_t s_pass[8];             // [0] items that fit, [1..3] sums behind the pass, [4] runs, [5] the pass cuts a run
+    __shared__ uint32_t s_declined;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = (uint32_t)tid >> 6;
+
+    // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
+    // list: nothing to do here, and nothing may be derived from its anchors
+    if (tid == 0) s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
+    __syncthreads();
+    if (s_declined) return;
+
+    // ---- the side list: wave-cooperative jobs dealt over ALL waves of the grid, wave-per-job classes (longest first) to the
+    // first waves: a long job starts at once and runs next to the tiles instead of behind them ----
+    if (!(a.debug & 4u)) {
+        uint64_t n_w = 0;
+#pragma unroll
+        for (uint32_t c = kClsW0; c < kClsW0 + 4; c++) n_w += a.cnt[kCntCls0 + c];
+        const uint64_t n_g16 = a.cnt[kCntCls0 + kClsG16];
+        uint64_t n_l = 0, n_m = 0;
+#pragma unroll
+        for (uint32_t c = kClsL0; c < kClsL0 + kClsLCount; c++) n_l += a.cnt[kCntCls0 + c];
+#pragma unroll
+        for (uint32_t c = kClsM0; c < kClsM0 + kClsMCount; c++) n_m += a.cnt[kCntCls0 + c];
+        // item order = list order: wave-per-job (longest first), 16-lane groups, lane-per-job (4 slots, then 8; by length)
+        const uint64_t it_g16 = (n_g16 + 3) / 4, it_l = (n_l + 63) / 64, it_m = (n_m + 63) / 64, items = n_w + it_g16 + it_l + it_m;
+        // The waves that draw the long items (a wave-per-job or 16-lane item: 30..150 us) take the short ones as well, in
+        // further rounds: their workgroups start on tiles late anyway, and every other workgroup starts at once.
+        // (debug 2048: all waves of the grid share the items, one round.)
+        const uint32_t all_waves = gridDim.x * kWaves, widx = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wv);
+        const uint32_t side_waves = (a.debug & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
+        const uint32_t n_items = (uint32_t)min<uint64_t>(items, 0xffffffffull);
+        // dealt like a snake: the wave that drew the longest item of a round draws the shortest of the next
+        // (item r * S + w in even rounds, r * S + S - 1 - w in odd ones: the stride alternates between 2S - 1 - 2w and 1 + 2w)
+        for (uint32_t it = widx < side_waves ? widx : n_items, step = (a.debug & 4096u) ? side_waves : 2u * side_waves - 1u - 2u * widx; it < n_items;
+             it += step, step = 2u * side_waves - step) {
+            if (it < n_w) {
+                if (a.debug & 32u) continue;
+                // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its
+                // SIMD with the waves around it -- it goes first in the issue order
+                const DevJob jb = a.ojobs[it];
+                const uint32_t len = max(jb.n, jb.m);
+                if (len >= 256u) __builtin_amdgcn_s_setprio(3);
+                else if (len >= 96u) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(1);
+                wreg_small_job(jb, lane, a.ev, a.ref, a.out);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            else if (a.debug & 64u) continue;
+            else if (it < n_w + it_g16) grp_wave<16>(a.ojobs + n_w, (uint32_t)n_g16, (uint32_t)(it - n_w), lane, a.ev, a.ref, a.out);
+            else if (it < n_w + it_g16 + it_l) lane_global_wave<4>(a.ojobs + n_w + n_g16, (uint32_t)n_l, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
+            else lane_global_wave<8>(a.ojobs + n_w + n_g16 + n_l, (uint32_t)n_m, (uint32_t)(it - n_w - it_g16 - it_l), lane, a.ev, a.ref, a.out);
+        }
+    }
+
+    // LDS-DMA: one wave instruction moves 16 (or 4) bytes a lane straight into LDS at `dst` + 16 (4) * lane; inactive lanes
+    // move nothing.  `dst` must be the same in every lane.
+    auto dma16 = [](const void *src, void *dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto dma4 = [](const void *src, void *dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+    };
+    // a tile's anchors (all waves: AT + 2 entries in 16-byte pieces; the list is readable up to an even number of entries)
+    // and, by wave 0, the table of its first kCT chains: offsets and bases
+    auto fetch_tile = [&](const uint32_t tile, const uint32_t c0) {
+        const uint64_t base = (uint64_t)tile * AT;
+        const uint32_t pieces = (AT + 2u) / 2u; // (AT is even)
+        for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
+            if (q0 + (uint32_t)lane < pieces && base + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
+                dma16(a.anchors + base + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
+        if (wv == 0) {
+            const uint64_t c = (uint64_t)c0 + ((uint32_t)lane >> 1);
+            if (c <= a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.anchor_off + c0) + lane, s_ct_off);
+            if (c < a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.ref_base + c0) + lane, s_ct_rb);
+            if ((uint32_t)lane < kCT && (uint64_t)c0 + (uint32_t)lane < a.n_chains) dma4(a.read_base + c0 + lane, s_ct_qb);
+        }
+    };
+    // wave 0, its DMA landed: the tile's chain-start mask from the table, the chain starts before each word of it
+    auto mark_tile = [&](const uint32_t tile, const uint32_t c0) {
+        const uint64_t base = (uint64_t)tile * AT;
+        if ((uint32_t)lane < kWords) s_mask[lane] = 0;
+        uint64_t s = ~0ull;
+        if ((uint32_t)lane < kCT && (uint64_t)c0 + (uint32_t)lane <= a.n_chains) {
+            s = (uint64_t)s_ct_off[2 * lane] | ((uint64_t)s_ct_off[2 * lane + 1] << 32);
+            if (s >= base && s <= base + AT) atomicOr(&s_mask[(uint32_t)(s - base) >> 5], 1u << ((uint32_t)(s - base) & 31u));
+        }
+        // chains beyond the table that may start inside the tile: the table's last entry is a chain start before the tile's end
+        const bool more = (uint32_t)lane == kCT - 1u && (uint64_t)c0 + kCT - 1u < a.n_chains && s < base + AT;
+        const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
+        uint32_t incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
+        const bool any_more = __any(more);
+        if (lane == 0) { s_c0 = c0; s_more = any_more ? 1u : 0u; }
+    };
+
+    // ---- tiles, pulled from the queue two ahead ----
+    const uint32_t n_tiles = a.n_tiles;
+    // thread 0's queue state: `head`, the resolved number of the next tile, the raw ticket of the one after it
+    uint32_t head = (a.debug & 8u) ? blockIdx.x : (blockIdx.x & 7u), t_next = 0xffffffffu;
+    unsigned long long ticket = 0;
+    if (tid == 0) {
+        const uint32_t t0 = next_tile(a, head, n_tiles);
+        t_next = t0 != 0xffffffffu ? next_tile(a, head, n_tiles) : 0xffffffffu;
+        s_tile[0] = t0;
+    }
+    for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
+    __syncthreads();
+    if (s_tile[0] == 0xffffffffu) return;
+    {   // the first tile's anchors and chains: nobody to fetch them ahead
+        const uint32_t t0 = s_tile[0], c0 = a.tile_chain[t0];
+        fetch_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (wv == 0) mark_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
+        __syncthreads();
+    }
+    uint32_t slot = 0, parity = 0;
+    const uint32_t budget = lds_floats & ~3u;
+    for (uint32_t tile = s_tile[0]; tile != 0xffffffffu; tile = s_tile[slot]) {
+        const uint64_t base = (uint64_t)tile * AT, end_nom = base + AT;
+        const uint32_t c0 = s_c0;
+        // thread 0: the next tile's number is published before the first barrier; the ticket of the one after it is drawn
+        // now and looked at when this tile is done
+        if (tid == 0) {
+            s_tile[slot ^ 1u] = t_next;
+            if (t_next != 0xffffffffu && !(a.debug & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+        }
+        if (s_more) { // (tiles of very short chains: the rest of the chain starts from memory)
+            (void)mark_chain_starts<TT>(a, (uint64_t)c0 + kCT, base, AT, s_mask);
+            if (wv == 0) {
+                const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
+                uint32_t incl = pc;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += o;
+                }
+                if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
+            }
+            __syncthreads();
+        }
+        uint32_t c0n = 0; // wave 0: the next tile's first chain (requested in the first pass, used behind its staging)
+        uint32_t u0 = 0, b0[3] = {0u, 0u, 0u}; // the pass's first item and the sums before it
+        for (uint32_t pass = 0;; pass++) {
+            // ---- 1. every item's part: windows, radius, class; the runs; the wave's share of the layout scan.  Item
+            // u = tid * KI + k ends at anchor end_nom - 1 - u (tile position AT - 1 - u) and starts at the entry behind it ----
+            rawdtw_anchor_t E[KI], S0;
+            {
+                const uint32_t p_hi = AT - 1u - (uint32_t)tid * KI; // the first item's position; its start: p_hi + 1
+                const uint2 x = anc[p_hi + 1u];
+                S0 = rawdtw_anchor_t{x.x, x.y};
+#pragma unroll
+                for (int k = 0; k < KI; k++) { const uint2 y = anc[p_hi - k]; E[k] = rawdtw_anchor_t{y.x, y.y}; }
+            }
+            uint32_t meta[KI];    // N | M << 7 | R << 14 | excl << 16 | swap << 17 | starts << 18 | ends << 19 | tile << 20
+            uint32_t ssum[KI][3]; // inclusive sums over the workgroup's items: event floats, reference floats, run starts
+            {
+                bool tl[KI];
+                Part pt[KI];
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
+                    const bool exists = base + p < a.n_anchors && !mask_bit(s_mask, p + 1);
+                    pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
+                    tl[k] = exists && pt[k].tile;
+                }
+                // a run continues from the item before (same thread, or the lane below) when both are tile parts: the item before
+                // u ends where u starts, and both existing puts them in one chain.  Runs break at wave boundaries (lane 0's
+                // first item starts one, lane 63's last ends one): four breaks a tile, and no run crosses waves.
+                const int t_first = tl[0] ? 1 : 0, t_last = tl[KI - 1] ? 1 : 0;
+                const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
+                const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
+                uint32_t run[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
+                    const bool prev_t = k ? tl[k - 1] : below, next_t = k + 1 < KI ? tl[k + 1 < KI ? k + 1 : k] : above;
+                    const bool starts = tl[k] && !prev_t, ends = tl[k] && !next_t;
+                    const uint32_t n = pt[k].n, m = pt[k].m, N = n > m ? n : m, M = n > m ? m : n;
+                    meta[k] = !tl[k] ? 0u : (N | (M << 7) | ((uint32_t)pt[k].R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((n < m ? 1u : 0u) << 17) |
+                                             ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19) | (1u << 20));
+                    if (tl[k]) {
+                        run[0] += (starts ? n + 3u : n - 1u) + (ends ? 3u : 0u);
+                        run[1] += (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u);
+                        run[2] += starts ? 1u : 0u;
+                    }
+                    ssum[k][0] = run[0]; ssum[k][1] = run[1]; ssum[k][2] = run[2];
+                }
+                // wave scan of the threads' totals
+                uint32_t inc[3] = {run[0], run[1], run[2]};
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const uint32_t o = (uint32_t)__shfl_up((int)inc[q], d);
+                        if (lane >= d) inc[q] += o;
+                    }
+                }
+                if (lane == 63) { s_wtot[parity][wv][0] = inc[0]; s_wtot[parity][wv][1] = inc[1]; s_wtot[parity][wv][2] = inc[2]; }
+#pragma unroll
+                for (int k = 0; k < KI; k++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) ssum[k][q] += inc[q] - run[q];
+            }
+            __syncthreads(); // B1: wave totals (and the next tile's number)
+            const uint32_t tile_n = s_tile[slot ^ 1u];
+            if (pass == 0 && wv == 0 && tile_n != 0xffffffffu) c0n = a.tile_chain[tile_n];
+            uint32_t tot[3] = {0u, 0u, 0u};
+            {
+                uint32_t pre[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (uint32_t w = 0; w < kWaves; w++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const uint32_t x = s_wtot[parity][w][q];
+                        if (w < wv) pre[q] += x;
+                        tot[q] += x;
+                    }
+#pragma unroll
+                for (int k = 0; k < KI; k++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) ssum[k][q] += pre[q];
+            }
+            parity ^= 1u;
+            // ---- the pass: all of the tile when its image fits the LDS budget and its runs the table (the rule) ----
+            const bool single = pass == 0 && ((tot[0] + 3u) & ~3u) + ((tot[1] + 3u) & ~3u) <= budget && tot[2] <= kStreamMaxSeg;
+            uint32_t u1 = AT, region = (tot[0] + 3u) & ~3u, n_runs = tot[2];
+            bool cut_run = false; // the pass's first item continues a run of the pass before: it starts one here
+            if (!single) {
+                // the items that fit: from u0 on, while the image of the parts so far stays inside the budget and their runs in
+                // the table (sums relative to the pass's start; + 4 + 4 floats and one run when the first item continues a run)
+                if (tid == 0) s_pass[0] = 0;
+                __syncthreads();
+                uint32_t fits = 0;
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = (uint32_t)tid * KI + k;
+                    if (u >= u0 && ((ssum[k][0] - b0[0] + 7u) & ~3u) + ((ssum[k][1] - b0[1] + 7u) & ~3u) <= budget && ssum[k][2] - b0[2] + 1u <= kStreamMaxSeg) fits++;
+                }
+                for (int off = 32; off > 0; off >>= 1) fits += (uint32_t)__shfl_down((int)fits, off);
+                if (lane == 0 && fits) atomicAdd(&s_pass[0], fits);
+                __syncthreads();
+                u1 = min(u0 + s_pass[0], AT);
+                if (u1 <= u0) { if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); u1 = AT; } // (cannot happen: one part always fits)
+                // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = (uint32_t)tid * KI + k;
+                    if (u == u1 - 1u) { s_pass[1] = ssum[k][0]; s_pass[2] = ssum[k][1]; s_pass[3] = ssum[k][2]; }
+                    if (u == u0) s_pass[5] = ((meta[k] >> 20) & 1u) && !((meta[k] >> 18) & 1u) ? 1u : 0u;
+                }
+                __syncthreads();
+                cut_run = s_pass[5] != 0u;
+                region = (s_pass[1] - b0[0] + (cut_run ? 4u : 0u) + 3u) & ~3u;
+                n_runs = s_pass[3] - b0[2] + (cut_run ? 1u : 0u);
+            }
+            const bool last = u1 >= AT;
+            // ---- 2. runs into the table, the sort's histogram ----
+            uint32_t bin[KI], rank[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                bin[k] = 0xffffffffu; rank[k] = 0;
+                const uint32_t u = (uint32_t)tid * KI + k;
+                if (!((meta[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
+                const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
+                const bool swap = (meta[k] >> 17) & 1u;
+                const uint32_t n = swap ? M : N, m = swap ? N : M;
+                const bool starts = ((meta[k] >> 18) & 1u) || u == u0, ends = ((meta[k] >> 19) & 1u) || u == u1 - 1u;
+                bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
+                rank[k] = atomicAdd(&hist[bin[k]], 1u);
+                const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
+                const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
+                const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
+                if (starts) {
+                    // the run's chain: c0 + the chain starts in tile positions 1 .. p (p: this item's anchor); its bases from the
+                    // table of the tile's first chains, or from memory beyond it
+                    const uint32_t p = AT - 1u - u;
+                    const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
+                    uint64_t rb;
+                    uint32_t qb;
+                    if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
+                    else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
+                    // sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
+                    const uint32_t own_r = ((meta[k] >> 18) & 1u ? n + 3u : n - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
+                    const uint32_t own_f = ((meta[k] >> 18) & 1u ? m + 3u : m - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
+                    const uint32_t c_r = ssum[k][0] - own_r - b0[0] + 4u * adj, c_f = ssum[k][1] - own_f - b0[1] + 4u * adj;
+                    const uint32_t off_r = qb + s.query_position;
+                    const uint64_t off_f = rb + s.target_position;
+                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
+                    s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
+                    s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
+                    s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
+                }
+                if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
+            }
+            if (tid == 0) s_seq = 0;
+            __syncthreads(); // B2: run table, histogram
+            // ---- 3. every wave: the bins' first places (three a lane, fetched across lanes), its items' places in the sorted
+            // order and their records; then its share of the staging ----
+            {
+                const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
+                const uint32_t sum = h0 + h1 + h2;
+                uint32_t incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += o;
+                }
+                const uint32_t ex0 = incl - sum, ex1 = ex0 + h0, ex2 = ex1 + h1;
+                if (tid == 63) s_njobs = incl;
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t b = bin[k] == 0xffffffffu ? 0u : bin[k], src = (b * 171u) >> 9, sl = b - 3u * src; // b / 3, b % 3
+                    const uint32_t v0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex0);
+                    const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex1);
+                    const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex2);
+                    if (bin[k] == 0xffffffffu) continue;
+                    const uint32_t u = (uint32_t)tid * KI + k;
+                    perm[(sl == 0u ? v0 : sl == 1u ? v1 : v2) + rank[k]] = (uint16_t)u;
+                    const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u;
+                    const rawdtw_anchor_t s = k ? E[k - 1] : S0;
+                    const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
+                    const bool swap = (meta[k] >> 17) & 1u;
+                    rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
+                }
+                if (!(a.debug & 2u)) {
+                    __builtin_amdgcn_s_setprio(2); // a fresh tile's loads must not queue behind the DP of the older workgroups
+                    // a run's chunk range, 16 bytes a lane, consecutive lanes consecutive chunks; nothing waits between a
+                    // wave's pieces: all of them are in flight at once
+                    for (uint32_t it = wv; it < 2u * n_runs; it += kWaves) {
+                        const uint32_t w = it & 1u, g = it >> 1;
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_run.lo[w][g] >> 2));
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((s_run.end[w][g] + (uint32_t)s_run.D[w][g] + 3u) >> 2));
+                        const float4 *src = reinterpret_cast<const float4 *>((w ? a.ref : a.ev) + s_run.src[w][g]);
+                        for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
+                            if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the barrier below covers the others')
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            __syncthreads(); // B3: image staged, sorted order and records written; the anchors are in registers or done with
+            for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0; // (for the next pass; nobody reads it any more)
+            // the next tile's anchors and chain table: on their way while this tile's DP runs
+            if (last && tile_n != 0xffffffffu) fetch_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
+            const uint32_t n_jobs = s_njobs;
+            // ---- 4. the DP: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
+            // workgroup finish together whatever the mix ----
+            while (!(a.debug & 1u)) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&s_seq, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c * 64u >= n_jobs) break;
+                const uint32_t r = c * 64u + lane;
+                const bool act = r < n_jobs;
+                const uint32_t u = min((uint32_t)perm[act ? r : n_jobs - 1], AT - 1u);
+                const uint2 rc = rec[u];
+                const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
+                const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
+                if (act) rec[u].x = __float_as_uint(res); // (the job's record is done with; its slot carries the result out)
+            }
+            __syncthreads(); // B4
+            // results out in item order: consecutive lanes, consecutive (descending) addresses
+            if (!(a.debug & 1u)) {
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = (uint32_t)tid * KI + k;
+                    if (bin[k] != 0xffffffffu) a.out[end_nom - 1 - u] = __uint_as_float(rec[u].x);
+                }
+            }
+            if (last) break;
+            u0 = u1; b0[0] = s_pass[1]; b0[1] = s_pass[2]; b0[2] = s_pass[3];
+            __syncthreads(); // (the pass's records and s_pass are read; the next pass rewrites them)
+        }
+        // the next tile: its anchors and table have landed (every wave waits for its own pieces), wave 0 builds its mask
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (wv == 0 && s_tile[slot ^ 1u] != 0xffffffffu) mark_tile(s_tile[slot ^ 1u], (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
+        if (tid == 0 && t_next != 0xffffffffu) { // the ticket into the number of the tile after the next
+            if (a.debug & 8u) t_next = next_tile(a, head, n_tiles);
+            else {
+                const unsigned long long t = ticket * 8ull + head;
+                t_next = t < n_tiles ? (uint32_t)t : next_tile(a, head, n_tiles); // (this head is dry: try the others)
+            }
+        }
+        slot ^= 1u;
+        __syncthreads();
+    }
+}
+
+// cells of a batch (reporting only; the walk costs as much as scoring the jobs): every part from its two anchors, plus the
+// statistics of the tiles
+__global__ __launch_bounds__(kT) void k_stream_cells(const StreamArgs a, unsigned long long *__restrict__ total)
+{
+    // thread = anchor index i; the part ending there exists iff anchor i + 1 belongs to the same chain: one 64-way search per
+    // wave for its first anchor's chain, then a walk along the offsets
+    const uint64_t i = (uint64_t)blockIdx.x * kT + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t i_w = i - lane;
+    unsigned long long cells = 0;
+    if (i_w < a.n_anchors) {
+        uint64_t c = find_chain(a.anchor_off, a.n_chains, i_w, lane);
+        if (i < a.n_anchors) {
+            while (a.anchor_off[c + 1] <= i) c++;
+            if (i + 1 < a.anchor_off[c + 1]) {
+                const rawdtw_anchor_t s = a.anchors[i + 1], e = a.anchors[i];
+                const Part pt = classify(a, s, e);
+                if (pt.asc) {
+                    int r0 = (int)((float)pt.n * a.frac);
+                    r0 = r0 > 1 ? r0 : 1;
+                    cells = d_banded_cells(pt.n, pt.m, d_slanted_radius(pt.n, pt.m, r0));
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) cells += __shfl_down(cells, off);
+    __shared__ unsigned long long s_c[kT / 64];
+    if (lane == 0) s_c[threadIdx.x >> 6] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kT / 64; w++) t += s_c[w];
+        if (t) atomicAdd(total, t);
+    }
+}
+
+// the tiles' statistics summed into the counter block (reporting only)
+__global__ __launch_bounds__(1024) void k_stream_stats(const StreamArgs a)
+{
+    unsigned long long t[3] = {0, 0, 0};
+    const uint64_t n_units = (a.n_anchors + kScanUnit - 1) / kScanUnit;
+    for (uint64_t u = threadIdx.x; u < n_units; u += 1024)
+        for (int q = 0; q < 3; q++) t[q] += a.tile_stats[3 * u + q];
+    __shared__ unsigned long long s_t[3];
+    if (threadIdx.x < 3) s_t[threadIdx.x] = 0;
+    __syncthreads();
+    for (int q = 0; q < 3; q++) {
+        for (int off = 32; off > 0; off >>= 1) t[q] += __shfl_down(t[q], off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_t[q], t[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { a.cnt[kCntTileJobs] = s_t[0]; a.cnt[kCntTileBytes] = s_t[1]; a.cnt[kCntOtherBytes] = s_t[2]; }
+}
+
+// scatter of the round's new events into the per-read event arrays (rawdtw_events_append): segment s copies
+// src[seg_src[s] .. seg_src[s + 1]) to dst[seg_dst[s] ..]
+__global__ __launch_bounds__(kT) void k_events_scatter(const float *__restrict__ src, float *__restrict__ dst,
+                                                       const uint64_t *__restrict__ seg_src, const uint32_t *__restrict__ seg_dst,
+                                                       uint32_t n_seg)
+{
+    // one wave per segment and step: segments are a chunk's worth of events (hundreds of floats)
+    const uint32_t wave = (blockIdx.x * kT + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = gridDim.x * (kT / 64);
+    for (uint32_t s = wave; s < n_seg; s += n_waves) {
+        const uint64_t b = seg_src[s], e = seg_src[s + 1];
+        const uint32_t d = seg_dst[s];
+        for (uint64_t k = b + lane; k < e; k += 64) dst[d + (k - b)] = src[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host-callable drivers
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
+} // namespace
+
+static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
+{
+    const uint32_t at = (uint32_t)threads * kStreamItems;
+    return lds_floats * 4u + at * 8u + at * 2u + kSortBins * 4u + (at + 2u) * 8u; // image, records, sorted order, histogram, anchors
+}
+
+// everything rawdtw_batch_create enqueues for a sparse + banded batch: the scan of the anchor list (side list, checks,
+// the tiles' first chains), the fold's chain records and order, the side list's class order
+hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s)
+{
+    (void)hipGetLastError();
+    if (a.n_anchors == 0 && a.n_chains == 0) return hipSuccess;
+    const uint32_t n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit);
+    const uint32_t grid = n_units + 1u + (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
+    hipLaunchKernelGGL(k_scan, dim3(grid), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// reset_queue: the batch has run before (the tile queue's heads start at zero with the counters' initial values)
+hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipError_t e = reset_queue ? hipMemsetAsync(&a.cnt[kCntHeads], 0, 8 * 16 * sizeof(unsigned long long), s) : hipSuccess;
+    if (e != hipSuccess) return e;
+    const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512>) : reinterpret_cast<const void *>(k_runs<256>);
+    if (lds_bytes > 64 * 1024) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    if (threads == 512) hipLaunchKernelGGL(k_runs<512>, dim3(blocks), dim3(512), lds_bytes, s, a, lds_floats);
+    else hipLaunchKernelGGL(k_runs<256>, dim3(blocks), dim3(256), lds_bytes, s, a, lds_floats);
+    return hipGetLastError();
+}
+
+// workgroups of k_runs one compute unit holds at this LDS size (for the persistent grid)
+int stream_blocks_per_cu(uint32_t lds_floats, int threads)
+{
+    int n = 0;
+    const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512>) : reinterpret_cast<const void *>(k_runs<256>);
+    if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds_bytes) != hipSuccess) return 0;
+    return n;
+}
+
+hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || a.n_anchors == 0) return e;
+    hipLaunchKernelGGL(k_stream_cells, dim3(blocks_for(a.n_anchors)), dim3(kT), 0, s, a, d_total);
+    return hipGetLastError();
+}
+
+hipError_t stream_sum_stats(const StreamArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stream_stats, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_events_scatter(const float *d_src, float *d_dst, const uint64_t *d_seg_src, const uint32_t *d_seg_dst,
+                                 uint32_t n_seg, hipStream_t s)
+{
+    if (n_seg == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n_seg * 64 + kT - 1) / kT, 4096);
+    hipLaunchKernelGGL(k_events_scatter, dim3(blocks), dim3(kT), 0, s, d_src, d_dst, d_seg_src, d_seg_dst, n_seg);
+    return hipGetLastError();
+}
+
+} // namespace rawdtw

@@ -39,7 +39,7 @@ for cfg in configs:
     ncnt = C.c_uint32()
     eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 32, C.byref(ncnt))
     if cfg == configs[0]:
-        print("counters: tile jobs %d  tiles %d  side list %d  classes %s" % (cnt[3], cnt[7], cnt[6], list(cnt[9:30])), flush=True)
+        print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
                                                                    ["%.4f" % m[2] for m in ms]), flush=True)
     b.close()
