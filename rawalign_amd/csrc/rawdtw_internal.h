@@ -127,10 +127,11 @@ enum StreamCounter : int {
     kCntCur0 = kCntCls0 + 21, // kStreamClasses scatter cursors
     kCntCells = kCntCur0 + 21,
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
+    kCntStamp0,         // 14 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
-static_assert(kCntOtherBytes < kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
+static_assert(kCntStamp0 + 14 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
     uint64_t n_anchors, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac

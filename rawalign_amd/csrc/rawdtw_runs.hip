@@ -122,6 +122,21 @@ __device__ __forceinline__ uint64_t find_chain(const uint64_t *__restrict__ anch
     return lo;
 }
 
+// Inclusive scan of one value per lane over the wave by DPP: shifts inside the rows of 16 lanes, then the rows' last lanes
+// broadcast into the rows behind them (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six dependent
+// VALU steps of a few cycles each; through __shfl_up the same scan is six round trips through the LDS crossbar
+// (ds_bpermute, ~70 cycles a step), and a tile has four such scans on its critical path.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 // bit p of a tile's chain-start mask: anchor (tile base + p) is the first entry of a chain (bit AT may be set as well:
 // the anchor behind the tile's last; the end of the anchor list counts as a chain start)
 __device__ __forceinline__ bool mask_bit(const uint32_t *mask, uint32_t p) { return (mask[p >> 5] >> (p & 31u)) & 1u; }
@@ -355,13 +370,14 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
 }
 
-// grid: [0, n_units) the scan units, n_units the fold order, the rest the chain records
+// grid: workgroup 0 the fold order (one workgroup's latency chain, ~30 us: dispatched first, it runs beside everything
+// else instead of behind it), then the chain records, then the scan units
 __global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
-    const uint32_t b = blockIdx.x, n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit);
-    if (b < n_units) scan_unit_body(a, b);
-    else if (b == n_units) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
-    else chain_desc_body(a, chains, (uint64_t)(b - n_units - 1) * kScanT + threadIdx.x);
+    const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
+    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
+    else scan_unit_body(a, b - 1 - n_desc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -405,6 +421,7 @@ __global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t kStamps = 14;
 constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
 
 // One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
@@ -455,9 +472,9 @@ __device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs
 // Tile queue: one returning atomic on a single word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md),
 // which a batch's ten thousand tiles would reach; eight heads on lines of their own, each dealing every eighth tile.
 // A workgroup starts on the head of its block index and moves on when a head runs dry.
-__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, uint32_t &head, uint32_t n_tiles)
+__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_t dbg, uint32_t &head, uint32_t n_tiles)
 {
-    if (a.debug & 8u) { // timing experiments: tiles dealt by block index, no queue
+    if (dbg & 8u) { // timing experiments: tiles dealt by block index, no queue
         const uint32_t t = head;
         head += gridDim.x;
         return t < n_tiles ? t : 0xffffffffu;
@@ -502,9 +519,16 @@ struct RunTab {
 // A tile whose image does not fit the LDS budget (long parts: rare) takes several passes; a pass does everything from
 // the anchors again (they stay in LDS until the tile's last pass) and carries nothing over but its first item and the
 // three sums before it, so the common single-pass tile keeps no state alive across its DP.
-template <int TT>
-__global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
+// Registers: 4 waves a SIMD = 128 VGPRs.  Four workgroups a CU (the LDS allows no more) are four waves a SIMD anyway; at
+// 96 registers the tile loop's uniform state no longer fits the scalar file, its overflow takes vector registers, and
+// those spill to scratch: 60 scratch loads a thread and tile (measured: launch alone 0.190 -> 0.177 ms, pipeline 533 ->
+// 554 GCUPS with 128).
+// DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
+// carries neither.
+template <int TT, bool DIAG>
+__global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
 {
+    const uint32_t dbg = DIAG ? dbg : 0u;
     constexpr int KI = (int)kStreamItems;
     constexpr uint32_t AT = TT * KI, kWords = AT / 32 + 1, kWaves = TT / 64, kCT = 32;
     static_assert(kWords <= 64, "one mask word a lane");
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
 
     // ---- the side list: wave-cooperative jobs dealt over ALL waves of the grid, wave-per-job classes (longest first) to the
     // first waves: a long job starts at once and runs next to the tiles instead of behind them ----
-    if (!(a.debug & 4u)) {
+    if (!(dbg & 4u)) {
         uint64_t n_w = 0;
 #pragma unroll
         for (uint32_t c = kClsW0; c < kClsW0 + 4; c++) n_w += a.cnt[kCntCls0 + c];
@@ -552,14 +576,14 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
         // further rounds: their workgroups start on tiles late anyway, and every other workgroup starts at once.
         // (debug 2048: all waves of the grid share the items, one round.)
         const uint32_t all_waves = gridDim.x * kWaves, widx = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wv);
-        const uint32_t side_waves = (a.debug & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
+        const uint32_t side_waves = (dbg & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
         const uint32_t n_items = (uint32_t)min<uint64_t>(items, 0xffffffffull);
         // dealt like a snake: the wave that drew the longest item of a round draws the shortest of the next
         // (item r * S + w in even rounds, r * S + S - 1 - w in odd ones: the stride alternates between 2S - 1 - 2w and 1 + 2w)
-        for (uint32_t it = widx < side_waves ? widx : n_items, step = (a.debug & 4096u) ? side_waves : 2u * side_waves - 1u - 2u * widx; it < n_items;
+        for (uint32_t it = widx < side_waves ? widx : n_items, step = (dbg & 4096u) ? side_waves : 2u * side_waves - 1u - 2u * widx; it < n_items;
              it += step, step = 2u * side_waves - step) {
             if (it < n_w) {
-                if (a.debug & 32u) continue;
+                if (dbg & 32u) continue;
                 // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its
                 // SIMD with the waves around it -- it goes first in the issue order
                 const DevJob jb = a.ojobs[it];
@@ -570,7 +594,7 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
                 wreg_small_job(jb, lane, a.ev, a.ref, a.out);
                 __builtin_amdgcn_s_setprio(0);
             }
-            else if (a.debug & 64u) continue;
+            else if (dbg & 64u) continue;
             else if (it < n_w + it_g16) grp_wave<16>(a.ojobs + n_w, (uint32_t)n_g16, (uint32_t)(it - n_w), lane, a.ev, a.ref, a.out);
             else if (it < n_w + it_g16 + it_l) lane_global_wave<4>(a.ojobs + n_w + n_g16, (uint32_t)n_l, (uint32_t)(it - n_w - it_g16), lane, a.ev, a.ref, a.out);
             else lane_global_wave<8>(a.ojobs + n_w + n_g16 + n_l, (uint32_t)n_m, (uint32_t)(it - n_w - it_g16 - it_l), lane, a.ev, a.ref, a.out);
@@ -612,25 +636,35 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
         // chains beyond the table that may start inside the tile: the table's last entry is a chain start before the tile's end
         const bool more = (uint32_t)lane == kCT - 1u && (uint64_t)c0 + kCT - 1u < a.n_chains && s < base + AT;
         const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
-        uint32_t incl = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += o;
-        }
+        const uint32_t incl = wave_scan_incl(pc);
         if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
         const bool any_more = __any(more);
         if (lane == 0) { s_c0 = c0; s_more = any_more ? 1u : 0u; }
     };
 
+    // diagnostic build of the launch ("stream_debug" 256): where a wave's cycles go, phase by phase (s_memtime around the
+    // phases, summed per wave in LDS and added to the counter block's words kCntStamp0.. at the end; it perturbs the run)
+    __shared__ unsigned long long s_stamp[kWaves][kStamps];
+    unsigned long long t_prev = 0;
+    const bool stamps = DIAG && (dbg & 256u) != 0u;
+    if (stamps) {
+        if (lane < (int)kStamps) s_stamp[wv][lane] = 0;
+        t_prev = __builtin_amdgcn_s_memtime();
+    }
+    auto stamp = [&](const int ph) {
+        if (!stamps) return;
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) s_stamp[wv][ph] += t - t_prev;
+        t_prev = t;
+    };
     // ---- tiles, pulled from the queue two ahead ----
     const uint32_t n_tiles = a.n_tiles;
     // thread 0's queue state: `head`, the resolved number of the next tile, the raw ticket of the one after it
-    uint32_t head = (a.debug & 8u) ? blockIdx.x : (blockIdx.x & 7u), t_next = 0xffffffffu;
+    uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), t_next = 0xffffffffu;
     unsigned long long ticket = 0;
     if (tid == 0) {
-        const uint32_t t0 = next_tile(a, head, n_tiles);
-        t_next = t0 != 0xffffffffu ? next_tile(a, head, n_tiles) : 0xffffffffu;
+        const uint32_t t0 = next_tile(a, dbg, head, n_tiles);
+        t_next = t0 != 0xffffffffu ? next_tile(a, dbg, head, n_tiles) : 0xffffffffu;
         s_tile[0] = t0;
     }
     for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
@@ -645,119 +679,260 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
     }
     uint32_t slot = 0, parity = 0;
     const uint32_t budget = lds_floats & ~3u;
+    // wave 0: the first chain of the next tile (for its chain table), requested a tile ahead
+    uint32_t c0n = 0;
+    if (wv == 0) {
+        const uint32_t tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
+        if (tn != 0xffffffffu) c0n = a.tile_chain[tn];
+    }
+    // the results of the tile before: they stay in the records until every wave is past this tile's first barrier (= done
+    // with that tile's DP) and leave in item order from there -- no barrier of their own, and a wave that finishes its share
+    // of a tile's DP early starts on the next tile at once
+    uint32_t pend_bits = 0, pend_end = 0; // items of this thread with a result pending; the anchor behind that tile's last
+    auto flush = [&]() {
+        if (!pend_bits || (dbg & 1u)) { pend_bits = 0; return; }
+#pragma unroll
+        for (int k = 0; k < KI; k++)
+            if ((pend_bits >> k) & 1u) { const uint32_t u = (uint32_t)tid * KI + k; a.out[pend_end - 1u - u] = __uint_as_float(rec[u].x); }
+        pend_bits = 0;
+    };
+    // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
+    // workgroup finish together whatever the mix
+    auto run_dp = [&]() {
+        const uint32_t n_jobs = s_njobs;
+        while (!(dbg & 1u)) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(&s_seq, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c * 64u >= n_jobs) break;
+            const uint32_t r = c * 64u + lane;
+            const bool act = r < n_jobs;
+            const uint32_t u = min((uint32_t)perm[act ? r : n_jobs - 1], AT - 1u);
+            const uint2 rc = rec[u];
+            const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
+            const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
+            if (act) rec[u].x = __float_as_uint(res); // (the job's record is done with; its slot carries the result out)
+        }
+    };
+    // every wave: the bins' first places (three a lane, fetched across lanes) -> each item's place in the sorted order
+    auto sorted_place = [&](const uint32_t (&bin)[KI], const uint32_t (&rank)[KI], uint32_t (&place)[KI]) {
+        const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
+        const uint32_t sum = h0 + h1 + h2;
+        const uint32_t incl = wave_scan_incl(sum);
+        const uint32_t ex0 = incl - sum, ex1 = ex0 + h0, ex2 = ex1 + h1;
+        if (tid == 63) s_njobs = incl;
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const uint32_t b = bin[k] == 0xffffffffu ? 0u : bin[k], src = (b * 171u) >> 9, sl = b - 3u * src; // b / 3, b % 3
+            const uint32_t v0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex0);
+            const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex1);
+            const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex2);
+            place[k] = (sl == 0u ? v0 : sl == 1u ? v1 : v2) + rank[k];
+        }
+    };
+    // a wave's share of the staging: a run's chunk range, 16 bytes a lane, consecutive lanes consecutive chunks; nothing waits
+    // between a wave's pieces: all of them are in flight at once
+    auto stage_runs = [&](const uint32_t n_runs) {
+        // (wave 0 has the next tile's chain table and mask to see to: the other waves share the runs)
+        if (wv == 0) return;
+        for (uint32_t it = wv - 1u; it < 2u * n_runs; it += kWaves - 1u) {
+            const uint32_t w = it & 1u, g = it >> 1;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_run.lo[w][g] >> 2));
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((s_run.end[w][g] + (uint32_t)s_run.D[w][g] + 3u) >> 2));
+            const float4 *src = reinterpret_cast<const float4 *>((w ? a.ref : a.ev) + s_run.src[w][g]);
+            for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
+                if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
+        }
+    };
     for (uint32_t tile = s_tile[0]; tile != 0xffffffffu; tile = s_tile[slot]) {
-        const uint64_t base = (uint64_t)tile * AT, end_nom = base + AT;
+        const uint32_t base = tile * AT, end_nom = base + AT; // (n_anchors < 2^31)
         const uint32_t c0 = s_c0;
         // thread 0: the next tile's number is published before the first barrier; the ticket of the one after it is drawn
         // now and looked at when this tile is done
         if (tid == 0) {
             s_tile[slot ^ 1u] = t_next;
-            if (t_next != 0xffffffffu && !(a.debug & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+            if (t_next != 0xffffffffu && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
         }
         if (s_more) { // (tiles of very short chains: the rest of the chain starts from memory)
             (void)mark_chain_starts<TT>(a, (uint64_t)c0 + kCT, base, AT, s_mask);
             if (wv == 0) {
                 const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
-                uint32_t incl = pc;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-                    if (lane >= d) incl += o;
-                }
+                const uint32_t incl = wave_scan_incl(pc);
                 if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
             }
             __syncthreads();
         }
-        uint32_t c0n = 0; // wave 0: the next tile's first chain (requested in the first pass, used behind its staging)
-        uint32_t u0 = 0, b0[3] = {0u, 0u, 0u}; // the pass's first item and the sums before it
-        for (uint32_t pass = 0;; pass++) {
-            // ---- 1. every item's part: windows, radius, class; the runs; the wave's share of the layout scan.  Item
-            // u = tid * KI + k ends at anchor end_nom - 1 - u (tile position AT - 1 - u) and starts at the entry behind it ----
-            rawdtw_anchor_t E[KI], S0;
-            {
-                const uint32_t p_hi = AT - 1u - (uint32_t)tid * KI; // the first item's position; its start: p_hi + 1
-                const uint2 x = anc[p_hi + 1u];
-                S0 = rawdtw_anchor_t{x.x, x.y};
+        // ---- 1. every item's part: windows, radius, class; the runs; the wave's share of the layout scan.  Item
+        // u = tid * KI + k ends at anchor end_nom - 1 - u (tile position AT - 1 - u) and starts at the entry behind it ----
+        rawdtw_anchor_t E[KI], S0;
+        {
+            const uint32_t p_hi = AT - 1u - (uint32_t)tid * KI; // the first item's position; its start: p_hi + 1
+            const uint2 x = anc[p_hi + 1u];
+            S0 = rawdtw_anchor_t{x.x, x.y};
 #pragma unroll
-                for (int k = 0; k < KI; k++) { const uint2 y = anc[p_hi - k]; E[k] = rawdtw_anchor_t{y.x, y.y}; }
+            for (int k = 0; k < KI; k++) { const uint2 y = anc[p_hi - k]; E[k] = rawdtw_anchor_t{y.x, y.y}; }
+        }
+        uint32_t meta[KI];    // N | M << 7 | R << 14 | excl << 16 | swap << 17 | starts << 18 | ends << 19 | tile << 20
+        uint32_t ssum[KI][3]; // inclusive sums over the workgroup's items: event floats, reference floats, run starts
+        {
+            bool tl[KI];
+            Part pt[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
+                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1);
+                pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
+                tl[k] = exists && pt[k].tile;
             }
-            uint32_t meta[KI];    // N | M << 7 | R << 14 | excl << 16 | swap << 17 | starts << 18 | ends << 19 | tile << 20
-            uint32_t ssum[KI][3]; // inclusive sums over the workgroup's items: event floats, reference floats, run starts
+            // a run continues from the item before (same thread, or the lane below) when both are tile parts: the item before
+            // u ends where u starts, and both existing puts them in one chain.  Runs break at wave boundaries (lane 0's
+            // first item starts one, lane 63's last ends one): four breaks a tile, and no run crosses waves.
+            const int t_first = tl[0] ? 1 : 0, t_last = tl[KI - 1] ? 1 : 0;
+            const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
+            const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
+            uint32_t run[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
+                const bool prev_t = k ? tl[k - 1] : below, next_t = k + 1 < KI ? tl[k + 1 < KI ? k + 1 : k] : above;
+                const bool starts = tl[k] && !prev_t, ends = tl[k] && !next_t;
+                const uint32_t n = pt[k].n, m = pt[k].m, N = n > m ? n : m, M = n > m ? m : n;
+                meta[k] = !tl[k] ? 0u : (N | (M << 7) | ((uint32_t)pt[k].R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((n < m ? 1u : 0u) << 17) |
+                                         ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19) | (1u << 20));
+                if (tl[k]) {
+                    run[0] += (starts ? n + 3u : n - 1u) + (ends ? 3u : 0u);
+                    run[1] += (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u);
+                    run[2] += starts ? 1u : 0u;
+                }
+                ssum[k][0] = run[0]; ssum[k][1] = run[1]; ssum[k][2] = run[2];
+            }
+            // wave scan of the threads' totals
+            const uint32_t inc[3] = {wave_scan_incl(run[0]), wave_scan_incl(run[1]), wave_scan_incl(run[2])};
+            if (lane == 63) { s_wtot[parity][wv][0] = inc[0]; s_wtot[parity][wv][1] = inc[1]; s_wtot[parity][wv][2] = inc[2]; }
+#pragma unroll
+            for (int k = 0; k < KI; k++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) ssum[k][q] += inc[q] - run[q];
+        }
+        stamp(0);
+        __syncthreads(); // B1: wave totals, the next tile's number; every wave is done with the DP of the tile before
+        stamp(1);
+        flush();
+        const uint32_t tile_n = s_tile[slot ^ 1u];
+        uint32_t tot[3] = {0u, 0u, 0u};
+        {
+            uint32_t pre[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t w = 0; w < kWaves; w++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const uint32_t x = s_wtot[parity][w][q];
+                    if (w < wv) pre[q] += x;
+                    tot[q] += x;
+                }
+#pragma unroll
+            for (int k = 0; k < KI; k++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) ssum[k][q] += pre[q];
+        }
+        parity ^= 1u;
+        // all of the tile in one pass when its image fits the LDS budget and its runs the table (the rule)
+        if (((tot[0] + 3u) & ~3u) + ((tot[1] + 3u) & ~3u) <= budget && tot[2] <= kStreamMaxSeg) {
+            const uint32_t region = (tot[0] + 3u) & ~3u;
+            // the next tile's anchors: every thread has read this tile's
+            if (tile_n != 0xffffffffu) {
+                const uint32_t pieces = (AT + 2u) / 2u;
+                const uint64_t nbase = (uint64_t)tile_n * AT;
+                for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
+                    if (q0 + (uint32_t)lane < pieces && nbase + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
+                        dma16(a.anchors + nbase + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
+            }
+            // ---- 2. runs into the table, the sort's histogram ----
+            uint32_t bin[KI], rank[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                bin[k] = 0xffffffffu; rank[k] = 0;
+                if (!((meta[k] >> 20) & 1u)) continue;
+                const uint32_t u = (uint32_t)tid * KI + k;
+                const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
+                const bool swap = (meta[k] >> 17) & 1u, starts = (meta[k] >> 18) & 1u, ends = (meta[k] >> 19) & 1u;
+                const uint32_t n = swap ? M : N, m = swap ? N : M;
+                bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
+                rank[k] = atomicAdd(&hist[bin[k]], 1u);
+                const uint32_t g = ssum[k][2] - 1u; // the item's run
+                const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
+                if (starts) {
+                    // the run's chain: c0 + the chain starts in tile positions 1 .. p (p: this item's anchor); its bases from the
+                    // table of the tile's first chains, or from memory beyond it
+                    const uint32_t p = AT - 1u - u;
+                    const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
+                    uint64_t rb;
+                    uint32_t qb;
+                    if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
+                    else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
+                    const uint32_t c_r = ssum[k][0] - (n + 3u) - (ends ? 3u : 0u), c_f = ssum[k][1] - (m + 3u) - (ends ? 3u : 0u); // the sums before the run
+                    const uint32_t off_r = qb + s.query_position;
+                    const uint64_t off_f = rb + s.target_position;
+                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
+                    s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
+                    s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
+                    s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
+                }
+                if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
+            }
+            if (tid == 0) s_seq = 0;
+            stamp(2);
+            __syncthreads(); // B2: run table, histogram; this tile's chain table and mask are done with
+            stamp(3);
+            // wave 0: the next tile's chain table (its first chain came in a tile ago)
+            if (wv == 0 && tile_n != 0xffffffffu) {
+                const uint32_t cn = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n);
+                const uint64_t c = (uint64_t)cn + ((uint32_t)lane >> 1);
+                if (c <= a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.anchor_off + cn) + lane, s_ct_off);
+                if (c < a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.ref_base + cn) + lane, s_ct_rb);
+                if ((uint32_t)lane < kCT && (uint64_t)cn + (uint32_t)lane < a.n_chains) dma4(a.read_base + cn + lane, s_ct_qb);
+            }
+            // ---- 3. every wave: its items' places in the sorted order and their records; its share of the staging ----
             {
-                bool tl[KI];
-                Part pt[KI];
+                uint32_t place[KI];
+                sorted_place(bin, rank, place);
 #pragma unroll
                 for (int k = 0; k < KI; k++) {
-                    const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                    const bool exists = base + p < a.n_anchors && !mask_bit(s_mask, p + 1);
-                    pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
-                    tl[k] = exists && pt[k].tile;
+                    if (bin[k] == 0xffffffffu) continue;
+                    const uint32_t u = (uint32_t)tid * KI + k;
+                    perm[place[k]] = (uint16_t)u;
+                    const uint32_t g = ssum[k][2] - 1u;
+                    const rawdtw_anchor_t s = k ? E[k - 1] : S0;
+                    const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
+                    const bool swap = (meta[k] >> 17) & 1u;
+                    rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
                 }
-                // a run continues from the item before (same thread, or the lane below) when both are tile parts: the item before
-                // u ends where u starts, and both existing puts them in one chain.  Runs break at wave boundaries (lane 0's
-                // first item starts one, lane 63's last ends one): four breaks a tile, and no run crosses waves.
-                const int t_first = tl[0] ? 1 : 0, t_last = tl[KI - 1] ? 1 : 0;
-                const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
-                const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
-                uint32_t run[3] = {0u, 0u, 0u};
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                    const bool prev_t = k ? tl[k - 1] : below, next_t = k + 1 < KI ? tl[k + 1 < KI ? k + 1 : k] : above;
-                    const bool starts = tl[k] && !prev_t, ends = tl[k] && !next_t;
-                    const uint32_t n = pt[k].n, m = pt[k].m, N = n > m ? n : m, M = n > m ? m : n;
-                    meta[k] = !tl[k] ? 0u : (N | (M << 7) | ((uint32_t)pt[k].R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((n < m ? 1u : 0u) << 17) |
-                                             ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19) | (1u << 20));
-                    if (tl[k]) {
-                        run[0] += (starts ? n + 3u : n - 1u) + (ends ? 3u : 0u);
-                        run[1] += (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u);
-                        run[2] += starts ? 1u : 0u;
-                    }
-                    ssum[k][0] = run[0]; ssum[k][1] = run[1]; ssum[k][2] = run[2];
-                }
-                // wave scan of the threads' totals
-                uint32_t inc[3] = {run[0], run[1], run[2]};
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const uint32_t o = (uint32_t)__shfl_up((int)inc[q], d);
-                        if (lane >= d) inc[q] += o;
-                    }
-                }
-                if (lane == 63) { s_wtot[parity][wv][0] = inc[0]; s_wtot[parity][wv][1] = inc[1]; s_wtot[parity][wv][2] = inc[2]; }
-#pragma unroll
-                for (int k = 0; k < KI; k++)
-#pragma unroll
-                    for (int q = 0; q < 3; q++) ssum[k][q] += inc[q] - run[q];
             }
-            __syncthreads(); // B1: wave totals (and the next tile's number)
-            const uint32_t tile_n = s_tile[slot ^ 1u];
-            if (pass == 0 && wv == 0 && tile_n != 0xffffffffu) c0n = a.tile_chain[tile_n];
-            uint32_t tot[3] = {0u, 0u, 0u};
-            {
-                uint32_t pre[3] = {0u, 0u, 0u};
+            stamp(4);
+            __builtin_amdgcn_s_setprio(2); // a fresh tile's loads must not queue behind the DP of the older workgroups
+            if (!(dbg & 2u)) stage_runs(tot[2]);
+            stamp(5);
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the barrier below covers the others')
+            __builtin_amdgcn_s_setprio(0);
+            stamp(6);
+            // wave 0: the next tile's chain-start mask from its table (landed with the staging)
+            if (wv == 0 && tile_n != 0xffffffffu) mark_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
+            pend_bits = 0;
 #pragma unroll
-                for (uint32_t w = 0; w < kWaves; w++)
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const uint32_t x = s_wtot[parity][w][q];
-                        if (w < wv) pre[q] += x;
-                        tot[q] += x;
-                    }
-#pragma unroll
-                for (int k = 0; k < KI; k++)
-#pragma unroll
-                    for (int q = 0; q < 3; q++) ssum[k][q] += pre[q];
-            }
-            parity ^= 1u;
-            // ---- the pass: all of the tile when its image fits the LDS budget and its runs the table (the rule) ----
-            const bool single = pass == 0 && ((tot[0] + 3u) & ~3u) + ((tot[1] + 3u) & ~3u) <= budget && tot[2] <= kStreamMaxSeg;
-            uint32_t u1 = AT, region = (tot[0] + 3u) & ~3u, n_runs = tot[2];
-            bool cut_run = false; // the pass's first item continues a run of the pass before: it starts one here
-            if (!single) {
-                // the items that fit: from u0 on, while the image of the parts so far stays inside the budget and their runs in
-                // the table (sums relative to the pass's start; + 4 + 4 floats and one run when the first item continues a run)
+            for (int k = 0; k < KI; k++) pend_bits |= (bin[k] != 0xffffffffu ? 1u : 0u) << k;
+            pend_end = end_nom;
+            __syncthreads(); // B3: image staged, sorted order and records written; the next tile's anchors, table and mask in place
+            stamp(7);
+            for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0; // (for the next tile; nobody reads it any more)
+            run_dp();
+            stamp(8);
+        } else {
+            // ---- a tile of several passes (long parts: rare).  A pass takes the items that fit, from u0 on; its results
+            // leave before the next pass reuses the records; the next tile is fetched in the last pass ----
+            uint32_t u0 = 0, b0[3] = {0u, 0u, 0u}; // the pass's first item and the sums before it
+            for (;;) {
+                // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table
+                // (sums relative to the pass's start; + 4 + 4 floats and one run when the first item continues a run)
                 if (tid == 0) s_pass[0] = 0;
                 __syncthreads();
                 uint32_t fits = 0;
@@ -769,7 +944,7 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
                 for (int off = 32; off > 0; off >>= 1) fits += (uint32_t)__shfl_down((int)fits, off);
                 if (lane == 0 && fits) atomicAdd(&s_pass[0], fits);
                 __syncthreads();
-                u1 = min(u0 + s_pass[0], AT);
+                uint32_t u1 = min(u0 + s_pass[0], AT);
                 if (u1 <= u0) { if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); u1 = AT; } // (cannot happen: one part always fits)
                 // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
 #pragma unroll
@@ -779,141 +954,98 @@ __global__ __launch_bounds__(TT, TT == 256 ? 5 : 4) void k_runs(const StreamArgs
                     if (u == u0) s_pass[5] = ((meta[k] >> 20) & 1u) && !((meta[k] >> 18) & 1u) ? 1u : 0u;
                 }
                 __syncthreads();
-                cut_run = s_pass[5] != 0u;
-                region = (s_pass[1] - b0[0] + (cut_run ? 4u : 0u) + 3u) & ~3u;
-                n_runs = s_pass[3] - b0[2] + (cut_run ? 1u : 0u);
-            }
-            const bool last = u1 >= AT;
-            // ---- 2. runs into the table, the sort's histogram ----
-            uint32_t bin[KI], rank[KI];
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                bin[k] = 0xffffffffu; rank[k] = 0;
-                const uint32_t u = (uint32_t)tid * KI + k;
-                if (!((meta[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
-                const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
-                const bool swap = (meta[k] >> 17) & 1u;
-                const uint32_t n = swap ? M : N, m = swap ? N : M;
-                const bool starts = ((meta[k] >> 18) & 1u) || u == u0, ends = ((meta[k] >> 19) & 1u) || u == u1 - 1u;
-                bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
-                rank[k] = atomicAdd(&hist[bin[k]], 1u);
-                const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
-                const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
-                const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
-                if (starts) {
-                    // the run's chain: c0 + the chain starts in tile positions 1 .. p (p: this item's anchor); its bases from the
-                    // table of the tile's first chains, or from memory beyond it
-                    const uint32_t p = AT - 1u - u;
-                    const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
-                    uint64_t rb;
-                    uint32_t qb;
-                    if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
-                    else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
-                    // sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
-                    const uint32_t own_r = ((meta[k] >> 18) & 1u ? n + 3u : n - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
-                    const uint32_t own_f = ((meta[k] >> 18) & 1u ? m + 3u : m - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
-                    const uint32_t c_r = ssum[k][0] - own_r - b0[0] + 4u * adj, c_f = ssum[k][1] - own_f - b0[1] + 4u * adj;
-                    const uint32_t off_r = qb + s.query_position;
-                    const uint64_t off_f = rb + s.target_position;
-                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
-                    s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
-                    s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
-                    s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
-                }
-                if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
-            }
-            if (tid == 0) s_seq = 0;
-            __syncthreads(); // B2: run table, histogram
-            // ---- 3. every wave: the bins' first places (three a lane, fetched across lanes), its items' places in the sorted
-            // order and their records; then its share of the staging ----
-            {
-                const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
-                const uint32_t sum = h0 + h1 + h2;
-                uint32_t incl = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-                    if (lane >= d) incl += o;
-                }
-                const uint32_t ex0 = incl - sum, ex1 = ex0 + h0, ex2 = ex1 + h1;
-                if (tid == 63) s_njobs = incl;
+                const bool cut_run = s_pass[5] != 0u; // the pass's first item continues a run of the pass before: it starts one here
+                const uint32_t region = (s_pass[1] - b0[0] + (cut_run ? 4u : 0u) + 3u) & ~3u;
+                const uint32_t n_runs = s_pass[3] - b0[2] + (cut_run ? 1u : 0u);
+                const bool last = u1 >= AT;
+                uint32_t bin[KI], rank[KI];
 #pragma unroll
                 for (int k = 0; k < KI; k++) {
-                    const uint32_t b = bin[k] == 0xffffffffu ? 0u : bin[k], src = (b * 171u) >> 9, sl = b - 3u * src; // b / 3, b % 3
-                    const uint32_t v0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex0);
-                    const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex1);
-                    const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex2);
-                    if (bin[k] == 0xffffffffu) continue;
+                    bin[k] = 0xffffffffu; rank[k] = 0;
                     const uint32_t u = (uint32_t)tid * KI + k;
-                    perm[(sl == 0u ? v0 : sl == 1u ? v1 : v2) + rank[k]] = (uint16_t)u;
-                    const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u;
-                    const rawdtw_anchor_t s = k ? E[k - 1] : S0;
-                    const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
+                    if (!((meta[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
+                    const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
                     const bool swap = (meta[k] >> 17) & 1u;
-                    rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
-                }
-                if (!(a.debug & 2u)) {
-                    __builtin_amdgcn_s_setprio(2); // a fresh tile's loads must not queue behind the DP of the older workgroups
-                    // a run's chunk range, 16 bytes a lane, consecutive lanes consecutive chunks; nothing waits between a
-                    // wave's pieces: all of them are in flight at once
-                    for (uint32_t it = wv; it < 2u * n_runs; it += kWaves) {
-                        const uint32_t w = it & 1u, g = it >> 1;
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_run.lo[w][g] >> 2));
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((s_run.end[w][g] + (uint32_t)s_run.D[w][g] + 3u) >> 2));
-                        const float4 *src = reinterpret_cast<const float4 *>((w ? a.ref : a.ev) + s_run.src[w][g]);
-                        for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
-                            if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
+                    const uint32_t n = swap ? M : N, m = swap ? N : M;
+                    const bool starts = ((meta[k] >> 18) & 1u) || u == u0, ends = ((meta[k] >> 19) & 1u) || u == u1 - 1u;
+                    bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
+                    rank[k] = atomicAdd(&hist[bin[k]], 1u);
+                    const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
+                    const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
+                    const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
+                    if (starts) {
+                        const uint32_t p = AT - 1u - u;
+                        const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
+                        uint64_t rb;
+                        uint32_t qb;
+                        if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
+                        else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
+                        // sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
+                        const uint32_t own_r = ((meta[k] >> 18) & 1u ? n + 3u : n - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
+                        const uint32_t own_f = ((meta[k] >> 18) & 1u ? m + 3u : m - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
+                        const uint32_t c_r = ssum[k][0] - own_r - b0[0] + 4u * adj, c_f = ssum[k][1] - own_f - b0[1] + 4u * adj;
+                        const uint32_t off_r = qb + s.query_position;
+                        const uint64_t off_f = rb + s.target_position;
+                        const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
+                        s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
+                        s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
+                        s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
                     }
-                    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the barrier below covers the others')
-                    __builtin_amdgcn_s_setprio(0);
+                    if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
                 }
-            }
-            __syncthreads(); // B3: image staged, sorted order and records written; the anchors are in registers or done with
-            for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0; // (for the next pass; nobody reads it any more)
-            // the next tile's anchors and chain table: on their way while this tile's DP runs
-            if (last && tile_n != 0xffffffffu) fetch_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
-            const uint32_t n_jobs = s_njobs;
-            // ---- 4. the DP: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
-            // workgroup finish together whatever the mix ----
-            while (!(a.debug & 1u)) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(&s_seq, 1u);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if (c * 64u >= n_jobs) break;
-                const uint32_t r = c * 64u + lane;
-                const bool act = r < n_jobs;
-                const uint32_t u = min((uint32_t)perm[act ? r : n_jobs - 1], AT - 1u);
-                const uint2 rc = rec[u];
-                const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
-                const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
-                if (act) rec[u].x = __float_as_uint(res); // (the job's record is done with; its slot carries the result out)
-            }
-            __syncthreads(); // B4
-            // results out in item order: consecutive lanes, consecutive (descending) addresses
-            if (!(a.debug & 1u)) {
+                if (tid == 0) s_seq = 0;
+                __syncthreads(); // run table, histogram
+                {
+                    uint32_t place[KI];
+                    sorted_place(bin, rank, place);
 #pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    const uint32_t u = (uint32_t)tid * KI + k;
-                    if (bin[k] != 0xffffffffu) a.out[end_nom - 1 - u] = __uint_as_float(rec[u].x);
+                    for (int k = 0; k < KI; k++) {
+                        if (bin[k] == 0xffffffffu) continue;
+                        const uint32_t u = (uint32_t)tid * KI + k;
+                        perm[place[k]] = (uint16_t)u;
+                        const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u;
+                        const rawdtw_anchor_t s = k ? E[k - 1] : S0;
+                        const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
+                        const bool swap = (meta[k] >> 17) & 1u;
+                        rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
+                    }
                 }
+                if (!(dbg & 2u)) stage_runs(n_runs);
+                if (last && tile_n != 0xffffffffu) fetch_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n)); // (every pass has read the anchors)
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                if (last && wv == 0 && tile_n != 0xffffffffu) mark_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
+                __syncthreads(); // image staged, sorted order and records written
+                for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
+                run_dp();
+                pend_bits = 0;
+#pragma unroll
+                for (int k = 0; k < KI; k++) pend_bits |= (bin[k] != 0xffffffffu ? 1u : 0u) << k;
+                pend_end = end_nom;
+                if (last) break; // (the last pass's results leave like a one-pass tile's)
+                __syncthreads();
+                flush();
+                u0 = u1; b0[0] = s_pass[1]; b0[1] = s_pass[2]; b0[2] = s_pass[3];
+                __syncthreads(); // (the pass's records and s_pass are read; the next pass rewrites them)
             }
-            if (last) break;
-            u0 = u1; b0[0] = s_pass[1]; b0[1] = s_pass[2]; b0[2] = s_pass[3];
-            __syncthreads(); // (the pass's records and s_pass are read; the next pass rewrites them)
         }
-        // the next tile: its anchors and table have landed (every wave waits for its own pieces), wave 0 builds its mask
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        if (wv == 0 && s_tile[slot ^ 1u] != 0xffffffffu) mark_tile(s_tile[slot ^ 1u], (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
-        if (tid == 0 && t_next != 0xffffffffu) { // the ticket into the number of the tile after the next
-            if (a.debug & 8u) t_next = next_tile(a, head, n_tiles);
+        // thread 0: the ticket into the number of the tile after the next; wave 0 asks for that tile's first chain
+        if (tid == 0 && t_next != 0xffffffffu) {
+            if (dbg & 8u) t_next = next_tile(a, dbg, head, n_tiles);
             else {
                 const unsigned long long t = ticket * 8ull + head;
-                t_next = t < n_tiles ? (uint32_t)t : next_tile(a, head, n_tiles); // (this head is dry: try the others)
+                t_next = t < n_tiles ? (uint32_t)t : next_tile(a, dbg, head, n_tiles); // (this head is dry: try the others)
             }
         }
+        if (wv == 0) {
+            const uint32_t tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
+            c0n = tn != 0xffffffffu ? a.tile_chain[tn] : 0u;
+        }
         slot ^= 1u;
-        __syncthreads();
+        stamp(9);
     }
+    __syncthreads(); // every wave is done with the last tile's DP
+    flush();
+    if (stamps && lane < (int)kStamps && s_stamp[wv][lane]) atomicAdd(&a.cnt[kCntStamp0 + lane], s_stamp[wv][lane]);
 }
 
 // cells of a batch (reporting only; the walk costs as much as scoring the jobs): every part from its two anchors, plus the
@@ -1019,14 +1151,17 @@ hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats,
     hipError_t e = reset_queue ? hipMemsetAsync(&a.cnt[kCntHeads], 0, 8 * 16 * sizeof(unsigned long long), s) : hipSuccess;
     if (e != hipSuccess) return e;
     const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
-    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512>) : reinterpret_cast<const void *>(k_runs<256>);
-    if (lds_bytes > 64 * 1024) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    if (threads == 512) hipLaunchKernelGGL(k_runs<512>, dim3(blocks), dim3(512), lds_bytes, s, a, lds_floats);
-    else hipLaunchKernelGGL(k_runs<256>, dim3(blocks), dim3(256), lds_bytes, s, a, lds_floats);
-    return hipGetLastError();
+    const bool diag = a.debug != 0;
+    auto launch = [&](auto kern, int tt) -> hipError_t {
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e2 != hipSuccess) return e2;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(tt), lds_bytes, s, a, lds_floats);
+        return hipGetLastError();
+    };
+    if (threads == 512) return diag ? launch(k_runs<512, true>, 512) : launch(k_runs<512, false>, 512);
+    return diag ? launch(k_runs<256, true>, 256) : launch(k_runs<256, false>, 256);
 }
 
 // workgroups of k_runs one compute unit holds at this LDS size (for the persistent grid)
@@ -1034,7 +1169,7 @@ int stream_blocks_per_cu(uint32_t lds_floats, int threads)
 {
     int n = 0;
     const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
-    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512>) : reinterpret_cast<const void *>(k_runs<256>);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512, false>) : reinterpret_cast<const void *>(k_runs<256, false>);
     if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds_bytes) != hipSuccess) return 0;
     return n;

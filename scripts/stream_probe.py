@@ -35,12 +35,17 @@ for cfg in configs:
     ms = b.run_reps(20, timed=True)
     pm = C.c_float()
     eng.lib.rawdtw_batch_plan_ms(eng._ctx, b._h, C.byref(pm))
-    cnt = (C.c_uint64 * 32)()
+    cnt = (C.c_uint64 * 64)()
     ncnt = C.c_uint32()
-    eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 32, C.byref(ncnt))
+    eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 64, C.byref(ncnt))
     if cfg == configs[0]:
         print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
                                                                    ["%.4f" % m[2] for m in ms]), flush=True)
+    if any(cnt[50:64]):  # "stream_debug" 256: cycles per phase of k_runs, summed over waves and runs
+        tot = float(sum(cnt[50:64]))
+        names = ["P1 classify+scan", "B1", "P2 runs+hist", "B2", "P3 sort+records", "stage issue", "stage wait", "B3", "DP", "B4",
+                 "output", "prefetch wait", "mark+ticket", "end barrier"]
+        print("   phase shares: " + "  ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, cnt[50:64])), flush=True)
     b.close()
     eng.close()
