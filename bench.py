@@ -5,15 +5,19 @@ Workload = BASELINE.json configs[1]: E. coli K-12 (4.6 Mb), r9.4-like reads, spa
 fill.  One "step" = one pass of the hot path over one batch = one chunk round of `--reads` reads per GPU: every DTW
 job of every candidate chain (src/rmap.cpp:509-530), the align_chain fold and the per-read accept/cut loop.
 
-Three figures come out of one run (all in the one JSON line):
+Figures of one run (all in the one JSON line):
 
-  value / mapped_reads_per_s   every step is a FRESH batch: rawdtw_batch_create (planning on the device), run, fetch of
-                               score/keep, destroy -- `--inflight` contexts deep, as the reference's kt_pipeline keeps
-                               mini-batches in flight (rmap.cpp:1033).  Inputs (event arenas, anchor lists) are resident
-                               in HBM when the timed region starts; nothing is cached between steps.
-  pipeline_pcie                the same loop with the host-side hand-over inside the step: the round's NEW events
-                               (rmap.cpp:554-567 is append-only) and the anchor lists cross PCIe from pinned memory.
-  kernel_replay                the launches of pre-planned resident batches only (what round 1 reported as `value`).
+  value = value_resident       every step is a FRESH batch: rawdtw_batch_submit (the scan of the anchor list, the DTW launch,
+                               fold and select: all enqueued by one call) and, when the context comes round again,
+                               rawdtw_batch_fetch_destroy -- `--inflight` contexts deep, as the reference's kt_pipeline
+                               keeps mini-batches in flight (rmap.cpp:1033).  Inputs (event arenas, anchor lists) are
+                               resident in HBM when the timed region starts; nothing is cached between steps.
+  value_pcie (pipeline_pcie)   the same loop with the host-side hand-over inside the step: the round's NEW events
+                               (rmap.cpp:554-567 is append-only) and the anchor lists cross PCIe from pinned memory --
+                               what a caller that produces its anchors on the host (rmap.cpp:396-507) gets end to end.
+  kernel_replay                the launches of already submitted resident batches only (what round 1 reported as `value`).
+  modes                        BASELINE.json configs[2] on the same GPU: global + full-fill scoring, and the traceback of
+                               every read's best chain (--dtw-output-cigar) with the device time of its kernels alone.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus N ...          # launches N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
@@ -58,6 +62,7 @@ def parse():
     ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
     ap.add_argument("--decoy-gap-median", type=float, default=None, help="workload sensitivity: decoy chain gap (events)")
     ap.add_argument("--decoys-per-read", type=float, default=None)
+    ap.add_argument("--modes-reads", type=int, default=8192, help="reads of the configs[2] block (0: skip it)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / reduction plumbing only: no device work, synthetic counters (CPU tests)")
     return ap.parse_args()
@@ -196,6 +201,92 @@ def vp(a):
     return C.c_void_p(a.ctypes.data)
 
 
+YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 439888, 745751, 666816, 1078177, 924431,
+         784333, 1091291, 948066, 85779]  # S. cerevisiae S288C chromosome lengths (12.1 Mb): BASELINE.json configs[2]
+
+
+def modes_block(local_rank, reads):
+    """BASELINE.json configs[2] on this GPU, one context: (a) global border constraint + full fill, score only
+    (DTW_global, dtw.cpp:37-66, one job per chain: rmap.cpp:192-237); (b) --dtw-output-cigar: the best chain of every
+    read through DTW_global_tb (dtw.cpp:595-667, rmap.cpp:715-717) with the packed 2-bit direction buffer in HBM.  For
+    (b) the device time of the fill and walk kernels alone (HIP events inside rawdtw_traceback_batch) next to the wall
+    time of the whole call (plan, fill, walk, paths D2H, copy into the caller's arrays)."""
+    import rawalign_amd as ra
+    from rawalign_amd import synth
+    from rawalign_amd._lib import AlignOpt
+
+    eng = ra.Engine(local_rank)
+    lib = eng.lib
+    ref = synth.make_reference(YEAST, seed=20231005 + 3)
+    eng.upload_reference(ref.forward, ref.reverse)
+    offs = {(s_, st): eng.reference_offset(s_, st) for s_ in range(ref.n_seq) for st in (0, 1)}
+    cb, _ = synth.make_candidate_batch(ref, offs, synth.SynthParams(n_reads=reads, max_chunks=6), seed=77)
+    eng.upload_events(cb.events)
+    out = {"workload": "scerevisiae_12.1Mb_r9.4_global_full_cigar", "reads": reads}
+    # (a) scoring
+    batch = ra.Batch(eng, ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0), cb)
+    info = batch.info()
+    batch.run_reps(1, timed=False)
+    steps = 5
+    t0 = time.perf_counter()
+    launches = batch.run_reps(steps, timed=True)
+    dt = (time.perf_counter() - t0) / steps
+    kms = sum(ms for k, _, ms in launches if k in (3,))  # the full-matrix fill launches
+    out["global_full_score"] = {"jobs": info["n_jobs"], "cells": info["cells"], "ms_per_step": dt * 1e3, "gcups": info["cells"] / dt / 1e9,
+                                "fill_kernels_ms": round(kms, 4), "fill_kernels_gcups": info["cells"] / max(kms, 1e-9) / 1e6,
+                                "algorithmic_bytes": info["algorithmic_bytes"],
+                                "hbm_frac": info["algorithmic_bytes"] / max(kms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                                "note": "score only reads 4(n+m)+36 bytes a job and writes nothing else: the kernel is bound by its "
+                                        "VALU recurrence (3 instructions a cell), not by HBM"}
+    batch.close()
+    # (b) traceback of the best (first) chain of every read, global + full (rmap.cpp:220-221)
+    copt = AlignOpt(0, 0, 0.10, 0.4, 20.0, 1)
+    firsts = [int(cb.chain_off[r]) for r in range(cb.n_reads) if cb.chain_off[r + 1] > cb.chain_off[r]]
+    jobs = np.zeros(len(firsts), ra.JOB_DTYPE)
+    one = np.zeros(1, ra.JOB_DTYPE)
+    for k, c in enumerate(firsts):
+        a = cb.anchors[int(cb.anchor_off[c]):int(cb.anchor_off[c + 1])]
+        lib.rawdtw_chain_build_jobs(C.byref(copt), a.ctypes.data_as(C.c_void_p), len(a), int(cb.ref_base[c]), int(cb.read_base[c]), 1,
+                                    one.ctypes.data_as(C.c_void_p))
+        jobs[k] = one[0]
+    n, m = jobs["n"].astype(np.int64), jobs["m"].astype(np.int64)
+    cells = int((n * m).sum())
+    poff = np.concatenate([[0], np.cumsum(n + m - 1)]).astype(np.uint64)
+    cost = np.zeros(len(jobs), np.float32); plen = np.zeros(len(jobs), np.uint32)
+    pi = np.zeros(int(poff[-1]), np.uint32); pj = np.zeros(int(poff[-1]), np.uint32); pd = np.zeros(int(poff[-1]), np.float32)
+
+    def tb():
+        eng._check(lib.rawdtw_traceback_batch(eng._ctx, vp(jobs), len(jobs), vp(cb.events), len(cb.events), vp(cost), vp(poff), vp(plen),
+                                              vp(pi), vp(pj), vp(pd)))
+    tb()  # first call: code loading, pinned staging and workspace sizing
+    best, timing = 1e9, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tb()
+        dt = time.perf_counter() - t0
+        if dt < best:
+            fill, walk, db, pe = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint64()
+            lib.rawdtw_traceback_timing(eng._ctx, C.byref(fill), C.byref(walk), C.byref(db), C.byref(pe))
+            best, timing = dt, (fill.value, walk.value, db.value, pe.value)
+    fill_ms, walk_ms, dir_bytes, path_elems = timing
+    # SURVEY.md 8d, per traceback job: operands + result + descriptor, ceil(nm/4) direction bytes written, ceil((n+m-1)/4)
+    # read back by the walk, 12 L path bytes out
+    alg = int((4 * (n + m) + 36 + (n * m + 3) // 4 + (n + m - 1 + 3) // 4).sum()) + 12 * int(path_elems)
+    kms = fill_ms + walk_ms
+    out["traceback"] = {"jobs": int(len(jobs)), "cells": cells, "path_elements": int(path_elems), "direction_bytes": int(dir_bytes),
+                        "kernels_ms": {"fill": round(fill_ms, 4), "walk": round(walk_ms, 4)},
+                        "kernels_gcups": cells / max(kms, 1e-9) / 1e6, "fill_gcups": cells / max(fill_ms, 1e-9) / 1e6,
+                        "algorithmic_bytes": alg, "achieved_gbs": alg / max(kms, 1e-9) / 1e6,
+                        "hbm_frac": alg / max(kms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                        "call_ms_end_to_end": round(best * 1e3, 3), "gcups_end_to_end": cells / best / 1e9,
+                        "note": "kernels_ms = HIP events around the fill (k_full_wave<.,true,.>: the matrix fill writing 2-bit "
+                                "directions) and the walk (k_tb_walk_wave + k_tb_finish) inside rawdtw_traceback_batch; the call "
+                                "also plans on the host, brings 12 bytes a path element back over PCIe and copies them into the "
+                                "caller's pageable arrays"}
+    eng.close()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -315,10 +406,26 @@ def main():
         e._check(st)
         live[sl] = True
 
+    def submit(sl, resident):
+        """rawdtw_batch_submit: create + run, one call"""
+        d, e = B[sl], engines[sl]
+        if resident:
+            st = lib.rawdtw_batch_submit(e._ctx, C.byref(copt), d["n_reads"], vp(d["chain_off"]), vp(d["anchor_off"]),
+                                         C.c_void_p(d["t_anchors"].data_ptr()), C.c_void_p(d["t_ref_base"].data_ptr()),
+                                         C.c_void_p(d["t_read_base"].data_ptr()), C.byref(handles[sl]))
+        else:
+            st = lib.rawdtw_batch_submit(e._ctx, C.byref(copt), d["n_reads"], vp(d["chain_off"]), vp(d["anchor_off"]),
+                                         vp(d["anchors"]), vp(d["ref_base"]), vp(d["read_base"]), C.byref(handles[sl]))
+        e._check(st)
+        live[sl] = True
+
     def fetch_destroy(sl, job_cost=None):
         d, e = B[sl], engines[sl]
-        e._check(lib.rawdtw_batch_fetch(e._ctx, handles[sl], vp(d["score"]), vp(d["keep"]), vp(job_cost) if job_cost is not None else None))
-        lib.rawdtw_batch_destroy(handles[sl])
+        if job_cost is None:
+            e._check(lib.rawdtw_batch_fetch_destroy(e._ctx, handles[sl], vp(d["score"]), vp(d["keep"])))
+        else:
+            e._check(lib.rawdtw_batch_fetch(e._ctx, handles[sl], vp(d["score"]), vp(d["keep"]), vp(job_cost)))
+            lib.rawdtw_batch_destroy(handles[sl])
         live[sl] = False
 
     def collect(sl, sink):
@@ -326,8 +433,8 @@ def main():
         engines[sl]._check(lib.rawdtw_batch_collect(engines[sl]._ctx, handles[sl], vp(ms), vp(kind), 8, C.byref(nl), C.byref(nr)))
         sink.append(ms[:nl.value].copy())
 
-    host_s = {"fetch": 0.0, "create": 0.0, "run": 0.0, "steps": 0}
-    issued = {"dtw": 0}  # DTW launches (k_stream dispatches) issued by this process so far: locates a pass in a kernel trace
+    host_s = {"fetch": 0.0, "submit": 0.0, "steps": 0}
+    issued = {"dtw": 0}  # DTW launches (k_runs dispatches) issued by this process so far: locates a pass in a kernel trace
 
     def pipeline(K, pcie, timed_launches=None, host=None):
         """K steps, every one a fresh batch; context k % slots; a context's previous batch is fetched before its next."""
@@ -346,15 +453,14 @@ def main():
             if pcie:  # the round's new events: one H2D of the packed chunk events + a scatter into the per-read arrays
                 e._check(lib.rawdtw_events_append(e._ctx, vp(d["new_events"]), len(d["new_events"]), d["n_reads"],
                                                   vp(d["seg_src"]), vp(d["seg_dst"])))
-            create(sl, not pcie)
-            t2 = pc()
             if timed_launches is None:
-                e._check(lib.rawdtw_batch_run(e._ctx, handles[sl]))
+                submit(sl, not pcie)
             else:  # HIP event pair around every launch, read when the context comes round again
+                create(sl, not pcie)
                 e._check(lib.rawdtw_batch_enqueue(e._ctx, handles[sl], 1))
             issued["dtw"] += 1
             if host is not None:
-                host["fetch"] += t1 - t0; host["create"] += t2 - t1; host["run"] += pc() - t2; host["steps"] += 1
+                host["fetch"] += t1 - t0; host["submit"] += pc() - t1; host["steps"] += 1
         for sl in range(slots):
             if live[sl]:
                 if timed_launches is not None:
@@ -407,6 +513,19 @@ def main():
     timed_pass_first = issued["dtw"]
     pipeline(max(K, 2 * slots), pcie=False, timed_launches=launches_in_pipeline)
     timed_pass_count = issued["dtw"] - timed_pass_first
+    # the scan launches of one batch alone on the chip (everything else has drained) ...
+    for e in engines:
+        e.sync()
+    plan_alone = []
+    for rep_ in range(3):
+        create(0, True)
+        ms = C.c_float()
+        engines[0].sync()
+        lib.rawdtw_batch_plan_ms(engines[0]._ctx, handles[0], C.byref(ms))
+        plan_alone.append(ms.value)
+        lib.rawdtw_batch_destroy(handles[0])
+        live[0] = False
+    # ... and with all contexts submitting at once
     plan_ms = []
     for sl in range(slots):
         create(sl, True)
@@ -465,17 +584,20 @@ def main():
 
     if rank == 0:
         T, Tp, Tr = float(np.median(r_fresh)), float(np.median(r_pcie)), float(np.median(r_replay))
-        lp = np.array(launches_in_pipeline)  # rows: steps, columns: [stream kernel, fold, select]
+        lp = np.array(launches_in_pipeline)  # rows: steps, columns: [k_runs, fold, select]
         dms = float(lp[:, 0].mean())
+        plan_pipe, plan_al = float(np.median(plan_ms)), float(np.median(plan_alone))
+        sum_pipe = plan_pipe + float(lp.mean(axis=0).sum())
+        sum_alone = plan_al + float(alone_ms[:3].sum())
         dbytes = infos[0]["algorithmic_bytes"]
         achieved = dbytes / (dms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == WORKLOAD and tj.get("reads") == args.reads:
-                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/traffic_r02.json (PMC passes of this command, collected separately; not measured by this run)"
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/traffic_r03.json (PMC passes over the same batch, collected separately; not measured by this run)"
             except Exception:
                 pass
         out = {
@@ -486,25 +608,39 @@ def main():
                        "border_constraint": "sparse", "fill_method": "banded=0.10", "batches_in_flight": slots,
                        "sharding": f"reads over {world} gpu(s), one resident reference arena per gpu",
                        "synth": {"hit_prob": sp.hit_prob, "decoy_gap_median": sp.decoy_gap_median, "decoys_per_read": sp.decoys_per_read}},
-            "value_is": "fresh batch every step (rawdtw_batch_create with planning on the device + run + fetch of score/keep + destroy), "
-                        "inputs resident in HBM, median of `repeats` regions of exactly `steps` steps",
+            "value_is": "value_resident: fresh batch every step (rawdtw_batch_submit = scan of the anchor list + DTW launch + fold + select "
+                        "enqueued by one call; rawdtw_batch_fetch_destroy of score/keep when the context comes round again), inputs "
+                        "resident in HBM, median of `repeats` regions of exactly `steps` steps",
+            "value_resident": cells_t / T / 1e9, "value_pcie": cells_t / Tp / 1e9,
+            "value_pcie_is": "the same loop with the step's host hand-over inside (new events + anchor lists from pinned host memory over "
+                             "PCIe): what a caller whose anchors are produced on the host gets end to end",
             "repeats": len(r_fresh), "timed_region_ms_total": round(sum(r_fresh) * 1e3, 3),
             "region_ms": {"median": round(T * 1e3, 4), "min": round(min(r_fresh) * 1e3, 4), "max": round(max(r_fresh) * 1e3, 4)},
-            "reads_per_s": reads_t / T, "mapped_reads_per_s": mapped_t / T, "jobs_per_s": jobs_t / T,
-            "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "mapped_reads_per_s": mapped_t / Tp, "ms_per_step": Tp / K * 1e3,
+            "reads_per_s": reads_t / T, "dtw_stage_rounds_per_s": mapped_t / T, "jobs_per_s": jobs_t / T,
+            "dtw_stage_rounds_is": "chunk rounds of the DTW stage per second in which >= 1 candidate chain of the (synthetic) read survives "
+                                   "dtw_min_score -- a capacity of this stage alone, not RawAlign's mapped reads/s: event detection, seeding "
+                                   "and chaining are imitated by their output (rawalign_amd/synth.py)",
+            "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "dtw_stage_rounds_per_s": mapped_t / Tp, "ms_per_step": Tp / K * 1e3,
                               "repeats": len(r_pcie),
                               "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["anchors"].nbytes + B[0]["ref_base"].nbytes + B[0]["read_base"].nbytes),
                               "note": "same loop with the step's host hand-over inside: the round's new events (last chunk of "
                                       "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory"},
             "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / K * 1e3, "repeats": len(r_replay),
-                              "note": "launches of pre-planned resident batches only (round 1's headline)"},
-            "host_ms_per_step": {k: round(host_s[k] / max(host_s["steps"], 1) * 1e3, 4) for k in ("fetch", "create", "run")} | {
-                "note": "host wall time inside the three calls of one step of the timed fresh-batch loop: `fetch` includes "
-                        "waiting for the context's previous batch (the only blocking call); `create` + `run` only enqueue"},
+                              "note": "launches of already submitted resident batches only (round 1's headline)"},
+            "host_ms_per_step": {k: round(host_s[k] / max(host_s["steps"], 1) * 1e3, 4) for k in ("fetch", "submit")} | {
+                "note": "host wall time inside the two calls of one step of the timed fresh-batch loop: `fetch` "
+                        "(rawdtw_batch_fetch_destroy) includes waiting for the context's previous batch -- the only blocking "
+                        "call; `submit` (rawdtw_batch_submit = create + run) only enqueues"},
             "batch_create_ms": {"steady": create_ms["resident"], "from_pinned_host": create_ms["from_host"],
-                                "note": "host wall time of one rawdtw_batch_create call, steady state: it only enqueues (no "
-                                        "synchronisation, no allocation); `planning_gpu_ms` is what its kernels cost the device",
-                                "planning_gpu_ms": round(float(np.median(plan_ms)), 4)},
+                                "note": "host wall time of one rawdtw_batch_create call, steady state: O(1) host work, it only enqueues (no "
+                                        "synchronisation, no allocation); `planning_gpu_ms` = its launches (k_scan + k_side) on the "
+                                        "device: alone on the chip / with all contexts submitting at once",
+                                "planning_gpu_ms": round(plan_al, 4), "planning_gpu_ms_in_pipeline": round(plan_pipe, 4)},
+            "kernel_ms_sum_per_batch": {"alone": round(sum_alone, 4), "in_pipeline": round(sum_pipe, 4),
+                                        "overlap_factor": round(sum_pipe / (T / K * 1e3), 3),
+                                        "note": "sum of a batch's launch durations (k_scan + k_side, k_runs, fold, select; HIP events): each "
+                                                "alone on the chip, and bracketed inside the pipeline, where the batches in flight stretch "
+                                                "each other -- overlap_factor = that sum / ms_per_step = batches effectively in flight"},
             "totals_over_timed_steps": {"reads": reads_t, "chains": chains_t, "dtw_jobs": jobs_t, "cells": cells_t,
                                         "mapped_reads": mapped_t, "algorithmic_bytes": bytes_t},
             "batch0": {"reads": args.reads, "chains": B[0]["n_chains"], "dtw_jobs": infos[0]["n_jobs"], "cells": infos[0]["cells"],
@@ -512,21 +648,25 @@ def main():
                        "tile_class_jobs": infos[0]["n_lane_jobs"], "wide_band_jobs": infos[0]["n_wave_band_jobs"]},
             "whole_step_hbm_frac": bytes_t / T / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_stream", "launch_ms": dms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_runs", "launch_ms": dms,
                          "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": infos[0]["n_jobs"],
                          "launch_window": {"first_dispatch": timed_pass_first, "count": timed_pass_count,
-                                           "note": "launch_ms is over these k_stream dispatches of the process (0-based, in issue "
+                                           "note": "launch_ms is over these k_runs dispatches of the process (0-based, in issue "
                                                    "order); scripts/trace_window.py averages the same ones in a rocprofv3 kernel trace"},
-                         "note": "launch_ms = mean HIP-event bracket of the batch's one DTW launch inside the fresh-batch pipeline "
-                                 "(recorded on the launch's own stream), where it shares the chip with the other contexts' "
-                                 "planning and DTW launches; `alone` = the same launch repeated on an idle chip",
+                         "note": "achieved = algorithmic bytes of the batch's jobs (4(n+m)+36 each, SURVEY.md 8d) / launch_ms, the mean "
+                                 "HIP-event bracket of the batch's one DTW launch inside the fresh-batch pipeline (recorded on the "
+                                 "launch's own stream).  That bracket is an OVERLAPPED wall bracket: the launch shares the chip with "
+                                 "the other contexts' launches (kernel_ms_sum_per_batch.overlap_factor).  `alone` = the same launch "
+                                 "repeated on an idle chip: the kernel's own figure; `traffic` = HBM bytes by PMC counters",
                          "alone": {"launch_ms": float(alone_ms[0]), "achieved": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9,
                                    "frac": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-            "launches": {"in_pipeline_ms": {"k_stream": round(dms, 5), "chain_fold": round(float(lp[:, 1].mean()), 5),
+            "launches": {"in_pipeline_ms": {"k_scan+k_side": round(plan_pipe, 5), "k_runs": round(dms, 5), "chain_fold": round(float(lp[:, 1].mean()), 5),
                                             "read_select": round(float(lp[:, 2].mean()), 5)},
-                         "alone_ms": {"k_stream": round(float(alone_ms[0]), 5), "chain_fold": round(float(alone_ms[1]), 5),
+                         "alone_ms": {"k_scan+k_side": round(plan_al, 5), "k_runs": round(float(alone_ms[0]), 5), "chain_fold": round(float(alone_ms[1]), 5),
                                       "read_select": round(float(alone_ms[2]), 5)}},
         }
+        if world == 1 and args.modes_reads > 0:
+            out["modes"] = modes_block(local_rank, args.modes_reads)
         if world == 1 and not args.no_cpu_baseline:
             cb = B[0]["cb"]
             job_off = np.zeros(cb.n_chains + 1, np.uint64)

@@ -199,6 +199,12 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
                            const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                            uint32_t *path_j, float *path_d);
 
+/* Device time of the most recent rawdtw_traceback_batch on this context (HIP events on its stream, summed over its
+ * sub-batches): fill = the full-matrix kernels that write the packed 2-bit directions, walk = the traceback walk and the
+ * path finish; direction_bytes = the packed direction buffers of its jobs; path_elements = the elements of all paths. */
+int rawdtw_traceback_timing(const rawdtw_ctx *ctx, float *fill_ms, float *walk_ms, uint64_t *direction_bytes,
+                            uint64_t *path_elements);
+
 /* ---- single-call drop-ins with the reference's own signatures flattened
  * (dtw.hpp:21,25,28).  Host pointers; convenient, not fast. ---- */
 int rawdtw_dtw_global(rawdtw_ctx *ctx, const float *a, uint32_t n, const float *b, uint32_t m,
@@ -386,6 +392,13 @@ int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
  * 7 tiles, 9.. jobs per side-list class.  *n_out = 0 for a batch planned on the host. */
 int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out);
 int rawdtw_batch_destroy(rawdtw_batch *batch);
+/* The two calls a pipelined host makes per mini-batch: submit = rawdtw_batch_create +
+ * rawdtw_batch_run (everything enqueued, nothing waited for; O(1) host work for sparse + banded batches), and, when the
+ * worker's slot comes round again, fetch_destroy = rawdtw_batch_fetch of score / keep + rawdtw_batch_destroy. */
+int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out);
+int rawdtw_batch_fetch_destroy(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep);
 
 #ifdef __cplusplus
 }

@@ -156,6 +156,9 @@ SYMBOLS = {
     "rawdtw_batch_plan_ms": (I32, [VP, VP, C.POINTER(F32)]),
     "rawdtw_batch_stream_counters": (I32, [VP, VP, VP, U32, VP]),
     "rawdtw_batch_destroy": (I32, [VP]),
+    "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_fetch_destroy": (I32, [VP, VP, VP, VP]),
+    "rawdtw_traceback_timing": (I32, [VP, VP, VP, VP, VP]),
     "rawdtw_batch_replay": (I32, [C.POINTER(AlignOpt), U64, VP, VP, VP, VP, VP, VP, VP]),
 }
 

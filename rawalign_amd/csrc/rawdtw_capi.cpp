@@ -98,6 +98,9 @@ struct rawdtw_ctx {
     size_t tb_paths_bytes = 0;
     void *h_pinned = nullptr;  // pinned host staging (traceback paths), grow-only
     size_t pinned_bytes = 0;
+    hipEvent_t tb_ev[3] = {nullptr, nullptr, nullptr}; // around the fill and the walk of a traceback sub-batch
+    float tb_fill_ms = 0.f, tb_walk_ms = 0.f;          // device time of the most recent rawdtw_traceback_batch
+    uint64_t tb_dir_written = 0, tb_path_elems = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
     int fold_mode = 3; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work), 3: lanes + a wave for each long chain
     uint32_t fold_long_parts = 768; // fold_mode 3: chains of at least this many parts are folded a wave each
@@ -1206,6 +1209,7 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     for (StreamWs &w : ctx->ws_free) { if (w.d) (void)hipFree(w.d); if (w.h) (void)hipHostFree(w.h); }
     if (ctx->d_append) (void)hipFree(ctx->d_append);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (hipEvent_t &e : ctx->tb_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->d_tb_dir) (void)hipFree(ctx->d_tb_dir);
     if (ctx->d_tb_paths) (void)hipFree(ctx->d_tb_paths);
     delete ctx;
@@ -1529,6 +1533,8 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
     int st = rawdtw_upload_events(ctx, h_events, n_events);
     if (st != RAWDTW_OK) return st;
     lap("events H2D");
+    for (hipEvent_t &e : ctx->tb_ev) if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+    ctx->tb_fill_ms = ctx->tb_walk_ms = 0.f; ctx->tb_dir_written = 0; ctx->tb_path_elems = 0;
 
     // sub-batches bounded by the direction-buffer budget
     uint64_t budget = 16ull << 30;
@@ -1578,8 +1584,10 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         hipError_t e = hipMemcpyAsync(d_poff, h_poff.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "path offsets upload"); }
         lap("path buffers");
+        (void)hipEventRecord(ctx->tb_ev[0], ctx->stream);
         st = rawdtw_plan_run(ctx, pl);
         if (st != RAWDTW_OK) { cleanup(); return st; }
+        (void)hipEventRecord(ctx->tb_ev[1], ctx->stream);
         lap("fill");
         for (const Launch &L : pl->launches) {
             // one wave per job over the direction buffer, then start-first order + distances (k_tb_finish)
@@ -1587,6 +1595,7 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
                                     pl->d_dir, d_poff + L.first, d_plen + L.first, d_ti, d_tj, d_pi, d_pj, d_pd, ctx->stream);
             if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback walk launch"); }
         }
+        (void)hipEventRecord(ctx->tb_ev[2], ctx->stream);
         lap("walk");
         std::vector<float> h_cost(cnt);
         std::vector<uint32_t> h_plen(cnt);
@@ -1610,18 +1619,35 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { cleanup(); return hip_fail(ctx, e, "traceback download"); }
         lap("paths D2H");
-        for (uint64_t p = 0; p < cnt; p++) {
-            const uint64_t k = begin + pl->order[p];
-            out_cost[k] = h_cost[pl->order[p]];
-            const uint32_t len = h_plen[p];
-            // device paths are start-first already (k_tb_finish, dtw.cpp:656-657); the reference pops the last
-            // element when exclude_last_element is set (dtw.cpp:659-663)
-            const uint32_t outlen = jobs[k].exclude_last ? len - 1 : len;
-            const uint64_t src = h_poff[p], dst = path_off[k];
-            memcpy(path_i + dst, h_pi.u() + src, (size_t)outlen * 4);
-            memcpy(path_j + dst, h_pj.u() + src, (size_t)outlen * 4);
-            memcpy(path_d + dst, h_pd.f() + src, (size_t)outlen * 4);
-            path_len[k] = outlen;
+        {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->tb_ev[0], ctx->tb_ev[1]) == hipSuccess) ctx->tb_fill_ms += ms;
+            if (hipEventElapsedTime(&ms, ctx->tb_ev[1], ctx->tb_ev[2]) == hipSuccess) ctx->tb_walk_ms += ms;
+            ctx->tb_dir_written += pl->dir_bytes;
+        }
+        // into the caller's arrays (pageable memory: the page faults of a first touch dominate, so the jobs are spread over
+        // a few threads)
+        {
+            int T = ctx->plan_threads > 0 ? ctx->plan_threads : (int)std::min<uint64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u), acc / (1u << 20) + 1);
+            T = std::max(1, std::min(T, 16));
+            std::vector<uint64_t> elems(T, 0);
+            parallel_for(T, [&](int t) {
+                for (uint64_t p = cnt * (uint64_t)t / T; p < cnt * (uint64_t)(t + 1) / T; p++) {
+                    const uint64_t k = begin + pl->order[p];
+                    out_cost[k] = h_cost[pl->order[p]];
+                    const uint32_t len = h_plen[p];
+                    // device paths are start-first already (k_tb_finish, dtw.cpp:656-657); the reference pops the last
+                    // element when exclude_last_element is set (dtw.cpp:659-663)
+                    const uint32_t outlen = jobs[k].exclude_last ? len - 1 : len;
+                    const uint64_t src = h_poff[p], dst = path_off[k];
+                    memcpy(path_i + dst, h_pi.u() + src, (size_t)outlen * 4);
+                    memcpy(path_j + dst, h_pj.u() + src, (size_t)outlen * 4);
+                    memcpy(path_d + dst, h_pd.f() + src, (size_t)outlen * 4);
+                    path_len[k] = outlen;
+                    elems[t] += outlen;
+                }
+            });
+            for (int t = 0; t < T; t++) ctx->tb_path_elems += elems[t];
         }
         lap("copy out");
         cleanup();
@@ -2469,6 +2495,34 @@ int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t 
     *n_out = n;
     for (uint32_t i = 0; i < n && i < cap && out; i++) out[i] = batch->h_cnt[i];
     return RAWDTW_OK;
+}
+
+int rawdtw_traceback_timing(const rawdtw_ctx *ctx, float *fill_ms, float *walk_ms, uint64_t *direction_bytes, uint64_t *path_elements)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (fill_ms) *fill_ms = ctx->tb_fill_ms;
+    if (walk_ms) *walk_ms = ctx->tb_walk_ms;
+    if (direction_bytes) *direction_bytes = ctx->tb_dir_written;
+    if (path_elements) *path_elements = ctx->tb_path_elems;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out)
+{
+    int st = rawdtw_batch_create(ctx, opt, n_reads, chain_off, anchor_off, anchors, ref_base, read_base, out);
+    if (st != RAWDTW_OK) return st;
+    st = batch_enqueue_one(ctx, *out, nullptr);
+    if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
+    return st;
+}
+
+int rawdtw_batch_fetch_destroy(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep)
+{
+    const int st = rawdtw_batch_fetch(ctx, batch, score, keep, nullptr);
+    if (batch && batch->ctx == ctx) rawdtw_batch_destroy(batch); // (a batch of another context is the caller's mistake, not ours to free)
+    return st;
 }
 
 // everything of a batch that lives on the device or in its context's pools; `ctx` = the batch's context

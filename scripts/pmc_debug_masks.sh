@@ -5,5 +5,5 @@ for cfg in ${CFGS:-"stream_debug=5" "stream_debug=4"}; do
   echo "== $cfg"; python3 scripts/pmc_summary.py $OUT | python3 -c "
 import json,sys; d=json.load(sys.stdin)
 for k,v in d.items():
-    if 'k_stream' in k and 'cells' not in k: print({a:round(b/1e6,2) for a,b in v.items() if a!='dispatches'})"
+    if 'k_runs' in k and 'cells' not in k: print({a:round(b/1e6,2) for a,b in v.items() if a!='dispatches'})"
 done

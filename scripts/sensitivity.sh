@@ -21,7 +21,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
     rows.append({"case": os.path.basename(f)[:-5], "synth": d["config"]["synth"], "gcups": round(d["value"], 1), "ms_per_step": round(d["ms_per_step"], 4),
                  "kernel_gcups": round(d["kernel_replay"]["gcups"], 1), "dtw_jobs": b["dtw_jobs"], "cells": b["cells"],
                  "cells_per_job": round(b["cells"] / b["dtw_jobs"], 1), "lane_class_share": round(b["tile_class_jobs"] / b["dtw_jobs"], 4),
-                 "k_stream_alone_ms": d["launches"]["alone_ms"]["k_stream"], "roofline_frac_alone": round(d["roofline"]["alone"]["frac"], 4)})
+                 "k_runs_alone_ms": d["launches"]["alone_ms"]["k_runs"], "roofline_frac_alone": round(d["roofline"]["alone"]["frac"], 4)})
 json.dump(rows, open(sys.argv[1] + "/summary.json", "w"), indent=1)
 for r in rows: print(r)
 PY

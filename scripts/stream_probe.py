@@ -1,4 +1,4 @@
-"""Timing probe for the sync-free batch path: one bench-like batch, k_stream alone under the `stream_debug` masks and a
+"""Timing probe for the sync-free batch path: one bench-like batch, k_runs alone under the `stream_debug` masks and a
 few tile sizes (GPU box).  Usage: python scripts/stream_probe.py [n_reads]"""
 import ctypes as C
 import os
