@@ -380,6 +380,12 @@ def main():
             "new_events": pin.copy(cb.events[idx]), "seg_src": pin.copy(seg_src), "seg_dst": pin.copy(seg_dst),
             "score": pin.empty(cb.n_chains, np.float32), "keep": pin.empty(cb.n_chains, np.uint8),
         }
+        # the anchor lists in the compact hand-over form (rawdtw_anchors_pack: 2-byte steps; what the `value_pcie` loop sends)
+        from rawalign_amd.align import pack_anchors
+        ca = pack_anchors(lib, cb.anchor_off, cb.anchors)
+        d["c_heads"], d["c_unit_abs"], d["c_steps"] = pin.copy(ca.heads), pin.copy(ca.unit_abs), pin.copy(ca.steps)
+        d["c_wide"], d["c_n_wide"] = pin.copy(ca.wide if len(ca.wide) else np.zeros(1, ca.wide.dtype)), len(ca.wide)
+        d["compact_bytes"] = int(ca.nbytes)
         # device-resident copies of the three big arrays (the `value` loop uses them in place)
         d["t_anchors"] = torch.from_numpy(cb.anchors.view(np.uint8).copy()).cuda(local_rank)
         d["t_ref_base"] = torch.from_numpy(cb.ref_base.astype(np.uint64).view(np.uint8).copy()).cuda(local_rank)
@@ -419,6 +425,13 @@ def main():
         e._check(st)
         live[sl] = True
 
+    def submit_compact(sl):
+        d, e = B[sl], engines[sl]
+        e._check(lib.rawdtw_batch_submit_compact(e._ctx, C.byref(copt), d["n_reads"], vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["c_heads"]),
+                                                 vp(d["c_unit_abs"]), vp(d["c_steps"]), vp(d["c_wide"]), d["c_n_wide"], vp(d["ref_base"]),
+                                                 vp(d["read_base"]), C.byref(handles[sl])))
+        live[sl] = True
+
     def fetch_destroy(sl, job_cost=None):
         d, e = B[sl], engines[sl]
         if job_cost is None:
@@ -453,7 +466,9 @@ def main():
             if pcie:  # the round's new events: one H2D of the packed chunk events + a scatter into the per-read arrays
                 e._check(lib.rawdtw_events_append(e._ctx, vp(d["new_events"]), len(d["new_events"]), d["n_reads"],
                                                   vp(d["seg_src"]), vp(d["seg_dst"])))
-            if timed_launches is None:
+            if pcie == "compact":
+                submit_compact(sl)
+            elif timed_launches is None:
                 submit(sl, not pcie)
             else:  # HIP event pair around every launch, read when the context comes round again
                 create(sl, not pcie)
@@ -490,8 +505,10 @@ def main():
     # ---- warm-up (workspace pools, code objects), then the three timed loops ----
     pipeline(max(args.warmup, slots), pcie=False)
     pipeline(slots, pcie=True)
+    pipeline(slots, pcie="compact")
     t_fresh = repeat_region(lambda: pipeline(K, pcie=False, host=host_s))
-    t_pcie = repeat_region(lambda: pipeline(K, pcie=True))
+    t_pcie = repeat_region(lambda: pipeline(K, pcie="compact"))
+    t_pcie_plain = repeat_region(lambda: pipeline(K, pcie=True))
     # host cost of one create call, steady state (inputs resident / from pinned host memory)
     create_ms = {}
     for mode, pc in (("resident", False), ("from_host", True)):
@@ -581,9 +598,11 @@ def main():
         return [float(x) for x in t.cpu()]
     (reads_t, chains_t, jobs_t, cells_t, mapped_t, bytes_t), _ = reduce_counters(dist, counters, 0.0, device=red_dev)
     r_fresh, r_pcie, r_replay = reduce_times(t_fresh), reduce_times(t_pcie), reduce_times(t_replay)
+    r_pcie_plain = reduce_times(t_pcie_plain)
 
     if rank == 0:
         T, Tp, Tr = float(np.median(r_fresh)), float(np.median(r_pcie)), float(np.median(r_replay))
+        Tpp = float(np.median(r_pcie_plain))
         lp = np.array(launches_in_pipeline)  # rows: steps, columns: [k_runs, fold, select]
         dms = float(lp[:, 0].mean())
         plan_pipe, plan_al = float(np.median(plan_ms)), float(np.median(plan_alone))
@@ -622,9 +641,16 @@ def main():
                                    "and chaining are imitated by their output (rawalign_amd/synth.py)",
             "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "dtw_stage_rounds_per_s": mapped_t / Tp, "ms_per_step": Tp / K * 1e3,
                               "repeats": len(r_pcie),
-                              "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["anchors"].nbytes + B[0]["ref_base"].nbytes + B[0]["read_base"].nbytes),
+                              "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["compact_bytes"] + B[0]["ref_base"].nbytes + B[0]["read_base"].nbytes +
+                                                        B[0]["anchor_off"].nbytes + B[0]["chain_off"].nbytes),
+                              "h2d_bytes": {"new_events": int(B[0]["new_events"].nbytes), "anchor_lists_compact": int(B[0]["compact_bytes"]),
+                                            "anchor_lists_plain": int(B[0]["anchors"].nbytes)},
                               "note": "same loop with the step's host hand-over inside: the round's new events (last chunk of "
-                                      "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory"},
+                                      "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory; the lists in "
+                                      "the compact form (rawdtw_batch_submit_compact: 2-byte steps, decoded inside k_scan)",
+                              "plain_anchor_lists": {"gcups": cells_t / Tpp / 1e9, "ms_per_step": Tpp / K * 1e3,
+                                                     "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["anchors"].nbytes + B[0]["ref_base"].nbytes +
+                                                                               B[0]["read_base"].nbytes + B[0]["anchor_off"].nbytes + B[0]["chain_off"].nbytes)}},
             "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / K * 1e3, "repeats": len(r_replay),
                               "note": "launches of already submitted resident batches only (round 1's headline)"},
             "host_ms_per_step": {k: round(host_s[k] / max(host_s["steps"], 1) * 1e3, 4) for k in ("fetch", "submit")} | {

@@ -392,6 +392,35 @@ int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
  * 7 tiles, 9.. jobs per side-list class.  *n_out = 0 for a batch planned on the host. */
 int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out);
 int rawdtw_batch_destroy(rawdtw_batch *batch);
+/* ---- compact hand-over of the anchor lists.  A mini-batch's anchors are its largest array (8 bytes an anchor: as much
+ * as the round's new events), and consecutive anchors of a chain differ by little: the chaining DP bounds the gaps
+ * (rmap.cpp:456-472, roptions.c:13-15).  The compact form sends, per chain, its first entry whole (= the chain's END:
+ * chains are stored end-first, rmap.cpp:193-196) and for every further entry the step back from the entry before it as
+ * two bytes (query step, target step), 2 bytes an anchor instead of 8; every RAWDTW_COMPACT_STRIDE-th entry of the flat
+ * list is sent whole as well (the decoder works in units of that many); a step of 255 or more in either component is an
+ * escape: the entry's two steps are listed in `wide`, ascending by index.  rawdtw_anchors_pack builds the form (pure host
+ * code; RAWDTW_ERR_INVALID when a chain's positions do not descend along its list -- such a chain no mapper produces, send
+ * the batch with rawdtw_batch_submit -- and RAWDTW_ERR_RANGE when wide_cap is too small, *n_wide then says how many).
+ * rawdtw_batch_submit_compact = rawdtw_batch_submit with the lists in that form: they are decoded on the device, inside the
+ * scan of the anchor list. ---- */
+#define RAWDTW_COMPACT_STRIDE 8192u
+typedef struct {
+    uint32_t index;                  /* position in the flat anchor list */
+    uint32_t query_step, target_step; /* anchors[index - 1] - anchors[index], per component */
+} rawdtw_wide_step_t;
+int rawdtw_anchors_pack(uint64_t n_chains, const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
+                        rawdtw_anchor_t *heads /* n_chains */, rawdtw_anchor_t *unit_abs /* ceil(n_anchors / STRIDE) */,
+                        uint16_t *steps /* n_anchors: query step | target step << 8 */, rawdtw_wide_step_t *wide,
+                        uint64_t wide_cap, uint64_t *n_wide);
+/* the inverse, on the host (tests; the library's own fallback paths) */
+int rawdtw_anchors_unpack(uint64_t n_chains, const uint64_t *anchor_off, const rawdtw_anchor_t *heads,
+                          const rawdtw_anchor_t *unit_abs, const uint16_t *steps, const rawdtw_wide_step_t *wide,
+                          uint64_t n_wide, rawdtw_anchor_t *anchors_out);
+int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                                const uint64_t *anchor_off, const rawdtw_anchor_t *heads, const rawdtw_anchor_t *unit_abs,
+                                const uint16_t *steps, const rawdtw_wide_step_t *wide, uint64_t n_wide,
+                                const uint64_t *ref_base, const uint32_t *read_base, rawdtw_batch **out);
+
 /* The two calls a pipelined host makes per mini-batch: submit = rawdtw_batch_create +
  * rawdtw_batch_run (everything enqueued, nothing waited for; O(1) host work for sparse + banded batches), and, when the
  * worker's slot comes round again, fetch_destroy = rawdtw_batch_fetch of score / keep + rawdtw_batch_destroy. */

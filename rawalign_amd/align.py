@@ -227,10 +227,59 @@ class CandidateBatch:
         return len(self.anchor_off) - 1
 
 
-class Batch:
-    """rawdtw_batch: DTW scoring + align_chain fold + per-read selection, all on the device."""
+COMPACT_STRIDE = 8192  # RAWDTW_COMPACT_STRIDE
+WIDE_STEP_DTYPE = np.dtype([("index", np.uint32), ("query_step", np.uint32), ("target_step", np.uint32)])
 
-    def __init__(self, engine: Engine, opt: MapOpt, cb: CandidateBatch):
+
+@dataclass
+class CompactAnchors:
+    """The anchor lists of a CandidateBatch in the compact hand-over form (include/rawdtw.h, rawdtw_anchors_pack): every
+    chain's first entry and every COMPACT_STRIDE-th entry whole, the others as 2-byte steps back, steps >= 255 listed."""
+
+    heads: np.ndarray
+    unit_abs: np.ndarray
+    steps: np.ndarray
+    wide: np.ndarray
+
+    @property
+    def nbytes(self):
+        return self.heads.nbytes + self.unit_abs.nbytes + self.steps.nbytes + self.wide.nbytes
+
+
+def pack_anchors(lib, anchor_off, anchors) -> CompactAnchors:
+    anchor_off = np.ascontiguousarray(anchor_off, np.uint64)
+    anchors = np.ascontiguousarray(anchors, ANCHOR_DTYPE)
+    nc, na = len(anchor_off) - 1, len(anchors)
+    heads = np.zeros(max(nc, 1), ANCHOR_DTYPE)
+    unit_abs = np.zeros(max((na + COMPACT_STRIDE - 1) // COMPACT_STRIDE, 1), ANCHOR_DTYPE)
+    steps = np.zeros(max(na, 1), np.uint16)
+    wide = np.zeros(64, WIDE_STEP_DTYPE)
+    nw = C.c_uint64()
+    st = lib.rawdtw_anchors_pack(nc, _ptr(anchor_off), _ptr(anchors), _ptr(heads), _ptr(unit_abs), _ptr(steps), _ptr(wide), len(wide), C.byref(nw))
+    if st == 4:  # RAWDTW_ERR_RANGE: more wide steps than the list holds
+        wide = np.zeros(nw.value, WIDE_STEP_DTYPE)
+        st = lib.rawdtw_anchors_pack(nc, _ptr(anchor_off), _ptr(anchors), _ptr(heads), _ptr(unit_abs), _ptr(steps), _ptr(wide), len(wide), C.byref(nw))
+    if st != 0:
+        raise ValueError("rawdtw_anchors_pack: status %d (a chain whose positions do not descend along its list?)" % st)
+    return CompactAnchors(heads[:max(nc, 0)] if nc else heads[:0], unit_abs, steps[:na], wide[:nw.value].copy())
+
+
+def unpack_anchors(lib, anchor_off, ca: CompactAnchors) -> np.ndarray:
+    anchor_off = np.ascontiguousarray(anchor_off, np.uint64)
+    na = int(anchor_off[-1])
+    out = np.zeros(max(na, 1), ANCHOR_DTYPE)
+    st = lib.rawdtw_anchors_unpack(len(anchor_off) - 1, _ptr(anchor_off), _ptr(ca.heads), _ptr(ca.unit_abs), _ptr(ca.steps), _ptr(ca.wide),
+                                   len(ca.wide), _ptr(out))
+    if st != 0:
+        raise ValueError("rawdtw_anchors_unpack: status %d" % st)
+    return out[:na]
+
+
+class Batch:
+    """rawdtw_batch: DTW scoring + align_chain fold + per-read selection, all on the device.  compact=True hands the anchor
+    lists over in the compact form (rawdtw_batch_submit_compact: the batch is then already running when this returns)."""
+
+    def __init__(self, engine: Engine, opt: MapOpt, cb: CandidateBatch, compact: bool = False):
         self.engine = engine
         self.cb = cb
         self._copt = opt.c_struct()
@@ -241,8 +290,16 @@ class Batch:
         ]
         h = C.c_void_p()
         a = self._arrays
-        engine._check(engine.lib.rawdtw_batch_create(engine._ctx, C.byref(self._copt), cb.n_reads, _ptr(a[0]),
-                                                     _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), C.byref(h)))
+        self._submitted = False
+        if compact:
+            self.compact = ca = pack_anchors(engine.lib, a[1], a[2])
+            engine._check(engine.lib.rawdtw_batch_submit_compact(engine._ctx, C.byref(self._copt), cb.n_reads, _ptr(a[0]), _ptr(a[1]),
+                                                                 _ptr(ca.heads), _ptr(ca.unit_abs), _ptr(ca.steps), _ptr(ca.wide), len(ca.wide),
+                                                                 _ptr(a[3]), _ptr(a[4]), C.byref(h)))
+            self._submitted = True
+        else:
+            engine._check(engine.lib.rawdtw_batch_create(engine._ctx, C.byref(self._copt), cb.n_reads, _ptr(a[0]),
+                                                         _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), C.byref(h)))
         self._h = h
         engine._children.add(self)
 
@@ -285,6 +342,9 @@ class Batch:
         return bool(dev.value)
 
     def run(self):
+        if self._submitted:  # (a compact batch was enqueued by its submit call)
+            self._submitted = False
+            return
         self.engine._check(self.engine.lib.rawdtw_batch_run(self.engine._ctx, self._h))
 
     def run_timed(self):

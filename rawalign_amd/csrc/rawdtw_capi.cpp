@@ -195,6 +195,11 @@ struct rawdtw_batch {
     const rawdtw_anchor_t *in_anchors = nullptr;
     const uint64_t *in_ref_base = nullptr;
     const uint32_t *in_read_base = nullptr;
+    // compact hand-over (rawdtw_batch_submit_compact): the lists in packed form instead of in_anchors
+    const rawdtw_anchor_t *in_heads = nullptr, *in_unit_abs = nullptr;
+    const uint16_t *in_steps = nullptr;
+    const rawdtw_wide_step_t *in_wide = nullptr;
+    uint64_t in_n_wide = 0;
     // "resident_arrays": the three big arrays are device pointers; host copies are made only if the job list is needed
     bool in_resident = false;
     std::vector<rawdtw_anchor_t> host_anchors;
@@ -1801,7 +1806,11 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.n_tiles = (uint32_t)((na + a.tile_anchors - 1) / a.tile_anchors);
     a.others_cap = std::min<uint64_t>(na, na / 4 + 4096);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t dev_bytes = al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
+    const bool compact = b->in_steps != nullptr;
+    const uint64_t n_units = (na + RAWDTW_COMPACT_STRIDE - 1) / RAWDTW_COMPACT_STRIDE;
+    const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
+    const size_t dev_bytes = compact_bytes +
+                             al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
                              al((size_t)a.n_tiles * 4) + al((size_t)a.n_tiles * 24) +                                           // per tile
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
                              al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
@@ -1826,6 +1835,14 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.debug = ctx->stream_debug;
     a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
     if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
+    rawdtw_anchor_t *d_heads = nullptr, *d_unit_abs = nullptr;
+    uint16_t *d_steps = nullptr;
+    rawdtw_wide_step_t *d_wide = nullptr;
+    if (compact) { // the packed lists; k_scan decodes them into d_anchors
+        d_heads = carve<rawdtw_anchor_t>(p, nc); d_unit_abs = carve<rawdtw_anchor_t>(p, n_units);
+        d_steps = carve<uint16_t>(p, n_units * RAWDTW_COMPACT_STRIDE); d_wide = carve<rawdtw_wide_step_t>(p, b->in_n_wide);
+        a.heads = d_heads; a.unit_abs = d_unit_abs; a.steps = d_steps; a.wide = d_wide; a.n_wide = b->in_n_wide; a.anchors_w = d_anchors;
+    }
     a.ev = ctx->d_ev; a.ref = ctx->d_ref;
     char *hp = b->ws.h;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
@@ -1839,7 +1856,14 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     }
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
-    if (!b->in_resident) {
+    if (compact) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_heads, b->in_heads, nc * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_unit_abs, b->in_unit_abs, n_units * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_steps, b->in_steps, na * 2, hipMemcpyHostToDevice, s));
+        if (b->in_n_wide) HIP_TRY(ctx, hipMemcpyAsync(d_wide, b->in_wide, b->in_n_wide * sizeof(rawdtw_wide_step_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+    } else if (!b->in_resident) {
         HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
@@ -1887,6 +1911,15 @@ void batch_count_jobs(rawdtw_batch *b)
 // "resident_arrays": bring the three device-resident arrays to the host (the job-list path reads them there)
 int materialise_host_arrays(rawdtw_ctx *ctx, rawdtw_batch *b)
 {
+    if (b->in_steps) { // the compact form: the job list is built from plain anchors
+        const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
+        try { b->host_anchors.resize(na); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+        if (rawdtw_anchors_unpack(nc, b->in_anchor_off, b->in_heads, b->in_unit_abs, b->in_steps, b->in_wide, b->in_n_wide, b->host_anchors.data()) != RAWDTW_OK)
+            return fail(ctx, RAWDTW_ERR_INVALID, "malformed compact anchor lists");
+        b->in_anchors = b->host_anchors.data();
+        b->in_steps = nullptr;
+        return RAWDTW_OK;
+    }
     if (!b->in_resident) return RAWDTW_OK;
     const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
     try { b->host_anchors.resize(na); b->host_ref_base.resize(nc); b->host_read_base.resize(nc); }
@@ -2037,13 +2070,22 @@ int stream_fallback(rawdtw_ctx *ctx, rawdtw_batch *b)
 // a batch whose (deferred) planning failed has neither form left: every entry point but destroy refuses it
 static bool batch_dead(const rawdtw_batch *b) { return !b->stream && !b->plan; }
 
-int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
-                        const uint32_t *read_base, rawdtw_batch **out)
+struct CompactIn {
+    const rawdtw_anchor_t *heads, *unit_abs;
+    const uint16_t *steps;
+    const rawdtw_wide_step_t *wide;
+    uint64_t n_wide;
+};
+
+static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                            const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const CompactIn *cin, const uint64_t *ref_base,
+                            const uint32_t *read_base, rawdtw_batch **out)
 {
     if (!out) return RAWDTW_ERR_INVALID;
     *out = nullptr;
-    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && n_reads) || !ref_base || !read_base)
+    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && !cin && n_reads) || !ref_base || !read_base)
+        return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (cin && (!cin->heads || !cin->unit_abs || !cin->steps || (!cin->wide && cin->n_wide)))
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     if (opt->border_constraint != 0 && opt->border_constraint != 1)
         return fail(ctx, RAWDTW_ERR_INVALID, "invalid border constraint (rmap.cpp:301-304)");
@@ -2055,7 +2097,8 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     b->ctx = ctx; b->opt = *opt; b->n_reads = n_reads; b->n_chains = n_chains;
     ctx->live_batches.push_back(b);
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
-    b->in_resident = ctx->resident_arrays;
+    b->in_resident = ctx->resident_arrays && !cin;
+    if (cin) { b->in_heads = cin->heads; b->in_unit_abs = cin->unit_abs; b->in_steps = cin->steps; b->in_wide = cin->wide; b->in_n_wide = cin->n_wide; }
     if (stream_eligible(ctx, opt, anchor_off[n_chains]))
         st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base);
     else {
@@ -2072,6 +2115,28 @@ int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
     *out = b;
     return RAWDTW_OK;
+}
+
+int rawdtw_batch_create(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                        const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                        const uint32_t *read_base, rawdtw_batch **out)
+{
+    return batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, anchors, nullptr, ref_base, read_base, out);
+}
+
+static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e);
+
+int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                                const uint64_t *anchor_off, const rawdtw_anchor_t *heads, const rawdtw_anchor_t *unit_abs,
+                                const uint16_t *steps, const rawdtw_wide_step_t *wide, uint64_t n_wide, const uint64_t *ref_base,
+                                const uint32_t *read_base, rawdtw_batch **out)
+{
+    const CompactIn cin{heads, unit_abs, steps, wide, n_wide};
+    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, nullptr, &cin, ref_base, read_base, out);
+    if (st != RAWDTW_OK) return st;
+    st = batch_enqueue_one(ctx, *out, nullptr);
+    if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
+    return st;
 }
 
 int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const rawdtw_job_t *jobs, uint64_t n_jobs,

@@ -379,3 +379,54 @@ int rawdtw_batch_replay(const rawdtw_align_opt_t *opt, uint64_t n_reads, const u
 }
 
 } // extern "C"
+
+// ---- compact anchor lists (include/rawdtw.h): steps back from the entry before, two bytes an anchor ----
+extern "C" int rawdtw_anchors_pack(uint64_t n_chains, const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, rawdtw_anchor_t *heads,
+                                   rawdtw_anchor_t *unit_abs, uint16_t *steps, rawdtw_wide_step_t *wide, uint64_t wide_cap, uint64_t *n_wide)
+{
+    if (!anchor_off || (!anchors && n_chains) || !heads || !unit_abs || !steps || !n_wide || (!wide && wide_cap)) return RAWDTW_ERR_INVALID;
+    uint64_t nw = 0;
+    for (uint64_t c = 0; c < n_chains; c++) {
+        const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+        if (a1 > a0) heads[c] = anchors[a0]; else heads[c] = rawdtw_anchor_t{0, 0};
+        for (uint64_t i = a0; i < a1; i++) {
+            if (i % RAWDTW_COMPACT_STRIDE == 0) unit_abs[i / RAWDTW_COMPACT_STRIDE] = anchors[i];
+            if (i == a0) { steps[i] = 0; continue; }
+            const rawdtw_anchor_t p = anchors[i - 1], x = anchors[i];
+            if (x.query_position > p.query_position || x.target_position > p.target_position) return RAWDTW_ERR_INVALID; // (not descending)
+            const uint32_t dq = p.query_position - x.query_position, dt = p.target_position - x.target_position;
+            if (dq >= 255u || dt >= 255u) {
+                if (nw < wide_cap) wide[nw] = rawdtw_wide_step_t{(uint32_t)i, dq, dt};
+                nw++;
+                steps[i] = 0xffffu;
+            } else steps[i] = (uint16_t)(dq | (dt << 8));
+        }
+    }
+    *n_wide = nw;
+    return nw > wide_cap ? RAWDTW_ERR_RANGE : RAWDTW_OK;
+}
+
+extern "C" int rawdtw_anchors_unpack(uint64_t n_chains, const uint64_t *anchor_off, const rawdtw_anchor_t *heads, const rawdtw_anchor_t *unit_abs,
+                                     const uint16_t *steps, const rawdtw_wide_step_t *wide, uint64_t n_wide, rawdtw_anchor_t *anchors_out)
+{
+    if (!anchor_off || !heads || !unit_abs || !steps || (!wide && n_wide) || (!anchors_out && n_chains)) return RAWDTW_ERR_INVALID;
+    uint64_t w = 0;
+    for (uint64_t c = 0; c < n_chains; c++) {
+        const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
+        for (uint64_t i = a0; i < a1; i++) {
+            if (i == a0) { anchors_out[i] = heads[c]; continue; }
+            uint32_t dq = steps[i] & 0xffu, dt = steps[i] >> 8;
+            if (steps[i] == 0xffffu) {
+                while (w < n_wide && wide[w].index < i) w++;
+                if (w >= n_wide || wide[w].index != i) return RAWDTW_ERR_INVALID;
+                dq = wide[w].query_step; dt = wide[w].target_step;
+            }
+            anchors_out[i] = rawdtw_anchor_t{anchors_out[i - 1].target_position - dt, anchors_out[i - 1].query_position - dq};
+            // (every STRIDE-th entry travels whole as well: the device decodes unit by unit; it must agree)
+            if (i % RAWDTW_COMPACT_STRIDE == 0 && (unit_abs[i / RAWDTW_COMPACT_STRIDE].target_position != anchors_out[i].target_position ||
+                                                   unit_abs[i / RAWDTW_COMPACT_STRIDE].query_position != anchors_out[i].query_position))
+                return RAWDTW_ERR_INVALID;
+        }
+    }
+    return RAWDTW_OK;
+}

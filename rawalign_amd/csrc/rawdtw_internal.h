@@ -149,6 +149,13 @@ struct StreamArgs {
     const uint64_t *ref_base;
     const uint32_t *read_base;
     const float *ev, *ref;
+    // compact hand-over (rawdtw_batch_submit_compact; `steps` null otherwise): k_scan decodes the lists into `anchors_w`
+    // (= `anchors`, writable) unit by unit before it looks at them
+    const rawdtw_anchor_t *heads, *unit_abs;
+    const uint16_t *steps;
+    const rawdtw_wide_step_t *wide;
+    uint64_t n_wide;
+    rawdtw_anchor_t *anchors_w;
     // workspace and outputs (device)
     uint32_t *tile_chain;        // per tile: the chain its first anchor belongs to (n_tiles entries, written by k_scan)
     unsigned long long *tile_stats; // per scan unit (8192 anchors): tile-class parts, their algorithmic bytes, the side list's bytes

@@ -137,6 +137,31 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x)
     return x;
 }
 
+// Decoding a compact anchor list (include/rawdtw.h) is a scan of maps: an entry sent whole is the constant map x -> v, an
+// entry sent as a step back is x -> x - step, and entry i's anchor is the composition of the maps of its unit's entries
+// 0 .. i applied to anything (the unit's first entry is sent whole).  `set` = constant map.
+struct StepMap { uint32_t set, q, t; };
+__device__ __forceinline__ StepMap compose(const StepMap later, const StepMap earlier)
+{
+    if (later.set) return later;
+    return StepMap{earlier.set, earlier.set ? earlier.q - later.q : earlier.q + later.q, earlier.set ? earlier.t - later.t : earlier.t + later.t};
+}
+#define RAWDTW_DPP_MAP(m, ctrl, rowmask)                                                                                      \
+    StepMap{(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(m).set, ctrl, rowmask, 0xf, false),                                  \
+            (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(m).q, ctrl, rowmask, 0xf, false),                                    \
+            (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(m).t, ctrl, rowmask, 0xf, false)}
+// inclusive scan of the lanes' maps over the wave (see wave_scan_incl; a lane without a source takes the identity map)
+__device__ __forceinline__ StepMap wave_scan_maps(StepMap m)
+{
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x111, 0xf));
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x112, 0xf));
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x114, 0xf));
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x118, 0xf));
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x142, 0xa));
+    m = compose(m, RAWDTW_DPP_MAP(m, 0x143, 0xc));
+    return m;
+}
+
 // bit p of a tile's chain-start mask: anchor (tile base + p) is the first entry of a chain (bit AT may be set as well:
 // the anchor behind the tile's last; the end of the anchor list counts as a chain start)
 __device__ __forceinline__ bool mask_bit(const uint32_t *mask, uint32_t p) { return (mask[p >> 5] >> (p & 31u)) & 1u; }
@@ -255,6 +280,8 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
 // a counter the whole grid shares: such a word takes ~88 atomics a microsecond, and at one workgroup per TILE (ten
 // thousand a batch) the launch spent 150 of its 176 us queueing there.
 constexpr uint32_t kScanUnit = 8192, kScanT = 1024, kScanKI = kScanUnit / kScanT;
+static_assert(kScanUnit == RAWDTW_COMPACT_STRIDE, "the compact hand-over is decoded unit by unit");
+template <bool COMPACT>
 __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32_t unit)
 {
     constexpr int NT = (int)kScanT, KI = (int)kScanKI;
@@ -273,8 +300,12 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     // last part), requested before the chain search waits for anything
     const uint64_t i0 = base + (uint64_t)tid * KI;
     rawdtw_anchor_t an[KI + 1];
+    uint4 steps8 = make_uint4(0u, 0u, 0u, 0u); // compact form: this thread's eight 2-byte steps
+    if (COMPACT) { if (i0 < a.n_anchors) steps8 = *reinterpret_cast<const uint4 *>(a.steps + i0); } // (the array is padded to whole units)
+    else {
 #pragma unroll
-    for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
+        for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
+    }
     if (tid < 64) {
         const uint64_t c = find_chain(a.anchor_off, a.n_chains, base, lane);
         if (tid == 0) s_c0 = c;
@@ -303,6 +334,53 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     auto chain_at = [&](uint32_t p) {
         return c0 + (s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u));
     };
+    if (COMPACT) {
+        // ---- decode the unit: every entry's map, the thread's eight composed in order, a scan over the workgroup's threads ----
+        static_assert(KI == 8, "eight 2-byte steps a thread");
+        __shared__ StepMap s_wagg[NT / 64];
+        __shared__ uint2 s_first[NT];
+        const uint32_t sv[8] = {steps8.x & 0xffffu, steps8.x >> 16, steps8.y & 0xffffu, steps8.y >> 16,
+                                steps8.z & 0xffffu, steps8.z >> 16, steps8.w & 0xffffu, steps8.w >> 16};
+        StepMap part[KI]; // the composition of this thread's entries 0 .. k
+        StepMap run{0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const uint32_t p = (uint32_t)tid * KI + k;
+            const uint64_t i = base + p;
+            StepMap m{0u, 0u, 0u};
+            if (i < a.n_anchors) {
+                if (mask_bit(s_mask, p)) { const rawdtw_anchor_t h = a.heads[chain_at(p)]; m = StepMap{1u, h.query_position, h.target_position}; }
+                else if (p == 0) { const rawdtw_anchor_t h = a.unit_abs[unit]; m = StepMap{1u, h.query_position, h.target_position}; }
+                else if (sv[k] == 0xffffu) { // an escape: the entry's steps are in the list of wide steps, ascending by index
+                    uint64_t lo = 0, hi = a.n_wide;
+                    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.wide[mid].index < (uint32_t)i) lo = mid + 1; else hi = mid; }
+                    if (lo < a.n_wide && a.wide[lo].index == (uint32_t)i) m = StepMap{0u, a.wide[lo].query_step, a.wide[lo].target_step};
+                    else atomicMin(&a.cnt[kCntBad], (unsigned long long)i); // (a malformed hand-over)
+                } else m = StepMap{0u, sv[k] & 0xffu, sv[k] >> 8};
+            }
+            run = compose(m, run);
+            part[k] = run;
+        }
+        const StepMap incl = wave_scan_maps(run);
+        if (lane == 63) s_wagg[tid >> 6] = incl;
+        __syncthreads();
+        StepMap pre = RAWDTW_DPP_MAP(incl, 0x138, 0xf); // the lanes before this one (lane 0: the identity)
+        {
+            StepMap wpre{0u, 0u, 0u}; // the waves before this one
+            for (int w = 0; w < (tid >> 6); w++) wpre = compose(s_wagg[w], wpre);
+            pre = compose(pre, wpre);
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const StepMap f = compose(part[k], pre); // (set: the unit's first entry is)
+            an[k] = rawdtw_anchor_t{f.t, f.q};
+            if (i0 + k < a.n_anchors) a.anchors_w[i0 + k] = an[k];
+        }
+        s_first[tid] = make_uint2(an[0].target_position, an[0].query_position);
+        __syncthreads();
+        if (tid + 1 < NT) { const uint2 x = s_first[tid + 1]; an[KI] = rawdtw_anchor_t{x.x, x.y}; }
+        else an[KI] = base + AT < a.n_anchors ? a.unit_abs[unit + 1] : rawdtw_anchor_t{0, 0}; // (the next unit's first entry travels whole)
+    }
     {   // every tile's first chain
         const uint32_t tiles_per_unit = AT / a.tile_anchors;
         const uint64_t t = (uint64_t)unit * tiles_per_unit + (uint32_t)tid;
@@ -377,7 +455,21 @@ __global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
     else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
-    else scan_unit_body(a, b - 1 - n_desc);
+    else scan_unit_body<false>(a, b - 1 - n_desc);
+}
+
+// The compact hand-over: the units decode their anchors first (rawdtw_batch_submit_compact).  The chain records read the
+// chains' first and last anchors: the first travels whole (`heads`), the last they cannot know before the units have
+// written it -- so they run as a launch of their own behind this one (k_scan_desc).
+__global__ __launch_bounds__(kScanT) void k_scan_compact(const StreamArgs a, uint32_t *__restrict__ order)
+{
+    const uint32_t b = blockIdx.x;
+    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    else scan_unit_body<true>(a, b - 1);
+}
+__global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainDesc *__restrict__ chains)
+{
+    chain_desc_body(a, chains, (uint64_t)blockIdx.x * kScanT + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1136,9 +1228,11 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
 {
     (void)hipGetLastError();
     if (a.n_anchors == 0 && a.n_chains == 0) return hipSuccess;
-    const uint32_t n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit);
-    const uint32_t grid = n_units + 1u + (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
-    hipLaunchKernelGGL(k_scan, dim3(grid), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    const uint32_t n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit), n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
+    if (a.steps) {
+        hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanT), 0, s, a, d_fold_order);
+        if (n_desc) hipLaunchKernelGGL(k_scan_desc, dim3(n_desc), dim3(kScanT), 0, s, a, d_chains);
+    } else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
     return hipGetLastError();
 }

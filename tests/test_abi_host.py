@@ -194,3 +194,38 @@ def test_product_package_never_touches_the_oracle():
                 for ln in open(os.path.join(dp, fn), encoding="utf-8"):
                     code = ln.split("#")[0] if fn.endswith(".py") else ln.split("//")[0]
                     assert not re.search(r"\boracle\b|liboracle|_ref/", code), (fn, ln)
+
+
+def test_compact_anchor_lists_round_trip():
+    """rawdtw_anchors_pack / _unpack (include/rawdtw.h): 2-byte steps back along every chain, chains' first entries and every
+    8192nd entry whole, steps of 255 or more in the escape list; a chain that does not descend is refused."""
+    import ctypes as C
+
+    from rawalign_amd.align import COMPACT_STRIDE, pack_anchors, unpack_anchors
+
+    lib = ra.load_library()
+    rng = np.random.default_rng(3)
+    lens = np.concatenate([rng.integers(0, 40, 300), [1, 2, 9000, 8192, 1, 0, 17000], rng.integers(1, 6, 2000)])
+    anchor_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    anchors = np.zeros(int(anchor_off[-1]), ra.ANCHOR_DTYPE)
+    for c, n in enumerate(lens):
+        if n == 0:
+            continue
+        dq = rng.integers(0, 30, n); dt = rng.integers(0, 30, n)
+        big = rng.random(n) < 0.02   # steps beyond a byte, in either component or both
+        dq[big] = rng.integers(200, 5000, int(big.sum())); dt[rng.random(n) < 0.01] = 254; dt[rng.random(n) < 0.01] = 255
+        q = 10 + np.cumsum(dq); t = 1000 + np.cumsum(dt)
+        a0 = int(anchor_off[c])
+        anchors["query_position"][a0:a0 + n] = q[::-1]   # end-first (rmap.cpp:193-196)
+        anchors["target_position"][a0:a0 + n] = t[::-1]
+    ca = pack_anchors(lib, anchor_off, anchors)
+    assert len(ca.steps) == len(anchors) and len(ca.unit_abs) == (len(anchors) + COMPACT_STRIDE - 1) // COMPACT_STRIDE
+    assert len(ca.wide) > 50 and np.all(np.diff(ca.wide["index"].astype(np.int64)) > 0)
+    back = unpack_anchors(lib, anchor_off, ca)
+    assert np.array_equal(back.view(np.uint8), anchors.view(np.uint8))
+    assert ca.nbytes < 0.4 * anchors.nbytes  # (2 300 chains of a handful of entries, 3 % escapes: the bench batch is at 0.26)
+    # not descending: refused
+    bad = anchors.copy()
+    bad["query_position"][int(anchor_off[302]) + 5] += 100000
+    with pytest.raises(ValueError):
+        pack_anchors(lib, anchor_off, bad)

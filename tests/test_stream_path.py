@@ -272,3 +272,34 @@ def test_incremental_events_shared_reference_and_resident_arrays(oracle):
     p = C.c_void_p()
     assert lib.rawdtw_host_alloc(4096, C.byref(p)) == 0 and p.value
     assert lib.rawdtw_host_free(p) == 0
+
+
+@pytest.mark.parametrize("shapes,n_reads,parts_range", [(_tiny, 400, (1, 120)), (_medium, 150, (1, 60)), (_wide, 120, (1, 40)), (_tiny, 2500, (0, 4)),
+                                                        (_tiny, 6, (4000, 5200))])
+def test_compact_hand_over_equals_plain(oracle, shapes, n_reads, parts_range):
+    """rawdtw_batch_submit_compact: the anchor lists cross as 2-byte steps and are decoded on the device, unit by unit of
+    8192 entries, inside the scan (chains over several units, units of hundreds of tiny chains, escapes for steps of 255 or
+    more).  Scores, keeps and every part's cost must equal the plain hand-over's, which the cases above pin to the oracle;
+    the first case is checked against the oracle directly as well."""
+    rng = np.random.default_rng(n_reads + parts_range[1])
+    ref = [rng.normal(size=90000).astype(np.float32), rng.normal(size=90000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, n_reads, 90000, shapes, parts_range)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    plain = ra.Batch(eng, opt, cb)
+    plain.run()
+    want = plain.fetch(with_job_costs=True)
+    plain.close()
+    b = ra.Batch(eng, opt, cb, compact=True)
+    assert b.verify_plan() is True
+    got = b.fetch(with_job_costs=True)
+    for x, y in zip(got, want):
+        assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
+    if shapes is _tiny and n_reads == 400:
+        _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, got[0], got[1], got[2], opt)
+    b.close()
