@@ -421,6 +421,30 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
                                 const uint16_t *steps, const rawdtw_wide_step_t *wide, uint64_t n_wide,
                                 const uint64_t *ref_base, const uint32_t *read_base, rawdtw_batch **out);
 
+/* ---- chunk rounds.  A read is consumed chunk by chunk (rmap.cpp:685-693) and every round re-aligns every surviving chain
+ * from scratch over all its anchors (rmap.cpp:516-517), although a part between two anchors that were there the round before
+ * has the same operands (events are append-only, rmap.cpp:554-567; the read keeps its place in the event arena) and
+ * therefore the same cost.  rawdtw_batch_submit_round = rawdtw_batch_submit, given the batch of the round before
+ * (`prev`: same context, not destroyed yet, fetched or not) and per chain the chain of `prev` it continues
+ * (carry_chain[c], or RAWDTW_NO_CHAIN).  A part whose two anchors and two bases equal those of the same part -- counted
+ * from the chain's START -- of that chain takes over its cost instead of being scored again; the device checks the
+ * equality itself, the hint only says where to look, so a wrong hint costs time, never correctness.  Results are
+ * bit-identical to scoring everything again: a part that was its chain's last then and is not now loses its last
+ * cell's distance exactly as the DTW functions take it off (dtw.cpp:514-519); the other way round it is scored again.
+ * `prev` and carry_chain may be let go of as soon as the call returns.  rawdtw_round_match_chains builds the hint on the
+ * host: for every chain the previous chain of the same read (same bases) that starts on the same anchor.
+ * rawdtw_batch_round_stats (waits for the scan): the parts scored and the parts taken over. ---- */
+#define RAWDTW_NO_CHAIN (~(uint64_t)0)
+int rawdtw_batch_submit_round(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                              const uint32_t *read_base, const rawdtw_batch *prev, const uint64_t *carry_chain, rawdtw_batch **out);
+int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *parts_scored, uint64_t *parts_reused);
+/* read r of the new round is read prev_read[r] of the previous one (or RAWDTW_NO_CHAIN: a new read) */
+int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain_off, const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
+                              const uint64_t *ref_base, const uint32_t *read_base, const uint64_t *prev_read,
+                              const uint64_t *prev_chain_off, const uint64_t *prev_anchor_off, const rawdtw_anchor_t *prev_anchors,
+                              const uint64_t *prev_ref_base, const uint32_t *prev_read_base, uint64_t *carry_chain);
+
 /* The two calls a pipelined host makes per mini-batch: submit = rawdtw_batch_create +
  * rawdtw_batch_run (everything enqueued, nothing waited for; O(1) host work for sparse + banded batches), and, when the
  * worker's slot comes round again, fetch_destroy = rawdtw_batch_fetch of score / keep + rawdtw_batch_destroy. */

@@ -200,6 +200,9 @@ struct rawdtw_batch {
     const uint16_t *in_steps = nullptr;
     const rawdtw_wide_step_t *in_wide = nullptr;
     uint64_t in_n_wide = 0;
+    // chunk rounds (rawdtw_batch_submit_round): the batch of the round before and the per-chain hint (read at create only)
+    const rawdtw_batch *in_prev = nullptr;
+    const uint64_t *in_carry_chain = nullptr;
     // "resident_arrays": the three big arrays are device pointers; host copies are made only if the job list is needed
     bool in_resident = false;
     std::vector<rawdtw_anchor_t> host_anchors;
@@ -1787,6 +1790,8 @@ void ws_release(rawdtw_ctx *ctx, StreamWs &w)
     w = StreamWs{};
 }
 
+bool stream_declined(const rawdtw_batch *b);
+
 // the stream path: everything rawdtw_batch_create does for a sparse + banded batch -- O(1) host work: a workspace from the
 // pool, five copies and three launches enqueued
 int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
@@ -1809,7 +1814,10 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const bool compact = b->in_steps != nullptr;
     const uint64_t n_units = (na + RAWDTW_COMPACT_STRIDE - 1) / RAWDTW_COMPACT_STRIDE;
     const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
-    const size_t dev_bytes = compact_bytes +
+    const rawdtw_batch *prev = b->in_prev;
+    const bool round = prev && b->in_carry_chain && prev->ctx == ctx && prev->stream && !(prev->cnt_valid && stream_declined(prev));
+    const size_t round_bytes = round ? al(nc * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
+    const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
                              al((size_t)a.n_tiles * 4) + al((size_t)a.n_tiles * 24) +                                           // per tile
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
@@ -1844,6 +1852,15 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         a.heads = d_heads; a.unit_abs = d_unit_abs; a.steps = d_steps; a.wide = d_wide; a.n_wide = b->in_n_wide; a.anchors_w = d_anchors;
     }
     a.ev = ctx->d_ev; a.ref = ctx->d_ref;
+    uint64_t *d_carry = nullptr;
+    if (round) { // (the previous batch's arrays are read by this batch's k_scan: stream order keeps them alive that long)
+        d_carry = carve<uint64_t>(p, nc);
+        a.carried = carve<uint8_t>(p, (uint64_t)a.n_tiles * (a.tile_anchors / 8));
+        a.carry_chain = d_carry;
+        a.prev_n_chains = prev->n_chains; a.prev_anchor_off = prev->sa.anchor_off; a.prev_anchors = prev->sa.anchors;
+        a.prev_ref_base = prev->sa.ref_base; a.prev_read_base = prev->sa.read_base; a.prev_out = prev->sa.out;
+        a.prev_cnt = prev->sa.cnt; a.prev_others_cap = prev->sa.others_cap;
+    }
     char *hp = b->ws.h;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
     unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the pinned block
@@ -1869,6 +1886,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
+    if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
     hipError_t e = stream_plan(a, b->d_chains, b->d_fold_order, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
@@ -2079,7 +2097,7 @@ struct CompactIn {
 
 static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
                             const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const CompactIn *cin, const uint64_t *ref_base,
-                            const uint32_t *read_base, rawdtw_batch **out)
+                            const uint32_t *read_base, rawdtw_batch **out, const rawdtw_batch *prev = nullptr, const uint64_t *carry_chain = nullptr)
 {
     if (!out) return RAWDTW_ERR_INVALID;
     *out = nullptr;
@@ -2098,6 +2116,7 @@ static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint
     ctx->live_batches.push_back(b);
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
     b->in_resident = ctx->resident_arrays && !cin;
+    b->in_prev = prev; b->in_carry_chain = carry_chain;
     if (cin) { b->in_heads = cin->heads; b->in_unit_abs = cin->unit_abs; b->in_steps = cin->steps; b->in_wide = cin->wide; b->in_n_wide = cin->n_wide; }
     if (stream_eligible(ctx, opt, anchor_off[n_chains]))
         st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base);
@@ -2112,6 +2131,7 @@ static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint
         if (st == RAWDTW_OK)
             st = batch_create_joblist(ctx, b, chain_off, anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
     }
+    b->in_prev = nullptr; b->in_carry_chain = nullptr; // (read at create only: the caller may let go of both)
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
     *out = b;
     return RAWDTW_OK;
@@ -2137,6 +2157,33 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
     st = batch_enqueue_one(ctx, *out, nullptr);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
     return st;
+}
+
+int rawdtw_batch_submit_round(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
+                              const uint32_t *read_base, const rawdtw_batch *prev, const uint64_t *carry_chain, rawdtw_batch **out)
+{
+    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, anchors, nullptr, ref_base, read_base, out, prev, carry_chain);
+    if (st != RAWDTW_OK) return st;
+    st = batch_enqueue_one(ctx, *out, nullptr);
+    if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
+    return st;
+}
+
+int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *parts_scored, uint64_t *parts_reused)
+{
+    if (!ctx || !batch || batch->ctx != ctx || batch_dead(batch)) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
+    batch_count_jobs(batch);
+    uint64_t reused = 0;
+    if (batch->stream) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        const int st = stream_counters(ctx, batch);
+        if (st != RAWDTW_OK) return st;
+        if (!stream_declined(batch)) reused = batch->h_cnt[kCntReused];
+    }
+    if (parts_reused) *parts_reused = reused;
+    if (parts_scored) *parts_scored = batch->n_jobs - reused;
+    return RAWDTW_OK;
 }
 
 int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const rawdtw_job_t *jobs, uint64_t n_jobs,

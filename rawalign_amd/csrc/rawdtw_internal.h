@@ -127,11 +127,12 @@ enum StreamCounter : int {
     kCntCur0 = kCntCls0 + 21, // kStreamClasses scatter cursors
     kCntCells = kCntCur0 + 21,
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
+    kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_round)
     kCntStamp0,         // 14 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
-static_assert(kCntStamp0 + 14 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
+static_assert(kCntStamp0 + 13 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
     uint64_t n_anchors, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
@@ -156,6 +157,19 @@ struct StreamArgs {
     const rawdtw_wide_step_t *wide;
     uint64_t n_wide;
     rawdtw_anchor_t *anchors_w;
+    // chunk rounds (rawdtw_batch_submit_round; `carry_chain` null otherwise): the batch of the round before.  A part whose two
+    // anchors and bases equal those of the same part (counted from the chain's start) of the chain `carry_chain` names takes
+    // that part's cost instead of being scored again (k_scan checks the equality itself: the hint only says where to look)
+    const uint64_t *carry_chain;      // per chain: a chain of the previous batch, or ~0
+    uint64_t prev_n_chains;
+    const uint64_t *prev_anchor_off;
+    const rawdtw_anchor_t *prev_anchors;
+    const uint64_t *prev_ref_base;
+    const uint32_t *prev_read_base;
+    const float *prev_out;
+    const unsigned long long *prev_cnt; // its counter block (a batch the scan declined has no costs to take over)
+    uint64_t prev_others_cap;
+    uint8_t *carried;                 // one bit per anchor (byte i / 8, bit i % 8): its part's cost was carried over
     // workspace and outputs (device)
     uint32_t *tile_chain;        // per tile: the chain its first anchor belongs to (n_tiles entries, written by k_scan)
     unsigned long long *tile_stats; // per scan unit (8192 anchors): tile-class parts, their algorithmic bytes, the side list's bytes

@@ -287,7 +287,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     constexpr int NT = (int)kScanT, KI = (int)kScanKI;
     constexpr uint32_t AT = kScanUnit, kWords = AT / 32 + 1;
     __shared__ uint32_t s_mask[kWords], s_pre[kWords];
-    __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses];
+    __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
     if (tid == 0) s_ocnt = 0;
     if (tid < 3) s_stats[tid] = 0;
-    if (tid < (int)kStreamClasses) s_cls[tid] = 0;
+    if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
     // last part), requested before the chain search waits for anything
     const uint64_t i0 = base + (uint64_t)tid * KI;
@@ -386,9 +386,18 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         const uint64_t t = (uint64_t)unit * tiles_per_unit + (uint32_t)tid;
         if ((uint32_t)tid < tiles_per_unit && t < a.n_tiles) a.tile_chain[t] = (uint32_t)chain_at((uint32_t)tid * a.tile_anchors);
     }
-    uint32_t my_tiles = 0, my_bytes = 0;
+    // (the round before must have stood: a batch the scan declined has no costs to take over)
+    const bool carry = a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
+                       a.prev_cnt[kCntOverflow] == ~0ull;
+    uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0, carried_bits = 0;
     unsigned long long my_obytes = 0;
     uint32_t o_slot[KI], o_cls[KI];
+    // chunk rounds: the chain-level values of the part's chain and of the chain it continues, kept while the thread's parts
+    // stay inside one chain (they mostly do)
+    uint64_t cc = ~0ull, c_a1 = 0, pa0 = 0, pa1 = 0;
+    bool c_ok = false;
+    uint64_t c_rb = 0;
+    uint32_t c_qb = 0;
 #pragma unroll
     for (int k = 0; k < KI; k++) {
         o_cls[k] = 0xffffffffu; o_slot[k] = 0;
@@ -397,6 +406,43 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
         const Part pt = classify(a, an[k + 1], an[k]);
         if (!pt.asc || pt.n >= 0x7fffffffu || pt.m >= 0x7fffffffu) { atomicMin(&a.cnt[kCntBad], (unsigned long long)i); continue; }
+        if (carry) {
+            // part p_idx of chain c (counted from the chain's start, rmap.cpp:248-293) = the part that ends at anchor a1 - 2 - p_idx
+            const uint64_t c = chain_at(p);
+            if (c != cc) {
+                cc = c;
+                c_a1 = a.anchor_off[c + 1];
+                const uint64_t pc = a.carry_chain[c];
+                c_ok = pc < a.prev_n_chains;
+                if (c_ok) {
+                    pa0 = a.prev_anchor_off[pc]; pa1 = a.prev_anchor_off[pc + 1];
+                    c_rb = a.ref_base[c]; c_qb = a.read_base[c];
+                    c_ok = pa1 > pa0 + 1 && a.prev_ref_base[pc] == c_rb && a.prev_read_base[pc] == c_qb;
+                }
+            }
+            const uint64_t p_idx = c_a1 - 2 - i;
+            if (c_ok && p_idx + 1 < pa1 - pa0) {
+                const uint64_t pi = pa1 - 2 - p_idx; // the same part of the chain before
+                const rawdtw_anchor_t pe = a.prev_anchors[pi], ps = a.prev_anchors[pi + 1];
+                const rawdtw_anchor_t e = an[k], s = an[k + 1];
+                if (pe.target_position == e.target_position && pe.query_position == e.query_position && ps.target_position == s.target_position &&
+                    ps.query_position == s.query_position) {
+                    // same operands, same radius: the same cost -- up to exclude_last_element (rmap.cpp:270), which only the
+                    // chain's LAST part goes without: a part that was the last one then and is not now loses its last cell's
+                    // distance exactly as the DTW functions take it off (dtw.cpp:514-519); the other way round there is no
+                    // exact way back, and the part is scored again
+                    const bool was_last = pi == pa0, is_last = mask_bit(s_mask, p);
+                    if (was_last == is_last || was_last) {
+                        float cost = a.prev_out[pi];
+                        if (was_last != is_last) cost = cost - dist(a.ev[(uint64_t)c_qb + e.query_position], a.ref[c_rb + e.target_position]);
+                        a.out[i] = cost;
+                        carried_bits |= 1u << k;
+                        my_reused++;
+                        continue;
+                    }
+                }
+            }
+        }
         if (pt.tile) { my_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
@@ -414,6 +460,11 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         o_slot[k] = atomicAdd(&s_ocnt, 1u);
         atomicAdd(&s_cls[cls], 1u);
     }
+    if (a.carried && i0 < a.n_anchors) a.carried[i0 >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
+    if (carry) {
+        for (int off = 32; off > 0; off >>= 1) my_reused += (uint32_t)__shfl_down((int)my_reused, off);
+        if (lane == 0 && my_reused) atomicAdd(&s_cls[kStreamClasses], my_reused);
+    }
     {   // statistics: tile parts (<= KI a thread) and their bytes (< 2^13 a thread) through one wave reduction
         unsigned long long packed = (unsigned long long)my_tiles | ((unsigned long long)my_bytes << 20);
         for (int off = 32; off > 0; off >>= 1) packed += __shfl_down(packed, off);
@@ -424,6 +475,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
     if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
+    if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
     __syncthreads();
     if (s_ocnt) {
         const uint64_t obase = s_obase;
@@ -513,7 +565,7 @@ __global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kStamps = 14;
+constexpr uint32_t kStamps = 13;
 constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
 
 // One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
@@ -620,7 +672,7 @@ struct RunTab {
 template <int TT, bool DIAG>
 __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
 {
-    const uint32_t dbg = DIAG ? dbg : 0u;
+    const uint32_t dbg = DIAG ? a.debug : 0u;
     constexpr int KI = (int)kStreamItems;
     constexpr uint32_t AT = TT * KI, kWords = AT / 32 + 1, kWaves = TT / 64, kCT = 32;
     static_assert(kWords <= 64, "one mask word a lane");
@@ -636,6 +688,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     __shared__ __attribute__((aligned(16))) uint32_t s_ct_off[2 * kCT]; // anchor_off[c0 .. c0 + kCT) as dword pairs
     __shared__ __attribute__((aligned(16))) uint32_t s_ct_rb[2 * kCT];  // ref_base[c0 .. c0 + kCT)
     __shared__ __attribute__((aligned(16))) uint32_t s_ct_qb[kCT];      // read_base[c0 .. c0 + kCT)
+    __shared__ __attribute__((aligned(16))) uint32_t s_carried[AT / 32]; // chunk rounds: the tile's anchors whose parts took their cost from the round before
     __shared__ uint32_t s_tile[2];
     __shared__ uint32_t s_c0, s_more;          // the tile's first chain; chains beyond the table may start inside the tile
     __shared__ uint32_t s_seq, s_njobs;
@@ -644,6 +697,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
 
+    if (tid < (int)(AT / 32)) s_carried[tid] = 0;
     // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
     // list: nothing to do here, and nothing may be derived from its anchors
     if (tid == 0) s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
@@ -709,6 +763,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
             if (q0 + (uint32_t)lane < pieces && base + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                 dma16(a.anchors + base + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
+        if (a.carried && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+            dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile * (AT / 32u) + lane, s_carried);
         if (wv == 0) {
             const uint64_t c = (uint64_t)c0 + ((uint32_t)lane >> 1);
             if (c <= a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.anchor_off + c0) + lane, s_ct_off);
@@ -872,7 +928,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
 #pragma unroll
             for (int k = 0; k < KI; k++) {
                 const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1);
+                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1) && !mask_bit(s_carried, p);
                 pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
                 tl[k] = exists && pt[k].tile;
             }
@@ -938,6 +994,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                 for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
                     if (q0 + (uint32_t)lane < pieces && nbase + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                         dma16(a.anchors + nbase + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
+                if (a.carried && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+                    dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile_n * (AT / 32u) + lane, s_carried);
             }
             // ---- 2. runs into the table, the sort's histogram ----
             uint32_t bin[KI], rank[KI];

@@ -149,3 +149,41 @@ def test_cigar_and_log_scores_flags_device_equals_oracle(oracle):
             assert any("\taln:s:(" in l for l in b)
         if opt.flag & RI_M_DTW_LOG_SCORES:
             assert lb
+
+
+@pytest.mark.gpu
+def test_device_side_carry_over_three_rounds_and_more(oracle):
+    """SURVEY.md 8(f-4) on the device (rawdtw_batch_submit_round): the part costs of a round stay in HBM and the next
+    round's batch takes over every part whose anchors did not change -- the host only says which chain continues which.
+    Every read runs through all of its chunks (>= 3 rounds); the PAF lines must equal the plain device path's and the
+    oracle's from-scratch loop (rmap.cpp:516-517), with fewer parts scored."""
+    from rawalign_amd.mapping import StopOpt
+
+    ref = synth.make_reference([29903], seed=20231005 + 1)
+    seeds = mapper.SyntheticSeeds(ref, 40, seed=3, max_chunks=5)
+    eng = ra.Engine(0)
+    eng.upload_reference(ref.forward, ref.reverse)
+    never = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
+    for opt in (ra.MapOpt(), ra.MapOpt(dtw_fill_method=0)):
+        plain = mapper.DeviceScorer(eng)
+        a, ra_ = mapper.map_reads(seeds, list(range(40)), plain, opt, never)
+        eng2 = ra.Engine(0)
+        eng2.upload_reference(ref.forward, ref.reverse)
+        carry = mapper.RoundScorer(eng2, slot_events=max(rd["n_ev"] for rd in seeds.reads) + 8, n_slots=40)
+        b, rb_ = mapper.map_reads(seeds, list(range(40)), carry, opt, never)
+        carry.close()
+        assert ra_ == rb_ and ra_ >= 3
+        assert a == b
+        c, rc_ = mapper.map_reads(seeds, list(range(40)), OracleScorer(oracle, ref), opt, never)
+        assert c == b and rc_ == rb_
+        if opt.dtw_fill_method == 1:   # (the sync-free path: sparse + banded; other modes go through the job list and score everything)
+            assert carry.jobs_reused > 0 and carry.jobs_scored < plain.jobs_scored
+        assert carry.jobs_scored + carry.jobs_reused == plain.jobs_scored
+    # the reference's own stop rule as well (reads drop out of the rounds at different times)
+    a, _ = mapper.map_reads(seeds, list(range(40)), mapper.DeviceScorer(eng), ra.MapOpt())
+    eng3 = ra.Engine(0)
+    eng3.upload_reference(ref.forward, ref.reverse)
+    carry = mapper.RoundScorer(eng3, slot_events=max(rd["n_ev"] for rd in seeds.reads) + 8, n_slots=40)
+    b, _ = mapper.map_reads(seeds, list(range(40)), carry, ra.MapOpt())
+    carry.close()
+    assert a == b

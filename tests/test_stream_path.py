@@ -303,3 +303,77 @@ def test_compact_hand_over_equals_plain(oracle, shapes, n_reads, parts_range):
     if shapes is _tiny and n_reads == 400:
         _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, got[0], got[1], got[2], opt)
     b.close()
+
+
+def test_round_carry_takes_over_unchanged_parts(oracle):
+    """rawdtw_batch_submit_round: round 2 = round 1's chains, some grown at their ends (the usual case), some unchanged, some
+    with a changed interior anchor, some new.  Every part whose two anchors were there before must be taken over (the
+    reused count says so), a chain's former last part loses its last cell's distance when it is no longer last, and all
+    scores, keeps and part costs equal a from-scratch batch of round 2 (which the cases above pin to the oracle)."""
+    import ctypes as C
+
+    rng = np.random.default_rng(99)
+    ref = [rng.normal(size=90000).astype(np.float32), rng.normal(size=90000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    lib = eng.lib
+    # round 2 first (the longer chains), round 1 = its chains cut back at their ends
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 300, 90000, _medium, (3, 90))
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb2 = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    nc = cb2.n_chains
+    a1, off1 = [], [0]
+    kinds = rng.integers(0, 4, nc)   # 0 grown at the end, 1 unchanged, 2 an interior anchor moved, 3 a chain round 1 did not have
+    expect_reused = 0
+    carry = np.full(nc, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    n1 = 0
+    for c in range(nc):
+        a = anchors[int(anchor_off[c]):int(anchor_off[c + 1])].copy()
+        parts = len(a) - 1
+        if kinds[c] == 3:
+            continue
+        if kinds[c] == 0 and parts >= 2:
+            cut = int(rng.integers(1, parts))        # round 1 lacks the last `cut` parts (end-first: the list's first entries)
+            a = a[cut:]
+            expect_reused += parts - cut
+        elif kinds[c] == 2 and parts >= 3:
+            k = int(rng.integers(1, len(a) - 1))     # an interior anchor that differs: the two parts around it are scored again
+            a[k]["query_position"] -= 0 if a[k]["query_position"] == a[k + 1]["query_position"] else 1
+            moved = a[k]["query_position"] != anchors[int(anchor_off[c]) + k]["query_position"]
+            expect_reused += parts - (2 if moved else 0)
+        else:
+            expect_reused += parts
+        carry[c] = n1
+        n1 += 1
+        a1.append(a)
+        off1.append(off1[-1] + len(a))
+    sel = [c for c in range(nc) if kinds[c] != 3]
+    # round 1's chains all in one read per original read is not needed: one read holds them all
+    cb1 = CandidateBatch(events, np.array([0, len(sel)], np.uint64), np.array(off1, np.uint64), np.concatenate(a1), ref_base[sel], read_base[sel])
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b1 = ra.Batch(eng, opt, cb1)
+    b1.run()
+    b1.fetch()
+    plain = ra.Batch(eng, opt, cb2)
+    plain.run()
+    want = plain.fetch(with_job_costs=True)
+    plain.close()
+    copt = opt.c_struct()
+    h = C.c_void_p()
+    arr = [np.ascontiguousarray(cb2.chain_off, np.uint64), np.ascontiguousarray(cb2.anchor_off, np.uint64), np.ascontiguousarray(cb2.anchors),
+           np.ascontiguousarray(cb2.ref_base, np.uint64), np.ascontiguousarray(cb2.read_base, np.uint32)]
+    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    eng._check(lib.rawdtw_batch_submit_round(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(arr[3]), vp(arr[4]),
+                                             b1._h, vp(carry), C.byref(h)))
+    b1.close()   # (the round before may go as soon as the call has returned)
+    score, keep = np.zeros(nc, np.float32), np.zeros(nc, np.uint8)
+    jc = np.zeros(len(want[2]), np.float32)
+    eng._check(lib.rawdtw_batch_fetch(eng._ctx, h, vp(score), vp(keep), vp(jc)))
+    sc, ru = C.c_uint64(), C.c_uint64()
+    eng._check(lib.rawdtw_batch_round_stats(eng._ctx, h, C.byref(sc), C.byref(ru)))
+    lib.rawdtw_batch_destroy(h)
+    assert np.array_equal(jc.view(np.uint32), want[2].view(np.uint32))
+    assert np.array_equal(score.view(np.uint32), want[0].view(np.uint32)) and np.array_equal(keep, want[1])
+    assert ru.value == expect_reused and sc.value + ru.value == len(jc) and ru.value > 1000
