@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
     ap.add_argument("--decoy-gap-median", type=float, default=None, help="workload sensitivity: decoy chain gap (events)")
     ap.add_argument("--decoys-per-read", type=float, default=None)
+    ap.add_argument("--rounds", type=int, default=4, help="chunk rounds of the cross-round cache block (0: skip it)")
     ap.add_argument("--modes-reads", type=int, default=8192, help="reads of the configs[2] block (0: skip it)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / reduction plumbing only: no device work, synthetic counters (CPU tests)")
@@ -199,6 +200,70 @@ class Pinned:
 
 def vp(a):
     return C.c_void_p(a.ctypes.data)
+
+
+def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank):
+    """SURVEY.md 8(f-4) at the bench batch's scale: `n_rounds` chunk rounds of one batch of reads (synth.make_rounds), each
+    submitted with the batch of the round before (rawdtw_batch_submit_round: parts whose anchors did not change take over
+    their cost on the device) and, for comparison, from scratch as the reference does (rmap.cpp:516-517).  One context,
+    rounds in sequence (a round needs the one before); wall time per round from submit to fetched scores."""
+    from rawalign_amd import synth
+
+    rounds = synth.make_rounds(cb, info, n_rounds)
+    arrs = [[np.ascontiguousarray(r.chain_off, np.uint64), np.ascontiguousarray(r.anchor_off, np.uint64), np.ascontiguousarray(r.anchors),
+             np.ascontiguousarray(r.ref_base, np.uint64), np.ascontiguousarray(r.read_base, np.uint32)] for r in rounds]
+    ident = np.arange(cb.n_chains, dtype=np.uint64)
+    import torch
+
+    dev = []   # the three big arrays of every round resident in HBM (as in the `value` loop): no PCIe in either mode
+    for a in arrs:
+        dev.append([torch.from_numpy(x.view(np.uint8).copy()).cuda(local_rank) for x in (a[2], a[3], a[4])])
+    torch.cuda.synchronize()
+    engine.set_option("resident_arrays", 1)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    out = {"rounds": n_rounds, "per_round": []}
+    same = True
+    for mode in ("warm", "scratch", "carried"):
+        prev = None
+        for k, a in enumerate(arrs):
+            h = C.c_void_p()
+            score, keep = np.zeros(cb.n_chains, np.float32), np.zeros(cb.n_chains, np.uint8)
+            engine.sync()
+            t0 = time.perf_counter()
+            if mode == "carried":
+                engine._check(lib.rawdtw_batch_submit_round(engine._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), P(dev[k][0]), P(dev[k][1]), P(dev[k][2]),
+                                                            prev, vp(ident), C.byref(h)))
+            else:
+                engine._check(lib.rawdtw_batch_submit(engine._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), P(dev[k][0]), P(dev[k][1]), P(dev[k][2]), C.byref(h)))
+            engine._check(lib.rawdtw_batch_fetch(engine._ctx, h, vp(score), vp(keep), None))
+            dt = time.perf_counter() - t0
+            if mode == "warm":
+                lib.rawdtw_batch_destroy(h)
+                continue
+            if mode == "scratch":
+                out["per_round"].append({"parts": int(max(int(a[1][-1]) - cb.n_chains, 0)), "scratch_ms": round(dt * 1e3, 4), "score": score.copy(), "keep": keep.copy()})
+                lib.rawdtw_batch_destroy(h)
+                continue
+            sc, ru = C.c_uint64(), C.c_uint64()
+            engine._check(lib.rawdtw_batch_round_stats(engine._ctx, h, C.byref(sc), C.byref(ru)))
+            rec = out["per_round"][k]
+            s0, k0 = rec.pop("score"), rec.pop("keep")
+            same = same and np.array_equal(s0.view(np.uint32), score.view(np.uint32)) and np.array_equal(k0, keep)
+            rec.update({"parts": int(sc.value + ru.value), "parts_scored": int(sc.value), "parts_reused": int(ru.value), "carried_ms": round(dt * 1e3, 4)})
+            if prev is not None:
+                lib.rawdtw_batch_destroy(prev)
+            prev = h
+        if prev is not None:
+            lib.rawdtw_batch_destroy(prev)
+    tot = sum(r["parts"] for r in out["per_round"])
+    out.update({"parts_total": tot, "parts_scored": sum(r["parts_scored"] for r in out["per_round"]),
+                "jobs_reused": sum(r["parts_reused"] for r in out["per_round"]),
+                "scratch_ms_total": round(sum(r["scratch_ms"] for r in out["per_round"]), 4),
+                "carried_ms_total": round(sum(r["carried_ms"] for r in out["per_round"]), 4),
+                "scores_identical_to_scratch": bool(same),
+                "note": "inputs resident in HBM in both modes; the carried rounds score only the parts whose anchors are new (their "
+                        "scan looks every other part up in the round before)"})
+    return out
 
 
 YEAST = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643, 439888, 745751, 666816, 1078177, 924431,
@@ -373,7 +438,7 @@ def main():
         seg_dst = (ev_off[1:] - new_len).astype(np.uint32)
         idx = np.repeat(seg_dst.astype(np.int64), new_len) + (np.arange(int(new_len.sum())) - np.repeat(seg_src[:-1].astype(np.int64), new_len))
         d = {
-            "cb": cb, "n_reads": cb.n_reads, "n_chains": cb.n_chains,
+            "cb": cb, "inf": inf, "n_reads": cb.n_reads, "n_chains": cb.n_chains,
             "events": pin.copy(cb.events), "chain_off": pin.copy(cb.chain_off.astype(np.uint64)),
             "anchor_off": pin.copy(cb.anchor_off.astype(np.uint64)), "anchors": pin.copy(cb.anchors),
             "ref_base": pin.copy(cb.ref_base.astype(np.uint64)), "read_base": pin.copy(cb.read_base.astype(np.uint32)),
@@ -691,6 +756,8 @@ def main():
                          "alone_ms": {"k_scan+k_side": round(plan_al, 5), "k_runs": round(float(alone_ms[0]), 5), "chain_fold": round(float(alone_ms[1]), 5),
                                       "read_select": round(float(alone_ms[2]), 5)}},
         }
+        if world == 1 and args.rounds > 0:
+            out["chunk_rounds"] = rounds_block(engines[0], lib, copt, B[0]["cb"], B[0]["inf"], args.rounds, local_rank)
         if world == 1 and args.modes_reads > 0:
             out["modes"] = modes_block(local_rank, args.modes_reads)
         if world == 1 and not args.no_cpu_baseline:

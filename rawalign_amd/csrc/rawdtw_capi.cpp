@@ -1819,7 +1819,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const size_t round_bytes = round ? al(nc * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
     const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
-                             al((size_t)a.n_tiles * 4) + al((size_t)a.n_tiles * 24) +                                           // per tile
+                             al((size_t)a.n_tiles * 8) + al((size_t)a.n_tiles * 24) +                                           // per tile
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
                              al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
     const size_t host_bytes = al(kStreamCounters * 8);
@@ -1832,7 +1832,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
-    a.tile_chain = carve<uint32_t>(p, a.n_tiles);
+    a.todo = carve<uint2>(p, a.n_tiles);
     a.tile_stats = carve<unsigned long long>(p, 3ull * a.n_tiles);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     b->d_chains = carve<ChainDesc>(p, nc);
@@ -2216,14 +2216,18 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         }
         const uint64_t nc = batch->n_chains, na = a.n_anchors;
         const uint64_t *aoff = batch->in_anchor_off;
-        std::vector<uint32_t> tc(a.n_tiles);
-        if (a.n_tiles) HIP_TRY(ctx, hipMemcpy(tc.data(), a.tile_chain, (size_t)a.n_tiles * 4, hipMemcpyDeviceToHost));
+        // the work list: (tile, first chain) of exactly the tiles that hold a tile-class job (checked below, once the jobs' classes are known)
+        const uint64_t n_todo = cnt[kCntTodo];
+        std::vector<uint2> todo(n_todo);
+        if (n_todo > a.n_tiles) e = "work list longer than the tiles";
+        else if (n_todo) HIP_TRY(ctx, hipMemcpy(todo.data(), a.todo, n_todo * sizeof(uint2), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> tile_first_chain(a.n_tiles);
         {
             uint64_t c = 0;
-            for (uint64_t t = 0; t < a.n_tiles && e.empty(); t++) {
+            for (uint64_t t = 0; t < a.n_tiles; t++) {
                 const uint64_t x = t * a.tile_anchors;
                 while (c + 1 < nc && aoff[c + 1] <= x) c++;
-                if (tc[t] != c) e = "tile " + S(t) + ": first chain " + S(tc[t]) + ", expected " + S(c);
+                tile_first_chain[t] = (uint32_t)c;
             }
         }
         const uint64_t n_other = cnt[kCntOthers];
@@ -2261,6 +2265,19 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         }
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
             if (!is_tile[k] && !oseen[k]) e = "job " + S(k) + " is in no launch";
+        if (e.empty() && cnt[kCntReused] == 0) { // (a round that took costs over leaves the tiles of carried parts out)
+            std::vector<uint8_t> want_tile(a.n_tiles, 0), got_tile(a.n_tiles, 0);
+            for (uint64_t i = 0; i < na; i++)
+                if (slot_job[i] != ~0ull && is_tile[slot_job[i]]) want_tile[i / a.tile_anchors] = 1;
+            for (uint64_t q = 0; q < n_todo && e.empty(); q++) {
+                const uint2 t = todo[q];
+                if (t.x >= a.n_tiles || got_tile[t.x]) e = "work list entry " + S(q) + ": tile " + S(t.x) + " twice or out of range";
+                else if (t.y != tile_first_chain[t.x]) e = "tile " + S(t.x) + ": first chain " + S(t.y) + ", expected " + S(tile_first_chain[t.x]);
+                else got_tile[t.x] = 1;
+            }
+            for (uint64_t t = 0; t < a.n_tiles && e.empty(); t++)
+                if (want_tile[t] != got_tile[t]) e = "tile " + S(t) + (want_tile[t] ? " holds tile-class jobs but is not on the work list" : " is on the work list without a job");
+        }
         if (e.empty()) {
             HIP_TRY(ctx, stream_sum_stats(a, ctx->stream));
             unsigned long long st3[3];

@@ -127,12 +127,13 @@ enum StreamCounter : int {
     kCntCur0 = kCntCls0 + 21, // kStreamClasses scatter cursors
     kCntCells = kCntCur0 + 21,
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
+    kCntTodo,           // entries of the DTW launch's work list
     kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_round)
     kCntStamp0,         // 14 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
-static_assert(kCntStamp0 + 13 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
+static_assert(kCntStamp0 + 12 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
     uint64_t n_anchors, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
@@ -171,7 +172,8 @@ struct StreamArgs {
     uint64_t prev_others_cap;
     uint8_t *carried;                 // one bit per anchor (byte i / 8, bit i % 8): its part's cost was carried over
     // workspace and outputs (device)
-    uint32_t *tile_chain;        // per tile: the chain its first anchor belongs to (n_tiles entries, written by k_scan)
+    uint2 *todo;                 // the DTW launch's work list (k_scan): (tile, the chain its first anchor belongs to) of every tile that
+                                 // has a part to score; cnt[kCntTodo] entries, at most n_tiles
     unsigned long long *tile_stats; // per scan unit (8192 anchors): tile-class parts, their algorithmic bytes, the side list's bytes
     DevJob *omix, *ojobs;
     uint8_t *ocls;

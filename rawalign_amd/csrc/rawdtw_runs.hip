@@ -290,10 +290,11 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
+    __shared__ uint32_t s_todo; // bit t: tile t of the unit has a part for the lane-per-job bodies to score
     const int tid = threadIdx.x, lane = tid & 63;
     const uint64_t base = (uint64_t)unit * AT;
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
-    if (tid == 0) s_ocnt = 0;
+    if (tid == 0) { s_ocnt = 0; s_todo = 0; }
     if (tid < 3) s_stats[tid] = 0;
     if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
@@ -381,11 +382,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         if (tid + 1 < NT) { const uint2 x = s_first[tid + 1]; an[KI] = rawdtw_anchor_t{x.x, x.y}; }
         else an[KI] = base + AT < a.n_anchors ? a.unit_abs[unit + 1] : rawdtw_anchor_t{0, 0}; // (the next unit's first entry travels whole)
     }
-    {   // every tile's first chain
-        const uint32_t tiles_per_unit = AT / a.tile_anchors;
-        const uint64_t t = (uint64_t)unit * tiles_per_unit + (uint32_t)tid;
-        if ((uint32_t)tid < tiles_per_unit && t < a.n_tiles) a.tile_chain[t] = (uint32_t)chain_at((uint32_t)tid * a.tile_anchors);
-    }
+
     // (the round before must have stood: a batch the scan declined has no costs to take over)
     const bool carry = a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
                        a.prev_cnt[kCntOverflow] == ~0ull;
@@ -461,6 +458,10 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         atomicAdd(&s_cls[cls], 1u);
     }
     if (a.carried && i0 < a.n_anchors) a.carried[i0 >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
+    {
+        const unsigned long long any_tile = __ballot(my_tiles != 0u); // (every lane votes: taken before the branch on the lane)
+        if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << (((uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
+    }
     if (carry) {
         for (int off = 32; off > 0; off >>= 1) my_reused += (uint32_t)__shfl_down((int)my_reused, off);
         if (lane == 0 && my_reused) atomicAdd(&s_cls[kStreamClasses], my_reused);
@@ -473,6 +474,14 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
     __syncthreads();
     if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
+    // The DTW launch's work list: the unit's tiles that have something to score, each with its first chain.  (Tiles without a
+    // tile-class part -- all of their parts carried over from the round before, or on the side list -- are never touched.)
+    if (tid == 0 && s_todo) {
+        const uint32_t tiles_per_unit = AT / a.tile_anchors, todo = s_todo;
+        uint64_t at = atomicAdd(&a.cnt[kCntTodo], (unsigned long long)__popc(todo));
+        for (uint32_t t = 0; t < tiles_per_unit; t++)
+            if ((todo >> t) & 1u) a.todo[at++] = make_uint2(unit * tiles_per_unit + t, (uint32_t)chain_at(t * a.tile_anchors));
+    }
     if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kStamps = 13;
+constexpr uint32_t kStamps = 12;
 constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
 
 // One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
@@ -805,21 +814,31 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         if (lane == 0) s_stamp[wv][ph] += t - t_prev;
         t_prev = t;
     };
-    // ---- tiles, pulled from the queue two ahead ----
-    const uint32_t n_tiles = a.n_tiles;
-    // thread 0's queue state: `head`, the resolved number of the next tile, the raw ticket of the one after it
-    uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), t_next = 0xffffffffu;
+    // ---- tiles: the entries of the scan's work list (tile, its first chain), pulled from the queue two ahead ----
+    const uint32_t n_tiles = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
+    // thread 0's queue state: `head`, the list index of the next tile, the raw ticket of the one after it; wave 0 holds the
+    // next tile's entry (asked for a tile ahead)
+    uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), i_next = 0xffffffffu;
     unsigned long long ticket = 0;
-    if (tid == 0) {
-        const uint32_t t0 = next_tile(a, dbg, head, n_tiles);
-        t_next = t0 != 0xffffffffu ? next_tile(a, dbg, head, n_tiles) : 0xffffffffu;
-        s_tile[0] = t0;
+    uint2 e_next = make_uint2(0xffffffffu, 0u);
+    if (wv == 0) {
+        uint32_t i0 = 0xffffffffu;
+        if (tid == 0) {
+            i0 = next_tile(a, dbg, head, n_tiles);
+            i_next = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_tiles) : 0xffffffffu;
+        }
+        i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+        const uint32_t i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
+        const uint2 e0 = i0 != 0xffffffffu ? a.todo[i0] : make_uint2(0xffffffffu, 0u);
+        if (i1 != 0xffffffffu) e_next = a.todo[i1];
+        if (tid == 0) { s_tile[0] = e0.x; s_c0 = e0.y; }
     }
     for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
     __syncthreads();
     if (s_tile[0] == 0xffffffffu) return;
     {   // the first tile's anchors and chains: nobody to fetch them ahead
-        const uint32_t t0 = s_tile[0], c0 = a.tile_chain[t0];
+        const uint32_t t0 = s_tile[0], c0 = s_c0;
+        __syncthreads(); // (s_c0 is read: mark_tile writes it again)
         fetch_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
         __builtin_amdgcn_s_waitcnt(0x0f70);
         if (wv == 0) mark_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
@@ -827,12 +846,6 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     }
     uint32_t slot = 0, parity = 0;
     const uint32_t budget = lds_floats & ~3u;
-    // wave 0: the first chain of the next tile (for its chain table), requested a tile ahead
-    uint32_t c0n = 0;
-    if (wv == 0) {
-        const uint32_t tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
-        if (tn != 0xffffffffu) c0n = a.tile_chain[tn];
-    }
     // the results of the tile before: they stay in the records until every wave is past this tile's first barrier (= done
     // with that tile's DP) and leave in item order from there -- no barrier of their own, and a wave that finishes its share
     // of a tile's DP early starts on the next tile at once
@@ -897,9 +910,10 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         const uint32_t c0 = s_c0;
         // thread 0: the next tile's number is published before the first barrier; the ticket of the one after it is drawn
         // now and looked at when this tile is done
+        const uint32_t c0n = e_next.y; // wave 0: the next tile's first chain (for its chain table)
         if (tid == 0) {
-            s_tile[slot ^ 1u] = t_next;
-            if (t_next != 0xffffffffu && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+            s_tile[slot ^ 1u] = e_next.x;
+            if (i_next != 0xffffffffu && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
         }
         if (s_more) { // (tiles of very short chains: the rest of the chain starts from memory)
             (void)mark_chain_starts<TT>(a, (uint64_t)c0 + kCT, base, AT, s_mask);
@@ -1178,17 +1192,17 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                 __syncthreads(); // (the pass's records and s_pass are read; the next pass rewrites them)
             }
         }
-        // thread 0: the ticket into the number of the tile after the next; wave 0 asks for that tile's first chain
-        if (tid == 0 && t_next != 0xffffffffu) {
-            if (dbg & 8u) t_next = next_tile(a, dbg, head, n_tiles);
+        // thread 0: the ticket into the list index of the tile after the next; wave 0 asks for that tile's entry
+        if (tid == 0 && i_next != 0xffffffffu) {
+            if (dbg & 8u) i_next = next_tile(a, dbg, head, n_tiles);
             else {
                 const unsigned long long t = ticket * 8ull + head;
-                t_next = t < n_tiles ? (uint32_t)t : next_tile(a, dbg, head, n_tiles); // (this head is dry: try the others)
+                i_next = t < n_tiles ? (uint32_t)t : next_tile(a, dbg, head, n_tiles); // (this head is dry: try the others)
             }
         }
         if (wv == 0) {
-            const uint32_t tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
-            c0n = tn != 0xffffffffu ? a.tile_chain[tn] : 0u;
+            const uint32_t in = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
+            e_next = in != 0xffffffffu ? a.todo[in] : make_uint2(0xffffffffu, 0u);
         }
         slot ^= 1u;
         stamp(9);

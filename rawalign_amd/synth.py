@@ -213,3 +213,34 @@ def make_candidate_batch(ref: Reference, ref_offsets, params: SynthParams, seed:
             # per read: offset of its event array in `events` (n_reads + 1 entries) and the events its last chunk added
             "ev_off": ev_off.astype(np.uint64), "events_per_chunk": int(round(P.bases_per_chunk * 1.28))}
     return cb, info
+
+
+def make_rounds(cb: CandidateBatch, info: dict, n_rounds: int):
+    """Chunk rounds of one batch of reads (rmap.cpp:685-693), for the cross-round cache: `cb` is the LAST
+    round; round k (1-based) sees every read without its last (n_rounds - k) chunks of events, and of every chain the
+    anchors that lie in the events seen so far -- chains grow at their ends from round to round, as the mapper's do
+    (rmap.cpp:344-357 re-seeds a round's chaining with the previous chains' anchors).  Every chain keeps its index and at
+    least its start anchor in every round, so chain c of round k continues chain c of round k - 1.  Read slots in the event
+    arena are those of the last round (a read keeps its place while it grows).  Returns a list of CandidateBatch."""
+    ev_off = info["ev_off"].astype(np.int64)
+    n_ev = np.diff(ev_off)
+    epc = int(info["events_per_chunk"])
+    ao = cb.anchor_off.astype(np.int64)
+    na_chain = np.diff(ao)
+    chain_read = np.repeat(np.arange(cb.n_reads), np.diff(cb.chain_off.astype(np.int64)))
+    anchor_chain = np.repeat(np.arange(cb.n_chains), na_chain)
+    q = cb.anchors["query_position"].astype(np.int64)
+    rounds = []
+    for k in range(1, n_rounds + 1):
+        if k == n_rounds:
+            rounds.append(cb)
+            break
+        vis = np.maximum(n_ev - (n_rounds - k) * epc, 0)                      # events of each read seen in round k
+        seen = q < vis[chain_read[anchor_chain]]
+        # positions descend along a chain's list: the anchors seen are a tail of it; a chain keeps at least its last entry (= its start)
+        cnt = np.maximum(np.bincount(anchor_chain[seen], minlength=cb.n_chains), np.minimum(na_chain, 1))
+        new_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        first = ao[1:] - cnt                                                  # first kept entry of each chain in the full list
+        idx = np.repeat(first - new_off[:-1], cnt) + np.arange(int(new_off[-1]))
+        rounds.append(CandidateBatch(cb.events, cb.chain_off, new_off.astype(np.uint64), cb.anchors[idx], cb.ref_base, cb.read_base))
+    return rounds
