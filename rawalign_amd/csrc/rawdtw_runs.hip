@@ -281,7 +281,7 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
 // thousand a batch) the launch spent 150 of its 176 us queueing there.
 constexpr uint32_t kScanUnit = 8192, kScanT = 1024, kScanKI = kScanUnit / kScanT;
 static_assert(kScanUnit == RAWDTW_COMPACT_STRIDE, "the compact hand-over is decoded unit by unit");
-template <bool COMPACT>
+template <bool COMPACT, bool CARRY>
 __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32_t unit)
 {
     constexpr int NT = (int)kScanT, KI = (int)kScanKI;
@@ -384,7 +384,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
 
     // (the round before must have stood: a batch the scan declined has no costs to take over)
-    const bool carry = a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
+    const bool carry = CARRY && a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
                        a.prev_cnt[kCntOverflow] == ~0ull;
     uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0, carried_bits = 0;
     unsigned long long my_obytes = 0;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         o_slot[k] = atomicAdd(&s_ocnt, 1u);
         atomicAdd(&s_cls[cls], 1u);
     }
-    if (a.carried && i0 < a.n_anchors) a.carried[i0 >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
+    if (CARRY && a.carried && i0 < a.n_anchors) a.carried[i0 >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
     {
         const unsigned long long any_tile = __ballot(my_tiles != 0u); // (every lane votes: taken before the branch on the lane)
         if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << (((uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
@@ -516,7 +516,15 @@ __global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
     else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
-    else scan_unit_body<false>(a, b - 1 - n_desc);
+    else scan_unit_body<false, false>(a, b - 1 - n_desc);
+}
+// (a chunk round that takes costs over from the round before: the units look every part up there first)
+__global__ __launch_bounds__(kScanT) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+{
+    const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
+    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
+    else scan_unit_body<false, true>(a, b - 1 - n_desc);
 }
 
 // The compact hand-over: the units decode their anchors first (rawdtw_batch_submit_compact).  The chain records read the
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(kScanT) void k_scan_compact(const StreamArgs a, uin
 {
     const uint32_t b = blockIdx.x;
     if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
-    else scan_unit_body<true>(a, b - 1);
+    else scan_unit_body<true, false>(a, b - 1);
 }
 __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainDesc *__restrict__ chains)
 {
@@ -678,7 +686,7 @@ struct RunTab {
 // 554 GCUPS with 128).
 // DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
 // carries neither.
-template <int TT, bool DIAG>
+template <int TT, bool DIAG, bool CARRY>
 __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
 {
     const uint32_t dbg = DIAG ? a.debug : 0u;
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
 
-    if (tid < (int)(AT / 32)) s_carried[tid] = 0;
+    if (CARRY && tid < (int)(AT / 32)) s_carried[tid] = 0;
     // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
     // list: nothing to do here, and nothing may be derived from its anchors
     if (tid == 0) s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
             if (q0 + (uint32_t)lane < pieces && base + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                 dma16(a.anchors + base + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-        if (a.carried && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+        if (CARRY && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
             dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile * (AT / 32u) + lane, s_carried);
         if (wv == 0) {
             const uint64_t c = (uint64_t)c0 + ((uint32_t)lane >> 1);
@@ -942,7 +950,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
 #pragma unroll
             for (int k = 0; k < KI; k++) {
                 const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1) && !mask_bit(s_carried, p);
+                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1) && !(CARRY && mask_bit(s_carried, p));
                 pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
                 tl[k] = exists && pt[k].tile;
             }
@@ -1008,7 +1016,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                 for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
                     if (q0 + (uint32_t)lane < pieces && nbase + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                         dma16(a.anchors + nbase + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-                if (a.carried && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+                if (CARRY && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
                     dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile_n * (AT / 32u) + lane, s_carried);
             }
             // ---- 2. runs into the table, the sort's histogram ----
@@ -1304,7 +1312,8 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     if (a.steps) {
         hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanT), 0, s, a, d_fold_order);
         if (n_desc) hipLaunchKernelGGL(k_scan_desc, dim3(n_desc), dim3(kScanT), 0, s, a, d_chains);
-    } else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    } else if (a.carry_chain) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
@@ -1326,8 +1335,9 @@ hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats,
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(tt), lds_bytes, s, a, lds_floats);
         return hipGetLastError();
     };
-    if (threads == 512) return diag ? launch(k_runs<512, true>, 512) : launch(k_runs<512, false>, 512);
-    return diag ? launch(k_runs<256, true>, 256) : launch(k_runs<256, false>, 256);
+    const bool carry = a.carried != nullptr;
+    if (threads == 512) return diag ? launch(k_runs<512, true, true>, 512) : carry ? launch(k_runs<512, false, true>, 512) : launch(k_runs<512, false, false>, 512);
+    return diag ? launch(k_runs<256, true, true>, 256) : carry ? launch(k_runs<256, false, true>, 256) : launch(k_runs<256, false, false>, 256);
 }
 
 // workgroups of k_runs one compute unit holds at this LDS size (for the persistent grid)
@@ -1335,7 +1345,7 @@ int stream_blocks_per_cu(uint32_t lds_floats, int threads)
 {
     int n = 0;
     const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
-    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512, false>) : reinterpret_cast<const void *>(k_runs<256, false>);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512, false, false>) : reinterpret_cast<const void *>(k_runs<256, false, false>);
     if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds_bytes) != hipSuccess) return 0;
     return n;
