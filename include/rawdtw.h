@@ -453,6 +453,52 @@ int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
                         const uint32_t *read_base, rawdtw_batch **out);
 int rawdtw_batch_fetch_destroy(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep);
 
+/* ---- the chunk-round mapping loop on the host side of the library: the control flow of map_worker_for / ri_map_frag /
+ * gen_chains (src/rmap.cpp:667-822, 545-578, 315-541) turned inside out so that every chunk round makes ONE device
+ * submission for all active reads, and the PAF line of a read (src/rmap.cpp:696-801, 950-965).  The caller keeps event
+ * detection and seeding (revent.c, rsketch.c, rawindex.cpp) and hands in, per round and active read, the chunk's events and
+ * seed hits; the mapper appends the events to the read's slot in the event arena (rmap.cpp:554-567), re-seeds with the
+ * previous chains' anchors (344-357), chains (396-507), orders the chains (512), scores them all in one batch on the
+ * device (509-530; with `carry` the unchanged parts' costs are taken over from the round before), and finishes the round:
+ * gen_primary_chains, comp_mapq, the stop rule (532-541, 692).  rawdtw_mapper_finish runs the --dtw-output-cigar
+ * traceback of every mapped read's best chain (715-717); rawdtw_mapper_paf writes a read's line (mt:f:, wall-clock in
+ * the reference, as 0).  The reference arrays must be on the context (rawdtw_upload_reference / rawdtw_index_upload);
+ * seq_len[s] is the length of sequence s's signal arrays.  rawalign_amd/mapper.py is the Python mirror. ---- */
+typedef struct rawdtw_mapper rawdtw_mapper;
+typedef struct {
+    int flag;                  /* RI_M_DTW_EVALUATE_CHAINS 0x2 | RI_M_DTW_OUTPUT_CIGAR 0x4 | RI_M_DTW_LOG_SCORES 0x8 (roptions.h:13-15) */
+    rawdtw_align_opt_t align;
+    rawdtw_chain_opt_t chain;
+    float min_bestmap_ratio, min_meanmap_ratio; /* roptions.c:28,31 */
+    uint32_t min_chain_anchor;                  /* roptions.c:25 */
+    uint32_t bp_per_sec, sample_rate, chunk_size, max_num_chunk; /* roptions.c:9-11, 24 */
+    uint32_t slot_events;      /* events a read may reach: its slot in the event arena */
+    uint32_t max_reads;        /* reads the mapper holds at a time */
+    int carry;                 /* 1: a round takes the unchanged parts' costs over from the round before (rawdtw_batch_submit_round) */
+} rawdtw_mapper_opt_t;
+typedef struct {
+    uint32_t ref_seq;
+    int32_t strand;
+    uint32_t target_position;
+    uint32_t query_position;   /* inside the chunk */
+} rawdtw_seed_hit_t;
+int rawdtw_mapper_create(rawdtw_ctx *ctx, const rawdtw_mapper_opt_t *opt, uint32_t n_seq, const char *const *seq_names,
+                         const uint32_t *seq_len, rawdtw_mapper **out);
+int rawdtw_mapper_add_read(rawdtw_mapper *m, const char *name, uint32_t qlen /* samples */, uint32_t n_chunks_available,
+                           uint32_t *read_id);
+/* one chunk round: read read_ids[k] gets events[event_off[k] .. event_off[k+1]) and hits[hit_off[k] .. hit_off[k+1]) */
+int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read_ids, const uint64_t *event_off,
+                        const float *events, const uint64_t *hit_off, const rawdtw_seed_hit_t *hits);
+int rawdtw_mapper_read_state(const rawdtw_mapper *m, uint32_t read_id, int *finished, uint32_t *chunks_done);
+int rawdtw_mapper_finish(rawdtw_mapper *m);
+/* *len = the line's length; RAWDTW_ERR_RANGE when buf (cap bytes) is too small for it and its terminator */
+int rawdtw_mapper_paf(const rawdtw_mapper *m, uint32_t read_id, char *buf, uint32_t cap, uint32_t *len);
+/* the lines --dtw-log-scores writes to stderr (rmap.cpp:308-312), in order */
+int rawdtw_mapper_log(const rawdtw_mapper *m, const char **text);
+int rawdtw_mapper_stats(const rawdtw_mapper *m, uint64_t *rounds, uint64_t *parts_scored, uint64_t *parts_reused);
+const char *rawdtw_mapper_last_error(const rawdtw_mapper *m);
+int rawdtw_mapper_destroy(rawdtw_mapper *m);
+
 #ifdef __cplusplus
 }
 #endif

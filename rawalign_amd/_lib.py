@@ -161,6 +161,16 @@ SYMBOLS = {
     "rawdtw_batch_submit_round": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_round_stats": (I32, [VP, VP, VP, VP]),
     "rawdtw_round_match_chains": (I32, [U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_mapper_create": (I32, [VP, VP, U32, VP, VP, VP]),
+    "rawdtw_mapper_add_read": (I32, [VP, C.c_char_p, U32, U32, VP]),
+    "rawdtw_mapper_round": (I32, [VP, U32, VP, VP, VP, VP, VP]),
+    "rawdtw_mapper_read_state": (I32, [VP, U32, VP, VP]),
+    "rawdtw_mapper_finish": (I32, [VP]),
+    "rawdtw_mapper_paf": (I32, [VP, U32, VP, U32, VP]),
+    "rawdtw_mapper_log": (I32, [VP, VP]),
+    "rawdtw_mapper_stats": (I32, [VP, VP, VP, VP]),
+    "rawdtw_mapper_last_error": (C.c_char_p, [VP]),
+    "rawdtw_mapper_destroy": (I32, [VP]),
     "rawdtw_anchors_pack": (I32, [U64, VP, VP, VP, VP, VP, VP, U64, VP]),
     "rawdtw_anchors_unpack": (I32, [U64, VP, VP, VP, VP, VP, U64, VP]),
     "rawdtw_batch_submit_compact": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, U64, VP, VP, VP]),

@@ -2,7 +2,7 @@
 # Workload sensitivity of the bench line (GPU box): anchor density of the true chains and the decoy chains' gaps.
 # Usage: bash scripts/sensitivity.sh <outdir>
 OUT=${1:-gpurun_out/sens}; mkdir -p $OUT
-run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "$name failed"; }
+run() { name=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline --modes-reads 0 --rounds 0 "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "$name failed"; }
 run hit0.10 --hit-prob 0.10
 run hit0.20 --hit-prob 0.20
 run hit0.40 --hit-prob 0.40

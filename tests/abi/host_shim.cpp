@@ -89,8 +89,119 @@ unsigned bits(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
 
 } // namespace
 
+// ---- `host_shim map.bin --map`: the chunk-round mapping loop through rawdtw_mapper_* (INTEGRATION.md section 5): what
+// map_worker_for / ri_map_frag / gen_chains do for a mini-batch of reads (rmap.cpp:667-822), one device submission per chunk
+// round, PAF lines out.  The blob holds what stays in RawAlign: every chunk's events (revent.c) and seed hits (rsketch.c,
+// rawindex.cpp). ----
+static int run_map(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot read %s\n", path); return 1; }
+    uint32_t magic = 0, n_seq = 0;
+    bool ok = rd(f, &magic, 1) && magic == 0x504D4452u && rd(f, &n_seq, 1);
+    std::vector<std::vector<float>> fwd(n_seq), rev(n_seq);
+    std::vector<uint32_t> len(n_seq);
+    for (uint32_t s = 0; ok && s < n_seq; s++) {
+        ok = rd(f, &len[s], 1);
+        fwd[s].resize(len[s]); rev[s].resize(len[s]);
+        ok = ok && rd(f, fwd[s].data(), len[s]) && rd(f, rev[s].data(), len[s]);
+    }
+    int32_t io[2], flag = 0, carry = 0, min_chain_anchor = 2; float fo[3], ratio[2];
+    uint32_t n_reads = 0;
+    ok = ok && rd(f, io, 2) && rd(f, fo, 3) && rd(f, &flag, 1) && rd(f, &carry, 1) && rd(f, ratio, 2) && rd(f, &min_chain_anchor, 1) && rd(f, &n_reads, 1);
+    struct Chunk { std::vector<float> ev; std::vector<rawdtw_seed_hit_t> hits; };
+    struct Rd { uint32_t qlen, n_chunks; std::vector<Chunk> chunks; };
+    std::vector<Rd> reads(n_reads);
+    uint32_t slot = 8;
+    for (uint32_t r = 0; ok && r < n_reads; r++) {
+        ok = rd(f, &reads[r].qlen, 1) && rd(f, &reads[r].n_chunks, 1);
+        reads[r].chunks.resize(reads[r].n_chunks);
+        uint32_t total = 0;
+        for (uint32_t c = 0; ok && c < reads[r].n_chunks; c++) {
+            uint32_t ne = 0, nh = 0;
+            ok = rd(f, &ne, 1);
+            reads[r].chunks[c].ev.resize(ne);
+            ok = ok && rd(f, reads[r].chunks[c].ev.data(), ne) && rd(f, &nh, 1);
+            reads[r].chunks[c].hits.resize(nh);
+            ok = ok && rd(f, reads[r].chunks[c].hits.data(), nh);
+            total += ne;
+        }
+        slot = total + 8 > slot ? total + 8 : slot;
+    }
+    fclose(f);
+    if (!ok) { fprintf(stderr, "malformed %s\n", path); return 1; }
+    rawdtw_ctx *dtw = nullptr;
+    if (rawdtw_create(0, &dtw) != RAWDTW_OK) { fprintf(stderr, "no device\n"); return 3; }
+    std::vector<const float *> pf(n_seq), pr(n_seq);
+    std::vector<std::string> names(n_seq);
+    std::vector<const char *> pn(n_seq);
+    for (uint32_t s = 0; s < n_seq; s++) { pf[s] = fwd[s].data(); pr[s] = rev[s].data(); names[s] = "seq" + std::to_string(s); pn[s] = names[s].c_str(); }
+    CHECK(rawdtw_upload_reference(dtw, n_seq, pf.data(), pr.data(), len.data()));
+    rawdtw_mapper_opt_t mo;
+    memset(&mo, 0, sizeof mo);
+    mo.flag = flag;
+    mo.align.border_constraint = io[0]; mo.align.fill_method = io[1]; mo.align.band_radius_frac = fo[0]; mo.align.match_bonus = fo[1];
+    mo.align.min_score = fo[2]; mo.align.fused_score = 1;
+    mo.chain.max_gap_length = 2000; mo.chain.max_target_gap_length = 5000; mo.chain.chaining_band_length = 5000; mo.chain.max_num_skips = 25;
+    mo.chain.min_num_anchors = 2; mo.chain.num_best_chains = 3; mo.chain.min_chaining_score = 10.0f; mo.chain.e = 6; // roptions.c:13-19, main.cpp:138
+    mo.min_bestmap_ratio = ratio[0]; mo.min_meanmap_ratio = ratio[1]; mo.min_chain_anchor = min_chain_anchor;        // roptions.c:25-31 (1.2, 5, 2)
+    mo.bp_per_sec = 450; mo.sample_rate = 4000; mo.chunk_size = 4000; mo.max_num_chunk = 30;                          // roptions.c:9-11, 24
+    mo.slot_events = slot; mo.max_reads = n_reads ? n_reads : 1; mo.carry = carry;
+    rawdtw_mapper *mp = nullptr;
+    CHECK(rawdtw_mapper_create(dtw, &mo, n_seq, pn.data(), len.data(), &mp));
+    std::vector<uint32_t> ids(n_reads);
+    for (uint32_t r = 0; r < n_reads; r++) {
+        const std::string nm = "read_" + std::to_string(r);
+        CHECK(rawdtw_mapper_add_read(mp, nm.c_str(), reads[r].qlen, reads[r].n_chunks, &ids[r]));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) { // chunk rounds until every read has stopped
+        std::vector<uint32_t> act;
+        std::vector<uint64_t> eoff{0}, hoff{0};
+        std::vector<float> ev;
+        std::vector<rawdtw_seed_hit_t> hits;
+        for (uint32_t r = 0; r < n_reads; r++) {
+            int fin = 0; uint32_t done = 0;
+            CHECK(rawdtw_mapper_read_state(mp, ids[r], &fin, &done));
+            if (fin || done >= reads[r].n_chunks) continue;
+            const Chunk &c = reads[r].chunks[done];
+            act.push_back(ids[r]);
+            ev.insert(ev.end(), c.ev.begin(), c.ev.end()); eoff.push_back(ev.size());
+            hits.insert(hits.end(), c.hits.begin(), c.hits.end()); hoff.push_back(hits.size());
+        }
+        if (act.empty()) break;
+        const int st = rawdtw_mapper_round(mp, (uint32_t)act.size(), act.data(), eoff.data(), ev.data(), hoff.data(), hits.data());
+        if (st != RAWDTW_OK) { fprintf(stderr, "round -> %d: %s\n", st, rawdtw_mapper_last_error(mp)); return 2; }
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+        const int st = rawdtw_mapper_finish(mp);
+        if (st == RAWDTW_ERR_UNSUPPORTED) { printf("cigar=unsupported\n"); return 0; } // rmap.cpp:223-225 assert(false)
+        if (st != RAWDTW_OK) { fprintf(stderr, "finish -> %d: %s\n", st, rawdtw_mapper_last_error(mp)); return 2; }
+    }
+    std::vector<char> buf(1 << 16);
+    for (uint32_t r = 0; r < n_reads; r++) {
+        uint32_t n = 0;
+        int st = rawdtw_mapper_paf(mp, ids[r], buf.data(), (uint32_t)buf.size(), &n);
+        if (st == RAWDTW_ERR_RANGE) { buf.resize((size_t)n + 1); st = rawdtw_mapper_paf(mp, ids[r], buf.data(), (uint32_t)buf.size(), &n); }
+        if (st != RAWDTW_OK) return 2;
+        printf("%s\n", buf.data());
+    }
+    const char *log = nullptr;
+    rawdtw_mapper_log(mp, &log);
+    for (const char *p = log; p && *p;) { const char *e = strchr(p, '\n'); printf("log %.*s\n", (int)(e ? e - p : (long)strlen(p)), p); p = e ? e + 1 : p + strlen(p); }
+    uint64_t rounds = 0, scored = 0, reused = 0;
+    rawdtw_mapper_stats(mp, &rounds, &scored, &reused);
+    printf("map rounds=%llu parts_scored=%llu parts_reused=%llu rounds_per_s=%.1f\n", (unsigned long long)rounds, (unsigned long long)scored,
+           (unsigned long long)reused, rounds / secs);
+    rawdtw_mapper_destroy(mp);
+    rawdtw_destroy(dtw);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && !strcmp(argv[2], "--map")) return run_map(argv[1]);
     if (argc < 2) { fprintf(stderr, "usage: host_shim batch.bin [--pipeline steps | --teardown]\n"); return 1; }
     const int pipeline_steps = (argc >= 4 && !strcmp(argv[2], "--pipeline")) ? atoi(argv[3]) : 0;
     const bool teardown = argc >= 3 && !strcmp(argv[2], "--teardown");

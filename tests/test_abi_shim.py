@@ -225,3 +225,78 @@ def test_cpp_shim_teardown_in_any_order(oracle, tmp_path):
     assert td == ["teardown mismatches=0"], (td, run.stderr)
     rest = [ln for ln in got if not ln.startswith("teardown ")]
     assert rest == _expected_lines(oracle, ref, cb, cseq, cstr, cscore, opt, 0x2)
+
+
+def _write_map_blob(path, ref, seeds, n_reads, opt, carry, stop):
+    """What stays in RawAlign, per read and chunk: the chunk's events (revent.c) and its seed hits (rsketch.c, rawindex.cpp)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x504D4452, ref.n_seq))
+        for s in range(ref.n_seq):
+            f.write(struct.pack("<I", len(ref.forward[s])))
+            f.write(ref.forward[s].astype("<f4").tobytes())
+            f.write(ref.reverse[s].astype("<f4").tobytes())
+        f.write(struct.pack("<iifffii", opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac, opt.dtw_match_bonus,
+                            opt.dtw_min_score, opt.flag, int(carry)))
+        f.write(struct.pack("<ffi", stop.min_bestmap_ratio, stop.min_meanmap_ratio, stop.min_chain_anchor))
+        f.write(struct.pack("<I", n_reads))
+        for r in range(n_reads):
+            rj = seeds.read_job(r)
+            f.write(struct.pack("<II", rj.qlen, rj.n_chunks_available))
+            for c in range(rj.n_chunks_available):
+                ev, hits = seeds.chunk(r, c)
+                f.write(struct.pack("<I", len(ev)))
+                f.write(ev.astype("<f4").tobytes())
+                f.write(struct.pack("<I", len(hits)))
+                f.write(np.array(hits, "<u4").reshape(-1, 4).astype("<u4").tobytes() if hits else b"")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("border,fill,flag,carry,never", [(1, 1, 0x2, 1, 0), (1, 1, 0x2, 0, 0), (1, 1, 0x2 | 0x4, 1, 0), (1, 0, 0x2 | 0x4, 0, 0),
+                                                          (0, 0, 0x2 | 0x4, 0, 0), (1, 1, 0x8, 1, 0), (1, 1, 0x2 | 0x4 | 0x8, 1, 0), (0, 1, 0x2, 0, 0),
+                                                          (1, 1, 0x2, 1, 1), (1, 1, 0x8, 1, 1)])
+def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_path, border, fill, flag, carry, never):
+    """f-2 in C++: the chunk-round loop, chaining, primary chains / MAPQ / stop rule and the PAF line run inside the library
+    (rawdtw_mapper_*, rawalign_amd/csrc/rawdtw_mapper.cpp), driven by the compiled shim.  Its PAF lines and --dtw-log-scores
+    lines must equal, character for character, those of the Python mirror (rawalign_amd.mapper.map_reads) scored on the
+    device AND scored by the oracle's sequential loop -- sparse and global, banded and full, with traceback tags, with
+    log-scores alone, with and without costs carried from round to round, under the reference's stop rule and with reads
+    that never stop early (every read through all of its chunks: the rounds in which carried costs are taken over).
+    d1-scale reference (configs[0])."""
+    from rawalign_amd import mapper
+    from rawalign_amd.mapping import StopOpt
+    from tests.util import OracleScorer
+
+    stop = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6) if never else StopOpt()
+
+    exe = _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
+    ref = synth.make_reference([29903], seed=20231005 + 1)
+    n = 36
+    seeds = mapper.SyntheticSeeds(ref, n, seed=7, max_chunks=4)
+    opt = ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill, flag=flag)
+    blob = os.path.join(str(tmp_path), "map.bin")
+    _write_map_blob(blob, ref, seeds, n, opt, carry, stop)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([exe, blob, "--map"], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stderr
+    got = run.stdout.rstrip("\n").split("\n")
+    stats = [ln for ln in got if ln.startswith("map rounds=")]
+    assert len(stats) == 1
+    paf = [ln for ln in got if not ln.startswith("map rounds=") and not ln.startswith("log ")]
+    log = [ln[4:] + "\n" for ln in got if ln.startswith("log ")]
+    lo = []
+    want, rounds = mapper.map_reads(seeds, list(range(n)), OracleScorer(oracle, ref), opt, stop, log=lo)
+    assert paf == want
+    if flag & 0x8:
+        assert log == lo and log
+    eng = ra.Engine(0)
+    eng.upload_reference(ref.forward, ref.reverse)
+    dev, _ = mapper.map_reads(seeds, list(range(n)), mapper.DeviceScorer(eng), opt, stop)
+    assert paf == dev
+    kv = dict(x.split("=") for x in stats[0].split(" ")[1:])
+    assert int(kv["rounds"]) == rounds and float(kv["rounds_per_s"]) > 0
+    if never:
+        assert rounds >= 3
+        if carry and border == 1 and fill == 1:   # (sparse + banded: the sync-free path, the one that carries)
+            assert int(kv["parts_reused"]) > 0
+    else:
+        assert any(ln.split("\t")[4] in "+-" for ln in paf)
