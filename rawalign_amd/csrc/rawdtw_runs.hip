@@ -690,6 +690,7 @@ template <int TT, bool DIAG, bool CARRY>
 __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
 {
     const uint32_t dbg = DIAG ? a.debug : 0u;
+    const bool carry = CARRY && (!DIAG || a.carried != nullptr); // (the diagnostic instance serves both kinds of batch)
     constexpr int KI = (int)kStreamItems;
     constexpr uint32_t AT = TT * KI, kWords = AT / 32 + 1, kWaves = TT / 64, kCT = 32;
     static_assert(kWords <= 64, "one mask word a lane");
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
             if (q0 + (uint32_t)lane < pieces && base + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                 dma16(a.anchors + base + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-        if (CARRY && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+        if (carry && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
             dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile * (AT / 32u) + lane, s_carried);
         if (wv == 0) {
             const uint64_t c = (uint64_t)c0 + ((uint32_t)lane >> 1);
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                 for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
                     if (q0 + (uint32_t)lane < pieces && nbase + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
                         dma16(a.anchors + nbase + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-                if (CARRY && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
+                if (carry && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
                     dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile_n * (AT / 32u) + lane, s_carried);
             }
             // ---- 2. runs into the table, the sort's histogram ----

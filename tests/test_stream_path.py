@@ -109,6 +109,9 @@ def _wide(rng):     # side list: 8-lane, 16-lane and wave-per-job classes
     (_medium, {"lane_max_radius": 1}), (_wide, {"stream_threads": 512}),
     # tiles of radius <= 2 / <= 1: the wider lane radii go to the side list's lane classes (lane_global_wave, lane_dp_r12)
     (_medium, {"stream_tile_radius": 2}), (_medium, {"stream_tile_radius": 1}), (_wide, {"stream_tile_radius": 2}),
+    # the diagnostic instance of k_runs (profiling runs: scripts/pmc_debug_masks.sh, stream_probe.py) -- no mask set (128), with
+    # the phase stamps (256), with the tiles dealt by block index (8): it has to score like the production instance
+    (_medium, {"stream_debug": 128}), (_wide, {"stream_debug": 256}), (_tiny, {"stream_debug": 256 | 8}),
 ])
 def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
     rng = np.random.default_rng(hash((shapes.__name__, tuple(sorted(opts)))) & 0xFFFF)
