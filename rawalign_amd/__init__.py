@@ -29,4 +29,4 @@ __all__ = [
     "load_library", "library_path", "LibraryMissing", "RawDTWError",
 ]
 
-DEFAULT_FOLD_MODE = 3  # rawdtw_set_option("fold_mode"): the library's default chain-fold kernel
+DEFAULT_FOLD_MODE = 4  # rawdtw_set_option("fold_mode"): the library's default chain-fold kernel

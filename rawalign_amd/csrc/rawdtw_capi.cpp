@@ -77,6 +77,7 @@ struct rawdtw_ctx {
     bool tile_lds_set = false;                  // "tile_lds_floats" was given: it also sizes the device-planned batches' tiles
     uint32_t lane_max_n = kLaneMaxN;
     uint32_t debug_skip_kinds = 0; // timing experiments: launches of these kinds are not issued (results are then wrong)
+    uint32_t debug_skip_tail = 0;  // timing experiments on the sync-free path: 1 no fold launch, 2 no select launch (results are then wrong)
     uint32_t sort_n = 0, sort_r1_n = 0, sort_r3 = 0, sorted_tile_jobs = 64; // see PlanCfg
     bool device_plan = true;  // rawdtw_batch_create takes the sync-free stream path (rawdtw_stream.hip) for sparse + banded batches
     uint64_t device_plan_min_jobs = 0; // smaller batches go through the job list
@@ -102,7 +103,8 @@ struct rawdtw_ctx {
     float tb_fill_ms = 0.f, tb_walk_ms = 0.f;          // device time of the most recent rawdtw_traceback_batch
     uint64_t tb_dir_written = 0, tb_path_elems = 0;
     bool merge_small = true; // tile + 16-lane-row + register-wave launches of a batch as one launch (k_band_merged)
-    int fold_mode = 3; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work), 3: lanes + a wave for each long chain
+    int fold_mode = 4; // 0: wave per chain, 1/2: lane per chain (16/32 parts per round; 30x less VALU work), 3: lanes + a wave for each long chain,
+                       // 4: sync-free batches fold and select in one launch out of LDS (k_fold_select), job-list batches as 3
     uint32_t fold_long_parts = 768; // fold_mode 3: chains of at least this many parts are folded a wave each
     int tile_threads = 256; // workgroup size of the tile kernel (256, 512, 1024)
     uint32_t tile_max_spans = kTileMaxSpans;
@@ -173,6 +175,7 @@ struct rawdtw_batch {
     ChainDesc *d_chains = nullptr;
     uint64_t *d_chain_off = nullptr;
     uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
+    bool fold_fused = false;          // sync-free batch: fold and select are one launch (k_fold_select), no fold order was built
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
     bool own_chain_arrays = false;  // the arrays above are hipMalloc'd (job-list path) rather than carved from `ws`
@@ -1241,6 +1244,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "debug_skip_tail")) { ctx->debug_skip_tail = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "sort_n")) { ctx->sort_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
     if (!strcmp(name, "sort_r1_n")) { ctx->sort_r1_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
     if (!strcmp(name, "sort_r3")) { ctx->sort_r3 = value != 0; return RAWDTW_OK; }
@@ -1253,7 +1257,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "resident_arrays")) { ctx->resident_arrays = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "time_plan")) { ctx->time_plan = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "merge_small")) { ctx->merge_small = value != 0; return RAWDTW_OK; }
-    if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3); return RAWDTW_OK; }
+    if (!strcmp(name, "fold_mode")) { ctx->fold_mode = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return RAWDTW_OK; }
     if (!strcmp(name, "fold_long_parts")) { ctx->fold_long_parts = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 30); return RAWDTW_OK; }
     if (!strcmp(name, "tile_threads")) { ctx->tile_threads = value >= 1024 ? 1024 : (value >= 512 ? 512 : 256); return RAWDTW_OK; }
     if (!strcmp(name, "tile_max_spans")) { ctx->tile_max_spans = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 8), 4096); return RAWDTW_OK; }
@@ -1887,7 +1891,8 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     }
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
     if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
-    hipError_t e = stream_plan(a, b->d_chains, b->d_fold_order, s);
+    b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
+    hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
     // the persistent grid: what the device holds at this LDS size
@@ -2367,9 +2372,14 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
 {
     hipError_t e;
     if (ctx->debug_skip_kinds & (1u << (which == 0 ? kKindChainFold : kKindReadSelect))) return RAWDTW_OK;
+    if (ctx->debug_skip_tail & (1u << which)) return RAWDTW_OK;
     const float *job_cost = b->stream ? b->sa.out : b->plan->d_cost;
-    if (which == 0)
-        e = launch_chain_fold(ctx->fold_mode, b->d_chains, b->d_fold_order, b->n_chains, job_cost, b->opt.match_bonus, b->opt.fused_score,
+    if (b->stream && b->fold_fused) {
+        if (which == 1) return RAWDTW_OK; // (done by the launch before)
+        e = stream_fold_select(b->sa, b->d_chains, b->d_chain_off, b->n_reads, b->opt.match_bonus, b->opt.fused_score, b->opt.min_score, b->d_full,
+                               b->d_gate, b->d_score, b->d_keep, ctx->stream);
+    } else if (which == 0)
+        e = launch_chain_fold(std::min(ctx->fold_mode, 3), b->d_chains, b->d_fold_order, b->n_chains, job_cost, b->opt.match_bonus, b->opt.fused_score,
                               b->d_full, b->d_gate, ctx->fold_long_parts, ctx->stream);
     else
         e = launch_read_select(b->d_chain_off, b->n_reads, b->d_full, b->d_gate, b->opt.min_score, b->d_score,
@@ -2618,6 +2628,7 @@ int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t 
     if (!ctx || !batch || batch->ctx != ctx || !n_out) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to batch_stream_counters");
     *n_out = 0;
     if (!batch->stream) return RAWDTW_OK;
+    batch->cnt_valid = false; // (a diagnostic call: runs since the last look have moved the phase stamps on)
     const int st = stream_counters(ctx, batch);
     if (st != RAWDTW_OK) return st;
     const uint32_t n = (uint32_t)kCntHeads; // (the queue heads behind them are the kernel's scratch)

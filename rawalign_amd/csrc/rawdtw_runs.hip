@@ -273,19 +273,25 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
 // k_scan: the pass over the anchor list ahead of the DTW launch.  Roles by workgroup: [0, n_tiles) one tile each,
 // n_tiles the fold order, the rest the chain records.
 // ---------------------------------------------------------------------------------------------------------------------
-// A scan unit = kScanUnit consecutive anchors = a whole number of tiles, one 1024-thread workgroup, eight consecutive
-// anchors a thread (forward order: the part of anchor i runs from anchors[i + 1] to anchors[i]).  It writes the first
+// A scan unit = kScanUnit consecutive anchors = a whole number of tiles, one workgroup, eight consecutive anchors a thread
+// and pass (forward order: the part of anchor i runs from anchors[i + 1] to anchors[i]).  It writes the first
 // chain of each of its tiles (4 bytes a tile), three statistics, and -- for the one part in two hundred the tiles do not
 // take -- a side-list record.  Units are large because every unit ends with one returning atomic per side-list class on
 // a counter the whole grid shares: such a word takes ~88 atomics a microsecond, and at one workgroup per TILE (ten
 // thousand a batch) the launch spent 150 of its 176 us queueing there.
-constexpr uint32_t kScanUnit = 8192, kScanT = 1024, kScanKI = kScanUnit / kScanT;
+constexpr uint32_t kScanUnit = 8192, kScanKI = 8;
+// Workgroups of kScanT threads take a unit in two halves (eight consecutive anchors a thread and half): three such
+// workgroups fit a compute unit -- all of a bench batch's 638 units are resident at once, where one 1024-thread workgroup
+// a compute unit took them in three rounds of the same latency chain -- and one fits beside the DTW launch's workgroups.
+// The compact form (kScanTC threads, one pass) decodes a unit with one scan over all of its entries.
+constexpr uint32_t kScanT = 512, kScanTC = 1024;
 static_assert(kScanUnit == RAWDTW_COMPACT_STRIDE, "the compact hand-over is decoded unit by unit");
 template <bool COMPACT, bool CARRY>
 __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32_t unit)
 {
-    constexpr int NT = (int)kScanT, KI = (int)kScanKI;
-    constexpr uint32_t AT = kScanUnit, kWords = AT / 32 + 1;
+    constexpr int NT = COMPACT ? (int)kScanTC : (int)kScanT, KI = (int)kScanKI;
+    constexpr uint32_t AT = kScanUnit, kWords = AT / 32 + 1, kHalf = (uint32_t)NT * KI, kHalves = AT / kHalf;
+    static_assert(kHalves * kHalf == AT && (!COMPACT || kHalves == 1), "a unit in whole passes; the compact form in one");
     __shared__ uint32_t s_mask[kWords], s_pre[kWords];
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
     __shared__ unsigned long long s_stats[3];
@@ -299,7 +305,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
     // last part), requested before the chain search waits for anything
-    const uint64_t i0 = base + (uint64_t)tid * KI;
+    const uint64_t i0 = base + (uint64_t)tid * KI; // the thread's first anchor (of the first half)
     rawdtw_anchor_t an[KI + 1];
     uint4 steps8 = make_uint4(0u, 0u, 0u, 0u); // compact form: this thread's eight 2-byte steps
     if (COMPACT) { if (i0 < a.n_anchors) steps8 = *reinterpret_cast<const uint4 *>(a.steps + i0); } // (the array is padded to whole units)
@@ -307,6 +313,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 #pragma unroll
         for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
     }
+    const rawdtw_anchor_t *const anchors_rd = COMPACT ? a.anchors_w : a.anchors; // (the decoded list, once this unit has written it)
     if (tid < 64) {
         const uint64_t c = find_chain(a.anchor_off, a.n_chains, base, lane);
         if (tid == 0) s_c0 = c;
@@ -386,9 +393,9 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     // (the round before must have stood: a batch the scan declined has no costs to take over)
     const bool carry = CARRY && a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
                        a.prev_cnt[kCntOverflow] == ~0ull;
-    uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0, carried_bits = 0;
+    uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0;
     unsigned long long my_obytes = 0;
-    uint32_t o_slot[KI], o_cls[KI];
+    uint32_t o_rec[kHalves][KI]; // the thread's side-list parts: slot | class << 16 | radius << 21 (0xffffffff: none)
     // chunk rounds: the chain-level values of the part's chain and of the chain it continues, kept while the thread's parts
     // stay inside one chain (they mostly do)
     uint64_t cc = ~0ull, c_a1 = 0, pa0 = 0, pa1 = 0;
@@ -396,9 +403,17 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     uint64_t c_rb = 0;
     uint32_t c_qb = 0;
 #pragma unroll
+    for (uint32_t h = 0; h < kHalves; h++) {
+    const uint64_t ih = i0 + (uint64_t)h * kHalf;
+    if (h) { // (the half's anchors: KI + 1 consecutive entries a thread)
+#pragma unroll
+        for (int k = 0; k <= KI; k++) an[k] = ih + k < a.n_anchors ? a.anchors[ih + k] : rawdtw_anchor_t{0, 0};
+    }
+    uint32_t carried_bits = 0, half_tiles = 0;
+#pragma unroll
     for (int k = 0; k < KI; k++) {
-        o_cls[k] = 0xffffffffu; o_slot[k] = 0;
-        const uint32_t p = (uint32_t)tid * KI + k; // position in the unit
+        o_rec[h][k] = 0xffffffffu;
+        const uint32_t p = h * kHalf + (uint32_t)tid * KI + k; // position in the unit
         const uint64_t i = base + p;
         if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
         const Part pt = classify(a, an[k + 1], an[k]);
@@ -440,7 +455,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
                 }
             }
         }
-        if (pt.tile) { my_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
+        if (pt.tile) { my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
         r0 = r0 > 1 ? r0 : 1;
@@ -453,14 +468,14 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
         else { atomicAdd(&a.cnt[kCntUnsupported], 1ull); continue; }
         my_obytes += 4ull * ((unsigned long long)pt.n + pt.m) + 36ull;
-        o_cls[k] = cls | ((uint32_t)R << 8);
-        o_slot[k] = atomicAdd(&s_ocnt, 1u);
+        o_rec[h][k] = atomicAdd(&s_ocnt, 1u) | (cls << 16) | ((uint32_t)R << 21); // (slot < 2^13, class < 2^5, R < 2^8)
         atomicAdd(&s_cls[cls], 1u);
     }
-    if (CARRY && a.carried && i0 < a.n_anchors) a.carried[i0 >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
+    if (CARRY && a.carried && ih < a.n_anchors) a.carried[ih >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
     {
-        const unsigned long long any_tile = __ballot(my_tiles != 0u); // (every lane votes: taken before the branch on the lane)
-        if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << (((uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
+        const unsigned long long any_tile = __ballot(half_tiles != 0u); // (every lane votes: taken before the branch on the lane)
+        if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << ((h * kHalf + (uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
+    }
     }
     if (carry) {
         for (int off = 32; off > 0; off >>= 1) my_reused += (uint32_t)__shfl_down((int)my_reused, off);
@@ -489,23 +504,27 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     if (s_ocnt) {
         const uint64_t obase = s_obase;
 #pragma unroll
-        for (int k = 0; k < KI; k++) {
-            if (o_cls[k] == 0xffffffffu) continue;
-            const uint64_t q = obase + o_slot[k];
-            if (q >= a.others_cap) continue; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
-            const uint32_t p = (uint32_t)tid * KI + k;
-            const uint64_t c = chain_at(p);
-            const rawdtw_anchor_t s = an[k + 1], e = an[k];
-            DevJob d;
-            d.ref_off = a.ref_base[c] + s.target_position;
-            d.read_off = a.read_base[c] + s.query_position;
-            d.n = e.query_position - s.query_position + 1;
-            d.m = e.target_position - s.target_position + 1;
-            d.R = (int32_t)(o_cls[k] >> 8);
-            d.flags = mask_bit(s_mask, p) ? 0u : kFlagExcludeLast; // rmap.cpp:270: every part but the chain's last (= its first entry)
-            d.aux = (uint32_t)(base + p);
-            a.omix[q] = d; a.ocls[q] = (uint8_t)(o_cls[k] & 0xffu);
-        }
+        for (uint32_t h = 0; h < kHalves; h++)
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                if (o_rec[h][k] == 0xffffffffu) continue;
+                const uint64_t q = obase + (o_rec[h][k] & 0xffffu);
+                if (q >= a.others_cap) continue; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
+                const uint32_t p = h * kHalf + (uint32_t)tid * KI + k;
+                const uint64_t c = chain_at(p);
+                // (rare: read again rather than kept; the compact form's next unit writes its first entry itself: that one travels whole)
+                const rawdtw_anchor_t e = anchors_rd[base + p];
+                const rawdtw_anchor_t s = (COMPACT && p + 1u == AT) ? a.unit_abs[unit + 1] : anchors_rd[base + p + 1];
+                DevJob d;
+                d.ref_off = a.ref_base[c] + s.target_position;
+                d.read_off = a.read_base[c] + s.query_position;
+                d.n = e.query_position - s.query_position + 1;
+                d.m = e.target_position - s.target_position + 1;
+                d.R = (int32_t)(o_rec[h][k] >> 21);
+                d.flags = mask_bit(s_mask, p) ? 0u : kFlagExcludeLast; // rmap.cpp:270: every part but the chain's last (= its first entry)
+                d.aux = (uint32_t)(base + p);
+                a.omix[q] = d; a.ocls[q] = (uint8_t)((o_rec[h][k] >> 16) & 0x1fu);
+            }
     }
 }
 
@@ -514,7 +533,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 __global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
-    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
     else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
     else scan_unit_body<false, false>(a, b - 1 - n_desc);
 }
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *
 __global__ __launch_bounds__(kScanT) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
-    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
     else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
     else scan_unit_body<false, true>(a, b - 1 - n_desc);
 }
@@ -530,10 +549,10 @@ __global__ __launch_bounds__(kScanT) void k_scan_round(const StreamArgs a, Chain
 // The compact hand-over: the units decode their anchors first (rawdtw_batch_submit_compact).  The chain records read the
 // chains' first and last anchors: the first travels whole (`heads`), the last they cannot know before the units have
 // written it -- so they run as a launch of their own behind this one (k_scan_desc).
-__global__ __launch_bounds__(kScanT) void k_scan_compact(const StreamArgs a, uint32_t *__restrict__ order)
+__global__ __launch_bounds__(kScanTC) void k_scan_compact(const StreamArgs a, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x;
-    if (b == 0) { if (a.n_chains) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
+    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanTC>(a.n_chains, a.anchor_off, order); }
     else scan_unit_body<true, false>(a, b - 1);
 }
 __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainDesc *__restrict__ chains)
@@ -1290,6 +1309,147 @@ __global__ __launch_bounds__(kT) void k_events_scatter(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_fold_select: the fold of align_chain (rmap.cpp:238-306) and the accept/cut loop of gen_chains (rmap.cpp:515-524) for
+// kFoldReads consecutive reads a wave.  A sync-free batch keeps one cost per ANCHOR (part p of a chain at out[a1 - 2 - p]),
+// and a read's chains are consecutive stretches of the anchor list.  The wave sweeps its reads' stretch from the top down
+// in windows of kFoldWin floats: a window comes into LDS in whole 16-byte pieces (coalesced), then every lane folds the
+// parts of its chain that lie in the window -- in the reference's order, one packed fp32 add a part (the fold is
+// inherently sequential) -- and carries its sums into the next window.  Going down the addresses meets the chains last to
+// first and every chain's parts first to last, so a lane with several chains (more than 64 chains a wave) finishes one
+// before it meets the next, and a chain of any length is folded out of LDS.  The first lanes then run their reads'
+// accept/cut loops over scores that never left the workgroup.
+// (The lane-per-chain fold over the arena read 4 bytes a lane from 64 different lines per instruction and needed the chains
+// sorted by length -- a one-workgroup sort on the scan's critical path; this one needs no order.)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFoldReads = 8, kFoldWin = 4096, kFoldCap = 256;
+__global__ __launch_bounds__(64) void k_fold_select(const StreamArgs a, const ChainDesc *__restrict__ chains, const uint64_t *__restrict__ chain_off,
+                                                    const uint64_t n_reads, const float bonus, const int fused, const float min_score,
+                                                    float *__restrict__ full_score, float *__restrict__ att_last, float *__restrict__ score,
+                                                    uint8_t *__restrict__ keep)
+{
+    __shared__ __attribute__((aligned(16))) float s_win[kFoldWin + 4];
+    __shared__ float s_full[kFoldCap], s_gate[kFoldCap];
+    const uint32_t lane = threadIdx.x;
+    // (a batch the scan or the DTW launch declined is redone through the job list: nothing here may be derived from it)
+    const bool declined = a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kFoldReads, r1 = min(r0 + (uint64_t)kFoldReads, n_reads);
+    const uint32_t nr = (uint32_t)(r1 - r0);
+    const uint64_t co = chain_off[r0 + min(lane, nr)], co1 = chain_off[r0 + min(lane + 1u, nr)]; // lane < nr: its read's chains
+    if (declined) return;
+    if (a.debug & 512u) return;
+    const bool tm = (a.debug & 16384u) != 0u;
+    unsigned long long t0 = tm ? wall_clock64() : 0ull, t1 = 0, t2 = 0;
+    const uint64_t cA = __shfl((unsigned long long)co, 0), cB = __shfl((unsigned long long)co, (int)nr);
+    if (cB <= cA) return;
+    const uint64_t aA = a.anchor_off[cA], aB = a.anchor_off[cB];
+    // the lane's chains: cA + lane + 64 k, the highest first
+    const uint64_t n_ch = cB - cA;
+    long long c = lane < n_ch ? (long long)(cA + lane + ((n_ch - 1u - lane) & ~63ull)) : -1; // (-1: none)
+    ChainDesc d = chains[c >= 0 ? (uint64_t)c : cA];
+    uint32_t p = 0; // parts of chain c folded so far
+    v2f acc = {0.0f, (float)d.span * bonus}; // {cost, attainable}  (rmap.cpp:205,246)
+    auto finish = [&](const float last) {
+        const float gate = d.n_jobs ? acc.y : __builtin_inff(); // tested before the last (or only) DTW call; none: no check
+        const float cost = d.n_jobs ? acc.x + last : acc.x;    // the last part only adds to the cost (rmap.cpp:279-280)
+        float sc;
+        if (fused) sc = __builtin_fmaf((float)d.num_aligned, bonus, -cost);
+        else { const float prod = (float)d.num_aligned * bonus; sc = prod - cost; }
+        full_score[c] = sc; att_last[c] = gate;
+        if ((uint64_t)c - cA < kFoldCap) { s_full[(uint64_t)c - cA] = sc; s_gate[(uint64_t)c - cA] = gate; }
+        c = (uint64_t)c >= cA + 64u ? c - 64 : -1;
+        if (c >= 0) { d = chains[c]; p = 0; acc = v2f{0.0f, (float)d.span * bonus}; }
+    };
+    for (uint64_t hi = aB; hi > aA;) { // (uniform)
+        const uint64_t lo4 = (hi > aA + kFoldWin ? hi - kFoldWin : aA) & ~3ull;
+        // LDS-DMA: 16 bytes a lane straight into LDS, every piece of the window in flight at once (the last piece of the
+        // list may reach past its end: element by element)
+        for (uint64_t i0 = lo4; i0 < hi; i0 += 256ull) { // (uniform)
+            const uint64_t i = i0 + 4ull * lane;
+            if (i < hi) {
+                if (i + 4 <= a.n_anchors)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.out + i),
+                                                     (__attribute__((address_space(3))) void *)(s_win + (i0 - lo4)), 16, 0, 0);
+                else
+                    for (uint64_t j = i; j < a.n_anchors; j++) s_win[j - lo4] = a.out[j];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+        __syncthreads();
+        if (tm && hi == aB) t1 = wall_clock64();
+        while (c >= 0 && !(a.debug & 1024u)) {
+            if (d.n_jobs == 0) { finish(0.0f); continue; }
+            const uint64_t idx = d.job_first - p; // the next part: out[job_first - p]
+            if (idx < lo4) break;                 // the rest lies in the windows below
+            const float *w = s_win + (idx - lo4);
+            const uint32_t body = d.n_jobs - 1u;
+            // parts of the body in this window: cost += sub (rmap.cpp:279), attainable -= sub (rmap.cpp:280), one packed add a part
+            const uint32_t nb = p < body ? (uint32_t)min<uint64_t>(body - p, idx - lo4 + 1ull) : 0u;
+            // The adds are two dependent chains (cost up, attainable down: 4 cycles an add, interleaved they never wait for
+            // each other); the parts come out of LDS sixteen at a time in 16-byte pieces, the next sixteen on their way
+            // while these are added.  Part q of this stretch is w[-q]: single parts until a piece ends on one.
+            uint32_t q = 0;
+            float cost = acc.x, att = acc.y;
+            const uint32_t j0 = (uint32_t)(idx - lo4); // w = s_win + j0
+            for (; q < nb && ((j0 - q) & 3u) != 3u; q++) { const float x = w[-(int)q]; cost += x; att -= x; }
+            if (q + 16u <= nb) {
+                float4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const float4 *>(w - (int)(q + 4u * u) - 3);
+#pragma unroll 2
+                for (; q + 32u <= nb; q += 16u) {
+                    float4 y[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) y[u] = *reinterpret_cast<const float4 *>(w - (int)(q + 16u + 4u * u) - 3);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        cost += x[u].w; att -= x[u].w; cost += x[u].z; att -= x[u].z;
+                        cost += x[u].y; att -= x[u].y; cost += x[u].x; att -= x[u].x;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) x[u] = y[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    cost += x[u].w; att -= x[u].w; cost += x[u].z; att -= x[u].z;
+                    cost += x[u].y; att -= x[u].y; cost += x[u].x; att -= x[u].x;
+                }
+                q += 16u;
+            }
+            for (; q < nb; q++) { const float x = w[-(int)q]; cost += x; att -= x; }
+            acc = v2f{cost, att};
+            p += nb;
+            if (p == body && idx - nb >= lo4 && idx >= nb) finish(w[-(int)nb]); // the last part is in this window too
+            else break;
+        }
+        __syncthreads();
+        hi = lo4;
+    }
+    if (tm) t2 = wall_clock64();
+    if (tm && lane == 0) {
+        atomicMax(&a.cnt[kCntStamp0 + 0], t1 - t0); atomicMax(&a.cnt[kCntStamp0 + 1], t2 - t1);
+        atomicAdd(&a.cnt[kCntStamp0 + 2], t1 - t0); atomicAdd(&a.cnt[kCntStamp0 + 3], t2 - t1);
+        atomicMax(&a.cnt[kCntStamp0 + 4], (unsigned long long)(aB - aA)); atomicMax(&a.cnt[kCntStamp0 + 5], (unsigned long long)(cB - cA));
+    }
+    if (lane < nr) {
+        float best = 0.0f; // rmap.cpp:515
+        for (uint64_t cc = co; cc < co1; cc++) {
+            float f, g;
+            if (cc - cA < kFoldCap) { f = s_full[cc - cA]; g = s_gate[cc - cA]; }
+            else { // (written by another lane of this wave: read past the vector cache)
+                f = __hip_atomic_load(&full_score[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g = __hip_atomic_load(&att_last[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float sv = (g < best) ? -1e10f : f; // rmap.cpp:206-209, 265-268
+            const bool k = sv >= min_score;           // rmap.cpp:518
+            if (k && sv > best) best = sv;            // rmap.cpp:519-521
+            score[cc] = sv;
+            keep[cc] = k ? 1 : 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host-callable drivers
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1311,11 +1471,22 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     if (a.n_anchors == 0 && a.n_chains == 0) return hipSuccess;
     const uint32_t n_units = (uint32_t)((a.n_anchors + kScanUnit - 1) / kScanUnit), n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (a.steps) {
-        hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanT), 0, s, a, d_fold_order);
+        hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanTC), 0, s, a, d_fold_order);
         if (n_desc) hipLaunchKernelGGL(k_scan_desc, dim3(n_desc), dim3(kScanT), 0, s, a, d_chains);
     } else if (a.carry_chain) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// fold + select of a sync-free batch in one launch (`chains`: the scan's records)
+hipError_t stream_fold_select(const StreamArgs &a, const ChainDesc *chains, const uint64_t *chain_off, uint64_t n_reads, float bonus, int fused,
+                              float min_score, float *full_score, float *att_last, float *score, uint8_t *keep, hipStream_t s)
+{
+    if (n_reads == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_fold_select, dim3((uint32_t)((n_reads + kFoldReads - 1) / kFoldReads)), dim3(64), 0, s, a, chains, chain_off, n_reads, bonus,
+                       fused, min_score, full_score, att_last, score, keep);
     return hipGetLastError();
 }
 

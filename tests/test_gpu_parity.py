@@ -247,13 +247,16 @@ def test_batch_matches_oracle_loop(engine, oracle, border, fill):
     batch = ra.Batch(engine, opt, cb)
     batch.run()
     score, keep = batch.fetch()
-    for mode, long_parts in ((0, 768), (1, 768), (2, 768), (3, 768), (3, 40), (3, 1)):
+    for mode, long_parts in ((0, 768), (1, 768), (2, 768), (3, 768), (3, 40), (3, 1), (4, 768)):
         # every fold kernel: wave per chain, lane per chain with 16 / 32 parts per round, lanes + a wave per long chain
-        # (with thresholds that give the wave role none, some and all of this batch's chains)
+        # (with thresholds that give the wave role none, some and all of this batch's chains), fold + select in one launch
+        # out of LDS (sync-free batches; a batch keeps the form it was created under)
         engine.set_option("fold_mode", mode)
         engine.set_option("fold_long_parts", long_parts)
-        batch.run()
-        s2, k2 = batch.fetch()
+        b2 = ra.Batch(engine, opt, cb)
+        b2.run()
+        s2, k2 = b2.fetch()
+        b2.close()
         assert np.array_equal(s2.view(np.uint32), score.view(np.uint32)) and np.array_equal(k2, keep), (mode, long_parts)
     engine.set_option("fold_mode", ra.DEFAULT_FOLD_MODE)
     engine.set_option("fold_long_parts", 768)
