@@ -611,41 +611,32 @@ __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, c
     return res;
 }
 
-// Radius 1 in every lane of the wave -- 97 % of a sparse batch's jobs: the body above with R = 1 folded in (sh = 1,
-// off = 1, S = 2 secondaries at slots 0 and 1, one primary at slot 1; slots 2 and 3 drop out).  Per column: the primary
-// cell (col, row), and, when the centre row advances, the two secondaries (col, row - 1) and (col - 1, row) before it.
-// State: prim = d1[1]; x0, x1 = d0[0], d0[1]; x0 always takes the secondary's value: it is read only behind
-// `prev_adv` (is_first / previous_increment_center_row, dtw.cpp:373-375, 392-397), when it is that value.  No low-side
-// mask: slot 0 of a secondary lies above row 0 only when the row did not advance, i.e. when nobody reads it, and slot 1
-// never does.  About 30 instructions per column against 50 for the generic body.
-__device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t n_max)
+// Radius 1 in every lane of the wave -- 97 % of a sparse batch's jobs.  Radius 1 means a SQUARE part: the reference's
+// radius is r0 + ((N - M) * r0 + N - 1) / N with r0 >= 1 (dtw.cpp:298-300), which is 1 only for r0 = 1 and N = M.  On a
+// square the centre row advances with every column (rem += M reaches N each time), so the body above with R = 1 folded in
+// (sh = 1, off = 1, S = 2 secondaries at slots 0 and 1, one primary at slot 1) loses its row bookkeeping and every select
+// on `adv`: per column the two secondaries (col, col - 1) and (col - 1, col), then the primary (col, col).
+// State: prim = d1[1]; x0, x1 = d0[0], d0[1] (the secondaries of the column before).  x0 is read behind
+// previous_increment_center_row (dtw.cpp:373-375, 392-397), false only in column 1 -- where x0 still holds 1e10, the value
+// the guard yields.  The 1e10 operands of the reference's guarded reads stay in the min3s (is_first: no top; is_last: no
+// left), so every value is the one the generic body computes.  About 15 instructions per column against 30.
+__device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, const uint32_t N, const uint32_t n_max)
 {
     float prim = dist(LA[0], LB[0]); // the corner (dtw.cpp:317-347)
     float x0 = kInf, x1 = kInf;
     float ap0 = LA[1], ap1 = LA[0];
-    float bp0 = LB[0], bp1 = LB[0];
+    float bp1 = LB[0];
     float a_next = LA[2], b_next = LB[1];
     float res = prim;
-    uint32_t rem = 0, row = 0;
-    bool prev_adv = false;
     for (uint32_t col = 1; col < n_max; col++) {
-        rem += M;
-        const bool adv = rem >= N;
-        rem -= adv ? N : 0u;
-        row += adv ? 1u : 0u;
-        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? b_next : bp1;
-        b_next = LB[row + 1];
-        const float g = prev_adv ? x0 : kInf;
-        const float sec0 = min3f(kInf, prim, g) + dist(ap0, bn0);   // (col, row - 1): no top (is_first)
-        const float sec1 = min3f(prim, kInf, x1) + dist(ap1, bn1);  // (col - 1, row): no left (is_last)
-        const float X1 = adv ? sec1 : prim;
-        const float top1 = adv ? sec0 : kInf;
-        const float tl1 = adv ? prim : g;
+        const float bn0 = bp1, bn1 = b_next;                         // the b-window moves with the row: every column
+        b_next = LB[col + 1];
+        const float sec0 = min3f(kInf, prim, x0) + dist(ap0, bn0);   // (col, col - 1): no top (is_first)
+        const float sec1 = min3f(prim, kInf, x1) + dist(ap1, bn1);   // (col - 1, col): no left (is_last)
         ap1 = ap0; ap0 = a_next;
         a_next = LA[col + 2];
-        const float pr1 = min3f(top1, X1, tl1) + dist(ap1, bn1);    // (col, row)
-        x0 = sec0; x1 = X1; prim = pr1; bp0 = bn0; bp1 = bn1;
-        prev_adv = adv;
+        const float pr1 = min3f(sec0, sec1, prim) + dist(ap1, bn1);  // (col, col)
+        x0 = sec0; x1 = sec1; prim = pr1; bp1 = bn1;
         res = (col == N - 1u) ? prim : res;
     }
     return res;

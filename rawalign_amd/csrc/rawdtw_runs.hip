@@ -530,7 +530,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 
 // grid: workgroup 0 the fold order (one workgroup's latency chain, ~30 us: dispatched first, it runs beside everything
 // else instead of behind it), then the chain records, then the scan units
-__global__ __launch_bounds__(kScanT) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+__global__ __launch_bounds__(kScanT, 8) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
@@ -602,20 +602,25 @@ __global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
 namespace {
 
 constexpr uint32_t kStamps = 12;
-constexpr uint32_t kSortBins = 192; // bin = (radius <= 2 ? 80 : 0) + (79 - longer side): radius 3 first, each run longest first
+constexpr uint32_t kSortBins = 192; // bin = (3 - radius) * 64 + (63 - longer side): radius 3 first, then 2, then 1 (waves of one radius take the
+                                     // shortest body), each run longest first (sides of 63 and more share a bin)
 
 // One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
-// first, then the others, both runs by longer side, descending; a wave takes the shortest body that covers its radii.
+// first, then 2, then 1, each run by longer side, descending; a wave takes the shortest body that covers its radii.
 __device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
 {
     const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u);
-    uint32_t n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)N); // lane 0 leads the wave's first run
-    if (r12) {                                                         // ... and the first lane of radius <= 2 the second
-        const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)r12) - 1);
-        n_max = max(n_max, (uint32_t)__builtin_amdgcn_readlane((int)N, l));
-    }
+    // the wave's longest side (its jobs come in up to three runs, each longest first; sides of 63 and more share a bin)
+    uint32_t n_max = N;
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x111, 0xf, 0xf, false)); // row_shr:1
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x112, 0xf, 0xf, false)); // row_shr:2
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x114, 0xf, 0xf, false)); // row_shr:4
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x118, 0xf, 0xf, false)); // row_shr:8
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x142, 0xa, 0xf, false)); // row_bcast:15
+    n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x143, 0xc, 0xf, false)); // row_bcast:31
+    n_max = (uint32_t)__builtin_amdgcn_readlane((int)n_max, 63);
     float res;
-    if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, M, n_max);
+    if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, n_max); // (radius 1: N == M)
     else if (~r12 == 0ull) res = lane_dp_r12(LA, LB, N, M, R, n_max);
     else res = lane_dp_gen(LA, LB, N, M, R, n_max);
     if (act && excl) res = res - dist(LA[N - 1], LB[M - 1]);
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                 const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
                 const bool swap = (meta[k] >> 17) & 1u, starts = (meta[k] >> 18) & 1u, ends = (meta[k] >> 19) & 1u;
                 const uint32_t n = swap ? M : N, m = swap ? N : M;
-                bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
+                bin[k] = (3u - R) * 64u + (63u - min(N, 63u));
                 rank[k] = atomicAdd(&hist[bin[k]], 1u);
                 const uint32_t g = ssum[k][2] - 1u; // the item's run
                 const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
@@ -1160,7 +1165,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
                     const bool swap = (meta[k] >> 17) & 1u;
                     const uint32_t n = swap ? M : N, m = swap ? N : M;
                     const bool starts = ((meta[k] >> 18) & 1u) || u == u0, ends = ((meta[k] >> 19) & 1u) || u == u1 - 1u;
-                    bin[k] = (R <= 2u ? 80u : 0u) + (79u - min(N, 79u));
+                    bin[k] = (3u - R) * 64u + (63u - min(N, 63u));
                     rank[k] = atomicAdd(&hist[bin[k]], 1u);
                     const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
                     const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
