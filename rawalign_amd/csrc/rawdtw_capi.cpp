@@ -1811,8 +1811,12 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // list's lane classes
     a.lane_max_radius = std::min(ctx->lane_max_radius, ctx->stream_tile_radius); a.side_lane_radius = ctx->lane_max_radius;
     a.lane_max_n = ctx->lane_max_n;
-    a.tile_anchors = (uint32_t)ctx->stream_threads * kStreamItems;
+    a.tile_anchors = kStreamTile;
     a.n_tiles = (uint32_t)((na + a.tile_anchors - 1) / a.tile_anchors);
+    // (a tile over the image budget or the run table takes further passes, a slot of copy orders each: rare in a mapper's
+    // batch, the rule for tiles of very short chains; a batch that runs out of slots is redone through the job list)
+    a.n_slots = 4 * a.n_tiles + 64;
+    a.lds_floats = lds_floats;
     a.others_cap = std::min<uint64_t>(na, na / 4 + 4096);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const bool compact = b->in_steps != nullptr;
@@ -1820,10 +1824,11 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
     const rawdtw_batch *prev = b->in_prev;
     const bool round = prev && b->in_carry_chain && prev->ctx == ctx && prev->stream && !(prev->cnt_valid && stream_declined(prev));
-    const size_t round_bytes = round ? al(nc * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
+    const size_t round_bytes = round ? al(nc * 8) : 0;
     const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
-                             al((size_t)a.n_tiles * 8) + al((size_t)a.n_tiles * 24) +                                           // per tile
+                             al((size_t)a.n_slots * 16) + al((size_t)a.n_tiles * 24) +                                          // work list, statistics
+                             al((size_t)a.n_tiles * kStreamRecStride * 8) + al((size_t)a.n_slots * 2 * kStreamMaxSeg * 16) +         // job records, copy orders
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
                              al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
     const size_t host_bytes = al(kStreamCounters * 8);
@@ -1836,7 +1841,9 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
-    a.todo = carve<uint2>(p, a.n_tiles);
+    a.todo = carve<uint4>(p, a.n_slots);
+    a.recs = carve<uint2>(p, (uint64_t)a.n_tiles * kStreamRecStride);
+    a.runtab = carve<uint4>(p, (uint64_t)a.n_slots * 2 * kStreamMaxSeg);
     a.tile_stats = carve<unsigned long long>(p, 3ull * a.n_tiles);
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     b->d_chains = carve<ChainDesc>(p, nc);
@@ -1859,7 +1866,6 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_carry = nullptr;
     if (round) { // (the previous batch's arrays are read by this batch's k_scan: stream order keeps them alive that long)
         d_carry = carve<uint64_t>(p, nc);
-        a.carried = carve<uint8_t>(p, (uint64_t)a.n_tiles * (a.tile_anchors / 8));
         a.carry_chain = d_carry;
         a.prev_n_chains = prev->n_chains; a.prev_anchor_off = prev->sa.anchor_off; a.prev_anchors = prev->sa.anchors;
         a.prev_ref_base = prev->sa.ref_base; a.prev_read_base = prev->sa.read_base; a.prev_out = prev->sa.out;
@@ -2206,9 +2212,9 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
     std::string e;
     if (batch->stream) {
         // What the scan left behind for the DTW launch, against the job list the host builds from the same chains
-        // (rawdtw_batch_build_jobs): every tile's first chain; every job either of the tile class by the class rule (then
-        // k_runs derives it from its anchors: tests/test_stream_path.py pins its costs part by part) or in the side list
-        // exactly once with the job's windows, shape, slanted radius and flag; the statistics.
+        // (rawdtw_batch_build_jobs): every job either of the tile class by the class rule, then in exactly one pass's
+        // records with its shape, radius, flag and windows, or in the side list exactly once with the job's windows,
+        // shape, slanted radius and flag; the statistics.
         rawdtw_batch *mb = const_cast<rawdtw_batch *>(batch);
         int st = stream_counters(ctx, mb);
         if (st != RAWDTW_OK) return st;
@@ -2221,20 +2227,11 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         }
         const uint64_t nc = batch->n_chains, na = a.n_anchors;
         const uint64_t *aoff = batch->in_anchor_off;
-        // the work list: (tile, first chain) of exactly the tiles that hold a tile-class job (checked below, once the jobs' classes are known)
+        // the work list: one entry a pass (checked below, once the jobs' classes are known)
         const uint64_t n_todo = cnt[kCntTodo];
-        std::vector<uint2> todo(n_todo);
-        if (n_todo > a.n_tiles) e = "work list longer than the tiles";
-        else if (n_todo) HIP_TRY(ctx, hipMemcpy(todo.data(), a.todo, n_todo * sizeof(uint2), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> tile_first_chain(a.n_tiles);
-        {
-            uint64_t c = 0;
-            for (uint64_t t = 0; t < a.n_tiles; t++) {
-                const uint64_t x = t * a.tile_anchors;
-                while (c + 1 < nc && aoff[c + 1] <= x) c++;
-                tile_first_chain[t] = (uint32_t)c;
-            }
-        }
+        std::vector<uint4> todo(n_todo);
+        if (n_todo > a.n_slots) e = "work list longer than the record slots";
+        else if (n_todo) HIP_TRY(ctx, hipMemcpy(todo.data(), a.todo, n_todo * sizeof(uint4), hipMemcpyDeviceToHost));
         const uint64_t n_other = cnt[kCntOthers];
         std::vector<DevJob> oj(n_other);
         if (n_other) HIP_TRY(ctx, hipMemcpy(oj.data(), a.ojobs, n_other * sizeof(DevJob), hipMemcpyDeviceToHost));
@@ -2270,18 +2267,65 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         }
         for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
             if (!is_tile[k] && !oseen[k]) e = "job " + S(k) + " is in no launch";
-        if (e.empty() && cnt[kCntReused] == 0) { // (a round that took costs over leaves the tiles of carried parts out)
-            std::vector<uint8_t> want_tile(a.n_tiles, 0), got_tile(a.n_tiles, 0);
-            for (uint64_t i = 0; i < na; i++)
-                if (slot_job[i] != ~0ull && is_tile[slot_job[i]]) want_tile[i / a.tile_anchors] = 1;
+        // Every pass: its records name tile-class jobs of its tile, each job once over all passes, with the job's shape,
+        // slanted radius and flag, in the order the lanes take them (radius class, longer side); a record's windows lie in the
+        // image, inside one of the pass's copy orders, and that order maps them onto the job's windows in the arenas.
+        if (e.empty()) {
+            std::vector<uint8_t> tseen(n_jobs, 0), slot_used(a.n_slots, 0);
+            std::vector<uint2> recs(kStreamTile);
+            std::vector<uint4> ords(2 * kStreamMaxSeg);
             for (uint64_t q = 0; q < n_todo && e.empty(); q++) {
-                const uint2 t = todo[q];
-                if (t.x >= a.n_tiles || got_tile[t.x]) e = "work list entry " + S(q) + ": tile " + S(t.x) + " twice or out of range";
-                else if (t.y != tile_first_chain[t.x]) e = "tile " + S(t.x) + ": first chain " + S(t.y) + ", expected " + S(tile_first_chain[t.x]);
-                else got_tile[t.x] = 1;
+                const uint4 t = todo[q];
+                const uint32_t nj = t.z & 0xffffu, nr = t.z >> 16, region = t.w & 0xffffu, rec0 = t.w >> 16;
+                if (t.x >= a.n_tiles || t.y >= a.n_slots || slot_used[t.y] || nj > kStreamTile || nr > kStreamMaxSeg || (nj && !nr) || (rec0 & 1u) || rec0 + nj > kStreamRecStride) {
+                    e = "work list entry " + S(q) + ": tile " + S(t.x) + ", slot " + S(t.y) + ", " + S(nj) + " jobs, " + S(nr) + " runs"; break;
+                }
+                slot_used[t.y] = 1;
+                if (!nj) continue;
+                HIP_TRY(ctx, hipMemcpy(recs.data(), a.recs + (uint64_t)t.x * kStreamRecStride + rec0, nj * sizeof(uint2), hipMemcpyDeviceToHost));
+                HIP_TRY(ctx, hipMemcpy(ords.data(), a.runtab + (uint64_t)t.y * 2 * kStreamMaxSeg, 2 * nr * sizeof(uint4), hipMemcpyDeviceToHost));
+                for (uint32_t o = 0; o < 2 * nr && e.empty(); o++) {
+                    const uint4 &od = ords[o];
+                    const bool evs = (o & 1u) == 0;
+                    if (od.x >= od.y || 4ull * od.y > a.lds_floats || (evs ? 4ull * od.y > region : 4ull * od.x < region))
+                        e = "pass " + S(q) + " (tile " + S(t.x) + ", " + S(nj) + " jobs, " + S(nr) + " runs, event region " + S(region) + " of " + S(a.lds_floats) +
+                            " floats): copy order " + S(o) + " = pieces [" + S(od.x) + ", " + S(od.y) + ") outside its region of the image";
+                }
+                uint32_t prev_bin = 0;
+                for (uint32_t r = 0; r < nj && e.empty(); r++) {
+                    const uint2 rc = recs[r];
+                    const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u, ex = (rc.y >> 16) & 1u, u = (rc.y >> 17) & (kStreamTile - 1u);
+                    const uint64_t i = ((uint64_t)t.x + 1) * kStreamTile - 1 - u;
+                    const uint64_t k = i < na ? slot_job[i] : ~0ull;
+                    const std::string who = "pass " + S(q) + " record " + S(r) + " (anchor " + S(i) + ")";
+                    if (k == ~0ull || !is_tile[k] || tseen[k]) { e = who + ": no job, not of the tile class, or in two passes"; break; }
+                    const rawdtw_job_t &j = jobs[k];
+                    const bool swap = j.n < j.m;
+                    if (N != std::max(j.n, j.m) || M != std::min(j.n, j.m) || (int)R != slanted_radius(j.n, j.m, j.band_radius) || (ex != 0) != (j.exclude_last != 0)) {
+                        e = who + ": shape, radius or flag differ from job " + S(k); break;
+                    }
+                    const uint32_t bin = (3u - R) * 64u + (63u - std::min(N, 63u));
+                    if (bin < prev_bin) { e = who + ": out of the lanes' order"; break; }
+                    prev_bin = bin;
+                    const uint32_t p_long = rc.x & 0xffffu, p_short = rc.x >> 16;
+                    const uint32_t p_ev = swap ? p_short : p_long, p_rf = swap ? p_long : p_short;
+                    for (int w = 0; w < 2 && e.empty(); w++) {
+                        const uint32_t pw = w ? p_rf : p_ev, len = w ? j.m : j.n;
+                        const uint64_t want = w ? j.ref_off : (uint64_t)j.read_off;
+                        bool ok = false;
+                        for (uint32_t g = 0; g < nr && !ok; g++) {
+                            const uint4 &od = ords[2 * g + w];
+                            const long long src = (long long)((unsigned long long)od.z | ((unsigned long long)od.w << 32));
+                            ok = 4ull * od.x <= pw && (uint64_t)pw + len <= 4ull * od.y && (long long)pw + src == (long long)want;
+                        }
+                        if (!ok) e = who + ": its " + (w ? "reference" : "event") + " window is in no copy order of the pass";
+                    }
+                    tseen[k] = 1;
+                }
             }
-            for (uint64_t t = 0; t < a.n_tiles && e.empty(); t++)
-                if (want_tile[t] != got_tile[t]) e = "tile " + S(t) + (want_tile[t] ? " holds tile-class jobs but is not on the work list" : " is on the work list without a job");
+            if (e.empty() && cnt[kCntReused] == 0) // (a round that took costs over leaves the carried parts out)
+                for (uint64_t k = 0; k < n_jobs && e.empty(); k++)
+                    if (is_tile[k] && !tseen[k]) e = "tile-class job " + S(k) + " is in no pass";
         }
         if (e.empty()) {
             HIP_TRY(ctx, stream_sum_stats(a, ctx->stream));

@@ -103,7 +103,8 @@ struct FullAux {
 //             parts p = 0 .. n - 2 in the reference's order are out[a1 - 2 - p]: the fold walks it downwards.
 //   side list parts the lane-per-job bodies do not take (radius > lane_max_radius or longer side > lane_max_n), found
 //             by k_scan ahead of the DTW launch and scored there first, wave-cooperatively, longest first.
-constexpr uint32_t kStreamItems = 2;          // anchors (= candidate parts) per thread of a tile
+constexpr uint32_t kStreamTile = 512;         // anchors (= candidate parts) of a tile: what one wave of the scan plans (eight a lane)
+constexpr uint32_t kStreamRecStride = 576;    // job records of a tile: its passes' records one behind the other, each pass on a 16-byte boundary
 constexpr uint32_t kStreamMaxSeg = 32;        // runs of one pass over a tile's image (more: the tile takes another pass)
 // side-list classes, in launch order: wave-per-job by longer side (>= 1024, >= 256, >= 64, shorter), 16-lane groups, 8-lane groups
 constexpr uint32_t kStreamClasses = 21, kClsW0 = 0, kClsG16 = 4, kClsL0 = 5, kClsLCount = 8, kClsM0 = 13, kClsMCount = 8;
@@ -129,11 +130,12 @@ enum StreamCounter : int {
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
     kCntTodo,           // entries of the DTW launch's work list
     kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_round)
-    kCntStamp0,         // 14 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
+    kCntPool,           // record slots handed out beyond one a tile (tiles whose image takes several passes)
+    kCntStamp0,         // 10 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
     kStreamCounters = kCntHeads + 8 * 16
 };
-static_assert(kCntStamp0 + 12 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
+static_assert(kCntStamp0 + 10 <= kCntHeads && kCntCur0 == kCntCls0 + kStreamClasses, "counter layout");
 struct StreamArgs {
     uint64_t n_anchors, n_chains, n_reads, n_ev, n_ref, others_cap;
     float frac;                  // dtw_band_radius_frac
@@ -141,7 +143,10 @@ struct StreamArgs {
     int32_t side_lane_radius;    // side-list lane classes: radius in (lane_max_radius, this], longer side <= lane_max_n
     uint32_t lane_max_n;
     uint32_t n_tiles;            // ceil(n_anchors / tile_anchors)
-    uint32_t tile_anchors;       // threads * kStreamItems of the DTW launch
+    uint32_t tile_anchors;       // kStreamTile: the anchors one wave of the scan plans together
+    uint32_t n_slots;            // copy-order slots (= the most passes a batch can have): one a tile, then a pool for the further passes
+                                 // of tiles that take several
+    uint32_t lds_floats;         // the DTW launch's image budget (floats): a pass's windows fit it
     uint32_t debug;              // timing experiments only (results wrong below 128 except 8): 1 no DP, 2 no staging, 4 no side
                                  // list, 32 no wave-per-job items, 64 no group / lane items; 8 tiles without the ticket queue,
                                  // 2048 side items over all waves, 4096 side items dealt straight (not alternating)
@@ -172,8 +177,15 @@ struct StreamArgs {
     uint64_t prev_others_cap;
     uint8_t *carried;                 // one bit per anchor (byte i / 8, bit i % 8): its part's cost was carried over
     // workspace and outputs (device)
-    uint2 *todo;                 // the DTW launch's work list (k_scan): (tile, the chain its first anchor belongs to) of every tile that
-                                 // has a part to score; cnt[kCntTodo] entries, at most n_tiles
+    uint4 *todo;                 // the DTW launch's work list (k_scan): one entry a PASS -- a tile's tile-class parts, or as many of them
+                                 // as fit the image budget and the run table: (tile, copy-order slot, jobs | runs << 16, floats of
+                                 // the image's event region | first record << 16); cnt[kCntTodo] entries, at most n_slots
+    uint2 *recs;                 // n_tiles x kStreamRecStride job records, a pass's in the order the lanes take them (radius class, then longer
+                                 // side, descending): x = event window | reference window << 16 (float offsets into the pass's
+                                 // image, longer sequence first), y = N | M << 7 | R << 14 | exclude_last << 16 | item << 17
+                                 // (item u = the part that ends at anchor (tile end - 1 - u): its cost goes to out[that anchor])
+    uint4 *runtab;               // n_slots x 2 kStreamMaxSeg copy orders of 16-byte pieces, entry 2 g + w = run g of arena w (0 events,
+                                 // 1 reference): pieces [x, y) of the image come from arena float index (4 piece + (int64)(z | w << 32))
     unsigned long long *tile_stats; // per scan unit (8192 anchors): tile-class parts, their algorithmic bytes, the side list's bytes
     DevJob *omix, *ojobs;
     uint8_t *ocls;

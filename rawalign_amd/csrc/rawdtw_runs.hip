@@ -122,6 +122,16 @@ __device__ __forceinline__ uint64_t find_chain(const uint64_t *__restrict__ anch
     return lo;
 }
 
+// Lanes of one wave that hand values to each other through LDS: the hardware runs a wave's LDS instructions in order, but
+// the compiler orders a thread's loads and stores by what THAT thread can observe (it may read a word before another
+// lane's store to it is issued, and forward a lane's own store) -- a fence at wave scope on both sides of the hand-over.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Inclusive scan of one value per lane over the wave by DPP: shifts inside the rows of 16 lanes, then the rows' last lanes
 // broadcast into the rows behind them (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six dependent
 // VALU steps of a few cycles each; through __shfl_up the same scan is six round trips through the LDS crossbar
@@ -273,6 +283,29 @@ __device__ __forceinline__ void fold_order_body(const uint64_t n_chains, const u
 // k_scan: the pass over the anchor list ahead of the DTW launch.  Roles by workgroup: [0, n_tiles) one tile each,
 // n_tiles the fold order, the rest the chain records.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSortBins = 192; // bin = (3 - radius) * 64 + (63 - longer side): radius 3 first, then 2, then 1 (waves of one radius take the
+                                     // shortest body), each run longest first (sides of 63 and more share a bin)
+
+// A tile's items in the order the image is laid out in: item u is the part that ends at anchor (tile end - 1 - u), so that
+// along a chain (stored end-first) u ascends with the positions -- a run's first part is the one with the lowest addresses,
+// and the scan that places the runs meets it first.
+//
+// Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive tile-class parts of a
+// chain (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every
+// part adds floats to the two regions' running sums: a run's first part its whole window plus 3 floats of slack, a
+// continuing part its window minus the shared first element, a run's last part 3 more (the run's END rounded up to a
+// 16-byte boundary never reaches the next run).  With c = the running sum BEFORE a run's first part the run starts at
+//     c + ((off - c) & 3)                 (off = the window's arena offset),
+// congruent to the arena offset modulo 4 -- 16-byte chunks of the image are 16-byte chunks of the arena -- and a part's
+// window starts at (its start anchor's position + D), D = the run's image start minus its first position.  So a tile is
+// staged by copying each run's chunk range, fully coalesced, and two runs never share a chunk.
+struct RunTab {
+    uint32_t lo[2][kStreamMaxSeg];    // first float of the run's first 16-byte chunk in the image [arena: 0 events, 1 reference]
+    uint32_t end[2][kStreamMaxSeg];   // the run's last position + 1 (query / target coordinates)
+    int32_t D[2][kStreamMaxSeg];      // image index = position + D
+    long long src[2][kStreamMaxSeg];  // arena index = image index + src (a multiple of 4)
+};
+
 // A scan unit = kScanUnit consecutive anchors = a whole number of tiles, one workgroup, eight consecutive anchors a thread
 // and pass (forward order: the part of anchor i runs from anchors[i + 1] to anchors[i]).  It writes the first
 // chain of each of its tiles (4 bytes a tile), three statistics, and -- for the one part in two hundred the tiles do not
@@ -296,11 +329,18 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
-    __shared__ uint32_t s_todo; // bit t: tile t of the unit has a part for the lane-per-job bodies to score
+    // planning of the DTW launch's passes, a wave a tile (see plan_tile below): the wave's sort histogram and run table, the
+    // unit's passes until its share of the work list is known
+    constexpr uint32_t kPassCap = 256;
+    __shared__ uint32_t s_hist[NT / 64][kSortBins];
+    __shared__ RunTab s_rtab[NT / 64];
+    __shared__ uint32_t s_tmp[NT / 64][8];
+    __shared__ uint4 s_pass[kPassCap];
+    __shared__ uint32_t s_npass, s_tbase;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint64_t base = (uint64_t)unit * AT;
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
-    if (tid == 0) { s_ocnt = 0; s_todo = 0; }
+    if (tid == 0) { s_ocnt = 0; s_npass = 0; }
     if (tid < 3) s_stats[tid] = 0;
     if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
@@ -409,10 +449,11 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 #pragma unroll
         for (int k = 0; k <= KI; k++) an[k] = ih + k < a.n_anchors ? a.anchors[ih + k] : rawdtw_anchor_t{0, 0};
     }
-    uint32_t carried_bits = 0, half_tiles = 0;
+    uint32_t half_tiles = 0;
+    uint32_t tm[KI]; // the tile parts: N | M << 7 | R << 14 | exclude_last << 16 | swapped << 17 | 1 << 20 (0: the lane bodies do not take it)
 #pragma unroll
     for (int k = 0; k < KI; k++) {
-        o_rec[h][k] = 0xffffffffu;
+        o_rec[h][k] = 0xffffffffu; tm[k] = 0u;
         const uint32_t p = h * kHalf + (uint32_t)tid * KI + k; // position in the unit
         const uint64_t i = base + p;
         if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
@@ -448,14 +489,18 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
                         float cost = a.prev_out[pi];
                         if (was_last != is_last) cost = cost - dist(a.ev[(uint64_t)c_qb + e.query_position], a.ref[c_rb + e.target_position]);
                         a.out[i] = cost;
-                        carried_bits |= 1u << k;
                         my_reused++;
                         continue;
                     }
                 }
             }
         }
-        if (pt.tile) { my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
+        if (pt.tile) {
+            my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u;
+            const uint32_t N = pt.n > pt.m ? pt.n : pt.m, M = pt.n > pt.m ? pt.m : pt.n;
+            tm[k] = N | (M << 7) | ((uint32_t)pt.R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((pt.n < pt.m ? 1u : 0u) << 17) | (1u << 20);
+            continue;
+        }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
         r0 = r0 > 1 ? r0 : 1;
@@ -471,10 +516,149 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         o_rec[h][k] = atomicAdd(&s_ocnt, 1u) | (cls << 16) | ((uint32_t)R << 21); // (slot < 2^13, class < 2^5, R < 2^8)
         atomicAdd(&s_cls[cls], 1u);
     }
-    if (CARRY && a.carried && ih < a.n_anchors) a.carried[ih >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
-    {
-        const unsigned long long any_tile = __ballot(half_tiles != 0u); // (every lane votes: taken before the branch on the lane)
-        if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << ((h * kHalf + (uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
+    // ---- the DTW launch's passes over this wave's tile (its 512 anchors): the image layout, the jobs' order, their records ----
+    // Lane L holds the tile's positions 8 L .. 8 L + 7; the item at position t ends at anchor t, starts at anchor t + 1 and is
+    // item u = 511 - t of the layout order: along a chain (stored end-first) u ascends with the addresses.  A run = consecutive
+    // tile parts of a chain; its first part (`starts`) is the one whose predecessor in u (position + 1) is no tile part.
+    if (__ballot(half_tiles != 0u)) { // (wave-uniform)
+        static_assert(KI == 8 && kStreamTile == 64 * KI, "a wave a tile, eight items a lane");
+        const uint32_t wv = (uint32_t)tid >> 6;
+        uint32_t *hist = s_hist[wv], *tmp = s_tmp[wv];
+        RunTab &rt = s_rtab[wv];
+        const uint32_t tile = unit * (AT / kStreamTile) + h * (kHalf / kStreamTile) + wv;
+        const int t_first = (int)((tm[0] >> 20) & 1u), t_last = (int)((tm[KI - 1] >> 20) & 1u);
+        const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
+        const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
+        uint32_t cr[KI], cf[KI]; // contributions to the regions' sums: floats | run start << 20; floats
+        uint32_t lr = 0, lf = 0;
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const bool t = (tm[k] >> 20) & 1u;
+            const bool pred = k + 1 < KI ? ((tm[k + 1 < KI ? k + 1 : k] >> 20) & 1u) != 0u : above;
+            const bool succ = k > 0 ? ((tm[k > 0 ? k - 1 : 0] >> 20) & 1u) != 0u : below;
+            const bool starts = t && !pred, ends = t && !succ;
+            const uint32_t N = tm[k] & 127u, M = (tm[k] >> 7) & 127u;
+            const bool swap = (tm[k] >> 17) & 1u;
+            const uint32_t n = swap ? M : N, m = swap ? N : M;
+            tm[k] |= ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19);
+            cr[k] = t ? ((starts ? n + 3u : n - 1u) + (ends ? 3u : 0u)) | ((starts ? 1u : 0u) << 20) : 0u;
+            cf[k] = t ? (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u) : 0u;
+            lr += cr[k]; lf += cf[k];
+        }
+        // sums in layout order from sums in position order: before item u lie the items at higher positions,
+        //     sum over v <= u  =  total - (sum over positions <= t) + own
+        const uint32_t ir = wave_scan_incl(lr), jf = wave_scan_incl(lf);
+        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)ir, 63), tot_f = (uint32_t)__builtin_amdgcn_readlane((int)jf, 63);
+        uint32_t ur[KI], uf[KI]; // inclusive sums in layout order (events | runs << 20; reference)
+        {
+            uint32_t ar = ir - lr, af = jf - lf;
+#pragma unroll
+            for (int k = 0; k < KI; k++) { ar += cr[k]; af += cf[k]; ur[k] = tot_r - ar + cr[k]; uf[k] = tot_f - af + cf[k]; }
+        }
+        const uint32_t budget = a.lds_floats & ~3u;
+        uint32_t u0 = 0, b0r = 0, b0f = 0, b0s = 0; // the pass's first item, the sums before it
+        uint32_t rec_off = 0;                       // the pass's first record in the tile's stretch of the record array
+        for (bool first = true;; first = false) { // (wave-uniform)
+            // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table (+ 4 + 4
+            // floats and one run when the first item continues a run); the sums ascend with u: the fitting items are a prefix
+            uint32_t fits = 0;
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), sr = ur[k] & 0xfffffu, ss = ur[k] >> 20;
+                if (u >= u0 && ((sr - b0r + 7u) & ~3u) + ((uf[k] - b0f + 7u) & ~3u) <= budget && ss - b0s + 1u <= kStreamMaxSeg) fits++;
+            }
+            fits = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fits), 63);
+            const uint32_t u1 = min(u0 + fits, kStreamTile);
+            if (u1 <= u0) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (cannot happen: one part always fits)
+            // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
+                if (u == u1 - 1u) { tmp[0] = ur[k] & 0xfffffu; tmp[1] = uf[k]; tmp[2] = ur[k] >> 20; }
+                if (u == u0) tmp[3] = ((tm[k] >> 20) & 1u) && !((tm[k] >> 18) & 1u) ? 1u : 0u;
+            }
+            wave_lds_sync();
+            const uint32_t e_r = tmp[0], e_f = tmp[1], e_s = tmp[2];
+            const bool cut_run = tmp[3] != 0u; // the pass's first item continues a run of the pass before: it starts one here
+            const uint32_t region = (e_r - b0r + (cut_run ? 4u : 0u) + 3u) & ~3u;
+            const uint32_t n_runs = e_s - b0s + (cut_run ? 1u : 0u);
+            const bool last = u1 >= kStreamTile;
+            wave_lds_sync(); // (the words are read: the next pass writes them again)
+            // the pass's record slot: the tile's own for its first pass, one of the pool's for the others
+            uint32_t slot = tile;
+            if (!first) {
+                uint32_t sl = 0;
+                if (lane == 0) sl = a.n_tiles + (uint32_t)atomicAdd(&a.cnt[kCntPool], 1ull);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+                if (slot >= a.n_slots) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; }
+            }
+            for (uint32_t b = (uint32_t)lane; b < kSortBins; b += 64u) hist[b] = 0;
+            wave_lds_sync();
+            uint32_t rank[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                rank[k] = 0xffffffffu;
+                const uint32_t tp = (uint32_t)lane * KI + k, u = kStreamTile - 1u - tp;
+                if (!((tm[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
+                const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
+                const bool starts = ((tm[k] >> 18) & 1u) || u == u0, ends = ((tm[k] >> 19) & 1u) || u == u1 - 1u;
+                rank[k] = atomicAdd(&hist[(3u - R) * 64u + (63u - min(N, 63u))], 1u);
+                const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
+                const uint32_t g = (ur[k] >> 20) - b0s + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
+                const rawdtw_anchor_t sa = an[k + 1], ea = an[k];
+                if (starts) {
+                    const uint64_t c = chain_at(h * kHalf + (uint32_t)tid * KI + k);
+                    const uint64_t rb = a.ref_base[c];
+                    const uint32_t qb = a.read_base[c];
+                    // the sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
+                    const uint32_t c_r = (ur[k] & 0xfffffu) - (cr[k] & 0xfffffu) - b0r + 4u * adj, c_f = uf[k] - cf[k] - b0f + 4u * adj;
+                    const uint32_t off_r = qb + sa.query_position;
+                    const uint64_t off_f = rb + sa.target_position;
+                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
+                    rt.lo[0][g] = p_r & ~3u; rt.lo[1][g] = p_f & ~3u;
+                    rt.D[0][g] = (int32_t)(p_r - sa.query_position); rt.D[1][g] = (int32_t)(p_f - sa.target_position);
+                    rt.src[0][g] = (long long)off_r - (long long)p_r; rt.src[1][g] = (long long)off_f - (long long)p_f;
+                }
+                if (ends) { rt.end[0][g] = ea.query_position + 1u; rt.end[1][g] = ea.target_position + 1u; }
+            }
+            wave_lds_sync(); // (the run table and the counts are complete)
+            // the bins' first places (three a lane), written back over the counts
+            const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
+            const uint32_t hsum = h0 + h1 + h2, hincl = wave_scan_incl(hsum);
+            const uint32_t n_jobs = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
+            hist[3 * lane] = hincl - hsum; hist[3 * lane + 1] = hincl - hsum + h0; hist[3 * lane + 2] = hincl - hsum + h0 + h1;
+            wave_lds_sync();
+            // the records, in the order the lanes of the DTW launch take them
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                if (rank[k] == 0xffffffffu) continue;
+                const uint32_t tp = (uint32_t)lane * KI + k, u = kStreamTile - 1u - tp;
+                const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
+                const uint32_t place = hist[(3u - R) * 64u + (63u - min(N, 63u))] + rank[k];
+                const uint32_t g = (ur[k] >> 20) - b0s + (cut_run ? 1u : 0u) - 1u;
+                const rawdtw_anchor_t sa = an[k + 1];
+                const uint32_t p_r = sa.query_position + (uint32_t)rt.D[0][g], p_f = sa.target_position + (uint32_t)rt.D[1][g];
+                const bool swap = (tm[k] >> 17) & 1u;
+                a.recs[(uint64_t)tile * kStreamRecStride + rec_off + place] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), (tm[k] & 0x1ffffu) | (u << 17));
+            }
+            // the copy orders: a run's range of 16-byte pieces, per arena
+            if ((uint32_t)lane < 2u * n_runs) {
+                const uint32_t g = (uint32_t)lane >> 1, w = (uint32_t)lane & 1u;
+                const long long src = rt.src[w][g];
+                a.runtab[(uint64_t)slot * (2u * kStreamMaxSeg) + lane] =
+                    make_uint4(rt.lo[w][g] >> 2, (rt.end[w][g] + (uint32_t)rt.D[w][g] + 3u) >> 2, (uint32_t)(unsigned long long)src, (uint32_t)((unsigned long long)src >> 32));
+            }
+            wave_lds_sync(); // (the run table and the bins are read: the next pass writes them again)
+            if (lane == 0) {
+                const uint32_t idx = atomicAdd(&s_npass, 1u);
+                if (idx < kPassCap) s_pass[idx] = make_uint4(tile, slot, n_jobs | (n_runs << 16), region | (rec_off << 16));
+                else atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile);
+            }
+            if (last) break;
+            rec_off += (n_jobs + 1u) & ~1u; // (passes start on 16-byte boundaries)
+            if (rec_off + (kStreamTile - u1) > kStreamRecStride) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (> 64 passes)
+            u0 = u1; b0r = e_r; b0f = e_f; b0s = e_s;
+        }
     }
     }
     if (carry) {
@@ -489,18 +673,13 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
     __syncthreads();
     if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
-    // The DTW launch's work list: the unit's tiles that have something to score, each with its first chain.  (Tiles without a
-    // tile-class part -- all of their parts carried over from the round before, or on the side list -- are never touched.)
-    if (tid == 0 && s_todo) {
-        const uint32_t tiles_per_unit = AT / a.tile_anchors, todo = s_todo;
-        uint64_t at = atomicAdd(&a.cnt[kCntTodo], (unsigned long long)__popc(todo));
-        for (uint32_t t = 0; t < tiles_per_unit; t++)
-            if ((todo >> t) & 1u) a.todo[at++] = make_uint2(unit * tiles_per_unit + t, (uint32_t)chain_at(t * a.tile_anchors));
-    }
+    // The DTW launch's work list: the unit's passes (one returning atomic a unit)
+    if (tid == 0 && s_npass) s_tbase = (uint32_t)atomicAdd(&a.cnt[kCntTodo], (unsigned long long)min(s_npass, kPassCap));
     if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
     __syncthreads();
+    if ((uint32_t)tid < min(s_npass, kPassCap) && (uint64_t)s_tbase + tid < a.n_slots) a.todo[s_tbase + tid] = s_pass[tid];
     if (s_ocnt) {
         const uint64_t obase = s_obase;
 #pragma unroll
@@ -601,9 +780,7 @@ __global__ __launch_bounds__(1024) void k_side(const StreamArgs a)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kStamps = 12;
-constexpr uint32_t kSortBins = 192; // bin = (3 - radius) * 64 + (63 - longer side): radius 3 first, then 2, then 1 (waves of one radius take the
-                                     // shortest body), each run longest first (sides of 63 and more share a bin)
+constexpr uint32_t kStamps = 10;
 
 // One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
 // first, then 2, then 1, each run by longer side, descending; a wave takes the shortest body that covers its radii.
@@ -673,76 +850,37 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_
     return 0xffffffffu;
 }
 
-// A tile's items in the order the image is laid out in: item u is the part that ends at anchor (tile end - 1 - u), so that
-// along a chain (stored end-first) u ascends with the positions -- a run's first part is the one with the lowest addresses,
-// and the scan that places the runs meets it first.
-//
-// Layout of a tile's LDS image.  The image has an event region and a reference region; consecutive tile-class parts of a
-// chain (a "run") share their anchor elements, so a run is ONE contiguous piece of each arena and of each region.  Every
-// part adds floats to the two regions' running sums: a run's first part its whole window plus 3 floats of slack, a
-// continuing part its window minus the shared first element, a run's last part 3 more (the run's END rounded up to a
-// 16-byte boundary never reaches the next run).  With c = the running sum BEFORE a run's first part the run starts at
-//     c + ((off - c) & 3)                 (off = the window's arena offset),
-// congruent to the arena offset modulo 4 -- 16-byte chunks of the image are 16-byte chunks of the arena -- and a part's
-// window starts at (its start anchor's position + D), D = the run's image start minus its first position.  So a tile is
-// staged by copying each run's chunk range, fully coalesced, and two runs never share a chunk.
-struct RunTab {
-    uint32_t lo[2][kStreamMaxSeg];    // first float of the run's first 16-byte chunk in the image [arena: 0 events, 1 reference]
-    uint32_t end[2][kStreamMaxSeg];   // the run's last position + 1 (query / target coordinates)
-    int32_t D[2][kStreamMaxSeg];      // image index = position + D
-    long long src[2][kStreamMaxSeg];  // arena index = image index + src (a multiple of 4)
-};
 
 } // namespace
 
-// TT threads per workgroup (256 or 512), KI = kStreamItems anchors a thread: tiles of AT = TT * KI anchors.
-//
-// Nothing a tile needs from memory is waited for at its start: while tile i is computed, tile i + 1's anchors and the
-// offsets and bases of its first chains come in by LDS-DMA (issued behind tile i's staging, landed before its last barrier),
-// wave 0 turns the offsets into the next tile's chain-start mask, and tile i + 2's number is being dequeued.
-//
-// A tile whose image does not fit the LDS budget (long parts: rare) takes several passes; a pass does everything from
-// the anchors again (they stay in LDS until the tile's last pass) and carries nothing over but its first item and the
-// three sums before it, so the common single-pass tile keeps no state alive across its DP.
-// Registers: 4 waves a SIMD = 128 VGPRs.  Four workgroups a CU (the LDS allows no more) are four waves a SIMD anyway; at
-// 96 registers the tile loop's uniform state no longer fits the scalar file, its overflow takes vector registers, and
-// those spill to scratch: 60 scratch loads a thread and tile (measured: launch alone 0.190 -> 0.177 ms, pipeline 533 ->
-// 554 GCUPS with 128).
+// k_runs: TT threads per workgroup (256 or 512), a persistent grid over the scan's work list.  A list entry is one PASS: up
+// to 512 tile-class parts whose windows fit the image budget, with its job records (sorted: radius class, then longer side)
+// and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- the scan planned them (plan of a
+// tile: scan_unit_body), so a pass here is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records
+// at a time), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
+// start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer (issued
+// before pass i's staging, landed before its first barrier), and pass i + 2's list entry is being dequeued.
 // DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
-// carries neither.
-template <int TT, bool DIAG, bool CARRY>
+// carries none of their branches.
+template <int TT, bool DIAG>
 __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
 {
     const uint32_t dbg = DIAG ? a.debug : 0u;
-    const bool carry = CARRY && (!DIAG || a.carried != nullptr); // (the diagnostic instance serves both kinds of batch)
-    constexpr int KI = (int)kStreamItems;
-    constexpr uint32_t AT = TT * KI, kWords = AT / 32 + 1, kWaves = TT / 64, kCT = 32;
-    static_assert(kWords <= 64, "one mask word a lane");
+    constexpr uint32_t kWaves = TT / 64, kRT = 2u * kStreamMaxSeg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *win = smem;                                                   // the tile's LDS image
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);           // one record per item
-    uint16_t *perm = reinterpret_cast<uint16_t *>(rec + AT);             // sorted order -> item
-    uint32_t *hist = reinterpret_cast<uint32_t *>(perm + AT);            // kSortBins
-    uint2 *anc = reinterpret_cast<uint2 *>(hist + kSortBins);            // AT + 2 anchors: the tile's, the entry behind its last, one of padding
-    __shared__ uint32_t s_mask[kWords], s_pre[kWords];
-    __shared__ uint32_t s_wtot[2][kWaves][3];  // the waves' scan totals, by parity
-    __shared__ RunTab s_run;
-    __shared__ __attribute__((aligned(16))) uint32_t s_ct_off[2 * kCT]; // anchor_off[c0 .. c0 + kCT) as dword pairs
-    __shared__ __attribute__((aligned(16))) uint32_t s_ct_rb[2 * kCT];  // ref_base[c0 .. c0 + kCT)
-    __shared__ __attribute__((aligned(16))) uint32_t s_ct_qb[kCT];      // read_base[c0 .. c0 + kCT)
-    __shared__ __attribute__((aligned(16))) uint32_t s_carried[AT / 32]; // chunk rounds: the tile's anchors whose parts took their cost from the round before
-    __shared__ uint32_t s_tile[2];
-    __shared__ uint32_t s_c0, s_more;          // the tile's first chain; chains beyond the table may start inside the tile
-    __shared__ uint32_t s_seq, s_njobs;
-    __shared__ uint32_t s_pass[8];             // [0] items that fit, [1..3] sums behind the pass, [4] runs, [5] the pass cuts a run
+    float *win = smem;                                                    // the pass's LDS image
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);            // 2 x kStreamTile job records
+    uint4 *rtab = reinterpret_cast<uint4 *>(rec + 2u * kStreamTile);      // 2 x kRT copy orders
+    __shared__ uint4 s_ent[2];                 // the passes' list entries, by parity (x = 0xffffffff: none)
+    __shared__ uint32_t s_seq;
     __shared__ uint32_t s_declined;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
 
-    if (CARRY && tid < (int)(AT / 32)) s_carried[tid] = 0;
     // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
-    // list: nothing to do here, and nothing may be derived from its anchors
-    if (tid == 0) s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
+    // list: nothing to do here, and nothing may be derived from its records
+    if (tid == 0)
+        s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
     __syncthreads();
     if (s_declined) return;
 
@@ -789,47 +927,18 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         }
     }
 
-    // LDS-DMA: one wave instruction moves 16 (or 4) bytes a lane straight into LDS at `dst` + 16 (4) * lane; inactive lanes
-    // move nothing.  `dst` must be the same in every lane.
+    // LDS-DMA: one wave instruction moves 16 bytes a lane straight into LDS at `dst` + 16 * lane; inactive lanes move
+    // nothing.  `dst` must be the same in every lane.
     auto dma16 = [](const void *src, void *dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    auto dma4 = [](const void *src, void *dst) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-    };
-    // a tile's anchors (all waves: AT + 2 entries in 16-byte pieces; the list is readable up to an even number of entries)
-    // and, by wave 0, the table of its first kCT chains: offsets and bases
-    auto fetch_tile = [&](const uint32_t tile, const uint32_t c0) {
-        const uint64_t base = (uint64_t)tile * AT;
-        const uint32_t pieces = (AT + 2u) / 2u; // (AT is even)
+    // a pass's records (all waves: two records a piece) and, by the last wave, its copy orders, into buffer `buf`
+    auto fetch_pass = [&](const uint4 e, const uint32_t buf) {
+        const uint32_t n_jobs = e.z & 0xffffu, n_ord = 2u * (e.z >> 16), pieces = (n_jobs + 1u) >> 1;
+        const uint2 *src = a.recs + (uint64_t)e.x * kStreamRecStride + (e.w >> 16);
         for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
-            if (q0 + (uint32_t)lane < pieces && base + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
-                dma16(a.anchors + base + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-        if (carry && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
-            dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile * (AT / 32u) + lane, s_carried);
-        if (wv == 0) {
-            const uint64_t c = (uint64_t)c0 + ((uint32_t)lane >> 1);
-            if (c <= a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.anchor_off + c0) + lane, s_ct_off);
-            if (c < a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.ref_base + c0) + lane, s_ct_rb);
-            if ((uint32_t)lane < kCT && (uint64_t)c0 + (uint32_t)lane < a.n_chains) dma4(a.read_base + c0 + lane, s_ct_qb);
-        }
-    };
-    // wave 0, its DMA landed: the tile's chain-start mask from the table, the chain starts before each word of it
-    auto mark_tile = [&](const uint32_t tile, const uint32_t c0) {
-        const uint64_t base = (uint64_t)tile * AT;
-        if ((uint32_t)lane < kWords) s_mask[lane] = 0;
-        uint64_t s = ~0ull;
-        if ((uint32_t)lane < kCT && (uint64_t)c0 + (uint32_t)lane <= a.n_chains) {
-            s = (uint64_t)s_ct_off[2 * lane] | ((uint64_t)s_ct_off[2 * lane + 1] << 32);
-            if (s >= base && s <= base + AT) atomicOr(&s_mask[(uint32_t)(s - base) >> 5], 1u << ((uint32_t)(s - base) & 31u));
-        }
-        // chains beyond the table that may start inside the tile: the table's last entry is a chain start before the tile's end
-        const bool more = (uint32_t)lane == kCT - 1u && (uint64_t)c0 + kCT - 1u < a.n_chains && s < base + AT;
-        const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
-        const uint32_t incl = wave_scan_incl(pc);
-        if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
-        const bool any_more = __any(more);
-        if (lane == 0) { s_c0 = c0; s_more = any_more ? 1u : 0u; }
+            if (q0 + (uint32_t)lane < pieces) dma16(src + 2u * (q0 + (uint32_t)lane), rec + buf * kStreamTile + 2u * q0);
+        if (wv == kWaves - 1u && (uint32_t)lane < n_ord) dma16(a.runtab + (uint64_t)e.y * kRT + lane, rtab + buf * kRT);
     };
 
     // diagnostic build of the launch ("stream_debug" 256): where a wave's cycles go, phase by phase (s_memtime around the
@@ -847,53 +956,34 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         if (lane == 0) s_stamp[wv][ph] += t - t_prev;
         t_prev = t;
     };
-    // ---- tiles: the entries of the scan's work list (tile, its first chain), pulled from the queue two ahead ----
-    const uint32_t n_tiles = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
-    // thread 0's queue state: `head`, the list index of the next tile, the raw ticket of the one after it; wave 0 holds the
-    // next tile's entry (asked for a tile ahead)
+    // ---- passes: the entries of the scan's work list, pulled from the queue two ahead ----
+    const uint32_t n_pass = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_slots);
+    // thread 0's queue state: `head`, the list index of the next pass, the raw ticket of the one after it; wave 0 holds the
+    // next pass's entry (asked for a pass ahead)
     uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), i_next = 0xffffffffu;
     unsigned long long ticket = 0;
-    uint2 e_next = make_uint2(0xffffffffu, 0u);
+    const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    uint4 e_next = none;
     if (wv == 0) {
         uint32_t i0 = 0xffffffffu;
         if (tid == 0) {
-            i0 = next_tile(a, dbg, head, n_tiles);
-            i_next = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_tiles) : 0xffffffffu;
+            i0 = next_tile(a, dbg, head, n_pass);
+            i_next = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_pass) : 0xffffffffu;
         }
         i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
         const uint32_t i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
-        const uint2 e0 = i0 != 0xffffffffu ? a.todo[i0] : make_uint2(0xffffffffu, 0u);
+        const uint4 e0 = i0 != 0xffffffffu ? a.todo[i0] : none;
         if (i1 != 0xffffffffu) e_next = a.todo[i1];
-        if (tid == 0) { s_tile[0] = e0.x; s_c0 = e0.y; }
+        if (tid == 0) s_ent[0] = e0;
     }
-    for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
     __syncthreads();
-    if (s_tile[0] == 0xffffffffu) return;
-    {   // the first tile's anchors and chains: nobody to fetch them ahead
-        const uint32_t t0 = s_tile[0], c0 = s_c0;
-        __syncthreads(); // (s_c0 is read: mark_tile writes it again)
-        fetch_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        if (wv == 0) mark_tile(t0, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0));
-        __syncthreads();
-    }
-    uint32_t slot = 0, parity = 0;
-    const uint32_t budget = lds_floats & ~3u;
-    // the results of the tile before: they stay in the records until every wave is past this tile's first barrier (= done
-    // with that tile's DP) and leave in item order from there -- no barrier of their own, and a wave that finishes its share
-    // of a tile's DP early starts on the next tile at once
-    uint32_t pend_bits = 0, pend_end = 0; // items of this thread with a result pending; the anchor behind that tile's last
-    auto flush = [&]() {
-        if (!pend_bits || (dbg & 1u)) { pend_bits = 0; return; }
-#pragma unroll
-        for (int k = 0; k < KI; k++)
-            if ((pend_bits >> k) & 1u) { const uint32_t u = (uint32_t)tid * KI + k; a.out[pend_end - 1u - u] = __uint_as_float(rec[u].x); }
-        pend_bits = 0;
-    };
+    if (s_ent[0].x == 0xffffffffu) return;
+    fetch_pass(s_ent[0], 0u); // the first pass's records: nobody to fetch them ahead
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
     // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
     // workgroup finish together whatever the mix
-    auto run_dp = [&]() {
-        const uint32_t n_jobs = s_njobs;
+    auto run_dp = [&](const uint2 *rc_base, const uint32_t n_jobs, const uint32_t end_nom) {
         while (!(dbg & 1u)) {
             uint32_t c = 0;
             if (lane == 0) c = atomicAdd(&s_seq, 1u);
@@ -901,347 +991,69 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
             if (c * 64u >= n_jobs) break;
             const uint32_t r = c * 64u + lane;
             const bool act = r < n_jobs;
-            const uint32_t u = min((uint32_t)perm[act ? r : n_jobs - 1], AT - 1u);
-            const uint2 rc = rec[u];
-            const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u;
+            const uint2 rc = rc_base[act ? r : n_jobs - 1u];
+            const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u, u = (rc.y >> 17) & (kStreamTile - 1u);
             const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
-            if (act) rec[u].x = __float_as_uint(res); // (the job's record is done with; its slot carries the result out)
+            if (act) a.out[end_nom - 1u - u] = res; // the part that ends at anchor (tile end - 1 - u)
         }
     };
-    // every wave: the bins' first places (three a lane, fetched across lanes) -> each item's place in the sorted order
-    auto sorted_place = [&](const uint32_t (&bin)[KI], const uint32_t (&rank)[KI], uint32_t (&place)[KI]) {
-        const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
-        const uint32_t sum = h0 + h1 + h2;
-        const uint32_t incl = wave_scan_incl(sum);
-        const uint32_t ex0 = incl - sum, ex1 = ex0 + h0, ex2 = ex1 + h1;
-        if (tid == 63) s_njobs = incl;
-#pragma unroll
-        for (int k = 0; k < KI; k++) {
-            const uint32_t b = bin[k] == 0xffffffffu ? 0u : bin[k], src = (b * 171u) >> 9, sl = b - 3u * src; // b / 3, b % 3
-            const uint32_t v0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex0);
-            const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex1);
-            const uint32_t v2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)ex2);
-            place[k] = (sl == 0u ? v0 : sl == 1u ? v1 : v2) + rank[k];
-        }
-    };
-    // a wave's share of the staging: a run's chunk range, 16 bytes a lane, consecutive lanes consecutive chunks; nothing waits
-    // between a wave's pieces: all of them are in flight at once
-    auto stage_runs = [&](const uint32_t n_runs) {
-        // (wave 0 has the next tile's chain table and mask to see to: the other waves share the runs)
-        if (wv == 0) return;
-        for (uint32_t it = wv - 1u; it < 2u * n_runs; it += kWaves - 1u) {
-            const uint32_t w = it & 1u, g = it >> 1;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s_run.lo[w][g] >> 2));
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((s_run.end[w][g] + (uint32_t)s_run.D[w][g] + 3u) >> 2));
-            const float4 *src = reinterpret_cast<const float4 *>((w ? a.ref : a.ev) + s_run.src[w][g]);
-            for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
-                if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
-        }
-    };
-    for (uint32_t tile = s_tile[0]; tile != 0xffffffffu; tile = s_tile[slot]) {
-        const uint32_t base = tile * AT, end_nom = base + AT; // (n_anchors < 2^31)
-        const uint32_t c0 = s_c0;
-        // thread 0: the next tile's number is published before the first barrier; the ticket of the one after it is drawn
-        // now and looked at when this tile is done
-        const uint32_t c0n = e_next.y; // wave 0: the next tile's first chain (for its chain table)
+    uint32_t cur = 0;
+    for (;;) {
+        const uint4 e = s_ent[cur];
+        if (e.x == 0xffffffffu) break;
+        const uint32_t n_jobs = e.z & 0xffffu, n_ord = 2u * (e.z >> 16);
+        // thread 0: the next pass's entry is published before this pass's first barrier; the ticket of the one after it is
+        // drawn now and looked at when this pass is done
         if (tid == 0) {
-            s_tile[slot ^ 1u] = e_next.x;
+            s_ent[cur ^ 1u] = e_next;
+            s_seq = 0;
             if (i_next != 0xffffffffu && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
         }
-        if (s_more) { // (tiles of very short chains: the rest of the chain starts from memory)
-            (void)mark_chain_starts<TT>(a, (uint64_t)c0 + kCT, base, AT, s_mask);
-            if (wv == 0) {
-                const uint32_t pc = (uint32_t)lane < kWords ? __popc(s_mask[lane]) : 0u;
-                const uint32_t incl = wave_scan_incl(pc);
-                if ((uint32_t)lane < kWords) s_pre[lane] = incl - pc;
-            }
-            __syncthreads();
-        }
-        // ---- 1. every item's part: windows, radius, class; the runs; the wave's share of the layout scan.  Item
-        // u = tid * KI + k ends at anchor end_nom - 1 - u (tile position AT - 1 - u) and starts at the entry behind it ----
-        rawdtw_anchor_t E[KI], S0;
-        {
-            const uint32_t p_hi = AT - 1u - (uint32_t)tid * KI; // the first item's position; its start: p_hi + 1
-            const uint2 x = anc[p_hi + 1u];
-            S0 = rawdtw_anchor_t{x.x, x.y};
-#pragma unroll
-            for (int k = 0; k < KI; k++) { const uint2 y = anc[p_hi - k]; E[k] = rawdtw_anchor_t{y.x, y.y}; }
-        }
-        uint32_t meta[KI];    // N | M << 7 | R << 14 | excl << 16 | swap << 17 | starts << 18 | ends << 19 | tile << 20
-        uint32_t ssum[KI][3]; // inclusive sums over the workgroup's items: event floats, reference floats, run starts
-        {
-            bool tl[KI];
-            Part pt[KI];
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                const bool exists = (uint64_t)base + p < a.n_anchors && !mask_bit(s_mask, p + 1) && !(CARRY && mask_bit(s_carried, p));
-                pt[k] = classify(a, k ? E[k - 1] : S0, E[k]);
-                tl[k] = exists && pt[k].tile;
-            }
-            // a run continues from the item before (same thread, or the lane below) when both are tile parts: the item before
-            // u ends where u starts, and both existing puts them in one chain.  Runs break at wave boundaries (lane 0's
-            // first item starts one, lane 63's last ends one): four breaks a tile, and no run crosses waves.
-            const int t_first = tl[0] ? 1 : 0, t_last = tl[KI - 1] ? 1 : 0;
-            const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
-            const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
-            uint32_t run[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                const uint32_t u = (uint32_t)tid * KI + k, p = AT - 1u - u;
-                const bool prev_t = k ? tl[k - 1] : below, next_t = k + 1 < KI ? tl[k + 1 < KI ? k + 1 : k] : above;
-                const bool starts = tl[k] && !prev_t, ends = tl[k] && !next_t;
-                const uint32_t n = pt[k].n, m = pt[k].m, N = n > m ? n : m, M = n > m ? m : n;
-                meta[k] = !tl[k] ? 0u : (N | (M << 7) | ((uint32_t)pt[k].R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((n < m ? 1u : 0u) << 17) |
-                                         ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19) | (1u << 20));
-                if (tl[k]) {
-                    run[0] += (starts ? n + 3u : n - 1u) + (ends ? 3u : 0u);
-                    run[1] += (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u);
-                    run[2] += starts ? 1u : 0u;
-                }
-                ssum[k][0] = run[0]; ssum[k][1] = run[1]; ssum[k][2] = run[2];
-            }
-            // wave scan of the threads' totals
-            const uint32_t inc[3] = {wave_scan_incl(run[0]), wave_scan_incl(run[1]), wave_scan_incl(run[2])};
-            if (lane == 63) { s_wtot[parity][wv][0] = inc[0]; s_wtot[parity][wv][1] = inc[1]; s_wtot[parity][wv][2] = inc[2]; }
-#pragma unroll
-            for (int k = 0; k < KI; k++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) ssum[k][q] += inc[q] - run[q];
-        }
         stamp(0);
-        __syncthreads(); // B1: wave totals, the next tile's number; every wave is done with the DP of the tile before
+        // ---- staging: a wave's share of the copy orders, 16 bytes a lane, consecutive lanes consecutive pieces; nothing
+        // waits between a wave's pieces: all of them are in flight at once ----
+        __builtin_amdgcn_s_setprio(2); // a fresh pass's loads must not queue behind the DP of the older workgroups
+        if (!(dbg & 2u)) {
+            const uint4 *ord = rtab + cur * kRT;
+            for (uint32_t it = wv; it < n_ord; it += kWaves) {
+                const uint4 o = ord[it];
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)o.x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)o.y);
+                const long long off = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)o.z) |
+                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)o.w) << 32));
+                const float4 *src = reinterpret_cast<const float4 *>(((it & 1u) ? a.ref : a.ev) + off);
+                for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
+                    if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
+            }
+        }
         stamp(1);
-        flush();
-        const uint32_t tile_n = s_tile[slot ^ 1u];
-        uint32_t tot[3] = {0u, 0u, 0u};
-        {
-            uint32_t pre[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (uint32_t w = 0; w < kWaves; w++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const uint32_t x = s_wtot[parity][w][q];
-                    if (w < wv) pre[q] += x;
-                    tot[q] += x;
-                }
-#pragma unroll
-            for (int k = 0; k < KI; k++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) ssum[k][q] += pre[q];
-        }
-        parity ^= 1u;
-        // all of the tile in one pass when its image fits the LDS budget and its runs the table (the rule)
-        if (((tot[0] + 3u) & ~3u) + ((tot[1] + 3u) & ~3u) <= budget && tot[2] <= kStreamMaxSeg) {
-            const uint32_t region = (tot[0] + 3u) & ~3u;
-            // the next tile's anchors: every thread has read this tile's
-            if (tile_n != 0xffffffffu) {
-                const uint32_t pieces = (AT + 2u) / 2u;
-                const uint64_t nbase = (uint64_t)tile_n * AT;
-                for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
-                    if (q0 + (uint32_t)lane < pieces && nbase + 2ull * (q0 + (uint32_t)lane) < a.n_anchors)
-                        dma16(a.anchors + nbase + 2ull * (q0 + (uint32_t)lane), anc + 2u * q0);
-                if (carry && wv == kWaves - 1u && (uint32_t)lane < AT / 32u)
-                    dma4(reinterpret_cast<const uint32_t *>(a.carried) + (uint64_t)tile_n * (AT / 32u) + lane, s_carried);
-            }
-            // ---- 2. runs into the table, the sort's histogram ----
-            uint32_t bin[KI], rank[KI];
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                bin[k] = 0xffffffffu; rank[k] = 0;
-                if (!((meta[k] >> 20) & 1u)) continue;
-                const uint32_t u = (uint32_t)tid * KI + k;
-                const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
-                const bool swap = (meta[k] >> 17) & 1u, starts = (meta[k] >> 18) & 1u, ends = (meta[k] >> 19) & 1u;
-                const uint32_t n = swap ? M : N, m = swap ? N : M;
-                bin[k] = (3u - R) * 64u + (63u - min(N, 63u));
-                rank[k] = atomicAdd(&hist[bin[k]], 1u);
-                const uint32_t g = ssum[k][2] - 1u; // the item's run
-                const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
-                if (starts) {
-                    // the run's chain: c0 + the chain starts in tile positions 1 .. p (p: this item's anchor); its bases from the
-                    // table of the tile's first chains, or from memory beyond it
-                    const uint32_t p = AT - 1u - u;
-                    const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
-                    uint64_t rb;
-                    uint32_t qb;
-                    if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
-                    else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
-                    const uint32_t c_r = ssum[k][0] - (n + 3u) - (ends ? 3u : 0u), c_f = ssum[k][1] - (m + 3u) - (ends ? 3u : 0u); // the sums before the run
-                    const uint32_t off_r = qb + s.query_position;
-                    const uint64_t off_f = rb + s.target_position;
-                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
-                    s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
-                    s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
-                    s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
-                }
-                if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
-            }
-            if (tid == 0) s_seq = 0;
-            stamp(2);
-            __syncthreads(); // B2: run table, histogram; this tile's chain table and mask are done with
-            stamp(3);
-            // wave 0: the next tile's chain table (its first chain came in a tile ago)
-            if (wv == 0 && tile_n != 0xffffffffu) {
-                const uint32_t cn = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n);
-                const uint64_t c = (uint64_t)cn + ((uint32_t)lane >> 1);
-                if (c <= a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.anchor_off + cn) + lane, s_ct_off);
-                if (c < a.n_chains) dma4(reinterpret_cast<const uint32_t *>(a.ref_base + cn) + lane, s_ct_rb);
-                if ((uint32_t)lane < kCT && (uint64_t)cn + (uint32_t)lane < a.n_chains) dma4(a.read_base + cn + lane, s_ct_qb);
-            }
-            // ---- 3. every wave: its items' places in the sorted order and their records; its share of the staging ----
-            {
-                uint32_t place[KI];
-                sorted_place(bin, rank, place);
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    if (bin[k] == 0xffffffffu) continue;
-                    const uint32_t u = (uint32_t)tid * KI + k;
-                    perm[place[k]] = (uint16_t)u;
-                    const uint32_t g = ssum[k][2] - 1u;
-                    const rawdtw_anchor_t s = k ? E[k - 1] : S0;
-                    const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
-                    const bool swap = (meta[k] >> 17) & 1u;
-                    rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
-                }
-            }
-            stamp(4);
-            __builtin_amdgcn_s_setprio(2); // a fresh tile's loads must not queue behind the DP of the older workgroups
-            if (!(dbg & 2u)) stage_runs(tot[2]);
-            stamp(5);
-            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the barrier below covers the others')
-            __builtin_amdgcn_s_setprio(0);
-            stamp(6);
-            // wave 0: the next tile's chain-start mask from its table (landed with the staging)
-            if (wv == 0 && tile_n != 0xffffffffu) mark_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
-            pend_bits = 0;
-#pragma unroll
-            for (int k = 0; k < KI; k++) pend_bits |= (bin[k] != 0xffffffffu ? 1u : 0u) << k;
-            pend_end = end_nom;
-            __syncthreads(); // B3: image staged, sorted order and records written; the next tile's anchors, table and mask in place
-            stamp(7);
-            for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0; // (for the next tile; nobody reads it any more)
-            run_dp();
-            stamp(8);
-        } else {
-            // ---- a tile of several passes (long parts: rare).  A pass takes the items that fit, from u0 on; its results
-            // leave before the next pass reuses the records; the next tile is fetched in the last pass ----
-            uint32_t u0 = 0, b0[3] = {0u, 0u, 0u}; // the pass's first item and the sums before it
-            for (;;) {
-                // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table
-                // (sums relative to the pass's start; + 4 + 4 floats and one run when the first item continues a run)
-                if (tid == 0) s_pass[0] = 0;
-                __syncthreads();
-                uint32_t fits = 0;
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    const uint32_t u = (uint32_t)tid * KI + k;
-                    if (u >= u0 && ((ssum[k][0] - b0[0] + 7u) & ~3u) + ((ssum[k][1] - b0[1] + 7u) & ~3u) <= budget && ssum[k][2] - b0[2] + 1u <= kStreamMaxSeg) fits++;
-                }
-                for (int off = 32; off > 0; off >>= 1) fits += (uint32_t)__shfl_down((int)fits, off);
-                if (lane == 0 && fits) atomicAdd(&s_pass[0], fits);
-                __syncthreads();
-                uint32_t u1 = min(u0 + s_pass[0], AT);
-                if (u1 <= u0) { if (tid == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); u1 = AT; } // (cannot happen: one part always fits)
-                // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    const uint32_t u = (uint32_t)tid * KI + k;
-                    if (u == u1 - 1u) { s_pass[1] = ssum[k][0]; s_pass[2] = ssum[k][1]; s_pass[3] = ssum[k][2]; }
-                    if (u == u0) s_pass[5] = ((meta[k] >> 20) & 1u) && !((meta[k] >> 18) & 1u) ? 1u : 0u;
-                }
-                __syncthreads();
-                const bool cut_run = s_pass[5] != 0u; // the pass's first item continues a run of the pass before: it starts one here
-                const uint32_t region = (s_pass[1] - b0[0] + (cut_run ? 4u : 0u) + 3u) & ~3u;
-                const uint32_t n_runs = s_pass[3] - b0[2] + (cut_run ? 1u : 0u);
-                const bool last = u1 >= AT;
-                uint32_t bin[KI], rank[KI];
-#pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    bin[k] = 0xffffffffu; rank[k] = 0;
-                    const uint32_t u = (uint32_t)tid * KI + k;
-                    if (!((meta[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
-                    const uint32_t N = meta[k] & 127u, M = (meta[k] >> 7) & 127u, R = (meta[k] >> 14) & 3u;
-                    const bool swap = (meta[k] >> 17) & 1u;
-                    const uint32_t n = swap ? M : N, m = swap ? N : M;
-                    const bool starts = ((meta[k] >> 18) & 1u) || u == u0, ends = ((meta[k] >> 19) & 1u) || u == u1 - 1u;
-                    bin[k] = (3u - R) * 64u + (63u - min(N, 63u));
-                    rank[k] = atomicAdd(&hist[bin[k]], 1u);
-                    const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
-                    const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
-                    const rawdtw_anchor_t s = k ? E[k - 1] : S0, e = E[k];
-                    if (starts) {
-                        const uint32_t p = AT - 1u - u;
-                        const uint32_t cs = s_pre[p >> 5] + __popc(s_mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (s_mask[0] & 1u);
-                        uint64_t rb;
-                        uint32_t qb;
-                        if (cs < kCT) { rb = (uint64_t)s_ct_rb[2 * cs] | ((uint64_t)s_ct_rb[2 * cs + 1] << 32); qb = s_ct_qb[cs]; }
-                        else { rb = a.ref_base[(uint64_t)c0 + cs]; qb = a.read_base[(uint64_t)c0 + cs]; }
-                        // sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
-                        const uint32_t own_r = ((meta[k] >> 18) & 1u ? n + 3u : n - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
-                        const uint32_t own_f = ((meta[k] >> 18) & 1u ? m + 3u : m - 1u) + (((meta[k] >> 19) & 1u) ? 3u : 0u);
-                        const uint32_t c_r = ssum[k][0] - own_r - b0[0] + 4u * adj, c_f = ssum[k][1] - own_f - b0[1] + 4u * adj;
-                        const uint32_t off_r = qb + s.query_position;
-                        const uint64_t off_f = rb + s.target_position;
-                        const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
-                        s_run.lo[0][g] = p_r & ~3u; s_run.lo[1][g] = p_f & ~3u;
-                        s_run.D[0][g] = (int32_t)(p_r - s.query_position); s_run.D[1][g] = (int32_t)(p_f - s.target_position);
-                        s_run.src[0][g] = (long long)off_r - (long long)p_r; s_run.src[1][g] = (long long)off_f - (long long)p_f;
-                    }
-                    if (ends) { s_run.end[0][g] = e.query_position + 1u; s_run.end[1][g] = e.target_position + 1u; }
-                }
-                if (tid == 0) s_seq = 0;
-                __syncthreads(); // run table, histogram
-                {
-                    uint32_t place[KI];
-                    sorted_place(bin, rank, place);
-#pragma unroll
-                    for (int k = 0; k < KI; k++) {
-                        if (bin[k] == 0xffffffffu) continue;
-                        const uint32_t u = (uint32_t)tid * KI + k;
-                        perm[place[k]] = (uint16_t)u;
-                        const uint32_t g = ssum[k][2] - b0[2] + (cut_run ? 1u : 0u) - 1u;
-                        const rawdtw_anchor_t s = k ? E[k - 1] : S0;
-                        const uint32_t p_r = s.query_position + (uint32_t)s_run.D[0][g], p_f = s.target_position + (uint32_t)s_run.D[1][g];
-                        const bool swap = (meta[k] >> 17) & 1u;
-                        rec[u] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), meta[k] & 0x1ffffu);
-                    }
-                }
-                if (!(dbg & 2u)) stage_runs(n_runs);
-                if (last && tile_n != 0xffffffffu) fetch_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n)); // (every pass has read the anchors)
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                if (last && wv == 0 && tile_n != 0xffffffffu) mark_tile(tile_n, (uint32_t)__builtin_amdgcn_readfirstlane((int)c0n));
-                __syncthreads(); // image staged, sorted order and records written
-                for (uint32_t b = tid; b < kSortBins; b += TT) hist[b] = 0;
-                run_dp();
-                pend_bits = 0;
-#pragma unroll
-                for (int k = 0; k < KI; k++) pend_bits |= (bin[k] != 0xffffffffu ? 1u : 0u) << k;
-                pend_end = end_nom;
-                if (last) break; // (the last pass's results leave like a one-pass tile's)
-                __syncthreads();
-                flush();
-                u0 = u1; b0[0] = s_pass[1]; b0[1] = s_pass[2]; b0[2] = s_pass[3];
-                __syncthreads(); // (the pass's records and s_pass are read; the next pass rewrites them)
-            }
-        }
-        // thread 0: the ticket into the list index of the tile after the next; wave 0 asks for that tile's entry
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's pieces have landed (the barrier below covers the others')
+        __builtin_amdgcn_s_setprio(0);
+        stamp(2);
+        __syncthreads(); // B1: the image is staged; the next pass's entry is published
+        stamp(3);
+        // the next pass's records into the other buffer (read last in the pass before this one: every wave is past that DP)
+        const uint4 en = s_ent[cur ^ 1u];
+        if (en.x != 0xffffffffu) fetch_pass(en, cur ^ 1u);
+        run_dp(rec + cur * kStreamTile, n_jobs, (e.x + 1u) * kStreamTile);
+        stamp(4);
+        // thread 0: the ticket into the list index of the pass after the next; wave 0 asks for that pass's entry
         if (tid == 0 && i_next != 0xffffffffu) {
-            if (dbg & 8u) i_next = next_tile(a, dbg, head, n_tiles);
+            if (dbg & 8u) i_next = next_tile(a, dbg, head, n_pass);
             else {
                 const unsigned long long t = ticket * 8ull + head;
-                i_next = t < n_tiles ? (uint32_t)t : next_tile(a, dbg, head, n_tiles); // (this head is dry: try the others)
+                i_next = t < n_pass ? (uint32_t)t : next_tile(a, dbg, head, n_pass); // (this head is dry: try the others)
             }
         }
         if (wv == 0) {
             const uint32_t in = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
-            e_next = in != 0xffffffffu ? a.todo[in] : make_uint2(0xffffffffu, 0u);
+            e_next = in != 0xffffffffu ? a.todo[in] : none;
         }
-        slot ^= 1u;
-        stamp(9);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // (the next pass's records have landed)
+        stamp(5);
+        __syncthreads(); // B2: every wave is done with the image and with this pass's records
+        stamp(6);
+        cur ^= 1u;
     }
-    __syncthreads(); // every wave is done with the last tile's DP
-    flush();
     if (stamps && lane < (int)kStamps && s_stamp[wv][lane]) atomicAdd(&a.cnt[kCntStamp0 + lane], s_stamp[wv][lane]);
 }
 
@@ -1464,8 +1276,8 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 
 static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
 {
-    const uint32_t at = (uint32_t)threads * kStreamItems;
-    return lds_floats * 4u + at * 8u + at * 2u + kSortBins * 4u + (at + 2u) * 8u; // image, records, sorted order, histogram, anchors
+    (void)threads;
+    return lds_floats * 4u + 2u * kStreamTile * 8u + 2u * 2u * kStreamMaxSeg * 16u; // image, two passes' records and copy orders
 }
 
 // everything rawdtw_batch_create enqueues for a sparse + banded batch: the scan of the anchor list (side list, checks,
@@ -1512,9 +1324,8 @@ hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats,
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(tt), lds_bytes, s, a, lds_floats);
         return hipGetLastError();
     };
-    const bool carry = a.carried != nullptr;
-    if (threads == 512) return diag ? launch(k_runs<512, true, true>, 512) : carry ? launch(k_runs<512, false, true>, 512) : launch(k_runs<512, false, false>, 512);
-    return diag ? launch(k_runs<256, true, true>, 256) : carry ? launch(k_runs<256, false, true>, 256) : launch(k_runs<256, false, false>, 256);
+    if (threads == 512) return diag ? launch(k_runs<512, true>, 512) : launch(k_runs<512, false>, 512);
+    return diag ? launch(k_runs<256, true>, 256) : launch(k_runs<256, false>, 256);
 }
 
 // workgroups of k_runs one compute unit holds at this LDS size (for the persistent grid)
@@ -1522,7 +1333,7 @@ int stream_blocks_per_cu(uint32_t lds_floats, int threads)
 {
     int n = 0;
     const uint32_t lds_bytes = stream_lds_bytes_t(lds_floats, threads);
-    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512, false, false>) : reinterpret_cast<const void *>(k_runs<256, false, false>);
+    const void *fn = threads == 512 ? reinterpret_cast<const void *>(k_runs<512, false>) : reinterpret_cast<const void *>(k_runs<256, false>);
     if (lds_bytes > 64 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds_bytes) != hipSuccess) return 0;
     return n;

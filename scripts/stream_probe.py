@@ -42,9 +42,9 @@ for cfg in configs:
         print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
                                                                    ["%.4f" % m[2] for m in ms]), flush=True)
-    if any(cnt[52:64]):  # "stream_debug" 256: cycles per phase of k_runs (kCntStamp0 = 52), summed over waves and runs
-        tot = float(sum(cnt[52:64]))
-        names = ["P1 classify+scan", "B1", "P2 runs+hist", "B2", "P3 sort+records", "stage issue", "stage wait", "B3", "DP", "ticket+entry"]
-        print("   phase shares: " + "  ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, cnt[52:64])), flush=True)
+    if any(cnt[53:63]):  # "stream_debug" 256: cycles per phase of k_runs (kCntStamp0 = 53), summed over waves and runs
+        tot = float(sum(cnt[53:63]))
+        names = ["entry", "stage issue", "stage wait", "B1", "DP + next records", "ticket + wait", "B2"]
+        print("   phase shares: " + "  ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, cnt[53:63])), flush=True)
     b.close()
     eng.close()
