@@ -1824,10 +1824,10 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
     const rawdtw_batch *prev = b->in_prev;
     const bool round = prev && b->in_carry_chain && prev->ctx == ctx && prev->stream && !(prev->cnt_valid && stream_declined(prev));
-    const size_t round_bytes = round ? al(nc * 8) : 0;
+    const size_t round_bytes = round ? al(nc * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
     const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
-                             al((size_t)a.n_slots * 16) + al((size_t)a.n_tiles * 24) +                                          // work list, statistics
+                             al((size_t)a.n_tiles * 8) + al((size_t)a.n_slots * 16) + al((size_t)a.n_tiles * 24) +               // tile list, work list, statistics
                              al((size_t)a.n_tiles * kStreamRecStride * 8) + al((size_t)a.n_slots * 2 * kStreamMaxSeg * 16) +         // job records, copy orders
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
                              al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
@@ -1841,6 +1841,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
     uint32_t *d_read_base = carve<uint32_t>(p, nc);
     b->d_chain_off = carve<uint64_t>(p, nr + 1);
+    a.tlist = carve<uint2>(p, a.n_tiles);
     a.todo = carve<uint4>(p, a.n_slots);
     a.recs = carve<uint2>(p, (uint64_t)a.n_tiles * kStreamRecStride);
     a.runtab = carve<uint4>(p, (uint64_t)a.n_slots * 2 * kStreamMaxSeg);
@@ -1866,6 +1867,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     uint64_t *d_carry = nullptr;
     if (round) { // (the previous batch's arrays are read by this batch's k_scan: stream order keeps them alive that long)
         d_carry = carve<uint64_t>(p, nc);
+        a.carried = carve<uint8_t>(p, (uint64_t)a.n_tiles * (a.tile_anchors / 8));
         a.carry_chain = d_carry;
         a.prev_n_chains = prev->n_chains; a.prev_anchor_off = prev->sa.anchor_off; a.prev_anchors = prev->sa.anchors;
         a.prev_ref_base = prev->sa.ref_base; a.prev_read_base = prev->sa.read_base; a.prev_out = prev->sa.out;
@@ -2228,10 +2230,13 @@ int rawdtw_batch_verify_plan(rawdtw_ctx *ctx, const rawdtw_batch *batch, const r
         const uint64_t nc = batch->n_chains, na = a.n_anchors;
         const uint64_t *aoff = batch->in_anchor_off;
         // the work list: one entry a pass (checked below, once the jobs' classes are known)
-        const uint64_t n_todo = cnt[kCntTodo];
+        const uint64_t n_first = cnt[kCntTodo], n_pool = cnt[kCntPool], n_todo = n_first + n_pool;
         std::vector<uint4> todo(n_todo);
-        if (n_todo > a.n_slots) e = "work list longer than the record slots";
-        else if (n_todo) HIP_TRY(ctx, hipMemcpy(todo.data(), a.todo, n_todo * sizeof(uint4), hipMemcpyDeviceToHost));
+        if (n_first > a.n_tiles || n_pool > a.n_slots - a.n_tiles) e = "work list longer than the slots";
+        else {
+            if (n_first) HIP_TRY(ctx, hipMemcpy(todo.data(), a.todo, n_first * sizeof(uint4), hipMemcpyDeviceToHost));
+            if (n_pool) HIP_TRY(ctx, hipMemcpy(todo.data() + n_first, a.todo + a.n_tiles, n_pool * sizeof(uint4), hipMemcpyDeviceToHost));
+        }
         const uint64_t n_other = cnt[kCntOthers];
         std::vector<DevJob> oj(n_other);
         if (n_other) HIP_TRY(ctx, hipMemcpy(oj.data(), a.ojobs, n_other * sizeof(DevJob), hipMemcpyDeviceToHost));

@@ -177,9 +177,12 @@ struct StreamArgs {
     uint64_t prev_others_cap;
     uint8_t *carried;                 // one bit per anchor (byte i / 8, bit i % 8): its part's cost was carried over
     // workspace and outputs (device)
-    uint4 *todo;                 // the DTW launch's work list (k_scan): one entry a PASS -- a tile's tile-class parts, or as many of them
+    uint2 *tlist;                // the scan's tile list: (tile, the chain its first anchor belongs to) of every tile that has a part for the
+                                 // lane bodies; cnt[kCntTodo] entries, at most n_tiles
+    uint4 *todo;                 // the DTW launch's work list (k_plan): one entry a PASS -- a tile's tile-class parts, or as many of them
                                  // as fit the image budget and the run table: (tile, copy-order slot, jobs | runs << 16, floats of
-                                 // the image's event region | first record << 16); cnt[kCntTodo] entries, at most n_slots
+                                 // the image's event region | first record << 16), at the index of its slot: [0, cnt[kCntTodo]) the listed
+                                 // tiles' first passes, [n_tiles, n_tiles + cnt[kCntPool]) the others
     uint2 *recs;                 // n_tiles x kStreamRecStride job records, a pass's in the order the lanes take them (radius class, then longer
                                  // side, descending): x = event window | reference window << 16 (float offsets into the pass's
                                  // image, longer sequence first), y = N | M << 7 | R << 14 | exclude_last << 16 | item << 17

@@ -329,18 +329,11 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
-    // planning of the DTW launch's passes, a wave a tile (see plan_tile below): the wave's sort histogram and run table, the
-    // unit's passes until its share of the work list is known
-    constexpr uint32_t kPassCap = 256;
-    __shared__ uint32_t s_hist[NT / 64][kSortBins];
-    __shared__ RunTab s_rtab[NT / 64];
-    __shared__ uint32_t s_tmp[NT / 64][8];
-    __shared__ uint4 s_pass[kPassCap];
-    __shared__ uint32_t s_npass, s_tbase;
+    __shared__ uint32_t s_todo; // bit t: tile t of the unit has a part for the lane-per-job bodies to score
     const int tid = threadIdx.x, lane = tid & 63;
     const uint64_t base = (uint64_t)unit * AT;
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
-    if (tid == 0) { s_ocnt = 0; s_npass = 0; }
+    if (tid == 0) { s_ocnt = 0; s_todo = 0; }
     if (tid < 3) s_stats[tid] = 0;
     if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
@@ -449,11 +442,10 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 #pragma unroll
         for (int k = 0; k <= KI; k++) an[k] = ih + k < a.n_anchors ? a.anchors[ih + k] : rawdtw_anchor_t{0, 0};
     }
-    uint32_t half_tiles = 0;
-    uint32_t tm[KI]; // the tile parts: N | M << 7 | R << 14 | exclude_last << 16 | swapped << 17 | 1 << 20 (0: the lane bodies do not take it)
+    uint32_t carried_bits = 0, half_tiles = 0;
 #pragma unroll
     for (int k = 0; k < KI; k++) {
-        o_rec[h][k] = 0xffffffffu; tm[k] = 0u;
+        o_rec[h][k] = 0xffffffffu;
         const uint32_t p = h * kHalf + (uint32_t)tid * KI + k; // position in the unit
         const uint64_t i = base + p;
         if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
@@ -489,18 +481,14 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
                         float cost = a.prev_out[pi];
                         if (was_last != is_last) cost = cost - dist(a.ev[(uint64_t)c_qb + e.query_position], a.ref[c_rb + e.target_position]);
                         a.out[i] = cost;
+                        carried_bits |= 1u << k;
                         my_reused++;
                         continue;
                     }
                 }
             }
         }
-        if (pt.tile) {
-            my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u;
-            const uint32_t N = pt.n > pt.m ? pt.n : pt.m, M = pt.n > pt.m ? pt.m : pt.n;
-            tm[k] = N | (M << 7) | ((uint32_t)pt.R << 14) | ((mask_bit(s_mask, p) ? 0u : 1u) << 16) | ((pt.n < pt.m ? 1u : 0u) << 17) | (1u << 20);
-            continue;
-        }
+        if (pt.tile) { my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
         r0 = r0 > 1 ? r0 : 1;
@@ -516,149 +504,10 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         o_rec[h][k] = atomicAdd(&s_ocnt, 1u) | (cls << 16) | ((uint32_t)R << 21); // (slot < 2^13, class < 2^5, R < 2^8)
         atomicAdd(&s_cls[cls], 1u);
     }
-    // ---- the DTW launch's passes over this wave's tile (its 512 anchors): the image layout, the jobs' order, their records ----
-    // Lane L holds the tile's positions 8 L .. 8 L + 7; the item at position t ends at anchor t, starts at anchor t + 1 and is
-    // item u = 511 - t of the layout order: along a chain (stored end-first) u ascends with the addresses.  A run = consecutive
-    // tile parts of a chain; its first part (`starts`) is the one whose predecessor in u (position + 1) is no tile part.
-    if (__ballot(half_tiles != 0u)) { // (wave-uniform)
-        static_assert(KI == 8 && kStreamTile == 64 * KI, "a wave a tile, eight items a lane");
-        const uint32_t wv = (uint32_t)tid >> 6;
-        uint32_t *hist = s_hist[wv], *tmp = s_tmp[wv];
-        RunTab &rt = s_rtab[wv];
-        const uint32_t tile = unit * (AT / kStreamTile) + h * (kHalf / kStreamTile) + wv;
-        const int t_first = (int)((tm[0] >> 20) & 1u), t_last = (int)((tm[KI - 1] >> 20) & 1u);
-        const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
-        const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
-        uint32_t cr[KI], cf[KI]; // contributions to the regions' sums: floats | run start << 20; floats
-        uint32_t lr = 0, lf = 0;
-#pragma unroll
-        for (int k = 0; k < KI; k++) {
-            const bool t = (tm[k] >> 20) & 1u;
-            const bool pred = k + 1 < KI ? ((tm[k + 1 < KI ? k + 1 : k] >> 20) & 1u) != 0u : above;
-            const bool succ = k > 0 ? ((tm[k > 0 ? k - 1 : 0] >> 20) & 1u) != 0u : below;
-            const bool starts = t && !pred, ends = t && !succ;
-            const uint32_t N = tm[k] & 127u, M = (tm[k] >> 7) & 127u;
-            const bool swap = (tm[k] >> 17) & 1u;
-            const uint32_t n = swap ? M : N, m = swap ? N : M;
-            tm[k] |= ((starts ? 1u : 0u) << 18) | ((ends ? 1u : 0u) << 19);
-            cr[k] = t ? ((starts ? n + 3u : n - 1u) + (ends ? 3u : 0u)) | ((starts ? 1u : 0u) << 20) : 0u;
-            cf[k] = t ? (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u) : 0u;
-            lr += cr[k]; lf += cf[k];
-        }
-        // sums in layout order from sums in position order: before item u lie the items at higher positions,
-        //     sum over v <= u  =  total - (sum over positions <= t) + own
-        const uint32_t ir = wave_scan_incl(lr), jf = wave_scan_incl(lf);
-        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)ir, 63), tot_f = (uint32_t)__builtin_amdgcn_readlane((int)jf, 63);
-        uint32_t ur[KI], uf[KI]; // inclusive sums in layout order (events | runs << 20; reference)
-        {
-            uint32_t ar = ir - lr, af = jf - lf;
-#pragma unroll
-            for (int k = 0; k < KI; k++) { ar += cr[k]; af += cf[k]; ur[k] = tot_r - ar + cr[k]; uf[k] = tot_f - af + cf[k]; }
-        }
-        const uint32_t budget = a.lds_floats & ~3u;
-        uint32_t u0 = 0, b0r = 0, b0f = 0, b0s = 0; // the pass's first item, the sums before it
-        uint32_t rec_off = 0;                       // the pass's first record in the tile's stretch of the record array
-        for (bool first = true;; first = false) { // (wave-uniform)
-            // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table (+ 4 + 4
-            // floats and one run when the first item continues a run); the sums ascend with u: the fitting items are a prefix
-            uint32_t fits = 0;
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), sr = ur[k] & 0xfffffu, ss = ur[k] >> 20;
-                if (u >= u0 && ((sr - b0r + 7u) & ~3u) + ((uf[k] - b0f + 7u) & ~3u) <= budget && ss - b0s + 1u <= kStreamMaxSeg) fits++;
-            }
-            fits = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fits), 63);
-            const uint32_t u1 = min(u0 + fits, kStreamTile);
-            if (u1 <= u0) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (cannot happen: one part always fits)
-            // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
-                if (u == u1 - 1u) { tmp[0] = ur[k] & 0xfffffu; tmp[1] = uf[k]; tmp[2] = ur[k] >> 20; }
-                if (u == u0) tmp[3] = ((tm[k] >> 20) & 1u) && !((tm[k] >> 18) & 1u) ? 1u : 0u;
-            }
-            wave_lds_sync();
-            const uint32_t e_r = tmp[0], e_f = tmp[1], e_s = tmp[2];
-            const bool cut_run = tmp[3] != 0u; // the pass's first item continues a run of the pass before: it starts one here
-            const uint32_t region = (e_r - b0r + (cut_run ? 4u : 0u) + 3u) & ~3u;
-            const uint32_t n_runs = e_s - b0s + (cut_run ? 1u : 0u);
-            const bool last = u1 >= kStreamTile;
-            wave_lds_sync(); // (the words are read: the next pass writes them again)
-            // the pass's record slot: the tile's own for its first pass, one of the pool's for the others
-            uint32_t slot = tile;
-            if (!first) {
-                uint32_t sl = 0;
-                if (lane == 0) sl = a.n_tiles + (uint32_t)atomicAdd(&a.cnt[kCntPool], 1ull);
-                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
-                if (slot >= a.n_slots) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; }
-            }
-            for (uint32_t b = (uint32_t)lane; b < kSortBins; b += 64u) hist[b] = 0;
-            wave_lds_sync();
-            uint32_t rank[KI];
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                rank[k] = 0xffffffffu;
-                const uint32_t tp = (uint32_t)lane * KI + k, u = kStreamTile - 1u - tp;
-                if (!((tm[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
-                const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
-                const bool starts = ((tm[k] >> 18) & 1u) || u == u0, ends = ((tm[k] >> 19) & 1u) || u == u1 - 1u;
-                rank[k] = atomicAdd(&hist[(3u - R) * 64u + (63u - min(N, 63u))], 1u);
-                const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
-                const uint32_t g = (ur[k] >> 20) - b0s + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
-                const rawdtw_anchor_t sa = an[k + 1], ea = an[k];
-                if (starts) {
-                    const uint64_t c = chain_at(h * kHalf + (uint32_t)tid * KI + k);
-                    const uint64_t rb = a.ref_base[c];
-                    const uint32_t qb = a.read_base[c];
-                    // the sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
-                    const uint32_t c_r = (ur[k] & 0xfffffu) - (cr[k] & 0xfffffu) - b0r + 4u * adj, c_f = uf[k] - cf[k] - b0f + 4u * adj;
-                    const uint32_t off_r = qb + sa.query_position;
-                    const uint64_t off_f = rb + sa.target_position;
-                    const uint32_t p_r = c_r + ((off_r - c_r) & 3u), p_f = region + c_f + (((uint32_t)off_f - c_f) & 3u);
-                    rt.lo[0][g] = p_r & ~3u; rt.lo[1][g] = p_f & ~3u;
-                    rt.D[0][g] = (int32_t)(p_r - sa.query_position); rt.D[1][g] = (int32_t)(p_f - sa.target_position);
-                    rt.src[0][g] = (long long)off_r - (long long)p_r; rt.src[1][g] = (long long)off_f - (long long)p_f;
-                }
-                if (ends) { rt.end[0][g] = ea.query_position + 1u; rt.end[1][g] = ea.target_position + 1u; }
-            }
-            wave_lds_sync(); // (the run table and the counts are complete)
-            // the bins' first places (three a lane), written back over the counts
-            const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
-            const uint32_t hsum = h0 + h1 + h2, hincl = wave_scan_incl(hsum);
-            const uint32_t n_jobs = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
-            hist[3 * lane] = hincl - hsum; hist[3 * lane + 1] = hincl - hsum + h0; hist[3 * lane + 2] = hincl - hsum + h0 + h1;
-            wave_lds_sync();
-            // the records, in the order the lanes of the DTW launch take them
-#pragma unroll
-            for (int k = 0; k < KI; k++) {
-                if (rank[k] == 0xffffffffu) continue;
-                const uint32_t tp = (uint32_t)lane * KI + k, u = kStreamTile - 1u - tp;
-                const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
-                const uint32_t place = hist[(3u - R) * 64u + (63u - min(N, 63u))] + rank[k];
-                const uint32_t g = (ur[k] >> 20) - b0s + (cut_run ? 1u : 0u) - 1u;
-                const rawdtw_anchor_t sa = an[k + 1];
-                const uint32_t p_r = sa.query_position + (uint32_t)rt.D[0][g], p_f = sa.target_position + (uint32_t)rt.D[1][g];
-                const bool swap = (tm[k] >> 17) & 1u;
-                a.recs[(uint64_t)tile * kStreamRecStride + rec_off + place] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), (tm[k] & 0x1ffffu) | (u << 17));
-            }
-            // the copy orders: a run's range of 16-byte pieces, per arena
-            if ((uint32_t)lane < 2u * n_runs) {
-                const uint32_t g = (uint32_t)lane >> 1, w = (uint32_t)lane & 1u;
-                const long long src = rt.src[w][g];
-                a.runtab[(uint64_t)slot * (2u * kStreamMaxSeg) + lane] =
-                    make_uint4(rt.lo[w][g] >> 2, (rt.end[w][g] + (uint32_t)rt.D[w][g] + 3u) >> 2, (uint32_t)(unsigned long long)src, (uint32_t)((unsigned long long)src >> 32));
-            }
-            wave_lds_sync(); // (the run table and the bins are read: the next pass writes them again)
-            if (lane == 0) {
-                const uint32_t idx = atomicAdd(&s_npass, 1u);
-                if (idx < kPassCap) s_pass[idx] = make_uint4(tile, slot, n_jobs | (n_runs << 16), region | (rec_off << 16));
-                else atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile);
-            }
-            if (last) break;
-            rec_off += (n_jobs + 1u) & ~1u; // (passes start on 16-byte boundaries)
-            if (rec_off + (kStreamTile - u1) > kStreamRecStride) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (> 64 passes)
-            u0 = u1; b0r = e_r; b0f = e_f; b0s = e_s;
-        }
+    if (CARRY && a.carried && ih < a.n_anchors) a.carried[ih >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
+    {
+        const unsigned long long any_tile = __ballot(half_tiles != 0u); // (every lane votes: taken before the branch on the lane)
+        if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << ((h * kHalf + (uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
     }
     }
     if (carry) {
@@ -673,13 +522,18 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
     __syncthreads();
     if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
-    // The DTW launch's work list: the unit's passes (one returning atomic a unit)
-    if (tid == 0 && s_npass) s_tbase = (uint32_t)atomicAdd(&a.cnt[kCntTodo], (unsigned long long)min(s_npass, kPassCap));
+    // The DTW launch's work list: the unit's tiles that have something to score, each with its first chain.  (Tiles without a
+    // tile-class part -- all of their parts carried over from the round before, or on the side list -- are never touched.)
+    if (tid == 0 && s_todo) {
+        const uint32_t tiles_per_unit = AT / a.tile_anchors, todo = s_todo;
+        uint64_t at = atomicAdd(&a.cnt[kCntTodo], (unsigned long long)__popc(todo));
+        for (uint32_t t = 0; t < tiles_per_unit; t++)
+            if ((todo >> t) & 1u) a.tlist[at++] = make_uint2(unit * tiles_per_unit + t, (uint32_t)chain_at(t * a.tile_anchors));
+    }
     if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
     __syncthreads();
-    if ((uint32_t)tid < min(s_npass, kPassCap) && (uint64_t)s_tbase + tid < a.n_slots) a.todo[s_tbase + tid] = s_pass[tid];
     if (s_ocnt) {
         const uint64_t obase = s_obase;
 #pragma unroll
@@ -737,6 +591,230 @@ __global__ __launch_bounds__(kScanTC) void k_scan_compact(const StreamArgs a, ui
 __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainDesc *__restrict__ chains)
 {
     chain_desc_body(a, chains, (uint64_t)blockIdx.x * kScanT + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_plan: the DTW launch's passes, a wave a tile of the scan's tile list.  A tile = 512 consecutive anchors; lane L holds its
+// positions 8 L .. 8 L + 7; the item at position t ends at anchor t, starts at anchor t + 1 and is item u = 511 - t of the
+// layout order: along a chain (stored end-first) u ascends with the addresses.  A run = consecutive tile parts of a chain;
+// its first part (`starts`) is the one whose predecessor in u (position + 1) is no tile part.  The wave lays the tile's
+// image out (RunTab), sorts its jobs into the order the lanes of k_runs take them, and leaves in memory, per PASS (all of the
+// tile's parts, or as many as fit the image budget and the run table): the job records, the copy orders, the list entry.
+// The waves of a workgroup share nothing: no workgroup barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPlanT = 256;
+__global__ __launch_bounds__(kPlanT) void k_plan(const StreamArgs a)
+{
+    constexpr int KI = 8;
+    constexpr uint32_t kWords = kStreamTile / 32 + 1;
+    static_assert(kStreamTile == 64 * KI, "a wave a tile, eight items a lane");
+    __shared__ uint32_t s_hist[kPlanT / 64][kSortBins];
+    __shared__ RunTab s_rtab[kPlanT / 64];
+    __shared__ uint32_t s_tmp[kPlanT / 64][8];
+    __shared__ uint32_t s_maskw[kPlanT / 64][kWords + 1], s_prew[kPlanT / 64][kWords + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = (uint32_t)tid >> 6;
+    // (a batch the scan declined is redone through the job list: nothing may be derived from its anchors)
+    if (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) return;
+    const uint32_t n_list = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
+    const uint32_t li = blockIdx.x * (kPlanT / 64) + wv; // the wave's entry of the tile list; its first pass takes the same index
+    if (li >= n_list) return;
+    const uint2 te = a.tlist[li];
+    const uint32_t tile = te.x;
+    const uint64_t c0 = te.y, base = (uint64_t)tile * kStreamTile;
+    uint32_t *hist = s_hist[wv], *tmp = s_tmp[wv], *mask = s_maskw[wv], *pre = s_prew[wv];
+    RunTab &rt = s_rtab[wv];
+    // the tile's anchors: KI + 1 consecutive entries a lane (the last one is the next lane's first)
+    rawdtw_anchor_t an[KI + 1];
+    const uint64_t i0 = base + (uint64_t)lane * KI;
+#pragma unroll
+    for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
+    uint32_t carried = 0;
+    if (a.carried && i0 < a.n_anchors) carried = a.carried[i0 >> 3]; // (chunk rounds: these parts took their cost from the round before)
+    // chain starts inside [base, base + 512] from the chains' offsets, starting at the chain that owns the tile's first anchor
+    // (the end of the anchor list counts as a chain start); chains are few a tile: mostly one round of loads
+    if ((uint32_t)lane < kWords) mask[lane] = 0;
+    wave_lds_sync();
+    for (uint64_t c = c0 + (uint32_t)lane;; c += 64) { // (the exit is wave-uniform)
+        const bool in = c <= a.n_chains;
+        const uint64_t st = in ? a.anchor_off[c] : ~0ull;
+        if (in && st >= base && st <= base + kStreamTile) atomicOr(&mask[(uint32_t)(st - base) >> 5], 1u << ((uint32_t)(st - base) & 31u));
+        const unsigned long long more = __ballot(in && st < base + kStreamTile);
+        if (!(more >> 63)) break; // (the offsets ascend: the last lane's is the largest)
+    }
+    wave_lds_sync();
+    {   // chain starts before each word of the mask
+        const uint32_t pc = (uint32_t)lane < kWords ? __popc(mask[lane]) : 0u;
+        const uint32_t incl = wave_scan_incl(pc);
+        if ((uint32_t)lane < kWords) pre[lane] = incl - pc;
+    }
+    wave_lds_sync();
+    // the chain of the anchor at position p of the tile: c0 + the chain starts in positions 1 .. p
+    auto chain_at = [&](uint32_t p) { return c0 + (pre[p >> 5] + __popc(mask[p >> 5] & (0xffffffffu >> (31u - (p & 31u)))) - (mask[0] & 1u)); };
+    // the tile parts: N | M << 7 | R << 14 | exclude_last << 16 | swapped << 17 | 1 << 20 (0: the lane bodies do not take it)
+    uint32_t tm[KI];
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        const uint32_t p = (uint32_t)lane * KI + k;
+        tm[k] = 0u;
+        if (base + p >= a.n_anchors || mask_bit(mask, p + 1) || ((carried >> k) & 1u)) continue; // no part ends here, or its cost is there already
+        const Part pt = classify(a, an[k + 1], an[k]);
+        if (!pt.tile) continue;
+        const uint32_t N = pt.n > pt.m ? pt.n : pt.m, M = pt.n > pt.m ? pt.m : pt.n;
+        tm[k] = N | (M << 7) | ((uint32_t)pt.R << 14) | ((mask_bit(mask, p) ? 0u : 1u) << 16) | ((pt.n < pt.m ? 1u : 0u) << 17) | (1u << 20);
+    }
+    const uint32_t n_first = n_list;
+    (void)n_first;
+    {
+        const int t_first = (int)((tm[0] >> 20) & 1u), t_last = (int)((tm[KI - 1] >> 20) & 1u);
+        const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
+        const bool above = __builtin_amdgcn_update_dpp(0, t_first, 0x130, 0xf, 0xf, false) != 0; // lane + 1's first item (lane 63: none)
+        // an item's contributions to the regions' running sums (events | run start << 20; reference), from its record
+        // (kept short on registers: recomputed where needed rather than held for the eight items)
+        auto contrib = [](const uint32_t t, uint32_t &c_r, uint32_t &c_f) {
+            const bool tl = (t >> 20) & 1u, starts = (t >> 18) & 1u, ends = (t >> 19) & 1u, swap = (t >> 17) & 1u;
+            const uint32_t N = t & 127u, M = (t >> 7) & 127u, n = swap ? M : N, m = swap ? N : M;
+            c_r = tl ? ((starts ? n + 3u : n - 1u) + (ends ? 3u : 0u)) | ((starts ? 1u : 0u) << 20) : 0u;
+            c_f = tl ? (starts ? m + 3u : m - 1u) + (ends ? 3u : 0u) : 0u;
+        };
+        uint32_t lr = 0, lf = 0;
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const bool t = (tm[k] >> 20) & 1u;
+            const bool pred = k + 1 < KI ? ((tm[k + 1 < KI ? k + 1 : k] >> 20) & 1u) != 0u : above;
+            const bool succ = k > 0 ? ((tm[k > 0 ? k - 1 : 0] >> 20) & 1u) != 0u : below;
+            tm[k] |= ((t && !pred ? 1u : 0u) << 18) | ((t && !succ ? 1u : 0u) << 19);
+            uint32_t c_r, c_f;
+            contrib(tm[k], c_r, c_f);
+            lr += c_r; lf += c_f;
+        }
+        // sums in layout order from sums in position order: before item u lie the items at higher positions,
+        //     sum over v <= u  =  total - (sum over positions <= t) + own
+        const uint32_t ir = wave_scan_incl(lr), jf = wave_scan_incl(lf);
+        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)ir, 63), tot_f = (uint32_t)__builtin_amdgcn_readlane((int)jf, 63);
+        const uint32_t base_r = tot_r - (ir - lr), base_f = tot_f - (jf - lf); // total - (the lanes below this one)
+        const uint32_t budget = a.lds_floats & ~3u;
+        uint32_t u0 = 0, b0r = 0, b0f = 0, b0s = 0; // the pass's first item, the sums before it
+        uint32_t rec_off = 0;                       // the pass's first record in the tile's stretch of the record array
+        for (bool first = true;; first = false) { // (wave-uniform)
+            // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table (+ 4 + 4
+            // floats and one run when the first item continues a run); the sums ascend with u: the fitting items are a prefix
+            uint32_t fits = 0;
+            {
+                uint32_t xr = base_r, xf = base_f; // inclusive layout-order sums: own + everything at higher positions
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    uint32_t c_r, c_f;
+                    contrib(tm[k], c_r, c_f);
+                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), sr = xr & 0xfffffu, ss = xr >> 20;
+                    if (u >= u0 && ((sr - b0r + 7u) & ~3u) + ((xf - b0f + 7u) & ~3u) <= budget && ss - b0s + 1u <= kStreamMaxSeg) fits++;
+                    xr -= c_r; xf -= c_f;
+                }
+            }
+            fits = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fits), 63);
+            const uint32_t u1 = min(u0 + fits, kStreamTile);
+            if (u1 <= u0) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (cannot happen: one part always fits)
+            // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
+            {
+                uint32_t xr = base_r, xf = base_f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    uint32_t c_r, c_f;
+                    contrib(tm[k], c_r, c_f);
+                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
+                    if (u == u1 - 1u) { tmp[0] = xr & 0xfffffu; tmp[1] = xf; tmp[2] = xr >> 20; }
+                    if (u == u0) tmp[3] = ((tm[k] >> 20) & 1u) && !((tm[k] >> 18) & 1u) ? 1u : 0u;
+                    xr -= c_r; xf -= c_f;
+                }
+            }
+            wave_lds_sync();
+            const uint32_t e_r = tmp[0], e_f = tmp[1], e_s = tmp[2];
+            const bool cut_run = tmp[3] != 0u; // the pass's first item continues a run of the pass before: it starts one here
+            const uint32_t region = (e_r - b0r + (cut_run ? 4u : 0u) + 3u) & ~3u;
+            const uint32_t n_runs = e_s - b0s + (cut_run ? 1u : 0u);
+            const bool last = u1 >= kStreamTile;
+            // the pass's slot of copy orders: the tile's own for its first pass, one of the pool's for the others
+            uint32_t slot = li;
+            if (!first) {
+                uint32_t sl = 0;
+                if (lane == 0) sl = a.n_tiles + (uint32_t)atomicAdd(&a.cnt[kCntPool], 1ull);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+                if (slot >= a.n_slots) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; }
+            }
+            for (uint32_t b = (uint32_t)lane; b < kSortBins; b += 64u) hist[b] = 0;
+            wave_lds_sync(); // (the words above are read, the bins are clear)
+            // the bins' sizes, the run table
+            {
+                uint32_t xr = base_r, xf = base_f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    uint32_t c_r, c_f;
+                    contrib(tm[k], c_r, c_f);
+                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
+                    const uint32_t sr = xr & 0xfffffu, sf = xf, ss = xr >> 20;
+                    xr -= c_r; xf -= c_f;
+                    if (!((tm[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
+                    const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
+                    const bool starts = ((tm[k] >> 18) & 1u) || u == u0, ends = ((tm[k] >> 19) & 1u) || u == u1 - 1u;
+                    atomicAdd(&hist[(3u - R) * 64u + (63u - min(N, 63u))], 1u);
+                    const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
+                    const uint32_t g = ss - b0s + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
+                    if (starts) {
+                        const rawdtw_anchor_t sa = an[k + 1];
+                        const uint64_t c = chain_at((uint32_t)lane * KI + k);
+                        const uint64_t rb = a.ref_base[c];
+                        const uint32_t qb = a.read_base[c];
+                        // the sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
+                        const uint32_t q_r = sr - (c_r & 0xfffffu) - b0r + 4u * adj, q_f = sf - c_f - b0f + 4u * adj;
+                        const uint32_t off_r = qb + sa.query_position;
+                        const uint64_t off_f = rb + sa.target_position;
+                        const uint32_t p_r = q_r + ((off_r - q_r) & 3u), p_f = region + q_f + (((uint32_t)off_f - q_f) & 3u);
+                        rt.lo[0][g] = p_r & ~3u; rt.lo[1][g] = p_f & ~3u;
+                        rt.D[0][g] = (int32_t)(p_r - sa.query_position); rt.D[1][g] = (int32_t)(p_f - sa.target_position);
+                        rt.src[0][g] = (long long)off_r - (long long)p_r; rt.src[1][g] = (long long)off_f - (long long)p_f;
+                    }
+                    if (ends) { rt.end[0][g] = an[k].query_position + 1u; rt.end[1][g] = an[k].target_position + 1u; }
+                }
+            }
+            wave_lds_sync(); // (the run table and the counts are complete)
+            // the bins' first places (three a lane), written back over the counts
+            const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
+            const uint32_t hsum = h0 + h1 + h2, hincl = wave_scan_incl(hsum);
+            const uint32_t n_jobs = (uint32_t)__builtin_amdgcn_readlane((int)hincl, 63);
+            hist[3 * lane] = hincl - hsum; hist[3 * lane + 1] = hincl - hsum + h0; hist[3 * lane + 2] = hincl - hsum + h0 + h1;
+            wave_lds_sync();
+            // the records, in the order the lanes of the DTW launch take them (a bin's jobs in any order: they are alike)
+            {
+                uint32_t xs = base_r >> 20;
+#pragma unroll
+                for (int k = 0; k < KI; k++) {
+                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), ss = xs;
+                    xs -= (tm[k] >> 18) & (tm[k] >> 20) & 1u; // (a run start counts once)
+                    if (!((tm[k] >> 20) & 1u) || u < u0 || u >= u1) continue;
+                    const uint32_t N = tm[k] & 127u, R = (tm[k] >> 14) & 3u;
+                    const uint32_t place = atomicAdd(&hist[(3u - R) * 64u + (63u - min(N, 63u))], 1u);
+                    const uint32_t g = ss - b0s + (cut_run ? 1u : 0u) - 1u;
+                    const rawdtw_anchor_t sa = an[k + 1];
+                    const uint32_t p_r = sa.query_position + (uint32_t)rt.D[0][g], p_f = sa.target_position + (uint32_t)rt.D[1][g];
+                    const bool swap = (tm[k] >> 17) & 1u;
+                    a.recs[(uint64_t)tile * kStreamRecStride + rec_off + place] = make_uint2((swap ? p_f : p_r) | ((swap ? p_r : p_f) << 16), (tm[k] & 0x1ffffu) | (u << 17));
+                }
+            }
+            // the copy orders: a run's range of 16-byte pieces, per arena
+            if ((uint32_t)lane < 2u * n_runs) {
+                const uint32_t g = (uint32_t)lane >> 1, w = (uint32_t)lane & 1u;
+                const long long src = rt.src[w][g];
+                a.runtab[(uint64_t)slot * (2u * kStreamMaxSeg) + lane] =
+                    make_uint4(rt.lo[w][g] >> 2, (rt.end[w][g] + (uint32_t)rt.D[w][g] + 3u) >> 2, (uint32_t)(unsigned long long)src, (uint32_t)((unsigned long long)src >> 32));
+            }
+            wave_lds_sync(); // (the run table and the bins are read: the next pass writes them again)
+            if (lane == 0) a.todo[slot] = make_uint4(tile, slot, n_jobs | (n_runs << 16), region | (rec_off << 16)); // (a pass's list entry sits at its slot)
+            if (last) break;
+            rec_off += (n_jobs + 1u) & ~1u; // (passes start on 16-byte boundaries)
+            if (rec_off + (kStreamTile - u1) > kStreamRecStride) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (> 64 passes)
+            u0 = u1; b0r = e_r; b0f = e_f; b0s = e_s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -957,7 +1035,10 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         t_prev = t;
     };
     // ---- passes: the entries of the scan's work list, pulled from the queue two ahead ----
-    const uint32_t n_pass = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_slots);
+    // list index i: the first pass of the scan's i-th tile (slot i), then the pool's passes (slots n_tiles ..)
+    const uint32_t n_first = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
+    const uint32_t n_pass = n_first + (uint32_t)min<unsigned long long>(a.cnt[kCntPool], (unsigned long long)(a.n_slots - a.n_tiles));
+    auto entry_of = [&](const uint32_t i) { return a.todo[i < n_first ? i : a.n_tiles + (i - n_first)]; };
     // thread 0's queue state: `head`, the list index of the next pass, the raw ticket of the one after it; wave 0 holds the
     // next pass's entry (asked for a pass ahead)
     uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), i_next = 0xffffffffu;
@@ -972,8 +1053,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         }
         i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
         const uint32_t i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
-        const uint4 e0 = i0 != 0xffffffffu ? a.todo[i0] : none;
-        if (i1 != 0xffffffffu) e_next = a.todo[i1];
+        const uint4 e0 = i0 != 0xffffffffu ? entry_of(i0) : none;
+        if (i1 != 0xffffffffu) e_next = entry_of(i1);
         if (tid == 0) s_ent[0] = e0;
     }
     __syncthreads();
@@ -1046,7 +1127,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         }
         if (wv == 0) {
             const uint32_t in = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
-            e_next = in != 0xffffffffu ? a.todo[in] : none;
+            e_next = in != 0xffffffffu ? entry_of(in) : none;
         }
         __builtin_amdgcn_s_waitcnt(0x0f70); // (the next pass's records have landed)
         stamp(5);
@@ -1293,6 +1374,7 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     } else if (a.carry_chain) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
+    if (a.n_tiles) hipLaunchKernelGGL(k_plan, dim3((a.n_tiles + kPlanT / 64 - 1) / (kPlanT / 64)), dim3(kPlanT), 0, s, a);
     return hipGetLastError();
 }
 
