@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--decoys-per-read", type=float, default=None)
     ap.add_argument("--rounds", type=int, default=4, help="chunk rounds of the cross-round cache block (0: skip it)")
     ap.add_argument("--modes-reads", type=int, default=8192, help="reads of the configs[2] block (0: skip it)")
+    ap.add_argument("--trace-fresh", type=int, default=0,
+                    help="profiling runs: only the fresh-batch loop (inputs resident), this many steps, no JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / reduction plumbing only: no device work, synthetic counters (CPU tests)")
     return ap.parse_args()
@@ -569,6 +571,10 @@ def main():
     K = args.steps
     # ---- warm-up (workspace pools, code objects), then the three timed loops ----
     pipeline(max(args.warmup, slots), pcie=False)
+    if args.trace_fresh:
+        t = timed_region(lambda: pipeline(args.trace_fresh, pcie=False))
+        print("fresh-batch loop: %d steps, %.4f ms per step" % (args.trace_fresh, t * 1e3 / args.trace_fresh), file=sys.stderr)
+        return
     pipeline(slots, pcie=True)
     pipeline(slots, pcie="compact")
     t_fresh = repeat_region(lambda: pipeline(K, pcie=False, host=host_s))

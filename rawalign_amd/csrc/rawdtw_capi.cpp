@@ -63,6 +63,8 @@ struct rawdtw_ctx {
     static constexpr int kSide = 3;
     hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr};
+    hipStream_t wide = nullptr;                 // sync-free batches: the side list's launch runs here, beside the tiles' launch
+    hipEvent_t ev_wide_fork = nullptr, ev_wide_join = nullptr;
     bool serial_launches = false;
     int n_side = 0; // side streams used to fork the launches of one batch (RAWDTW_SIDE_STREAMS, 0..kSide). 0: the
                     // launches of a batch run in sequence on its one stream and overlap comes from several batches in
@@ -83,7 +85,8 @@ struct rawdtw_ctx {
     uint64_t device_plan_min_jobs = 0; // smaller batches go through the job list
     std::vector<StreamWs> ws_free;     // workspaces of destroyed batches, reused by the next ones (no hipMalloc in the steady state)
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
-    int stream_threads = 256;                   // workgroup size of k_stream (256 or 512: 1024 / 2048 jobs per tile)
+    int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
+    uint32_t wide_blocks = 512;                 // workgroups (four waves each) of the side list's launch
     int stream_threads_cached = 0;
     int stream_blocks_per_cu = 4;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
     int stream_bpc_cached = -1;
@@ -176,6 +179,7 @@ struct rawdtw_batch {
     uint64_t *d_chain_off = nullptr;
     uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
     bool fold_fused = false;          // sync-free batch: fold and select are one launch (k_fold_select), no fold order was built
+    bool wide_forked = false;         // the side list's launch for the next run is out already (it went with the planning launches)
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
     bool own_chain_arrays = false;  // the arrays above are hipMalloc'd (job-list path) rather than carved from `ws`
@@ -1160,7 +1164,10 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
     if (const char *e = getenv("RAWDTW_SIDE_STREAMS")) ctx->n_side = std::min(std::max(atoi(e), 0), (int)rawdtw_ctx::kSide);
     // only the side streams that will be used: HIP maps streams onto a handful of hardware queues, and an
     // idle stream still takes a slot in that rotation
-    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->wide, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_wide_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_wide_join, hipEventDisableTiming) == hipSuccess;
     for (int k = 0; k < ctx->n_side && ok; k++)
         ok = hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) == hipSuccess;
@@ -1214,6 +1221,9 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->wide) { (void)hipStreamSynchronize(ctx->wide); (void)hipStreamDestroy(ctx->wide); }
+    if (ctx->ev_wide_fork) (void)hipEventDestroy(ctx->ev_wide_fork);
+    if (ctx->ev_wide_join) (void)hipEventDestroy(ctx->ev_wide_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     drop_reference(ctx);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
@@ -1244,6 +1254,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "wide_blocks")) { ctx->wide_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_tail")) { ctx->debug_skip_tail = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "sort_n")) { ctx->sort_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
     if (!strcmp(name, "sort_r1_n")) { ctx->sort_r1_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
@@ -1796,6 +1807,17 @@ void ws_release(rawdtw_ctx *ctx, StreamWs &w)
 
 bool stream_declined(const rawdtw_batch *b);
 
+// the side list's launch on the context's second stream: behind everything enqueued on the main stream so far; the main
+// stream joins it (ev_wide_join) before the fold
+static hipError_t stream_wide_fork(rawdtw_ctx *ctx, const StreamArgs &a)
+{
+    hipError_t he = hipEventRecord(ctx->ev_wide_fork, ctx->stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ctx->wide, ctx->ev_wide_fork, 0);
+    if (he == hipSuccess) he = stream_wide(a, ctx->wide_blocks, ctx->wide);
+    if (he == hipSuccess) he = hipEventRecord(ctx->ev_wide_join, ctx->wide);
+    return he;
+}
+
 // the stream path: everything rawdtw_batch_create does for a sparse + banded batch -- O(1) host work: a workspace from the
 // pool, five copies and three launches enqueued
 int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
@@ -1901,6 +1923,14 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
     b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
     hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
+    // the side list's launch forks off here, beside the pass planning and the tiles' launch (batch_enqueue_one joins it before
+    // the fold; a batch that is run again launches it again there)
+    b->wide_forked = false;
+    if (e == hipSuccess && !(ctx->stream_debug & 4u)) {
+        e = stream_wide_fork(ctx, a);
+        b->wide_forked = e == hipSuccess;
+    }
+    if (e == hipSuccess) e = stream_plan_passes(a, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
     // the persistent grid: what the device holds at this LDS size
@@ -2453,12 +2483,20 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
         if (ctx->n_ev < batch->sa.n_ev || ctx->n_ref < batch->sa.n_ref)
             return fail(ctx, RAWDTW_ERR_INVALID, "an arena shrank after the batch was created: create the batch again");
         batch->sa.ev = ctx->d_ev; batch->sa.ref = ctx->d_ref;
-        if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        // the side list beside the tiles: fork onto the context's second stream behind the planning launches, join before the fold
+        const bool wide = !(ctx->stream_debug & 4u);
+        if (wide && !batch->wide_forked) { // (a batch that runs again; the first run's launch went out with the planning)
+            const hipError_t he = stream_wide_fork(ctx, batch->sa);
+            if (he != hipSuccess) st = hip_fail(ctx, he, "side list launch");
+        }
+        batch->wide_forked = false;
+        if (st == RAWDTW_OK && e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) {
             hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, batch->stream_runs++ > 0, ctx->stream);
             if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
         }
         if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && wide && hipStreamWaitEvent(ctx->stream, ctx->ev_wide_join, 0) != hipSuccess) st = RAWDTW_ERR_DEVICE;
     } else st = run_all_launches(ctx, batch->plan, e);
     for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
         if (e && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;

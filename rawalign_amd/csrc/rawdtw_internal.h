@@ -198,6 +198,8 @@ struct StreamArgs {
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
+hipError_t stream_plan_passes(const StreamArgs &a, hipStream_t s);
+hipError_t stream_wide(const StreamArgs &a, uint32_t blocks, hipStream_t s);
 hipError_t stream_fold_select(const StreamArgs &a, const ChainDesc *chains, const uint64_t *chain_off, uint64_t n_reads, float bonus, int fused,
                               float min_score, float *full_score, float *att_last, float *score, uint8_t *keep, hipStream_t s);
 hipError_t stream_count_cells(const StreamArgs &a, unsigned long long *d_total, hipStream_t s);

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainD
 // The waves of a workgroup share nothing: no workgroup barrier.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPlanT = 256;
-__global__ __launch_bounds__(kPlanT) void k_plan(const StreamArgs a)
+__global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
 {
     constexpr int KI = 8;
     constexpr uint32_t kWords = kStreamTile / 32 + 1;
@@ -699,37 +699,43 @@ __global__ __launch_bounds__(kPlanT) void k_plan(const StreamArgs a)
         for (bool first = true;; first = false) { // (wave-uniform)
             // the items that fit: while the image of the parts so far stays inside the budget and their runs in the table (+ 4 + 4
             // floats and one run when the first item continues a run); the sums ascend with u: the fitting items are a prefix
-            uint32_t fits = 0;
-            {
-                uint32_t xr = base_r, xf = base_f; // inclusive layout-order sums: own + everything at higher positions
+            // (the rule: everything that is left fits -- the totals say so, and no item has to be looked at)
+            const bool all_fit = ((((tot_r & 0xfffffu) - b0r + 7u) & ~3u) + ((tot_f - b0f + 7u) & ~3u) <= budget) && ((tot_r >> 20) - b0s + 1u <= kStreamMaxSeg);
+            uint32_t u1 = kStreamTile, e_r = tot_r & 0xfffffu, e_f = tot_f, e_s = tot_r >> 20;
+            bool cut_run = false;
+            if (!all_fit || u0 != 0u) {
+                uint32_t fits = 0;
+                {
+                    uint32_t xr = base_r, xf = base_f; // inclusive layout-order sums: own + everything at higher positions
 #pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    uint32_t c_r, c_f;
-                    contrib(tm[k], c_r, c_f);
-                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), sr = xr & 0xfffffu, ss = xr >> 20;
-                    if (u >= u0 && ((sr - b0r + 7u) & ~3u) + ((xf - b0f + 7u) & ~3u) <= budget && ss - b0s + 1u <= kStreamMaxSeg) fits++;
-                    xr -= c_r; xf -= c_f;
+                    for (int k = 0; k < KI; k++) {
+                        uint32_t c_r, c_f;
+                        contrib(tm[k], c_r, c_f);
+                        const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k), sr = xr & 0xfffffu, ss = xr >> 20;
+                        if (u >= u0 && ((sr - b0r + 7u) & ~3u) + ((xf - b0f + 7u) & ~3u) <= budget && ss - b0s + 1u <= kStreamMaxSeg) fits++;
+                        xr -= c_r; xf -= c_f;
+                    }
                 }
-            }
-            fits = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fits), 63);
-            const uint32_t u1 = min(u0 + fits, kStreamTile);
-            if (u1 <= u0) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (cannot happen: one part always fits)
-            // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
-            {
-                uint32_t xr = base_r, xf = base_f;
+                fits = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(fits), 63);
+                u1 = min(u0 + fits, kStreamTile);
+                if (u1 <= u0) { if (lane == 0) atomicMin(&a.cnt[kCntOverflow], (unsigned long long)tile); break; } // (cannot happen: one part always fits)
+                // the owner of the pass's last item publishes the sums behind it; the owner of its first item, whether it cuts a run
+                {
+                    uint32_t xr = base_r, xf = base_f;
 #pragma unroll
-                for (int k = 0; k < KI; k++) {
-                    uint32_t c_r, c_f;
-                    contrib(tm[k], c_r, c_f);
-                    const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
-                    if (u == u1 - 1u) { tmp[0] = xr & 0xfffffu; tmp[1] = xf; tmp[2] = xr >> 20; }
-                    if (u == u0) tmp[3] = ((tm[k] >> 20) & 1u) && !((tm[k] >> 18) & 1u) ? 1u : 0u;
-                    xr -= c_r; xf -= c_f;
+                    for (int k = 0; k < KI; k++) {
+                        uint32_t c_r, c_f;
+                        contrib(tm[k], c_r, c_f);
+                        const uint32_t u = kStreamTile - 1u - ((uint32_t)lane * KI + k);
+                        if (u == u1 - 1u) { tmp[0] = xr & 0xfffffu; tmp[1] = xf; tmp[2] = xr >> 20; }
+                        if (u == u0) tmp[3] = ((tm[k] >> 20) & 1u) && !((tm[k] >> 18) & 1u) ? 1u : 0u;
+                        xr -= c_r; xf -= c_f;
+                    }
                 }
+                wave_lds_sync();
+                e_r = tmp[0]; e_f = tmp[1]; e_s = tmp[2];
+                cut_run = tmp[3] != 0u; // the pass's first item continues a run of the pass before: it starts one here
             }
-            wave_lds_sync();
-            const uint32_t e_r = tmp[0], e_f = tmp[1], e_s = tmp[2];
-            const bool cut_run = tmp[3] != 0u; // the pass's first item continues a run of the pass before: it starts one here
             const uint32_t region = (e_r - b0r + (cut_run ? 4u : 0u) + 3u) & ~3u;
             const uint32_t n_runs = e_s - b0s + (cut_run ? 1u : 0u);
             const bool last = u1 >= kStreamTile;
@@ -931,37 +937,17 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_
 
 } // namespace
 
-// k_runs: TT threads per workgroup (256 or 512), a persistent grid over the scan's work list.  A list entry is one PASS: up
-// to 512 tile-class parts whose windows fit the image budget, with its job records (sorted: radius class, then longer side)
-// and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- the scan planned them (plan of a
-// tile: scan_unit_body), so a pass here is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records
-// at a time), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
-// start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer (issued
-// before pass i's staging, landed before its first barrier), and pass i + 2's list entry is being dequeued.
-// DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
-// carries none of their branches.
-template <int TT, bool DIAG>
-__global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
+// k_wide: the side list -- the one part in two hundred whose band the lane bodies of the tiles do not take -- as a launch of
+// its own, on a stream of its own beside the tiles' launch (it needs no LDS image and fits the registers the tiles' three
+// workgroups a compute unit leave free): wave-cooperative jobs, longest first, dealt over the waves of the grid.
+__global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 {
-    const uint32_t dbg = DIAG ? a.debug : 0u;
-    constexpr uint32_t kWaves = TT / 64, kRT = 2u * kStreamMaxSeg;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *win = smem;                                                    // the pass's LDS image
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);            // 2 x kStreamTile job records
-    uint4 *rtab = reinterpret_cast<uint4 *>(rec + 2u * kStreamTile);      // 2 x kRT copy orders
-    __shared__ uint4 s_ent[2];                 // the passes' list entries, by parity (x = 0xffffffff: none)
-    __shared__ uint32_t s_seq;
-    __shared__ uint32_t s_declined;
+    const uint32_t dbg = a.debug;
+    constexpr uint32_t kWaves = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
-
-    // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
-    // list: nothing to do here, and nothing may be derived from its records
-    if (tid == 0)
-        s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
-    __syncthreads();
-    if (s_declined) return;
-
+    // (a batch the scan declined is redone through the job list)
+    if (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) return;
     // ---- the side list: wave-cooperative jobs dealt over ALL waves of the grid, wave-per-job classes (longest first) to the
     // first waves: a long job starts at once and runs next to the tiles instead of behind them ----
     if (!(dbg & 4u)) {
@@ -1004,6 +990,39 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
             else lane_global_wave<8>(a.ojobs + n_w + n_g16 + n_l, (uint32_t)n_m, (uint32_t)(it - n_w - it_g16 - it_l), lane, a.ev, a.ref, a.out);
         }
     }
+
+}
+
+// k_runs: TT threads per workgroup (256 or 512), a persistent grid over the scan's work list.  A list entry is one PASS: up
+// to 512 tile-class parts whose windows fit the image budget, with its job records (sorted: radius class, then longer side)
+// and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- the scan planned them (plan of a
+// tile: scan_unit_body), so a pass here is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records
+// at a time), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
+// start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer (issued
+// before pass i's staging, landed before its first barrier), and pass i + 2's list entry is being dequeued.
+// DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
+// carries none of their branches.
+template <int TT, bool DIAG>
+__global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32_t lds_floats)
+{
+    const uint32_t dbg = DIAG ? a.debug : 0u;
+    constexpr uint32_t kWaves = TT / 64, kRT = 2u * kStreamMaxSeg;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *win = smem;                                                    // the pass's LDS image
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);            // 2 x kStreamTile job records
+    uint4 *rtab = reinterpret_cast<uint4 *>(rec + 2u * kStreamTile);      // 2 x kRT copy orders
+    __shared__ uint4 s_ent[2];                 // the passes' list entries, by parity (x = 0xffffffff: none)
+    __shared__ uint32_t s_seq;
+    __shared__ uint32_t s_declined;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wv = (uint32_t)tid >> 6;
+
+    // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
+    // list: nothing to do here, and nothing may be derived from its records
+    if (tid == 0)
+        s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
+    __syncthreads();
+    if (s_declined) return;
 
     // LDS-DMA: one wave instruction moves 16 bytes a lane straight into LDS at `dst` + 16 * lane; inactive lanes move
     // nothing.  `dst` must be the same in every lane.
@@ -1374,7 +1393,24 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     } else if (a.carry_chain) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
-    if (a.n_tiles) hipLaunchKernelGGL(k_plan, dim3((a.n_tiles + kPlanT / 64 - 1) / (kPlanT / 64)), dim3(kPlanT), 0, s, a);
+    return hipGetLastError();
+}
+
+// ... and the passes of the DTW launch (behind the scan: the side list's launch can start beside this one)
+hipError_t stream_plan_passes(const StreamArgs &a, hipStream_t s)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_plan, dim3((a.n_tiles + kPlanT / 64 - 1) / (kPlanT / 64)), dim3(kPlanT), 0, s, a);
+    return hipGetLastError();
+}
+
+// the side list's launch (beside the tiles': its own stream)
+hipError_t stream_wide(const StreamArgs &a, uint32_t blocks, hipStream_t s)
+{
+    if (a.n_tiles == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_wide, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
