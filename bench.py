@@ -614,7 +614,7 @@ def main():
         lib.rawdtw_batch_destroy(handles[0])
         live[0] = False
     # ... and with all contexts submitting at once
-    plan_ms = []
+    plan_ms, wide_ms = [], []
     for sl in range(slots):
         create(sl, True)
         engines[sl]._check(lib.rawdtw_batch_run(engines[sl]._ctx, handles[sl]))
@@ -623,6 +623,8 @@ def main():
         engines[sl].sync()
         lib.rawdtw_batch_plan_ms(engines[sl]._ctx, handles[sl], C.byref(ms))
         plan_ms.append(ms.value)
+        lib.rawdtw_batch_wide_ms(engines[sl]._ctx, handles[sl], C.byref(ms))
+        wide_ms.append(ms.value)
     for e in engines:
         e.set_option("time_plan", 0)
     # ---- kernel replay: the resident planned batches' launches only ----
@@ -631,6 +633,11 @@ def main():
         pi, nc = ra._lib.PlanInfo(), C.c_uint64()
         engines[sl]._check(lib.rawdtw_batch_info(handles[sl], C.byref(pi), C.byref(nc)))
         infos.append({k: int(getattr(pi, k)) for k, _ in ra._lib.PlanInfo._fields_})
+    # the tiles' launch (k_runs) moves the tile-class jobs' bytes; the side list's are k_wide's (counter words: rawdtw_internal.h)
+    cntw = (C.c_uint64 * 64)(); ncw = C.c_uint32()
+    engines[0]._check(lib.rawdtw_batch_stream_counters(engines[0]._ctx, handles[0], cntw, 64, C.byref(ncw)))
+    K_TILE_JOBS, K_TILE_BYTES = 47, 48
+    tile_jobs0, tile_bytes0 = (int(cntw[K_TILE_JOBS]), int(cntw[K_TILE_BYTES])) if ncw.value else (infos[0]["n_jobs"], infos[0]["algorithmic_bytes"])
 
     def replay():
         for k in range(K):
@@ -674,12 +681,12 @@ def main():
     if rank == 0:
         T, Tp, Tr = float(np.median(r_fresh)), float(np.median(r_pcie)), float(np.median(r_replay))
         Tpp = float(np.median(r_pcie_plain))
-        lp = np.array(launches_in_pipeline)  # rows: steps, columns: [k_runs, fold, select]
-        dms = float(lp[:, 0].mean())
+        lp = np.array(launches_in_pipeline)  # rows: steps, columns: [k_wide, k_runs, fold + select, (select: in the launch before)]
+        dms = float(lp[:, 1].mean())
         plan_pipe, plan_al = float(np.median(plan_ms)), float(np.median(plan_alone))
-        sum_pipe = plan_pipe + float(lp.mean(axis=0).sum())
-        sum_alone = plan_al + float(alone_ms[:3].sum())
-        dbytes = infos[0]["algorithmic_bytes"]
+        sum_pipe = plan_pipe + float(np.median(wide_ms)) + float(lp.mean(axis=0).sum())  # (a fresh batch's k_wide goes out with its planning launches)
+        sum_alone = plan_al + float(alone_ms[:4].sum())
+        dbytes = tile_bytes0  # the passes' jobs: what k_runs moves (the side list's jobs are k_wide's)
         achieved = dbytes / (dms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
@@ -730,12 +737,12 @@ def main():
                         "call; `submit` (rawdtw_batch_submit = create + run) only enqueues"},
             "batch_create_ms": {"steady": create_ms["resident"], "from_pinned_host": create_ms["from_host"],
                                 "note": "host wall time of one rawdtw_batch_create call, steady state: O(1) host work, it only enqueues (no "
-                                        "synchronisation, no allocation); `planning_gpu_ms` = its launches (k_scan + k_side) on the "
+                                        "synchronisation, no allocation); `planning_gpu_ms` = its launches (k_scan + k_side + k_plan) on the "
                                         "device: alone on the chip / with all contexts submitting at once",
                                 "planning_gpu_ms": round(plan_al, 4), "planning_gpu_ms_in_pipeline": round(plan_pipe, 4)},
             "kernel_ms_sum_per_batch": {"alone": round(sum_alone, 4), "in_pipeline": round(sum_pipe, 4),
                                         "overlap_factor": round(sum_pipe / (T / K * 1e3), 3),
-                                        "note": "sum of a batch's launch durations (k_scan + k_side, k_runs, fold, select; HIP events): each "
+                                        "note": "sum of a batch's launch durations (planning, k_wide, k_runs, fold + select; HIP events): each "
                                                 "alone on the chip, and bracketed inside the pipeline, where the batches in flight stretch "
                                                 "each other -- overlap_factor = that sum / ms_per_step = batches effectively in flight"},
             "totals_over_timed_steps": {"reads": reads_t, "chains": chains_t, "dtw_jobs": jobs_t, "cells": cells_t,
@@ -746,21 +753,24 @@ def main():
             "whole_step_hbm_frac": bytes_t / T / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_runs", "launch_ms": dms,
-                         "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": infos[0]["n_jobs"],
+                         "algorithmic_bytes_per_launch": dbytes, "jobs_per_launch": tile_jobs0,
                          "launch_window": {"first_dispatch": timed_pass_first, "count": timed_pass_count,
                                            "note": "launch_ms is over these k_runs dispatches of the process (0-based, in issue "
                                                    "order); scripts/trace_window.py averages the same ones in a rocprofv3 kernel trace"},
-                         "note": "achieved = algorithmic bytes of the batch's jobs (4(n+m)+36 each, SURVEY.md 8d) / launch_ms, the mean "
-                                 "HIP-event bracket of the batch's one DTW launch inside the fresh-batch pipeline (recorded on the "
-                                 "launch's own stream).  That bracket is an OVERLAPPED wall bracket: the launch shares the chip with "
+                         "note": "achieved = algorithmic bytes of the launch's jobs (4(n+m)+36 each, SURVEY.md 8d: the tile-class jobs, "
+                                 "99.5 % of the batch's; the wide bands are k_wide's) / launch_ms, the mean HIP-event bracket of the "
+                                 "batch's k_runs launch inside the fresh-batch pipeline (recorded on the launch's own stream).  That bracket is an OVERLAPPED wall bracket: the launch shares the chip with "
                                  "the other contexts' launches (kernel_ms_sum_per_batch.overlap_factor).  `alone` = the same launch "
                                  "repeated on an idle chip: the kernel's own figure; `traffic` = HBM bytes by PMC counters",
-                         "alone": {"launch_ms": float(alone_ms[0]), "achieved": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9,
-                                   "frac": dbytes / (float(alone_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-            "launches": {"in_pipeline_ms": {"k_scan+k_side": round(plan_pipe, 5), "k_runs": round(dms, 5), "chain_fold": round(float(lp[:, 1].mean()), 5),
-                                            "read_select": round(float(lp[:, 2].mean()), 5)},
-                         "alone_ms": {"k_scan+k_side": round(plan_al, 5), "k_runs": round(float(alone_ms[0]), 5), "chain_fold": round(float(alone_ms[1]), 5),
-                                      "read_select": round(float(alone_ms[2]), 5)}},
+                         "alone": {"launch_ms": float(alone_ms[1]), "achieved": dbytes / (float(alone_ms[1]) * 1e-3) / 1e9,
+                                   "frac": dbytes / (float(alone_ms[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "launches": {"in_pipeline_ms": {"k_scan+k_side+k_plan": round(plan_pipe, 5), "k_wide": round(float(np.median(wide_ms)), 5), "k_runs": round(dms, 5),
+                                            "k_fold_select": round(float(lp[:, 2].mean()), 5)},
+                         "alone_ms": {"k_scan+k_side+k_plan": round(plan_al, 5), "k_wide": round(float(alone_ms[0]), 5), "k_runs": round(float(alone_ms[1]), 5),
+                                      "k_fold_select": round(float(alone_ms[2]), 5)},
+                         "note": "a batch's launches in stream order: the planning (scan of the anchor list, side list's class order, the "
+                                 "passes' records and copy orders), the side list's wide bands (k_wide: 0.5 % of the jobs), the tiles' passes "
+                                 "(k_runs), fold + select"},
         }
         if world == 1 and args.rounds > 0:
             out["chunk_rounds"] = rounds_block(engines[0], lib, copt, B[0]["cb"], B[0]["inf"], args.rounds, local_rank)

@@ -384,8 +384,11 @@ int rawdtw_batch_launch_stats(const rawdtw_batch *batch, uint32_t i, uint32_t *k
 /* job_cost may be NULL; otherwise receives the per-job costs too */
 int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep,
                        float *job_cost);
-/* GPU time of the batch's planning kernels (HIP events; 0 unless the option "time_plan" was set before create) */
+/* GPU time of the batch's planning kernels (HIP events; 0 unless the option "time_plan" was set before create): the scan of
+ * the anchor list, the side list's class order, the passes' records and copy orders.  The wide bands' launch that goes out
+ * between them for the batch's first run is DTW work: rawdtw_batch_wide_ms. */
 int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
+int rawdtw_batch_wide_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
 /* Diagnostics of a device-planned batch (waits for its planning kernels): the planner's counters, in the order of
  * rawdtw_internal.h's StreamCounter -- 0 first invalid job (~0 none), 1 first tile over a capacity (~0 none), 2 jobs with
  * a band the side list does not take, 3 tile jobs, 4 their algorithmic bytes, 5 the side list's bytes, 6 side-list jobs,

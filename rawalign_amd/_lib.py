@@ -154,6 +154,7 @@ SYMBOLS = {
     "rawdtw_batch_launch_stats": (I32, [VP, U32, C.POINTER(U32), C.POINTER(I32), C.POINTER(U64), C.POINTER(U64), C.POINTER(U64)]),
     "rawdtw_batch_fetch": (I32, [VP, VP, VP, VP, VP]),
     "rawdtw_batch_plan_ms": (I32, [VP, VP, C.POINTER(F32)]),
+    "rawdtw_batch_wide_ms": (I32, [VP, VP, C.POINTER(F32)]),
     "rawdtw_batch_stream_counters": (I32, [VP, VP, VP, U32, VP]),
     "rawdtw_batch_destroy": (I32, [VP]),
     "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),

@@ -86,7 +86,9 @@ struct rawdtw_ctx {
     std::vector<StreamWs> ws_free;     // workspaces of destroyed batches, reused by the next ones (no hipMalloc in the steady state)
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
-    uint32_t wide_blocks = 512;                 // workgroups (four waves each) of the side list's launch
+    uint32_t wide_blocks = 256;                 // workgroups (four waves each) of the side list's launch
+    int wide_beside = 0;                        // 1: that launch on the context's second stream, beside the tiles' launch; 0: in line (measured:
+                                                // the fork and join cost the fresh-batch pipeline 8 % and the PCIe loop 17 %)
     int stream_threads_cached = 0;
     int stream_blocks_per_cu = 4;               // 0: what the occupancy query gives; else at most this many (leaves room for other streams' kernels)
     int stream_bpc_cached = -1;
@@ -179,7 +181,6 @@ struct rawdtw_batch {
     uint64_t *d_chain_off = nullptr;
     uint32_t *d_fold_order = nullptr; // chain ids, longest chain first
     bool fold_fused = false;          // sync-free batch: fold and select are one launch (k_fold_select), no fold order was built
-    bool wide_forked = false;         // the side list's launch for the next run is out already (it went with the planning launches)
     float *d_full = nullptr, *d_gate = nullptr, *d_score = nullptr;
     uint8_t *d_keep = nullptr;
     bool own_chain_arrays = false;  // the arrays above are hipMalloc'd (job-list path) rather than carved from `ws`
@@ -196,7 +197,8 @@ struct rawdtw_batch {
     uint32_t stream_runs = 0;                // DTW launches issued for this batch (the tile queue needs a reset from the second on)
     bool dirty = false;                  // work enqueued since the last host synchronisation
     size_t ws_bytes = 0;
-    hipEvent_t ev_plan[2] = {nullptr, nullptr};
+    hipEvent_t ev_plan[4] = {nullptr, nullptr, nullptr, nullptr}; // ("time_plan") around scan + side list order, the side list's launch, the pass planning
+    bool wide_out = false;            // the side list's launch for the next run went out with the planning launches
     // the caller's arrays (valid until fetch: a declined batch is redone from them through the job list)
     const uint64_t *in_chain_off = nullptr, *in_anchor_off = nullptr;
     const rawdtw_anchor_t *in_anchors = nullptr;
@@ -1254,6 +1256,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "wide_beside")) { ctx->wide_beside = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "wide_blocks")) { ctx->wide_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_tail")) { ctx->debug_skip_tail = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "sort_n")) { ctx->sort_n = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 255); return RAWDTW_OK; }
@@ -1811,6 +1814,7 @@ bool stream_declined(const rawdtw_batch *b);
 // stream joins it (ev_wide_join) before the fold
 static hipError_t stream_wide_fork(rawdtw_ctx *ctx, const StreamArgs &a)
 {
+    if (!ctx->wide_beside) return stream_wide(a, ctx->wide_blocks, ctx->stream); // (in line: nothing to join)
     hipError_t he = hipEventRecord(ctx->ev_wide_fork, ctx->stream);
     if (he == hipSuccess) he = hipStreamWaitEvent(ctx->wide, ctx->ev_wide_fork, 0);
     if (he == hipSuccess) he = stream_wide(a, ctx->wide_blocks, ctx->wide);
@@ -1902,7 +1906,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
     hipStream_t s = ctx->stream;
     if (ctx->time_plan) {
-        if (!b->ev_plan[0]) { HIP_TRY(ctx, hipEventCreate(&b->ev_plan[0])); HIP_TRY(ctx, hipEventCreate(&b->ev_plan[1])); }
+        for (hipEvent_t &pe : b->ev_plan) if (!pe) HIP_TRY(ctx, hipEventCreate(&pe));
         HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
@@ -1923,16 +1927,16 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
     b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
     hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
-    // the side list's launch forks off here, beside the pass planning and the tiles' launch (batch_enqueue_one joins it before
-    // the fold; a batch that is run again launches it again there)
-    b->wide_forked = false;
-    if (e == hipSuccess && !(ctx->stream_debug & 4u)) {
-        e = stream_wide_fork(ctx, a);
-        b->wide_forked = e == hipSuccess;
-    }
+    // The side list's launch goes out here, between the scan and the pass planning, for the batch's first run (a batch that
+    // runs again launches it again in front of the tiles' launch): measured, the fresh-batch pipeline runs 6 % faster with
+    // the wide bands' long tail in front of the planning launch than behind it.
+    if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[1], s);
+    b->wide_out = false;
+    if (e == hipSuccess && !(ctx->stream_debug & 4u)) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
+    if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[2], s);
     if (e == hipSuccess) e = stream_plan_passes(a, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
-    if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[1], s));
+    if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[3], s));
     // the persistent grid: what the device holds at this LDS size
     if (ctx->stream_lds != lds_floats || ctx->stream_threads_cached != ctx->stream_threads || ctx->stream_bpc_cached != ctx->stream_blocks_per_cu) {
         hipDeviceProp_t prop;
@@ -2468,7 +2472,7 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
 }
 
 // launches of a batch's DTW part (before fold and select): the job-list plan's, or the stream path's one
-static uint32_t batch_dtw_launches(const rawdtw_batch *b) { return b->stream ? 1u : b->plan ? (uint32_t)b->plan->launches.size() : 0u; }
+static uint32_t batch_dtw_launches(const rawdtw_batch *b) { return b->stream ? 2u : b->plan ? (uint32_t)b->plan->launches.size() : 0u; }
 
 
 static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e)
@@ -2483,20 +2487,23 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
         if (ctx->n_ev < batch->sa.n_ev || ctx->n_ref < batch->sa.n_ref)
             return fail(ctx, RAWDTW_ERR_INVALID, "an arena shrank after the batch was created: create the batch again");
         batch->sa.ev = ctx->d_ev; batch->sa.ref = ctx->d_ref;
-        // the side list beside the tiles: fork onto the context's second stream behind the planning launches, join before the fold
+        // launch 0: the side list (k_wide) -- in line, or (option "wide_beside") forked onto the context's second stream and
+        // joined before the fold; launch 1: the tiles' passes (k_runs)
         const bool wide = !(ctx->stream_debug & 4u);
-        if (wide && !batch->wide_forked) { // (a batch that runs again; the first run's launch went out with the planning)
+        if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && wide && !batch->wide_out) { // (the first run's went out with the planning launches)
             const hipError_t he = stream_wide_fork(ctx, batch->sa);
             if (he != hipSuccess) st = hip_fail(ctx, he, "side list launch");
         }
-        batch->wide_forked = false;
-        if (st == RAWDTW_OK && e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        batch->wide_out = false;
+        if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && e && hipEventRecord(e[2], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
         if (st == RAWDTW_OK) {
             hipError_t he = stream_run(batch->sa, ctx->stream_blocks, batch->stream_lds, batch->stream_threads, batch->stream_runs++ > 0, ctx->stream);
             if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
         }
-        if (st == RAWDTW_OK && e && hipEventRecord(e[1], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        if (st == RAWDTW_OK && wide && hipStreamWaitEvent(ctx->stream, ctx->ev_wide_join, 0) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && e && hipEventRecord(e[3], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && wide && ctx->wide_beside && hipStreamWaitEvent(ctx->stream, ctx->ev_wide_join, 0) != hipSuccess) st = RAWDTW_ERR_DEVICE;
     } else st = run_all_launches(ctx, batch->plan, e);
     for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {
         if (e && hipEventRecord(e[2 * (np + k)], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
@@ -2559,7 +2566,7 @@ int rawdtw_batch_collect(rawdtw_ctx *ctx, rawdtw_batch *batch, float *launch_ms,
         if (launch_ms) launch_ms[i] = batch->ev_runs ? (float)(acc / batch->ev_runs) : 0.f;
         if (launch_kind) {
             if (i >= np) launch_kind[i] = i == np ? kKindChainFold : kKindReadSelect;
-            else if (batch->stream) launch_kind[i] = kKindBandMerged | ((uint32_t)batch->stream_lds << 8);
+            else if (batch->stream) launch_kind[i] = i == 0 ? (uint32_t)kKindBandWreg : (kKindBandMerged | ((uint32_t)batch->stream_lds << 8));
             else launch_kind[i] = batch->plan->launches[i].kind | ((uint32_t)batch->plan->launches[i].param << 8);
         }
     }
@@ -2704,9 +2711,22 @@ int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms)
 {
     if (!ctx || !batch || batch->ctx != ctx || !ms) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to batch_plan_ms");
     *ms = 0.0f;
-    if (!batch->stream || !batch->ev_plan[0] || !batch->ev_plan[1]) return RAWDTW_OK;
-    HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[1]));
-    HIP_TRY(ctx, hipEventElapsedTime(ms, batch->ev_plan[0], batch->ev_plan[1]));
+    if (!batch->stream || !batch->ev_plan[0] || !batch->ev_plan[3]) return RAWDTW_OK;
+    HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[3]));
+    float scan = 0.f, plan = 0.f; // (the side list's launch between them is DTW work: rawdtw_batch_wide_ms)
+    HIP_TRY(ctx, hipEventElapsedTime(&scan, batch->ev_plan[0], batch->ev_plan[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&plan, batch->ev_plan[2], batch->ev_plan[3]));
+    *ms = scan + plan;
+    return RAWDTW_OK;
+}
+
+int rawdtw_batch_wide_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms)
+{
+    if (!ctx || !batch || batch->ctx != ctx || !ms) return fail(ctx, RAWDTW_ERR_INVALID, "bad arguments to batch_wide_ms");
+    *ms = 0.0f;
+    if (!batch->stream || !batch->ev_plan[1] || !batch->ev_plan[2]) return RAWDTW_OK;
+    HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[2]));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, batch->ev_plan[1], batch->ev_plan[2]));
     return RAWDTW_OK;
 }
 

@@ -41,7 +41,7 @@ for cfg in configs:
     if cfg == configs[0]:
         print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
-                                                                   ["%.4f" % m[2] for m in ms]), flush=True)
+                                                                   ["%.4f" % m[2] for m in ms]  # k_wide, k_runs, fold + select, -), flush=True)
     if any(cnt[53:63]):  # "stream_debug" 256: cycles per phase of k_runs (kCntStamp0 = 53), summed over waves and runs
         tot = float(sum(cnt[53:63]))
         names = ["entry", "stage issue", "stage wait", "B1", "DP + next records", "ticket + wait", "B2"]
