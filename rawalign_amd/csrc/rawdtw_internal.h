@@ -147,9 +147,10 @@ struct StreamArgs {
     uint32_t n_slots;            // copy-order slots (= the most passes a batch can have): one a tile, then a pool for the further passes
                                  // of tiles that take several
     uint32_t lds_floats;         // the DTW launch's image budget (floats): a pass's windows fit it
-    uint32_t debug;              // timing experiments only (results wrong below 128 except 8): 1 no DP, 2 no staging, 4 no side
-                                 // list, 32 no wave-per-job items, 64 no group / lane items; 8 tiles without the ticket queue,
-                                 // 2048 side items over all waves, 4096 side items dealt straight (not alternating)
+    uint32_t debug;              // timing experiments only (results wrong below 128 except 8; != 0 selects k_runs' diagnostic
+                                 // instance): k_runs 1 no DP, 2 no staging, 8 passes dealt by block index, 256 phase stamps;
+                                 // k_wide 32 no wave-per-job items, 64 no group / lane items, 2048 items over all waves, 4096
+                                 // items dealt straight (not alternating); 4 no k_wide launch at all
     // inputs (device)
     const uint64_t *anchor_off;
     const rawdtw_anchor_t *anchors;

@@ -663,8 +663,6 @@ __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
         const uint32_t N = pt.n > pt.m ? pt.n : pt.m, M = pt.n > pt.m ? pt.m : pt.n;
         tm[k] = N | (M << 7) | ((uint32_t)pt.R << 14) | ((mask_bit(mask, p) ? 0u : 1u) << 16) | ((pt.n < pt.m ? 1u : 0u) << 17) | (1u << 20);
     }
-    const uint32_t n_first = n_list;
-    (void)n_first;
     {
         const int t_first = (int)((tm[0] >> 20) & 1u), t_last = (int)((tm[KI - 1] >> 20) & 1u);
         const bool below = __builtin_amdgcn_update_dpp(0, t_last, 0x138, 0xf, 0xf, false) != 0;  // lane - 1's last item (lane 0: none)
@@ -1255,9 +1253,6 @@ __global__ __launch_bounds__(64) void k_fold_select(const StreamArgs a, const Ch
     const uint32_t nr = (uint32_t)(r1 - r0);
     const uint64_t co = chain_off[r0 + min(lane, nr)], co1 = chain_off[r0 + min(lane + 1u, nr)]; // lane < nr: its read's chains
     if (declined) return;
-    if (a.debug & 512u) return;
-    const bool tm = (a.debug & 16384u) != 0u;
-    unsigned long long t0 = tm ? wall_clock64() : 0ull, t1 = 0, t2 = 0;
     const uint64_t cA = __shfl((unsigned long long)co, 0), cB = __shfl((unsigned long long)co, (int)nr);
     if (cB <= cA) return;
     const uint64_t aA = a.anchor_off[cA], aB = a.anchor_off[cB];
@@ -1294,8 +1289,7 @@ __global__ __launch_bounds__(64) void k_fold_select(const StreamArgs a, const Ch
         }
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
         __syncthreads();
-        if (tm && hi == aB) t1 = wall_clock64();
-        while (c >= 0 && !(a.debug & 1024u)) {
+        while (c >= 0) {
             if (d.n_jobs == 0) { finish(0.0f); continue; }
             const uint64_t idx = d.job_first - p; // the next part: out[job_first - p]
             if (idx < lo4) break;                 // the rest lies in the windows below
@@ -1342,12 +1336,6 @@ __global__ __launch_bounds__(64) void k_fold_select(const StreamArgs a, const Ch
         }
         __syncthreads();
         hi = lo4;
-    }
-    if (tm) t2 = wall_clock64();
-    if (tm && lane == 0) {
-        atomicMax(&a.cnt[kCntStamp0 + 0], t1 - t0); atomicMax(&a.cnt[kCntStamp0 + 1], t2 - t1);
-        atomicAdd(&a.cnt[kCntStamp0 + 2], t1 - t0); atomicAdd(&a.cnt[kCntStamp0 + 3], t2 - t1);
-        atomicMax(&a.cnt[kCntStamp0 + 4], (unsigned long long)(aB - aA)); atomicMax(&a.cnt[kCntStamp0 + 5], (unsigned long long)(cB - cA));
     }
     if (lane < nr) {
         float best = 0.0f; // rmap.cpp:515

@@ -1,24 +1,46 @@
 #!/bin/bash
-# Everything profiles/ holds for round 3, from one GPU box and one tree (run on the GPU box; copy the files named at the
-# end from gpurun_out/r03/ into profiles/).  Usage: bash scripts/collect_r03.sh
+# Everything profiles/ holds for round 3, from one GPU box and one tree (run on the GPU box; the files named r03_* and
+# traffic_r03.json are then copied from gpurun_out/r03/ into profiles/).  Every step prints a line when it ends, and long
+# steps write under gpurun_out/ as they go.  Usage: bash scripts/collect_r03.sh [first_step [last_step]]
 OUT=gpurun_out/r03; mkdir -p $OUT
-python bench.py > $OUT/r03_bench.json 2> $OUT/bench.err || echo "bench failed"
-bash scripts/prof_bench.sh $OUT/prof --no-cpu-baseline > $OUT/kernel_stats_top.txt
-cp $OUT/prof/run_kernel_stats.csv $OUT/r03_kernel_stats.csv; cp $OUT/prof/bench.json $OUT/r03_bench_under_rocprof.json
-python3 scripts/trace_window.py $OUT/prof $OUT/prof/bench.json > $OUT/r03_trace_window.json
-# counters over one bench batch, every launch alone on the chip (separate passes: SQ x2, FETCH_SIZE, WRITE_SIZE)
-bash scripts/pmc_r02.sh $OUT/pmc > $OUT/pmc_top.txt
-cp $OUT/pmc/summary.json $OUT/r03_pmc_summary.json
-python3 scripts/make_traffic.py $OUT/pmc/summary.json "k_runs<256, false, false>" 16384 > $OUT/traffic_r03.json
-# attribution of the DTW launch's instructions: stream_debug masks (4 no side list, 1 no DP, 2 no staging) on the diagnostic instance
-CFGS="stream_debug=128 stream_debug=132 stream_debug=133 stream_debug=135" bash scripts/pmc_debug_masks.sh > $OUT/r03_pmc_attribution.txt 2>&1
-python scripts/stream_probe.py 16384 "" stream_debug=256 stream_debug=4 stream_debug=5 stream_debug=7 stream_blocks_per_cu=3 > $OUT/r03_stream_probe.txt 2>&1
-python scripts/rounds_probe.py > $OUT/r03_rounds_probe.txt 2>&1
-# configs[2]: the traceback kernels
-( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p $OUT/tb && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tb -o run -- python3 scripts/bench_modes.py --mode traceback --reads 8192 > $OUT/tb/out.json 2> $OUT/tb/err.txt )
-cp $OUT/tb/run_kernel_stats.csv $OUT/r03_tb_kernel_stats.csv
-mkdir -p $OUT/r03_modes
-for m in "global_full 8192" "global_banded 8192" "traceback 8192"; do set -- $m
-  python scripts/bench_modes.py --mode $1 --reads $2 > $OUT/r03_modes/$1_$2.json 2> $OUT/r03_modes/$1_$2.err || echo "mode $1 $2 failed"; done
-bash scripts/sensitivity.sh $OUT/sens > $OUT/sens_top.txt; cp $OUT/sens/summary.json $OUT/r03_sensitivity.json
+FIRST=${1:-1}; LAST=${2:-99}
+step() { echo "[$(date +%T)] step $1: $2"; }
+want() { [ $1 -ge $FIRST ] && [ $1 -le $LAST ]; }
+if want 1; then
+  timeout -k 10 900 python -u bench.py > $OUT/r03_bench.json 2> $OUT/bench.err; step 1 "bench rc=$?"
+fi
+if want 2; then
+  bash scripts/prof_bench.sh $OUT/prof --no-cpu-baseline > $OUT/kernel_stats_top.txt; step 2 "bench under rocprofv3 rc=$?"
+  cp $OUT/prof/run_kernel_stats.csv $OUT/r03_kernel_stats.csv; cp $OUT/prof/bench.json $OUT/r03_bench_under_rocprof.json
+  python3 scripts/trace_window.py $OUT/prof $OUT/prof/bench.json > $OUT/r03_trace_window.json; step 2 "trace window rc=$?"
+fi
+if want 3; then  # counters over one bench batch, every launch alone on the chip (separate passes: SQ x2, FETCH_SIZE, WRITE_SIZE)
+  timeout -k 10 600 bash scripts/pmc_r02.sh $OUT/pmc 16384 > $OUT/pmc_top.txt 2>&1; step 3 "pmc passes rc=$?"
+  cp $OUT/pmc/summary.json $OUT/r03_pmc_summary.json
+  python3 scripts/make_traffic.py $OUT/pmc/summary.json "k_runs<256, false>" 16384 > $OUT/traffic_r03.json; step 3 "traffic rc=$?"
+fi
+if want 4; then  # attribution of k_runs' instructions: stream_debug masks on the diagnostic instance (1 no DP, 2 no staging)
+  : > $OUT/r03_pmc_attribution.txt
+  for cfg in stream_debug=128 stream_debug=129 stream_debug=131; do
+    CFGS="$cfg" PMC_OUT=$OUT/pmc_masks timeout -k 10 300 bash scripts/pmc_debug_masks.sh >> $OUT/r03_pmc_attribution.txt 2>&1; step 4 "attribution $cfg rc=$?"
+  done
+fi
+if want 5; then
+  timeout -k 10 400 python -u scripts/stream_probe.py 16384 "" stream_debug=256 stream_debug=1 stream_debug=3 stream_debug=4 stream_blocks_per_cu=3 wide_beside=1 fold_mode=3 > $OUT/r03_stream_probe.txt 2>&1; step 5 "stream_probe rc=$?"
+  timeout -k 10 400 python -u scripts/rounds_probe.py > $OUT/r03_rounds_probe.txt 2>&1; step 5 "rounds_probe rc=$?"
+fi
+if want 6; then  # configs[2]: the traceback kernels
+  ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p $OUT/tb && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tb -o run -- python3 scripts/bench_modes.py --mode traceback --reads 8192 > $OUT/tb/out.json 2> $OUT/tb/err.txt ); step 6 "traceback profile rc=$?"
+  cp $OUT/tb/run_kernel_stats.csv $OUT/r03_tb_kernel_stats.csv
+  mkdir -p $OUT/r03_modes
+  for m in "global_full 8192" "global_banded 8192" "traceback 8192"; do set -- $m
+    timeout -k 10 400 python -u scripts/bench_modes.py --mode $1 --reads $2 > $OUT/r03_modes/$1_$2.json 2> $OUT/r03_modes/$1_$2.err; step 6 "mode $1 $2 rc=$?"; done
+fi
+if want 7; then  # how the batches in flight share the chip: kernel trace of the fresh-batch loop alone
+  bash scripts/prof_bench.sh $OUT/ovl --no-cpu-baseline --modes-reads 0 --rounds 0 --trace-fresh 400 > /dev/null
+  { tail -1 $OUT/ovl/bench.err; python3 scripts/experiments/trace_overlap.py $OUT/ovl/run_kernel_trace.csv k_scan; } > $OUT/r03_pipeline_overlap.txt 2>&1; step 7 "pipeline overlap rc=$?"
+fi
+if want 8; then
+  bash scripts/sensitivity.sh $OUT/sens > $OUT/sens_top.txt; cp $OUT/sens/summary.json $OUT/r03_sensitivity.json; step 8 "sensitivity rc=$?"
+fi
 ls $OUT

@@ -1,5 +1,5 @@
 """Timing probe for the cross-round cache: the last of four chunk rounds of a bench-like batch, submitted from scratch and
-with the round before to take costs over from; the scan launches (k_scan + k_side) and the DTW launch alone on the chip.
+with the round before to take costs over from; the planning launches (k_scan + k_side + k_plan) and the DTW launches alone on the chip.
 Usage (GPU box): python scripts/rounds_probe.py [n_reads]"""
 import ctypes as C
 import os
@@ -48,7 +48,7 @@ for mode in ("scratch", "carried"):
         sc, ru = C.c_uint64(), C.c_uint64()
         lib.rawdtw_batch_round_stats(eng._ctx, h, C.byref(sc), C.byref(ru))
         if rep:
-            print("%-8s parts scored %d reused %d   scan (k_scan + k_side, with the H2D copies) %.4f ms   k_runs %.4f ms  fold %.4f  select %.4f"
+            print("%-8s parts scored %d reused %d   planning (k_scan + k_side + k_plan, with the H2D copies) %.4f ms   k_wide %.4f ms  k_runs %.4f ms  fold + select %.4f"
                   % (mode, sc.value, ru.value, pm.value, ms[0], ms[1], ms[2]), flush=True)
         lib.rawdtw_batch_destroy(h)
     lib.rawdtw_batch_destroy(prev)

@@ -40,8 +40,8 @@ for cfg in configs:
     eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 64, C.byref(ncnt))
     if cfg == configs[0]:
         print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
-    print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value,
-                                                                   ["%.4f" % m[2] for m in ms]  # k_wide, k_runs, fold + select, -), flush=True)
+    # launches: k_wide, k_runs, fold + select (one launch), -
+    print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value, ["%.4f" % m[2] for m in ms]), flush=True)
     if any(cnt[53:63]):  # "stream_debug" 256: cycles per phase of k_runs (kCntStamp0 = 53), summed over waves and runs
         tot = float(sum(cnt[53:63]))
         names = ["entry", "stage issue", "stage wait", "B1", "DP + next records", "ticket + wait", "B2"]

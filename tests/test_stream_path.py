@@ -1,4 +1,4 @@
-"""The sync-free batch path (rawdtw_stream.hip) against the oracle: every shape class the tile kernel and its side list take
+"""The sync-free batch path (rawdtw_runs.hip: k_scan, k_side, k_plan, k_wide, k_runs, k_fold_select) against the oracle: every shape class the tiles' passes and the side list take
 (radii 1..3 with any slant, shorter sides down to 1-2 events, wide bands, bands it declines), its tuning knobs, the
 incremental event upload and the shared / device-resident inputs.  Parts are the DTW sub-problems align_chain issues
 between consecutive anchors (src/rmap.cpp:248-293) through DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520)."""
@@ -112,6 +112,8 @@ def _wide(rng):     # side list: 8-lane, 16-lane and wave-per-job classes
     # the diagnostic instance of k_runs (profiling runs: scripts/pmc_debug_masks.sh, stream_probe.py) -- no mask set (128), with
     # the phase stamps (256), with the tiles dealt by block index (8): it has to score like the production instance
     (_medium, {"stream_debug": 128}), (_wide, {"stream_debug": 256}), (_tiny, {"stream_debug": 256 | 8}),
+    # the side list's launch forked onto the context's second stream and joined before the fold, instead of in line
+    (_wide, {"wide_beside": 1}), (_medium, {"wide_beside": 1, "wide_blocks": 7}),
 ])
 def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
     rng = np.random.default_rng(hash((shapes.__name__, tuple(sorted(opts)))) & 0xFFFF)
