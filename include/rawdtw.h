@@ -75,15 +75,18 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "tile_threads" 256/512/1024: kernel selection
  *   "sort_n", "sort_r1_n", "sort_r3", "sorted_tile_jobs": optional by-shape tiles for long / rare tile jobs (default off)
  *   "device_plan" 0/1, "device_plan_min_jobs": rawdtw_batch_create takes the sync-free path (planning on the device, in LDS)
- *   "stream_tile_radius" 1..3 (default 3), "stream_threads" 256/512, "stream_blocks_per_cu" (default 4; 0 = as many as
- *   fit): the device-planned batch's DTW launch -- tiles take radii up to stream_tile_radius, the radii between that and
- *   lane_max_radius are scored a lane per job from the side list, bucketed by length over the whole batch; its tiles'
- *   LDS image is 7000 floats unless "tile_lds_floats" is given
+ *   "stream_tile_radius" 1..3 (default 3), "stream_threads" 256/512, "stream_blocks_per_cu" (default 0 = as many as fit:
+ *   4): the device-planned batch's DTW launch over the tiles' passes (k_runs) -- tiles (512 consecutive anchors) take radii up
+ *   to stream_tile_radius, the radii between that and lane_max_radius are scored a lane per job from the side list, bucketed
+ *   by length over the whole batch; a pass's LDS image is 7000 floats unless "tile_lds_floats" is given
+ *   "wide_blocks" (default 256): workgroups of the side list's launch (k_wide); "wide_beside" 0/1 (default 0): that launch
+ *   on the context's second stream beside the tiles' launch instead of in line (measured slower)
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place
  *   "time_plan" 0/1: event pair around a batch's planning kernels
  *   "merge_small" 0/1: a sparse batch's tile, 16-lane-row and register-wave kernels as ONE launch (default 1)
- *   "fold_mode" 0/1/2/3: chain fold as a wave per chain, a lane per chain with 16 / 32 parts per round, or (default 3) a lane
- *   per chain plus a wave for each chain of at least "fold_long_parts" (768) parts
+ *   "fold_mode" 0..4: chain fold as a wave per chain, a lane per chain with 16 / 32 parts per round, a lane per chain plus a
+ *   wave for each chain of at least "fold_long_parts" (768) parts (3), or (default 4) device-planned batches fold and select
+ *   in one launch out of LDS and job-list batches as 3; a batch keeps the form it was created under
  *   "debug_skip_kinds": timing experiments only -- launches of the masked kinds are not issued (results wrong)
  * The environment variable RAWDTW_OPTS="name=value,..." applies options at rawdtw_create. */
 int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);
