@@ -87,6 +87,7 @@ struct rawdtw_ctx {
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
     uint32_t wide_blocks = 256;                 // workgroups (four waves each) of the side list's launch
+    int wide_order = 0;                         // 0: k_wide between the scan and the pass planning (first run), 1: in front of k_runs, 2: behind it
     int wide_beside = 0;                        // 1: that launch on the context's second stream, beside the tiles' launch; 0: in line (measured:
                                                 // the fork and join cost the fresh-batch pipeline 8 % and the PCIe loop 17 %)
     int stream_threads_cached = 0;
@@ -1256,6 +1257,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "wide_order")) { ctx->wide_order = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "wide_beside")) { ctx->wide_beside = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "wide_blocks")) { ctx->wide_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_tail")) { ctx->debug_skip_tail = (uint32_t)value; return RAWDTW_OK; }
@@ -1932,7 +1934,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // the wide bands' long tail in front of the planning launch than behind it.
     if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[1], s);
     b->wide_out = false;
-    if (e == hipSuccess && !(ctx->stream_debug & 4u)) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
+    if (e == hipSuccess && !(ctx->stream_debug & 4u) && ctx->wide_order == 0) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
     if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[2], s);
     if (e == hipSuccess) e = stream_plan_passes(a, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
@@ -2491,7 +2493,8 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
         // joined before the fold; launch 1: the tiles' passes (k_runs)
         const bool wide = !(ctx->stream_debug & 4u);
         if (e && hipEventRecord(e[0], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
-        if (st == RAWDTW_OK && wide && !batch->wide_out) { // (the first run's went out with the planning launches)
+        const bool wide_now = wide && !batch->wide_out; // (the first run's went out with the planning launches)
+        if (st == RAWDTW_OK && wide_now && ctx->wide_order != 2) {
             const hipError_t he = stream_wide_fork(ctx, batch->sa);
             if (he != hipSuccess) st = hip_fail(ctx, he, "side list launch");
         }
@@ -2503,6 +2506,10 @@ static int batch_enqueue_one(rawdtw_ctx *ctx, rawdtw_batch *batch, hipEvent_t *e
             if (he != hipSuccess) st = hip_fail(ctx, he, "batch kernel launch");
         }
         if (st == RAWDTW_OK && e && hipEventRecord(e[3], ctx->stream) != hipSuccess) st = RAWDTW_ERR_DEVICE;
+        if (st == RAWDTW_OK && wide_now && ctx->wide_order == 2) { // (timing experiments: the side list behind the tiles)
+            const hipError_t he = stream_wide_fork(ctx, batch->sa);
+            if (he != hipSuccess) st = hip_fail(ctx, he, "side list launch");
+        }
         if (st == RAWDTW_OK && wide && ctx->wide_beside && hipStreamWaitEvent(ctx->stream, ctx->ev_wide_join, 0) != hipSuccess) st = RAWDTW_ERR_DEVICE;
     } else st = run_all_launches(ctx, batch->plan, e);
     for (int k = 0; k < 2 && st == RAWDTW_OK; k++) {

@@ -611,6 +611,49 @@ __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, c
     return res;
 }
 
+// Radius 2 in every lane of the wave -- two thirds of a sparse batch's jobs and three quarters of its cells (every
+// non-square part whose read side is under 20 events): the body above with R = 2 folded in (S = 2 secondaries at slots 0
+// and 1, P = 3 primaries at slots 0..2, no shift): the selects on the radius drop out (is_first / is_last belong to odd
+// radii, previous_increment_center_row to radius 1), the ones on the per-lane row advance stay.
+__device__ __forceinline__ float lane_dp_r2(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t n_max)
+{
+    const int iM = (int)M;
+    float d00 = kInf, d01 = kInf;                           // the antidiagonal before the latest: slots 0, 1
+    float d10 = kInf, d11 = dist(LA[0], LB[0]), d12 = kInf; // the latest: the corner at the centre slot (dtw.cpp:317-347)
+    float ap0 = LA[1], ap1 = LA[0], ap2 = LA[0];
+    float bp0 = LB[0], bp1 = LB[0], bp2 = LB[iM > 1 ? 1 : 0];
+    float a_next = LA[2], b_next = LB[2];
+    float res = d11;
+    uint32_t rem = 0, row = 0;
+    for (uint32_t col = 1; col < n_max; col++) {
+        rem += M;
+        const bool adv = rem >= N;
+        rem -= adv ? N : 0u;
+        row += adv ? 1u : 0u;
+        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? bp2 : bp1, bn2 = adv ? b_next : bp2;
+        b_next = LB[row + 2];
+        // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
+        const float sec0 = min3f(d10, d11, d00) + dist(ap0, bn0);
+        const float sec1 = min3f(d11, d12, d01) + dist(ap1, bn1);
+        const float X0 = adv ? sec0 : d10, X1 = adv ? sec1 : d11;
+        ap2 = ap1; ap1 = ap0; ap0 = a_next;
+        a_next = LA[col + 2];
+        // primary antidiagonal (dtw.cpp:416-485)
+        const float left2 = adv ? kInf : d12;
+        const float tl0 = adv ? d10 : kInf;
+        const float tl1 = adv ? d11 : d00;
+        const float tl2 = adv ? d12 : d01;
+        float pr0 = min3f(kInf, X0, tl0) + dist(ap0, bn0);
+        const float pr1 = min3f(X0, X1, tl1) + dist(ap1, bn1);
+        const float pr2 = min3f(X1, left2, tl2) + dist(ap2, bn2);
+        pr0 = row == 0u ? kInf : pr0;                             // (col + 1, -1): above the matrix
+        d00 = X0; d01 = X1; d10 = pr0; d11 = pr1; d12 = pr2;
+        bp0 = bn0; bp1 = bn1; bp2 = bn2;
+        res = (col == N - 1u) ? d11 : res;
+    }
+    return res;
+}
+
 // Radius 1 in every lane of the wave -- 97 % of a sparse batch's jobs.  Radius 1 means a SQUARE part: the reference's
 // radius is r0 + ((N - M) * r0 + N - 1) / N with r0 >= 1 (dtw.cpp:298-300), which is 1 only for r0 = 1 and N = M.  On a
 // square the centre row advances with every column (rem += M reaches N each time), so the body above with R = 1 folded in

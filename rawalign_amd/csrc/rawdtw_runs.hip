@@ -868,7 +868,7 @@ constexpr uint32_t kStamps = 10;
 // first, then 2, then 1, each run by longer side, descending; a wave takes the shortest body that covers its radii.
 __device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
 {
-    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u);
+    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u), r2 = __ballot(R == 2u);
     // the wave's longest side (its jobs come in up to three runs, each longest first; sides of 63 and more share a bin)
     uint32_t n_max = N;
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x111, 0xf, 0xf, false)); // row_shr:1
@@ -880,6 +880,7 @@ __device__ __forceinline__ float stream_lane_job(const float *LA, const float *L
     n_max = (uint32_t)__builtin_amdgcn_readlane((int)n_max, 63);
     float res;
     if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, n_max); // (radius 1: N == M)
+    else if (~r2 == 0ull) res = lane_dp_r2(LA, LB, N, M, n_max);
     else if (~r12 == 0ull) res = lane_dp_r12(LA, LB, N, M, R, n_max);
     else res = lane_dp_gen(LA, LB, N, M, R, n_max);
     if (act && excl) res = res - dist(LA[N - 1], LB[M - 1]);
