@@ -737,7 +737,8 @@ def main():
                         "call; `submit` (rawdtw_batch_submit = create + run) only enqueues"},
             "batch_create_ms": {"steady": create_ms["resident"], "from_pinned_host": create_ms["from_host"],
                                 "note": "host wall time of one rawdtw_batch_create call, steady state: O(1) host work, it only enqueues (no "
-                                        "synchronisation, no allocation); `planning_gpu_ms` = its launches (k_scan + k_side + k_plan) on the "
+                                        "synchronisation, no allocation); `planning_gpu_ms` = its launches (k_scan + k_side + k_plan; HIP events behind the "
+                                        "hand-over's copies) on the "
                                         "device: alone on the chip / with all contexts submitting at once",
                                 "planning_gpu_ms": round(plan_al, 4), "planning_gpu_ms_in_pipeline": round(plan_pipe, 4)},
             "kernel_ms_sum_per_batch": {"alone": round(sum_alone, 4), "in_pipeline": round(sum_pipe, 4),

@@ -87,6 +87,7 @@ struct rawdtw_ctx {
     uint32_t stream_lds = 0, stream_blocks = 0; // persistent grid of k_stream at the current tile size
     int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
     uint32_t wide_blocks = 256;                 // workgroups (four waves each) of the side list's launch
+    int pass_pool = -1;                         // copy-order slots beyond one a tile (tests: a batch that runs out is redone through the job list); -1: 3 a tile + 64
     int wide_order = 0;                         // 0: k_wide between the scan and the pass planning (first run), 1: in front of k_runs, 2: behind it
     int wide_beside = 0;                        // 1: that launch on the context's second stream, beside the tiles' launch; 0: in line (measured:
                                                 // the fork and join cost the fresh-batch pipeline 8 % and the PCIe loop 17 %)
@@ -1257,6 +1258,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "tile_max_jobs")) { ctx->tile_max_jobs = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 64), 65535); return RAWDTW_OK; }
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
+    if (!strcmp(name, "pass_pool")) { ctx->pass_pool = (int)std::min<int64_t>(std::max<int64_t>(value, -1), 1 << 24); return RAWDTW_OK; }
     if (!strcmp(name, "wide_order")) { ctx->wide_order = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "wide_beside")) { ctx->wide_beside = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "wide_blocks")) { ctx->wide_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 65535); return RAWDTW_OK; }
@@ -1843,7 +1845,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.n_tiles = (uint32_t)((na + a.tile_anchors - 1) / a.tile_anchors);
     // (a tile over the image budget or the run table takes further passes, a slot of copy orders each: rare in a mapper's
     // batch, the rule for tiles of very short chains; a batch that runs out of slots is redone through the job list)
-    a.n_slots = 4 * a.n_tiles + 64;
+    a.n_slots = ctx->pass_pool >= 0 ? a.n_tiles + (uint32_t)ctx->pass_pool : 4 * a.n_tiles + 64;
     a.lds_floats = lds_floats;
     a.others_cap = std::min<uint64_t>(na, na / 4 + 4096);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1907,10 +1909,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     for (int i = 0; i < kStreamCounters; i++) h_init[i] = 0;
     h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
     hipStream_t s = ctx->stream;
-    if (ctx->time_plan) {
-        for (hipEvent_t &pe : b->ev_plan) if (!pe) HIP_TRY(ctx, hipEventCreate(&pe));
-        HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s));
-    }
+    if (ctx->time_plan) for (hipEvent_t &pe : b->ev_plan) if (!pe) HIP_TRY(ctx, hipEventCreate(&pe));
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     if (compact) {
@@ -1928,6 +1927,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
     if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
     b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
+    if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s)); // ("time_plan": the planning LAUNCHES, behind the hand-over's copies)
     hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
     // The side list's launch goes out here, between the scan and the pass planning, for the batch's first run (a batch that
     // runs again launches it again in front of the tiles' launch): measured, the fresh-batch pipeline runs 6 % faster with

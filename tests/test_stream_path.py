@@ -159,6 +159,35 @@ def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
     _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
 
 
+def test_batch_that_runs_out_of_pass_slots_is_redone_through_the_job_list(oracle):
+    """A tile whose parts do not fit one pass (image budget, or more than 32 runs) takes further passes, each with a slot of
+    copy orders from a pool; a batch that runs out of slots is declined by the planner -- the later launches return at
+    once -- and rawdtw_batch_fetch redoes it through the job list: same results as ever."""
+    rng = np.random.default_rng(77)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.set_option("tile_lds_floats", 2048)
+    eng.set_option("pass_pool", 1)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 300, 60000, _medium, (1, 30))
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is False  # declined: more passes than slots
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+    eng.set_option("pass_pool", -1)
+    b2 = ra.Batch(eng, opt, cb)
+    assert b2.verify_plan() is True
+    b2.run()
+    s2, k2, j2 = b2.fetch(with_job_costs=True)
+    assert np.array_equal(s2.view(np.uint32), score.view(np.uint32)) and np.array_equal(k2, keep) and np.array_equal(j2.view(np.uint32), jc.view(np.uint32))
+
+
 @pytest.mark.parametrize("ref_len,tail", [(60001, 0), (60003, 0), (60002, 1)])
 def test_windows_that_end_with_the_arenas(oracle, ref_len, tail):
     """The last part of the last chain ends on the last reference element and the last event (arena lengths that are
