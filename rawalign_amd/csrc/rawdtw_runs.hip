@@ -603,6 +603,9 @@ __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainD
 // The waves of a workgroup share nothing: no workgroup barrier.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPlanT = 256;
+// (three waves a SIMD: 168 registers, 7 of them spilled; at four the spills cost more than the occupancy brings, at two the
+// launch is 15 % slower; a version with the items in LDS and rolled loops -- 71 registers, 35 KB of LDS a workgroup -- ran as
+// fast alone and 5 % slower inside the pipeline, as did one-wave workgroups)
 __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
 {
     constexpr int KI = 8;
