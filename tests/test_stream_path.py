@@ -159,6 +159,48 @@ def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
     _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
 
 
+@pytest.mark.parametrize("chains_per_read", [12, 45])
+def test_reads_with_many_chains(oracle, chains_per_read):
+    """k_fold_select takes 8 reads a wave, a chain a lane: with more than 64 chains among them a lane folds several chains
+    one after the other (the sweep down the anchor list meets them last to first), and beyond 256 the accept/cut loop reads
+    the scores back from memory instead of LDS.  (--num-best-chains bounds the chains of a read in the mapper: roptions.c:19;
+    the boundary takes any number.)"""
+    rng = np.random.default_rng(chains_per_read)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, read_base, slot = [], [0], [0], [], [], []
+    ev_at = 0
+    for r in range(40):
+        read_len = 0
+        for _ in range(chains_per_read):
+            parts = int(rng.integers(0, 12))
+            dq = rng.integers(1, 7, size=parts); dt = np.maximum(1, dq + rng.integers(-1, 2, size=parts))
+            q = np.concatenate([[int(rng.integers(0, 5))], np.cumsum(dq)]).astype(np.int64); q[1:] += q[0]
+            t0 = int(rng.integers(0, 60000 - int(dt.sum()) - 2))
+            t = np.concatenate([[t0], t0 + np.cumsum(dt)]).astype(np.int64)
+            a = np.zeros(len(q), ra.ANCHOR_DTYPE)
+            a["query_position"] = q[::-1]; a["target_position"] = t[::-1]
+            anchors.append(a); anchor_off.append(anchor_off[-1] + len(a)); read_base.append(ev_at); slot.append(int(rng.integers(0, 2)))
+            read_len = max(read_len, int(q[-1]) + 1)
+        events.append(rng.normal(size=read_len).astype(np.float32))
+        chain_off.append(len(anchor_off) - 1)
+        ev_at += read_len
+    events = np.concatenate(events)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, np.array(chain_off, np.uint64), np.array(anchor_off, np.uint64), np.concatenate(anchors), ref_base,
+                        np.array(read_base, np.uint32))
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=-12.0)  # (random signals: scores around -10: some chains pass, some are cut by the running best)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is True
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+    assert keep.any()
+
+
 def test_batch_that_runs_out_of_pass_slots_is_redone_through_the_job_list(oracle):
     """A tile whose parts do not fit one pass (image budget, or more than 32 runs) takes further passes, each with a slot of
     copy orders from a pool; a batch that runs out of slots is declined by the planner -- the later launches return at
