@@ -7,4 +7,5 @@ run default ""
 run nofold "debug_skip_tail=1"
 run notail "debug_skip_tail=3"
 run nodp "stream_debug=1"
-run bookkeeping "stream_debug=7"
+run nostage "stream_debug=3"
+run nowide "stream_debug=4"
