@@ -88,6 +88,7 @@ struct rawdtw_ctx {
     int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
     uint32_t wide_blocks = 256;                 // workgroups (four waves each) of the side list's launch
     int pass_pool = -1;                         // copy-order slots beyond one a tile (tests: a batch that runs out is redone through the job list); -1: 3 a tile + 64
+    bool in_submit = false;                     // inside rawdtw_batch_submit*: create and run are one call
     int wide_order = 0;                         // 0: k_wide between the scan and the pass planning (first run), 1: in front of k_runs, 2: behind it
     int wide_beside = 0;                        // 1: that launch on the context's second stream, beside the tiles' launch; 0: in line (measured:
                                                 // the fork and join cost the fresh-batch pipeline 8 % and the PCIe loop 17 %)
@@ -1934,7 +1935,9 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     // the wide bands' long tail in front of the planning launch than behind it.
     if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[1], s);
     b->wide_out = false;
-    if (e == hipSuccess && !(ctx->stream_debug & 4u) && ctx->wide_order == 0) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
+    // (only inside rawdtw_batch_submit*: between a separate create and run the caller may upload new events, and a run reads
+    // the arenas as they are then)
+    if (e == hipSuccess && !(ctx->stream_debug & 4u) && ctx->wide_order == 0 && ctx->in_submit) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
     if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[2], s);
     if (e == hipSuccess) e = stream_plan_passes(a, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
@@ -2201,7 +2204,9 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
                                 const uint32_t *read_base, rawdtw_batch **out)
 {
     const CompactIn cin{heads, unit_abs, steps, wide, n_wide};
+    if (ctx) ctx->in_submit = true;
     int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, nullptr, &cin, ref_base, read_base, out);
+    if (ctx) ctx->in_submit = false;
     if (st != RAWDTW_OK) return st;
     st = batch_enqueue_one(ctx, *out, nullptr);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
@@ -2212,7 +2217,9 @@ int rawdtw_batch_submit_round(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, ui
                               const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
                               const uint32_t *read_base, const rawdtw_batch *prev, const uint64_t *carry_chain, rawdtw_batch **out)
 {
+    if (ctx) ctx->in_submit = true;
     int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, anchors, nullptr, ref_base, read_base, out, prev, carry_chain);
+    if (ctx) ctx->in_submit = false;
     if (st != RAWDTW_OK) return st;
     st = batch_enqueue_one(ctx, *out, nullptr);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
@@ -2765,7 +2772,9 @@ int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
                         const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
                         const uint32_t *read_base, rawdtw_batch **out)
 {
+    if (ctx) ctx->in_submit = true;
     int st = rawdtw_batch_create(ctx, opt, n_reads, chain_off, anchor_off, anchors, ref_base, read_base, out);
+    if (ctx) ctx->in_submit = false;
     if (st != RAWDTW_OK) return st;
     st = batch_enqueue_one(ctx, *out, nullptr);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }

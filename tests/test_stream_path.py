@@ -201,6 +201,29 @@ def test_reads_with_many_chains(oracle, chains_per_read):
     assert keep.any()
 
 
+def test_run_reads_the_events_uploaded_after_create(oracle):
+    """A run reads the context's arenas as they are when it is enqueued (include/rawdtw.h): events uploaded between
+    rawdtw_batch_create and rawdtw_batch_run count -- for the tiles' passes and for the side list's wide bands alike (the
+    wide bands' launch goes out with the planning launches only inside rawdtw_batch_submit, where nothing can come between)."""
+    rng = np.random.default_rng(5)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 120, 60000, _wide)
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    b = ra.Batch(eng, opt, cb)
+    events2 = rng.normal(size=len(events)).astype(np.float32)
+    eng.upload_events(events2)
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    cb2 = CandidateBatch(events2, chain_off, anchor_off, anchors, ref_base, read_base)
+    _oracle_check(oracle, cb2, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+
+
 def test_batch_that_runs_out_of_pass_slots_is_redone_through_the_job_list(oracle):
     """A tile whose parts do not fit one pass (image budget, or more than 32 runs) takes further passes, each with a slot of
     copy orders from a pool; a batch that runs out of slots is declined by the planner -- the later launches return at
