@@ -1060,20 +1060,24 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     const uint32_t n_first = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
     const uint32_t n_pass = n_first + (uint32_t)min<unsigned long long>(a.cnt[kCntPool], (unsigned long long)(a.n_slots - a.n_tiles));
     auto entry_of = [&](const uint32_t i) { return a.todo[i < n_first ? i : a.n_tiles + (i - n_first)]; };
-    // thread 0's queue state: `head`, the list index of the next pass, the raw ticket of the one after it; wave 0 holds the
-    // next pass's entry (asked for a pass ahead)
-    uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u), i_next = 0xffffffffu;
+    // The queue, three passes deep, so that no pass waits for a round trip at its start.  At the top of pass t thread 0 turns
+    // the ticket it drew a pass ago into the list index of pass t + 2 and draws the ticket of pass t + 3; wave 0 asks for
+    // the entry of pass t + 2 (it has the whole pass to arrive) and publishes the entry of pass t + 1 (asked for a pass ago).
+    uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u);
     unsigned long long ticket = 0;
+    bool more = false; // (thread 0) a ticket is out
     const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);
-    uint4 e_next = none;
+    uint4 e_next = none, e_load = none;
     if (wv == 0) {
-        uint32_t i0 = 0xffffffffu;
+        uint32_t i0 = 0xffffffffu, i1 = 0xffffffffu;
         if (tid == 0) {
             i0 = next_tile(a, dbg, head, n_pass);
-            i_next = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_pass) : 0xffffffffu;
+            i1 = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_pass) : 0xffffffffu;
+            more = i1 != 0xffffffffu;
+            if (more && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull); // pass 2's
         }
         i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
-        const uint32_t i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
+        i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i1);
         const uint4 e0 = i0 != 0xffffffffu ? entry_of(i0) : none;
         if (i1 != 0xffffffffu) e_next = entry_of(i1);
         if (tid == 0) s_ent[0] = e0;
@@ -1104,12 +1108,25 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         const uint4 e = s_ent[cur];
         if (e.x == 0xffffffffu) break;
         const uint32_t n_jobs = e.z & 0xffffu, n_ord = 2u * (e.z >> 16);
-        // thread 0: the next pass's entry is published before this pass's first barrier; the ticket of the one after it is
-        // drawn now and looked at when this pass is done
+        // thread 0: the next pass's entry is published before this pass's first barrier; the pass after that gets its list
+        // index (the ticket drawn a pass ago) and wave 0 asks for its entry; the ticket of the pass after THAT is drawn
+        uint32_t i2 = 0xffffffffu;
         if (tid == 0) {
             s_ent[cur ^ 1u] = e_next;
             s_seq = 0;
-            if (i_next != 0xffffffffu && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+            if (more) {
+                if (dbg & 8u) i2 = next_tile(a, dbg, head, n_pass);
+                else {
+                    const unsigned long long t = ticket * 8ull + head;
+                    i2 = t < n_pass ? (uint32_t)t : next_tile(a, dbg, head, n_pass); // (this head is dry: try the others)
+                }
+                more = i2 != 0xffffffffu;
+                if (more && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
+            }
+        }
+        if (wv == 0) {
+            i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i2);
+            e_load = i2 != 0xffffffffu ? entry_of(i2) : none;
         }
         stamp(0);
         // ---- staging: a wave's share of the copy orders, 16 bytes a lane, consecutive lanes consecutive pieces; nothing
@@ -1138,18 +1155,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         if (en.x != 0xffffffffu) fetch_pass(en, cur ^ 1u);
         run_dp(rec + cur * kStreamTile, n_jobs, (e.x + 1u) * kStreamTile);
         stamp(4);
-        // thread 0: the ticket into the list index of the pass after the next; wave 0 asks for that pass's entry
-        if (tid == 0 && i_next != 0xffffffffu) {
-            if (dbg & 8u) i_next = next_tile(a, dbg, head, n_pass);
-            else {
-                const unsigned long long t = ticket * 8ull + head;
-                i_next = t < n_pass ? (uint32_t)t : next_tile(a, dbg, head, n_pass); // (this head is dry: try the others)
-            }
-        }
-        if (wv == 0) {
-            const uint32_t in = (uint32_t)__builtin_amdgcn_readfirstlane((int)i_next);
-            e_next = in != 0xffffffffu ? entry_of(in) : none;
-        }
+        if (wv == 0) e_next = e_load; // (asked for at this pass's start)
         __builtin_amdgcn_s_waitcnt(0x0f70); // (the next pass's records have landed)
         stamp(5);
         __syncthreads(); // B2: every wave is done with the image and with this pass's records
