@@ -598,6 +598,9 @@ def main():
     launches_in_pipeline = []
     for e in engines:
         e.set_option("time_plan", 1)
+        # (the timed passes create and enqueue in two calls with nothing in between: the wide bands' launch goes out with the
+        # planning launches as inside rawdtw_batch_submit, so that the brackets are those of the loop `value` times)
+        e.set_option("wide_at_create", 1)
     timed_pass_first = issued["dtw"]
     pipeline(max(K, 2 * slots), pcie=False, timed_launches=launches_in_pipeline)
     timed_pass_count = issued["dtw"] - timed_pass_first
@@ -627,6 +630,7 @@ def main():
         wide_ms.append(ms.value)
     for e in engines:
         e.set_option("time_plan", 0)
+        e.set_option("wide_at_create", 0)
     # ---- kernel replay: the resident planned batches' launches only ----
     infos = []
     for sl in range(slots):

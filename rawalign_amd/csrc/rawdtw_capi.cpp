@@ -88,6 +88,7 @@ struct rawdtw_ctx {
     int stream_threads = 256;                   // workgroup size of k_runs (256 or 512)
     uint32_t wide_blocks = 256;                 // workgroups (four waves each) of the side list's launch
     int pass_pool = -1;                         // copy-order slots beyond one a tile (tests: a batch that runs out is redone through the job list); -1: 3 a tile + 64
+    int wide_at_create = 0;                     // 1: also after a plain rawdtw_batch_create (the caller leaves the arenas alone until the run)
     bool in_submit = false;                     // inside rawdtw_batch_submit*: create and run are one call
     int wide_order = 0;                         // 0: k_wide between the scan and the pass planning (first run), 1: in front of k_runs, 2: behind it
     int wide_beside = 0;                        // 1: that launch on the context's second stream, beside the tiles' launch; 0: in line (measured:
@@ -1260,6 +1261,7 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     if (!strcmp(name, "plan_threads")) { ctx->plan_threads = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); return RAWDTW_OK; }
     if (!strcmp(name, "debug_skip_kinds")) { ctx->debug_skip_kinds = (uint32_t)value; return RAWDTW_OK; }
     if (!strcmp(name, "pass_pool")) { ctx->pass_pool = (int)std::min<int64_t>(std::max<int64_t>(value, -1), 1 << 24); return RAWDTW_OK; }
+    if (!strcmp(name, "wide_at_create")) { ctx->wide_at_create = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "wide_order")) { ctx->wide_order = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return RAWDTW_OK; }
     if (!strcmp(name, "wide_beside")) { ctx->wide_beside = value != 0; return RAWDTW_OK; }
     if (!strcmp(name, "wide_blocks")) { ctx->wide_blocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 65535); return RAWDTW_OK; }
@@ -1937,7 +1939,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     b->wide_out = false;
     // (only inside rawdtw_batch_submit*: between a separate create and run the caller may upload new events, and a run reads
     // the arenas as they are then)
-    if (e == hipSuccess && !(ctx->stream_debug & 4u) && ctx->wide_order == 0 && ctx->in_submit) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
+    if (e == hipSuccess && !(ctx->stream_debug & 4u) && ctx->wide_order == 0 && (ctx->in_submit || ctx->wide_at_create)) { e = stream_wide_fork(ctx, a); b->wide_out = e == hipSuccess; }
     if (e == hipSuccess && ctx->time_plan) e = hipEventRecord(b->ev_plan[2], s);
     if (e == hipSuccess) e = stream_plan_passes(a, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "batch planning launches");
