@@ -940,8 +940,10 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_
 } // namespace
 
 // k_wide: the side list -- the one part in two hundred whose band the lane bodies of the tiles do not take -- as a launch of
-// its own, on a stream of its own beside the tiles' launch (it needs no LDS image and fits the registers the tiles' three
-// workgroups a compute unit leave free): wave-cooperative jobs, longest first, dealt over the waves of the grid.
+// its own (inside k_runs its waves kept a third of the workgroups from the tiles for a third of the launch): wave-
+// cooperative jobs, longest first, dealt over the waves of the grid.  It needs no LDS and ends with its longest job
+// (a wave per job: 163 ns a column).  In line on the batch's stream, between the scan and the pass planning
+// (rawdtw_capi.cpp: stream_wide_fork; on a second stream beside the tiles it cost more in fork / join than it hid).
 __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 {
     const uint32_t dbg = a.debug;
@@ -1000,8 +1002,8 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 // and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- the scan planned them (plan of a
 // tile: scan_unit_body), so a pass here is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records
 // at a time), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
-// start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer (issued
-// before pass i's staging, landed before its first barrier), and pass i + 2's list entry is being dequeued.
+// start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer, pass
+// i + 2's list entry is on its way and pass i + 3's ticket is being drawn.
 // DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
 // carries none of their branches.
 template <int TT, bool DIAG>
