@@ -1092,10 +1092,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
     // workgroup finish together whatever the mix
     auto run_dp = [&](const uint2 *rc_base, const uint32_t n_jobs, const uint32_t end_nom) {
-        while (!(dbg & 1u)) {
-            uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(&s_seq, 1u);
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        for (uint32_t c = wv; !(dbg & 1u);) { // (a wave's first chunk is its own number: no round trip through the counter)
             if (c * 64u >= n_jobs) break;
             const uint32_t r = c * 64u + lane;
             const bool act = r < n_jobs;
@@ -1103,6 +1100,9 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
             const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u, u = (rc.y >> 17) & (kStreamTile - 1u);
             const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
             if (act) a.out[end_nom - 1u - u] = res; // the part that ends at anchor (tile end - 1 - u)
+            uint32_t cn = 0;
+            if (lane == 0) cn = atomicAdd(&s_seq, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cn);
         }
     };
     uint32_t cur = 0;
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         uint32_t i2 = 0xffffffffu;
         if (tid == 0) {
             s_ent[cur ^ 1u] = e_next;
-            s_seq = 0;
+            s_seq = kWaves; // (the chunks behind the waves' first ones)
             if (more) {
                 if (dbg & 8u) i2 = next_tile(a, dbg, head, n_pass);
                 else {
@@ -1135,12 +1135,14 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         // waits between a wave's pieces: all of them are in flight at once ----
         __builtin_amdgcn_s_setprio(2); // a fresh pass's loads must not queue behind the DP of the older workgroups
         if (!(dbg & 2u)) {
-            const uint4 *ord = rtab + cur * kRT;
+            // (one LDS read for all of the pass's orders, a lane each; the wave's share comes out of it by v_readlane: no LDS
+            // round trip per order in front of its copies)
+            static_assert(kRT <= 64, "an order a lane");
+            const uint4 o_all = (uint32_t)lane < n_ord ? rtab[cur * kRT + lane] : make_uint4(0u, 0u, 0u, 0u);
             for (uint32_t it = wv; it < n_ord; it += kWaves) {
-                const uint4 o = ord[it];
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)o.x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)o.y);
-                const long long off = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)o.z) |
-                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)o.w) << 32));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)o_all.x, (int)it), hi = (uint32_t)__builtin_amdgcn_readlane((int)o_all.y, (int)it);
+                const long long off = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)o_all.z, (int)it) |
+                                                  ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)o_all.w, (int)it) << 32));
                 const float4 *src = reinterpret_cast<const float4 *>(((it & 1u) ? a.ref : a.ev) + off);
                 for (uint32_t q0 = lo; q0 < hi; q0 += 64u)
                     if (q0 + (uint32_t)lane < hi) dma16(src + q0 + lane, win + 4u * q0);
