@@ -1034,12 +1034,12 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
     // a pass's records (all waves: two records a piece) and, by the last wave, its copy orders, into buffer `buf`
-    auto fetch_pass = [&](const uint4 e, const uint32_t buf) {
+    auto fetch_pass = [&](const uint4 e, const uint32_t buf, const bool one_wave) {
         const uint32_t n_jobs = e.z & 0xffffu, n_ord = 2u * (e.z >> 16), pieces = (n_jobs + 1u) >> 1;
         const uint2 *src = a.recs + (uint64_t)e.x * kStreamRecStride + (e.w >> 16);
-        for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += TT)
+        for (uint32_t q0 = one_wave ? 0u : wv * 64u; q0 < pieces; q0 += one_wave ? 64u : (uint32_t)TT)
             if (q0 + (uint32_t)lane < pieces) dma16(src + 2u * (q0 + (uint32_t)lane), rec + buf * kStreamTile + 2u * q0);
-        if (wv == kWaves - 1u && (uint32_t)lane < n_ord) dma16(a.runtab + (uint64_t)e.y * kRT + lane, rtab + buf * kRT);
+        if ((one_wave || wv == kWaves - 1u) && (uint32_t)lane < n_ord) dma16(a.runtab + (uint64_t)e.y * kRT + lane, rtab + buf * kRT);
     };
 
     // diagnostic build of the launch ("stream_debug" 256): where a wave's cycles go, phase by phase (s_memtime around the
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     }
     __syncthreads();
     if (s_ent[0].x == 0xffffffffu) return;
-    fetch_pass(s_ent[0], 0u); // the first pass's records: nobody to fetch them ahead
+    fetch_pass(s_ent[0], 0u, false); // the first pass's records: nobody to fetch them ahead
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
@@ -1129,6 +1129,11 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         if (wv == 0) {
             i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i2);
             e_load = i2 != 0xffffffffu ? entry_of(i2) : none;
+            // the next pass's records and copy orders into the other buffer (read last in the pass before this one: every wave
+            // is past that DP): wave 0 holds the entry -- five DMA instructions, in flight beside this pass's staging and
+            // landed with it (the wait in front of B1), so that nothing has to be waited for behind the DP: the costs' stores
+            // need no acknowledgement before the next pass
+            if (e_next.x != 0xffffffffu) fetch_pass(e_next, cur ^ 1u, true);
         }
         stamp(0);
         // ---- staging: a wave's share of the copy orders, 16 bytes a lane, consecutive lanes consecutive pieces; nothing
@@ -1154,13 +1159,9 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         stamp(2);
         __syncthreads(); // B1: the image is staged; the next pass's entry is published
         stamp(3);
-        // the next pass's records into the other buffer (read last in the pass before this one: every wave is past that DP)
-        const uint4 en = s_ent[cur ^ 1u];
-        if (en.x != 0xffffffffu) fetch_pass(en, cur ^ 1u);
         run_dp(rec + cur * kStreamTile, n_jobs, (e.x + 1u) * kStreamTile);
         stamp(4);
         if (wv == 0) e_next = e_load; // (asked for at this pass's start)
-        __builtin_amdgcn_s_waitcnt(0x0f70); // (the next pass's records have landed)
         stamp(5);
         __syncthreads(); // B2: every wave is done with the image and with this pass's records
         stamp(6);
