@@ -429,12 +429,6 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0;
     unsigned long long my_obytes = 0;
     uint32_t o_rec[kHalves][KI]; // the thread's side-list parts: slot | class << 16 | radius << 21 (0xffffffff: none)
-    // chunk rounds: the chain-level values of the part's chain and of the chain it continues, kept while the thread's parts
-    // stay inside one chain (they mostly do)
-    uint64_t cc = ~0ull, c_a1 = 0, pa0 = 0, pa1 = 0;
-    bool c_ok = false;
-    uint64_t c_rb = 0;
-    uint32_t c_qb = 0;
 #pragma unroll
     for (uint32_t h = 0; h < kHalves; h++) {
     const uint64_t ih = i0 + (uint64_t)h * kHalf;
@@ -443,15 +437,18 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         for (int k = 0; k <= KI; k++) an[k] = ih + k < a.n_anchors ? a.anchors[ih + k] : rawdtw_anchor_t{0, 0};
     }
     uint32_t carried_bits = 0, half_tiles = 0;
+    if (carry) {
+        // Chunk rounds, a pass of its own in front of the classification (so that neither loop carries the other's registers):
+        // a part whose two anchors and bases equal those of the same part of the chain it continues takes that part's cost
+        uint64_t cc = ~0ull, c_a1 = 0, pa0 = 0, pa1 = 0;
+        bool c_ok = false;
+        uint64_t c_rb = 0;
+        uint32_t c_qb = 0;
 #pragma unroll
-    for (int k = 0; k < KI; k++) {
-        o_rec[h][k] = 0xffffffffu;
-        const uint32_t p = h * kHalf + (uint32_t)tid * KI + k; // position in the unit
-        const uint64_t i = base + p;
-        if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
-        const Part pt = classify(a, an[k + 1], an[k]);
-        if (!pt.asc || pt.n >= 0x7fffffffu || pt.m >= 0x7fffffffu) { atomicMin(&a.cnt[kCntBad], (unsigned long long)i); continue; }
-        if (carry) {
+        for (int k = 0; k < KI; k++) {
+            const uint32_t p = h * kHalf + (uint32_t)tid * KI + k;
+            const uint64_t i = base + p;
+            if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue;
             // part p_idx of chain c (counted from the chain's start, rmap.cpp:248-293) = the part that ends at anchor a1 - 2 - p_idx
             const uint64_t c = chain_at(p);
             if (c != cc) {
@@ -483,11 +480,20 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
                         a.out[i] = cost;
                         carried_bits |= 1u << k;
                         my_reused++;
-                        continue;
                     }
                 }
             }
         }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; k++) {
+        o_rec[h][k] = 0xffffffffu;
+        const uint32_t p = h * kHalf + (uint32_t)tid * KI + k; // position in the unit
+        const uint64_t i = base + p;
+        if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
+        const Part pt = classify(a, an[k + 1], an[k]);
+        if (!pt.asc || pt.n >= 0x7fffffffu || pt.m >= 0x7fffffffu) { atomicMin(&a.cnt[kCntBad], (unsigned long long)i); continue; }
+        if (carry && ((carried_bits >> k) & 1u)) continue; // (its cost came from the round before: the pass above)
         if (pt.tile) { my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(kScanT, 8) void k_scan(const StreamArgs a, ChainDes
     else scan_unit_body<false, false>(a, b - 1 - n_desc);
 }
 // (a chunk round that takes costs over from the round before: the units look every part up there first)
-__global__ __launch_bounds__(kScanT) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+__global__ __launch_bounds__(kScanT, 6) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
