@@ -148,7 +148,8 @@ struct StreamArgs {
                                  // of tiles that take several
     uint32_t lds_floats;         // the DTW launch's image budget (floats): a pass's windows fit it
     uint32_t debug;              // timing experiments only (results wrong below 128 except 8; != 0 selects k_runs' diagnostic
-                                 // instance): k_runs 1 no DP, 2 no staging, 8 passes dealt by block index, 256 phase stamps;
+                                 // instance): k_runs 1 no DP, 2 no staging, 8 passes dealt by block index, 256 phase stamps, 512 a pass without its
+                                 // first chunk of 64 jobs, 1024 a pass's first chunk only;
                                  // k_wide 32 no wave-per-job items, 64 no group / lane items, 2048 items over all waves, 4096
                                  // items dealt straight (not alternating); 4 no k_wide launch at all
     // inputs (device)

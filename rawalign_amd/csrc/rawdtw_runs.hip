@@ -1100,6 +1100,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     auto run_dp = [&](const uint2 *rc_base, const uint32_t n_jobs, const uint32_t end_nom) {
         for (uint32_t c = wv; !(dbg & 1u);) { // (a wave's first chunk is its own number: no round trip through the counter)
             if (c * 64u >= n_jobs) break;
+            if ((dbg & 512u) && c == 0u) { uint32_t cn0 = 0; if (lane == 0) cn0 = atomicAdd(&s_seq, 1u); c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cn0); continue; } // (timing: a pass without its first chunk)
+            if ((dbg & 1024u) && c != 0u) break; // (timing: a pass's first chunk only)
             const uint32_t r = c * 64u + lane;
             const bool act = r < n_jobs;
             const uint2 rc = rc_base[act ? r : n_jobs - 1u];
