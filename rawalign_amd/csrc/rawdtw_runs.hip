@@ -773,23 +773,33 @@ __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
                     const uint32_t adj = (cut_run && u > u0) ? 1u : 0u;
                     const uint32_t g = ss - b0s + (cut_run ? 1u : 0u) - 1u; // the item's run in this pass
                     if (starts) {
+                        // the run's first part leaves what its run's table entry is made of -- the sums before it (its own
+                        // contribution off; a cut run's first part counts as a start: + 4 behind it), its start anchor, its
+                        // position -- in the entry's words; lane g makes the entry of it below, once for all runs (here the
+                        // chain's bases would be fetched in eight divergent rounds, one per item of a lane)
                         const rawdtw_anchor_t sa = an[k + 1];
-                        const uint64_t c = chain_at((uint32_t)lane * KI + k);
-                        const uint64_t rb = a.ref_base[c];
-                        const uint32_t qb = a.read_base[c];
-                        // the sums before the item (its own contribution off; a cut run's first part counts as a start: + 4 behind it)
-                        const uint32_t q_r = sr - (c_r & 0xfffffu) - b0r + 4u * adj, q_f = sf - c_f - b0f + 4u * adj;
-                        const uint32_t off_r = qb + sa.query_position;
-                        const uint64_t off_f = rb + sa.target_position;
-                        const uint32_t p_r = q_r + ((off_r - q_r) & 3u), p_f = region + q_f + (((uint32_t)off_f - q_f) & 3u);
-                        rt.lo[0][g] = p_r & ~3u; rt.lo[1][g] = p_f & ~3u;
-                        rt.D[0][g] = (int32_t)(p_r - sa.query_position); rt.D[1][g] = (int32_t)(p_f - sa.target_position);
-                        rt.src[0][g] = (long long)off_r - (long long)p_r; rt.src[1][g] = (long long)off_f - (long long)p_f;
+                        rt.lo[0][g] = sr - (c_r & 0xfffffu) - b0r + 4u * adj; rt.lo[1][g] = sf - c_f - b0f + 4u * adj;
+                        rt.D[0][g] = (int32_t)sa.query_position; rt.D[1][g] = (int32_t)sa.target_position;
+                        rt.src[0][g] = (long long)((uint32_t)lane * KI + k);
                     }
                     if (ends) { rt.end[0][g] = an[k].query_position + 1u; rt.end[1][g] = an[k].target_position + 1u; }
                 }
             }
-            wave_lds_sync(); // (the run table and the counts are complete)
+            wave_lds_sync(); // (the runs' first parts and the counts are complete)
+            if ((uint32_t)lane < n_runs) { // run g = lane: its chain (a popcount over the chain-start mask), its bases, its place in the image
+                const uint32_t g = (uint32_t)lane;
+                const uint32_t q_r = rt.lo[0][g], q_f = rt.lo[1][g], sq = (uint32_t)rt.D[0][g], st = (uint32_t)rt.D[1][g];
+                const uint64_t c = chain_at((uint32_t)rt.src[0][g]);
+                const uint64_t rb = a.ref_base[c];
+                const uint32_t qb = a.read_base[c];
+                const uint32_t off_r = qb + sq;
+                const uint64_t off_f = rb + st;
+                const uint32_t p_r = q_r + ((off_r - q_r) & 3u), p_f = region + q_f + (((uint32_t)off_f - q_f) & 3u);
+                rt.lo[0][g] = p_r & ~3u; rt.lo[1][g] = p_f & ~3u;
+                rt.D[0][g] = (int32_t)(p_r - sq); rt.D[1][g] = (int32_t)(p_f - st);
+                rt.src[0][g] = (long long)off_r - (long long)p_r; rt.src[1][g] = (long long)off_f - (long long)p_f;
+            }
+            wave_lds_sync(); // (the run table is complete)
             // the bins' first places (three a lane), written back over the counts
             const uint32_t h0 = hist[3 * lane], h1 = hist[3 * lane + 1], h2 = hist[3 * lane + 2];
             const uint32_t hsum = h0 + h1 + h2, hincl = wave_scan_incl(hsum);
