@@ -330,6 +330,8 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
     __shared__ uint32_t s_todo; // bit t: tile t of the unit has a part for the lane-per-job bodies to score
+    constexpr uint32_t kOList = 2048;
+    __shared__ uint32_t s_olist[kOList]; // the unit's side-list parts by slot: position | class << 13 | radius << 18
     const int tid = threadIdx.x, lane = tid & 63;
     const uint64_t base = (uint64_t)unit * AT;
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
@@ -507,7 +509,13 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         else if (K <= 256) cls = N >= 1024 ? kClsW0 : N >= 256 ? kClsW0 + 1 : N >= 64 ? kClsW0 + 2 : kClsW0 + 3;
         else { atomicAdd(&a.cnt[kCntUnsupported], 1ull); continue; }
         my_obytes += 4ull * ((unsigned long long)pt.n + pt.m) + 36ull;
-        o_rec[h][k] = atomicAdd(&s_ocnt, 1u) | (cls << 16) | ((uint32_t)R << 21); // (slot < 2^13, class < 2^5, R < 2^8)
+        {   // a slot in the unit's share of the side list; what the record is made of goes to the slot's word in LDS, where
+            // the unit's threads make the records one each, side by side (below) -- or, beyond that list's length, stays with
+            // the thread (position < 2^13, class < 2^5, R < 2^8)
+            const uint32_t slot = atomicAdd(&s_ocnt, 1u);
+            if (slot < kOList) s_olist[slot] = p | (cls << 13) | ((uint32_t)R << 18);
+            else o_rec[h][k] = slot | (cls << 16) | ((uint32_t)R << 21);
+        }
         atomicAdd(&s_cls[cls], 1u);
     }
     if (CARRY && a.carried && ih < a.n_anchors) a.carried[ih >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
@@ -540,29 +548,36 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
     if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
     __syncthreads();
-    if (s_ocnt) {
+    auto side_record = [&](const uint32_t p, const uint32_t cls, const uint32_t R, const uint64_t q) {
+        if (q >= a.others_cap) return; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
+        const uint64_t c = chain_at(p);
+        // (rare: read again rather than kept; the compact form's next unit writes its first entry itself: that one travels whole)
+        const rawdtw_anchor_t e = anchors_rd[base + p];
+        const rawdtw_anchor_t s = (COMPACT && p + 1u == AT) ? a.unit_abs[unit + 1] : anchors_rd[base + p + 1];
+        DevJob d;
+        d.ref_off = a.ref_base[c] + s.target_position;
+        d.read_off = a.read_base[c] + s.query_position;
+        d.n = e.query_position - s.query_position + 1;
+        d.m = e.target_position - s.target_position + 1;
+        d.R = (int32_t)R;
+        d.flags = mask_bit(s_mask, p) ? 0u : kFlagExcludeLast; // rmap.cpp:270: every part but the chain's last (= its first entry)
+        d.aux = (uint32_t)(base + p);
+        a.omix[q] = d; a.ocls[q] = (uint8_t)cls;
+    };
+    // the side list's records: one a thread out of the LDS list (a unit has some forty: one round of loads instead of one per
+    // item of a thread that holds one) ...
+    for (uint32_t t = (uint32_t)tid; t < min(s_ocnt, kOList); t += NT) {
+        const uint32_t w = s_olist[t];
+        side_record(w & 0x1fffu, (w >> 13) & 0x1fu, w >> 18, (uint64_t)s_obase + t);
+    }
+    if (s_ocnt > kOList) { // ... and those beyond the list's length from the threads that found them
         const uint64_t obase = s_obase;
 #pragma unroll
         for (uint32_t h = 0; h < kHalves; h++)
 #pragma unroll
             for (int k = 0; k < KI; k++) {
                 if (o_rec[h][k] == 0xffffffffu) continue;
-                const uint64_t q = obase + (o_rec[h][k] & 0xffffu);
-                if (q >= a.others_cap) continue; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
-                const uint32_t p = h * kHalf + (uint32_t)tid * KI + k;
-                const uint64_t c = chain_at(p);
-                // (rare: read again rather than kept; the compact form's next unit writes its first entry itself: that one travels whole)
-                const rawdtw_anchor_t e = anchors_rd[base + p];
-                const rawdtw_anchor_t s = (COMPACT && p + 1u == AT) ? a.unit_abs[unit + 1] : anchors_rd[base + p + 1];
-                DevJob d;
-                d.ref_off = a.ref_base[c] + s.target_position;
-                d.read_off = a.read_base[c] + s.query_position;
-                d.n = e.query_position - s.query_position + 1;
-                d.m = e.target_position - s.target_position + 1;
-                d.R = (int32_t)(o_rec[h][k] >> 21);
-                d.flags = mask_bit(s_mask, p) ? 0u : kFlagExcludeLast; // rmap.cpp:270: every part but the chain's last (= its first entry)
-                d.aux = (uint32_t)(base + p);
-                a.omix[q] = d; a.ocls[q] = (uint8_t)((o_rec[h][k] >> 16) & 0x1fu);
+                side_record(h * kHalf + (uint32_t)tid * KI + k, (o_rec[h][k] >> 16) & 0x1fu, o_rec[h][k] >> 21, obase + (o_rec[h][k] & 0xffffu));
             }
     }
 }
