@@ -638,12 +638,12 @@ __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
     __shared__ uint32_t s_maskw[kPlanT / 64][kWords + 1], s_prew[kPlanT / 64][kWords + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
+    const uint32_t li = blockIdx.x * (kPlanT / 64) + wv; // the wave's entry of the tile list; its first pass takes the same index
+    const uint2 te = a.tlist[min(li, a.n_tiles - 1u)];  // (asked for with the counters: one round trip, not two; used if it exists)
     // (a batch the scan declined is redone through the job list: nothing may be derived from its anchors)
     if (a.cnt[kCntBad] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) return;
     const uint32_t n_list = (uint32_t)min<unsigned long long>(a.cnt[kCntTodo], (unsigned long long)a.n_tiles);
-    const uint32_t li = blockIdx.x * (kPlanT / 64) + wv; // the wave's entry of the tile list; its first pass takes the same index
     if (li >= n_list) return;
-    const uint2 te = a.tlist[li];
     const uint32_t tile = te.x;
     const uint64_t c0 = te.y, base = (uint64_t)tile * kStreamTile;
     uint32_t *hist = s_hist[wv], *tmp = s_tmp[wv], *mask = s_maskw[wv], *pre = s_prew[wv];
