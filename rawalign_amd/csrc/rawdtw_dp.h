@@ -451,7 +451,11 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
     uint32_t col = 1;
     // first columns: some lane still has cells above row 0 (or left of column 0) inside its band
     for (; col < n_max && __any((g.row < off || col < 3u) && col < N); col++) lane_gen_step<true, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
-    for (; col < n_max; col++) lane_gen_step<false, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
+    for (; col + 1u < n_max; col += 2u) { // (two columns a round: the window and antidiagonal moves of one fold into the other's operands)
+        lane_gen_step<false, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
+        lane_gen_step<false, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col + 1u);
+    }
+    if (col < n_max) lane_gen_step<false, CLAMP>(g, LA, LB, N, M, off, sh, r1, r2, col);
     return g.res;
 }
 
@@ -577,7 +581,7 @@ __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, c
     float res = d11;
     uint32_t rem = 0, row = 0;
     bool prev_adv = false;
-    for (uint32_t col = 1; col < n_max; col++) {
+    auto step = [&](const uint32_t col) {
         rem += M;
         const bool adv = rem >= N;
         rem -= adv ? N : 0u;
@@ -607,7 +611,10 @@ __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, c
         bp0 = bn0; bp1 = bn1; bp2 = bn2;
         prev_adv = adv;
         res = (col == N - 1u) ? d11 : res;
-    }
+    };
+    uint32_t col = 1;
+    for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
+    if (col < n_max) step(col);
     return res;
 }
 
@@ -625,7 +632,7 @@ __device__ __forceinline__ float lane_dp_r2(const float *LA, const float *LB, co
     float a_next = LA[2], b_next = LB[2];
     float res = d11;
     uint32_t rem = 0, row = 0;
-    for (uint32_t col = 1; col < n_max; col++) {
+    auto step = [&](const uint32_t col) {
         rem += M;
         const bool adv = rem >= N;
         rem -= adv ? N : 0u;
@@ -650,7 +657,10 @@ __device__ __forceinline__ float lane_dp_r2(const float *LA, const float *LB, co
         d00 = X0; d01 = X1; d10 = pr0; d11 = pr1; d12 = pr2;
         bp0 = bn0; bp1 = bn1; bp2 = bn2;
         res = (col == N - 1u) ? d11 : res;
-    }
+    };
+    uint32_t col = 1;
+    for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
+    if (col < n_max) step(col);
     return res;
 }
 
@@ -671,7 +681,7 @@ __device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, co
     float bp1 = LB[0];
     float a_next = LA[2], b_next = LB[1];
     float res = prim;
-    for (uint32_t col = 1; col < n_max; col++) {
+    auto step = [&](const uint32_t col) {
         const float bn0 = bp1, bn1 = b_next;                         // the b-window moves with the row: every column
         b_next = LB[col + 1];
         const float sec0 = min3f(kInf, prim, x0) + dist(ap0, bn0);   // (col, col - 1): no top (is_first)
@@ -681,7 +691,10 @@ __device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, co
         const float pr1 = min3f(sec0, sec1, prim) + dist(ap1, bn1);  // (col, col)
         x0 = sec0; x1 = sec1; prim = pr1; bp1 = bn1;
         res = (col == N - 1u) ? prim : res;
-    }
+    };
+    uint32_t col = 1;
+    for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
+    if (col < n_max) step(col);
     return res;
 }
 
