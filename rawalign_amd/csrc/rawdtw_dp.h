@@ -459,6 +459,97 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
     return g.res;
 }
 
+// Radius 3 with the band's four slots over the four lanes of a QUAD: sixteen jobs a wave.  A tile holds some ten radius-3
+// parts (read side of 20..39 events): one a lane they fill a sixth of a wave, which then runs the four-slot body above for
+// the longest of them -- the tile's slowest wave.  Here lane p of a quad keeps slot p of the job's two antidiagonals (d0,
+// d1), of its a-window and of its b-window; a column costs a lane one secondary and one primary cell, the neighbours'
+// values come by DPP quad permutes.  Same cells, same operands and the same guarded reads as lane_gen_step with
+// sh = 1, off = 2, r1 = r2 = false (R = 3: P = 3 primaries at slots 1..3, S = 4 secondaries):
+//     sec[p] = min3(p == 0 ? 1e10 : d1[p],  p == 3 ? 1e10 : d1[p + 1],  p == 0 && !prev_adv ? 1e10 : d0[p]) + |ap[p] - bn[p]|
+//     pr[p]  = min3(p == 0 || (p == 1 && !adv) ? 1e10 : X[p - 1],  X[p],
+//                   adv ? d1[p] : (p == 0 || (p == 1 && !prev_adv) ? 1e10 : d0[p - 1]))             + |ap'[p] - bn[p]|
+// The job's bookkeeping (rem, row, the operand loads) runs in all four lanes alike.  The result is the centre slot's:
+// lane 2 of the quad.
+__device__ __forceinline__ float quad_up(float v) // lane p of a quad: lane p + 1's value (lane 3: its own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xF9, 0xf, 0xf, false)); // quad_perm:[1,2,3,3]
+}
+__device__ __forceinline__ float quad_dn(float v) // lane p of a quad: lane p - 1's value (lane 0: its own)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x90, 0xf, 0xf, false)); // quad_perm:[0,0,1,2]
+}
+
+struct QuadLane {
+    float d0, d1, ap, bp;
+    float a_next, b_next, res;
+    uint32_t rem;
+    int row;
+    bool prev_adv;
+};
+
+template <bool MASKED>
+__device__ __forceinline__ void quad_r3_step(QuadLane &g, const float *LA, const float *LB, const uint32_t N, const uint32_t M, const int p,
+                                             const uint32_t col)
+{
+    const bool is0 = p == 0, is1 = p == 1, is3 = p == 3;
+    g.rem += M;
+    const bool adv = g.rem >= N;
+    g.rem -= adv ? N : 0u;
+    g.row += adv ? 1 : 0;
+    // b-window: one step when the row advances
+    const float b_up = quad_up(g.bp);
+    const float bn = adv ? (is3 ? g.b_next : b_up) : g.bp;
+    g.b_next = LB[g.row + 2];
+    // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
+    const float d1_up = quad_up(g.d1);
+    float sec = min3f(is0 ? kInf : g.d1, is3 ? kInf : d1_up, (is0 && !g.prev_adv) ? kInf : g.d0) + dist(g.ap, bn);
+    if (MASKED && (p < 2 - g.row || p > (int)col + 1)) sec = kInf; // low side: j = row - 2 + p >= 0 and i = col + 1 - p >= 0
+    const float X = adv ? sec : g.d1; // the antidiagonal just before this column's primary
+    // a-window: one step per column
+    const float a_dn = quad_dn(g.ap);
+    g.ap = is0 ? g.a_next : a_dn;
+    g.a_next = LA[col + 3u];
+    // primary antidiagonal (dtw.cpp:416-485)
+    const float X_dn = quad_dn(X), d0_dn = quad_dn(g.d0);
+    const float top = (is0 || (is1 && !adv)) ? kInf : X_dn;
+    const float stay = (is0 || (is1 && !g.prev_adv)) ? kInf : d0_dn;
+    float pr = min3f(top, X, adv ? g.d1 : stay) + dist(g.ap, bn);
+    if (MASKED && p < 2 - g.row) pr = kInf; // low side: j = row - 2 + p >= 0
+    g.d0 = X; g.d1 = pr; g.bp = bn;
+    g.prev_adv = adv;
+    g.res = (col == N - 1u) ? pr : g.res; // (dtw.cpp:506-512: the centre of the last primary, in the quad's lane 2)
+}
+
+// N, M of the quad's job in all four of its lanes (R = 3: N >= M, N >= 20); n_max = the largest N of the wave.  The result is
+// valid in lane 2 of the quad.  Operands beyond a window's end are read unclamped (a tile's image has slack behind it).
+__device__ __forceinline__ float quad_dp_r3(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const int lane,
+                                            const uint32_t n_max)
+{
+    const int p = lane & 3;
+    const int iN = (int)N, iM = (int)M;
+    QuadLane g;
+    g.d0 = kInf;
+    {
+        const int ia = 2 - p, ib = p - 2;
+        g.ap = LA[ia < 0 ? 0 : (ia >= iN ? iN - 1 : ia)];
+        g.bp = LB[ib < 0 ? 0 : (ib >= iM ? iM - 1 : ib)];
+    }
+    g.d1 = p == 2 ? dist(LA[0], LB[0]) : kInf; // column 0: only the corner (dtw.cpp:317-347), at the centre slot
+    g.res = g.d1;
+    g.rem = 0; g.row = 0; g.prev_adv = false;
+    g.a_next = LA[3];
+    g.b_next = LB[2];
+    uint32_t col = 1;
+    // first columns: some job still has cells above row 0 (or left of column 0) inside its band
+    for (; col < n_max && __any((g.row < 2 || col < 3u) && col < N); col++) quad_r3_step<true>(g, LA, LB, N, M, p, col);
+    for (; col + 1u < n_max; col += 2u) {
+        quad_r3_step<false>(g, LA, LB, N, M, p, col);
+        quad_r3_step<false>(g, LA, LB, N, M, p, col + 1u);
+    }
+    if (col < n_max) quad_r3_step<false>(g, LA, LB, N, M, p, col);
+    return g.res;
+}
+
 // One lane per job for bands of up to 8 slots (radius <= 7), any radius mix in a wave: the scheme of wreg_gen_step with
 // the band's slots in the lane's own registers instead of across lanes.  Physical slot p of a secondary antidiagonal is
 // cell (col - 1 + off - p, row - off + p), of a primary (col + off - p, row - off + p); primaries live at slots SH ..

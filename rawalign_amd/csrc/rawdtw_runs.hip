@@ -898,20 +898,25 @@ namespace {
 
 constexpr uint32_t kStamps = 10;
 
-// One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
-// first, then 2, then 1, each run by longer side, descending; a wave takes the shortest body that covers its radii.
-__device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
+// the largest value of the wave, in every lane
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t n_max)
 {
-    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u), r2 = __ballot(R == 2u);
-    // the wave's longest side (its jobs come in up to three runs, each longest first; sides of 63 and more share a bin)
-    uint32_t n_max = N;
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x111, 0xf, 0xf, false)); // row_shr:1
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x112, 0xf, 0xf, false)); // row_shr:2
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x114, 0xf, 0xf, false)); // row_shr:4
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x118, 0xf, 0xf, false)); // row_shr:8
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x142, 0xa, 0xf, false)); // row_bcast:15
     n_max = max(n_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)n_max, 0x143, 0xc, 0xf, false)); // row_bcast:31
-    n_max = (uint32_t)__builtin_amdgcn_readlane((int)n_max, 63);
+    return (uint32_t)__builtin_amdgcn_readlane((int)n_max, 63);
+}
+
+// One sorted chunk of a tile: 64 lanes, one job each.  The chunks of a tile are cut from one order -- the jobs of radius 3
+// first, then 2, then 1, each run by longer side, descending; a wave takes the shortest body that covers its radii.
+__device__ __forceinline__ float stream_lane_job(const float *LA, const float *LB, uint32_t N, uint32_t M, uint32_t R, bool excl, bool act)
+{
+    const unsigned long long r12 = __ballot(R <= 2u), r1 = __ballot(R == 1u), r2 = __ballot(R == 2u);
+    // the wave's longest side (its jobs come in up to three runs, each longest first; sides of 63 and more share a bin)
+    const uint32_t n_max = wave_max_u32(N);
     float res;
     if (~r1 == 0ull) res = lane_dp_r1(LA, LB, N, n_max); // (radius 1: N == M)
     else if (~r2 == 0ull) res = lane_dp_r2(LA, LB, N, M, n_max);
@@ -1123,16 +1128,38 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
     // workgroup finish together whatever the mix
     auto run_dp = [&](const uint2 *rc_base, const uint32_t n_jobs, const uint32_t end_nom) {
+        // The radius-3 records come first in the order: those among the pass's first 64 go sixteen to a wave, four lanes a
+        // job (quad_dp_r3) -- chunks 0 .. q3 - 1; the records behind them 64 to a wave as ever (a tile with more than 64
+        // radius-3 parts leaves the others to the lanes' generic body).
+        uint32_t n3;
+        {
+            const uint2 r0 = rc_base[min((uint32_t)lane, n_jobs - 1u)];
+            n3 = (uint32_t)__popcll(__ballot((uint32_t)lane < n_jobs && ((r0.y >> 14) & 3u) == 3u));
+        }
+        const uint32_t q3 = (n3 + 15u) >> 4, n_chunks = q3 + ((n_jobs - n3 + 63u) >> 6);
         for (uint32_t c = wv; !(dbg & 1u);) { // (a wave's first chunk is its own number: no round trip through the counter)
-            if (c * 64u >= n_jobs) break;
+            if (c >= n_chunks) break;
             if ((dbg & 512u) && c == 0u) { uint32_t cn0 = 0; if (lane == 0) cn0 = atomicAdd(&s_seq, 1u); c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cn0); continue; } // (timing: a pass without its first chunk)
             if ((dbg & 1024u) && c != 0u) break; // (timing: a pass's first chunk only)
-            const uint32_t r = c * 64u + lane;
-            const bool act = r < n_jobs;
-            const uint2 rc = rc_base[act ? r : n_jobs - 1u];
-            const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u, u = (rc.y >> 17) & (kStreamTile - 1u);
-            const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
-            if (act) a.out[end_nom - 1u - u] = res; // the part that ends at anchor (tile end - 1 - u)
+            if (c < q3) {
+                const uint32_t r = c * 16u + ((uint32_t)lane >> 2);
+                const bool act = r < n3;
+                const uint2 rc = rc_base[act ? r : n3 - 1u];
+                const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, u = (rc.y >> 17) & (kStreamTile - 1u);
+                const float *LA = win + (rc.x & 0xffffu), *LB = win + (rc.x >> 16);
+                float res = quad_dp_r3(LA, LB, N, M, lane, wave_max_u32(N));
+                if (act && ((lane & 3) == 2)) {
+                    if ((rc.y >> 16) & 1u) res = res - dist(LA[N - 1], LB[M - 1]);
+                    a.out[end_nom - 1u - u] = res;
+                }
+            } else {
+                const uint32_t r = n3 + (c - q3) * 64u + lane;
+                const bool act = r < n_jobs;
+                const uint2 rc = rc_base[act ? r : n_jobs - 1u];
+                const uint32_t N = rc.y & 127u, M = (rc.y >> 7) & 127u, R = (rc.y >> 14) & 3u, u = (rc.y >> 17) & (kStreamTile - 1u);
+                const float res = stream_lane_job(win + (rc.x & 0xffffu), win + (rc.x >> 16), N, M, R, (rc.y >> 16) & 1u, act);
+                if (act) a.out[end_nom - 1u - u] = res; // the part that ends at anchor (tile end - 1 - u)
+            }
             uint32_t cn = 0;
             if (lane == 0) cn = atomicAdd(&s_seq, 1u);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cn);

@@ -93,6 +93,13 @@ def _medium(rng):   # radii 1..3, shorter side down to 2, up to the tile class's
     return dq, max(1, int(round(dq * rng.uniform(0.3, 2.2))))
 
 
+def _sprinkled(rng):  # the bench batch's mix: small parts with a radius-3 part now and then (a few a tile: partly filled
+    if rng.random() < 0.03:  # waves of quad_dp_r3, four lanes a job) -- read side 20..39, the other side close to it
+        dq = int(rng.integers(20, 40))
+        return dq, max(1, dq + int(rng.integers(-9, 10)))
+    return _tiny(rng)
+
+
 def _degenerate(rng):  # windows of one or two elements on either side (anchors that share a position), next to small ones
     return int(rng.integers(0, 3)), int(rng.integers(0, 4))
 
@@ -103,7 +110,7 @@ def _wide(rng):     # side list: 8-lane, 16-lane and wave-per-job classes
 
 
 @pytest.mark.parametrize("shapes,opts", [
-    (_tiny, {}), (_medium, {}), (_wide, {}), (_degenerate, {}), (_degenerate, {"stream_tile_radius": 1}),
+    (_tiny, {}), (_medium, {}), (_wide, {}), (_degenerate, {}), (_sprinkled, {}), (_sprinkled, {"tile_lds_floats": 2048}), (_degenerate, {"stream_tile_radius": 1}),
     (_medium, {"stream_threads": 512, "tile_lds_floats": 9000}),
     (_medium, {"tile_lds_floats": 2048}), (_tiny, {"micro_max_n": 0}), (_medium, {"micro_max_n": 4, "lane_max_n": 20}),
     (_medium, {"lane_max_radius": 1}), (_wide, {"stream_threads": 512}),
