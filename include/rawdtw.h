@@ -78,7 +78,7 @@ int rawdtw_sync(rawdtw_ctx *ctx);
  *   "stream_tile_radius" 1..3 (default 3), "stream_threads" 256/512, "stream_blocks_per_cu" (default 0 = as many as fit:
  *   4): the device-planned batch's DTW launch over the tiles' passes (k_runs) -- tiles (512 consecutive anchors) take radii up
  *   to stream_tile_radius, the radii between that and lane_max_radius are scored a lane per job from the side list, bucketed
- *   by length over the whole batch; a pass's LDS image is 7000 floats unless "tile_lds_floats" is given
+ *   by length over the whole batch; a pass's LDS image is 5800 floats unless "tile_lds_floats" is given
  *   "wide_blocks" (default 256): workgroups of the side list's launch (k_wide); "wide_beside" 0/1 (default 0): that launch
  *   on the context's second stream beside the tiles' launch instead of in line (measured slower)
  *   "resident_arrays" 0/1: rawdtw_batch_create's anchors / ref_base / read_base are device pointers, used in place

@@ -196,7 +196,10 @@ struct rawdtw_batch {
     StreamArgs sa{};
     uint32_t stream_lds = 0;
     int stream_threads = 256;
-    unsigned long long *h_cnt = nullptr; // pinned landing zone of the counter block
+    unsigned long long *h_cnt = nullptr; // pinned landing zone of the counter block ...
+    float *h_score = nullptr;            // ... and, behind it at the device block's offsets, of the scores and the keep flags: counters, scores
+    uint8_t *h_keep = nullptr;           // and flags lie one behind the other in the workspace and come home in ONE copy (rawdtw_batch_fetch:
+    size_t res_bytes = 0;                // every operation on a batch's stream is a step of its latency through the pipeline: three copies -> one, + 2 %)
     bool cnt_valid = false, cells_counted = false;
     uint32_t stream_runs = 0;                // DTW launches issued for this batch (the tile queue needs a reset from the second on)
     bool dirty = false;                  // work enqueued since the last host synchronisation
@@ -1864,11 +1867,13 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
                              al((size_t)a.n_tiles * kStreamRecStride * 8) + al((size_t)a.n_slots * 2 * kStreamMaxSeg * 16) +         // job records, copy orders
                              2 * al(a.others_cap * sizeof(DevJob)) + al(a.others_cap) +                                           // side list
                              al(nc * sizeof(ChainDesc)) + 4 * al(nc * 4) + al(nc) + al(na * 4);                                   // fold, results
-    const size_t host_bytes = al(kStreamCounters * 8);
+    const size_t host_bytes = al(kStreamCounters * 8) + al(nc * 4) + al(nc);
     int st = ws_acquire(ctx, dev_bytes, host_bytes, &b->ws);
     if (st != RAWDTW_OK) return st;
     char *p = b->ws.d;
     a.cnt = carve<unsigned long long>(p, kStreamCounters);
+    b->d_score = carve<float>(p, nc); b->d_keep = carve<uint8_t>(p, nc); // (right behind the counters: one copy brings all three home)
+    b->res_bytes = (size_t)(reinterpret_cast<char *>(b->d_keep) - reinterpret_cast<char *>(a.cnt)) + nc;
     uint64_t *d_anchor_off = carve<uint64_t>(p, nc + 1);
     rawdtw_anchor_t *d_anchors = carve<rawdtw_anchor_t>(p, na);
     uint64_t *d_ref_base = carve<uint64_t>(p, nc);
@@ -1882,8 +1887,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.omix = carve<DevJob>(p, a.others_cap); a.ojobs = carve<DevJob>(p, a.others_cap); a.ocls = carve<uint8_t>(p, a.others_cap);
     b->d_chains = carve<ChainDesc>(p, nc);
     b->d_fold_order = carve<uint32_t>(p, nc);
-    b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc); b->d_score = carve<float>(p, nc);
-    b->d_keep = carve<uint8_t>(p, nc);
+    b->d_full = carve<float>(p, nc); b->d_gate = carve<float>(p, nc);
     a.out = carve<float>(p, na);
     a.debug = ctx->stream_debug;
     a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
@@ -1908,6 +1912,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     }
     char *hp = b->ws.h;
     b->h_cnt = carve<unsigned long long>(hp, kStreamCounters);
+    b->h_score = carve<float>(hp, nc); b->h_keep = carve<uint8_t>(hp, nc); // (same offsets as on the device)
     unsigned long long *h_init = b->h_cnt; // the counters' initial values travel from the pinned block
     for (int i = 0; i < kStreamCounters; i++) h_init[i] = 0;
     h_init[kCntBad] = h_init[kCntOverflow] = ~0ull;
@@ -2130,6 +2135,7 @@ int stream_fallback(rawdtw_ctx *ctx, rawdtw_batch *b)
     if (st != RAWDTW_OK) return fail(ctx, st, "job counting failed");
     b->stream = false; b->jobs_counted = true; // (batch_create_joblist sets n_jobs)
     ws_release(ctx, b->ws);
+    b->h_cnt = nullptr; b->h_score = nullptr; b->h_keep = nullptr; b->res_bytes = 0; // (they lay in the workspace)
     b->d_chains = nullptr; b->d_chain_off = nullptr; b->d_fold_order = nullptr;
     b->d_full = b->d_gate = b->d_score = nullptr; b->d_keep = nullptr;
     st = batch_create_joblist(ctx, b, b->in_chain_off, b->in_anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
@@ -2689,7 +2695,11 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 2; attempt++) {
         const float *d_cost = batch->stream ? batch->sa.out : batch->plan->d_cost;
-        if (batch->n_chains) {
+        // a sync-free batch: counters, scores and keep flags in one copy into the batch's pinned block, and from there into the
+        // caller's arrays (200 KB of host copying against two more operations on the stream)
+        const bool block = batch->stream && batch->n_chains && (score || keep);
+        if (block) HIP_TRY(ctx, hipMemcpyAsync(batch->h_cnt, batch->sa.cnt, batch->res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        else if (batch->n_chains) {
             if (score) HIP_TRY(ctx, hipMemcpyAsync(score, batch->d_score, batch->n_chains * 4, hipMemcpyDeviceToHost, ctx->stream));
             if (keep) HIP_TRY(ctx, hipMemcpyAsync(keep, batch->d_keep, batch->n_chains, hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -2700,13 +2710,17 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
             HIP_TRY(ctx, hipMemcpyAsync(per_anchor.data(), d_cost, batch->sa.n_anchors * 4, hipMemcpyDeviceToHost, ctx->stream));
         } else if (job_cost && !batch->stream && batch->n_jobs)
             HIP_TRY(ctx, hipMemcpyAsync(job_cost, d_cost, batch->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (batch->stream && !batch->cnt_valid)
+        if (batch->stream && !batch->cnt_valid && !block)
             HIP_TRY(ctx, hipMemcpyAsync(batch->h_cnt, batch->sa.cnt, kStreamCounters * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         batch->dirty = false;
         if (!batch->stream) return RAWDTW_OK;
         batch->cnt_valid = true;
         if (!stream_declined(batch)) {
+            if (block) {
+                if (score) memcpy(score, batch->h_score, batch->n_chains * 4);
+                if (keep) memcpy(keep, batch->h_keep, batch->n_chains);
+            }
             if (job_cost) { // chain c's part p (rmap.cpp:248-293) ends at anchor a1 - 2 - p
                 const uint64_t *aoff = batch->in_anchor_off;
                 uint64_t k = 0;

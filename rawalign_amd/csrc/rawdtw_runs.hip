@@ -1035,9 +1035,9 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 
 // k_runs: TT threads per workgroup (256 or 512), a persistent grid over the scan's work list.  A list entry is one PASS: up
 // to 512 tile-class parts whose windows fit the image budget, with its job records (sorted: radius class, then longer side)
-// and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- the scan planned them (plan of a
-// tile: scan_unit_body), so a pass here is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records
-// at a time), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
+// and its copy orders (a run's range of 16-byte pieces, per arena) waiting in memory -- k_plan wrote them -- so a pass here
+// is: stage the image by LDS-DMA, one barrier, the lanes' DP (a wave pulls 64 records at a time; the radius-3 records at
+// the head of the order sixteen at a time, four lanes a job: run_dp), the costs straight to out[anchor], one barrier.  Nothing a pass needs from memory is waited for at its
 // start: while pass i is computed, pass i + 1's records and copy orders come in by LDS-DMA into the other buffer, pass
 // i + 2's list entry is on its way and pass i + 3's ticket is being drawn.
 // DIAG: the instance with the timing experiments ("stream_debug" masks) and the phase stamps; the production instance
@@ -1125,8 +1125,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     fetch_pass(s_ent[0], 0u, false); // the first pass's records: nobody to fetch them ahead
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    // the DP of one pass: one lane per job; waves pull 64 sorted jobs at a time (the heavy class first), so the waves of the
-    // workgroup finish together whatever the mix
+    // the DP of one pass: waves pull chunks of the sorted records (the heavy class first), so the waves of the workgroup
+    // finish together whatever the mix
     auto run_dp = [&](const uint2 *rc_base, const uint32_t n_jobs, const uint32_t end_nom) {
         // The radius-3 records come first in the order: those among the pass's first 64 go sixteen to a wave, four lanes a
         // job (quad_dp_r3) -- chunks 0 .. q3 - 1; the records behind them 64 to a wave as ever (a tile with more than 64
