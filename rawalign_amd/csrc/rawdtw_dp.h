@@ -18,6 +18,27 @@ __device__ __forceinline__ float min3f(float top, float left, float tl)
 
 __device__ __forceinline__ float dist(float x, float y) { return __builtin_fabsf(x - y); }
 
+// Per-lane selects on a 64-bit lane mask, written as the instruction's VOP3 form.  Left to itself the compiler keeps a
+// compare's result in VCC and shrinks the selects on it to the 32-bit encoding (v_cndmask_b32_e32 ..., vcc), which gfx950
+// issues at 16-23 clocks a wave instruction whatever else the SIMD has to do; the 64-bit encoding with the mask in an SGPR
+// pair (or VCC) takes 4.5, as v_min3_f32 does (scripts/experiments/valu_rate.hip; v_add_f32 / v_sub_f32: 2.5-3).  The
+// lane bodies' row advance is per lane -- a third of their instructions are such selects.
+typedef unsigned long long lmask;
+__device__ __forceinline__ float selm(const lmask m, const float t, const float f) // m ? t : f
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t selm(const lmask m, const uint32_t t, const uint32_t f)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+// rem >= N ? rem - N : rem without a compare (unsigned: the difference wraps far above rem when rem < N)
+__device__ __forceinline__ uint32_t wrap_sub(const uint32_t rem, const uint32_t N) { return min(rem, rem - N); }
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float wave_shr1(float v, float fill)
@@ -353,29 +374,30 @@ struct GenLane {
     float a_next, b_next, res;
     uint32_t rem;
     int row;
-    bool prev_adv;
+    lmask prev_adv;
 };
 
 template <bool MASKED, bool CLAMP>
 __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const float *LB, const uint32_t N, const uint32_t M,
-                                              const int off, const bool sh, const bool r1, const bool r2, const uint32_t col)
+                                              const int off, const lmask sh, const lmask r1, const lmask r2, const uint32_t col)
 {
+    // (every per-lane select on a lane mask, by selm: see there)
     g.rem += M;
-    const bool adv = g.rem >= N;
-    g.rem -= adv ? N : 0u;
-    g.row += adv ? 1 : 0;
+    const lmask adv = __ballot(g.rem >= N);
+    g.rem = wrap_sub(g.rem, N);
+    g.row = (int)selm(adv, (uint32_t)g.row + 1u, (uint32_t)g.row);
     // b-window: one step when the row advances (b_next is a function of the row alone)
     float bn[4];
 #pragma unroll
-    for (int p = 0; p < 3; p++) bn[p] = adv ? g.bp[p + 1] : g.bp[p];
-    bn[3] = adv ? g.b_next : g.bp[3];
+    for (int p = 0; p < 3; p++) bn[p] = selm(adv, g.bp[p + 1], g.bp[p]);
+    bn[3] = selm(adv, g.b_next, g.bp[3]);
     g.b_next = LB[CLAMP ? min(g.row + 4 - off, (int)M - 1) : g.row + 4 - off];
     // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column, b-window of the new row
     float X[4];
     {
-        const float top0 = sh ? kInf : g.d1[0];                          // is_first
-        const float tl0 = (sh && !g.prev_adv) ? kInf : g.d0[0];          // previous_increment_center_row
-        const float left1 = r1 ? kInf : g.d1[2];                         // is_last (radius 1: S - 1 = 1; radius 3: slot 3 below)
+        const float top0 = selm(sh, kInf, g.d1[0]);                       // is_first
+        const float tl0 = selm(sh & ~g.prev_adv, kInf, g.d0[0]);          // previous_increment_center_row
+        const float left1 = selm(r1, kInf, g.d1[2]);                      // is_last (radius 1: S - 1 = 1; radius 3: slot 3 below)
         float sec[4];
         sec[0] = min3f(top0, g.d1[1], tl0) + dist(g.ap[0], bn[0]);
         sec[1] = min3f(g.d1[1], left1, g.d0[1]) + dist(g.ap[1], bn[1]);
@@ -383,24 +405,23 @@ __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const
         sec[3] = min3f(g.d1[3], kInf, g.d0[3]) + dist(g.ap[3], bn[3]);
         if (MASKED) { // low side: j = row - off + p >= 0 and i = col - 1 + off - p >= 0
 #pragma unroll
-            for (int p = 0; p < 4; p++)
-                if (p < off - g.row || p > (int)col - 1 + off) sec[p] = kInf;
+            for (int p = 0; p < 4; p++) sec[p] = selm(__ballot(p < off - g.row || p > (int)col - 1 + off), kInf, sec[p]);
         }
 #pragma unroll
-        for (int p = 0; p < 4; p++) X[p] = adv ? sec[p] : g.d1[p]; // the antidiagonal just before this column's primary
+        for (int p = 0; p < 4; p++) X[p] = selm(adv, sec[p], g.d1[p]); // the antidiagonal just before this column's primary
     }
     // a-window: one step per column
     g.ap[3] = g.ap[2]; g.ap[2] = g.ap[1]; g.ap[1] = g.ap[0]; g.ap[0] = g.a_next;
     g.a_next = LA[CLAMP ? min(col + 1u + (uint32_t)off, N - 1u) : col + 1u + (uint32_t)off];
     // primary antidiagonal (dtw.cpp:416-485)
     {
-        const float top1 = (sh && !adv) ? kInf : X[0];                   // o == 0 of an odd radius when the row stays
-        const float left2 = (r2 && adv) ? kInf : X[2];                   // last offset of an even radius after a secondary
-        const float t1 = g.prev_adv ? g.d0[0] : kInf;                    // (o == 0, odd radius: only after an advance)
-        const float tl0 = adv ? g.d1[0] : kInf;
-        const float tl1 = adv ? g.d1[1] : (sh ? t1 : g.d0[0]);
-        const float tl2 = adv ? g.d1[2] : g.d0[1];
-        const float tl3 = adv ? g.d1[3] : g.d0[2];
+        const float top1 = selm(sh & ~adv, kInf, X[0]);                   // o == 0 of an odd radius when the row stays
+        const float left2 = selm(r2 & adv, kInf, X[2]);                   // last offset of an even radius after a secondary
+        const float t1 = selm(g.prev_adv, g.d0[0], kInf);                 // (o == 0, odd radius: only after an advance)
+        const float tl0 = selm(adv, g.d1[0], kInf);
+        const float tl1 = selm(adv, g.d1[1], selm(sh, t1, g.d0[0]));
+        const float tl2 = selm(adv, g.d1[2], g.d0[1]);
+        const float tl3 = selm(adv, g.d1[3], g.d0[2]);
         float pr[4];
         pr[0] = min3f(kInf, X[0], tl0) + dist(g.ap[0], bn[0]);
         pr[1] = min3f(top1, X[1], tl1) + dist(g.ap[1], bn[1]);
@@ -408,16 +429,15 @@ __device__ __forceinline__ void lane_gen_step(GenLane &g, const float *LA, const
         pr[3] = min3f(X[2], X[3], tl3) + dist(g.ap[3], bn[3]);
         if (MASKED) { // low side: j = row - off + p >= 0 (i = col + off - p >= 0 for every slot of the antidiagonal)
 #pragma unroll
-            for (int p = 0; p < 4; p++)
-                if (p < off - g.row) pr[p] = kInf;
+            for (int p = 0; p < 4; p++) pr[p] = selm(__ballot(p < off - g.row), kInf, pr[p]);
         }
 #pragma unroll
         for (int p = 0; p < 4; p++) { g.d0[p] = X[p]; g.d1[p] = pr[p]; g.bp[p] = bn[p]; }
     }
     g.prev_adv = adv;
     // dtw.cpp:506-512: the centre of the last primary
-    const float centre = off == 1 ? g.d1[1] : g.d1[2];
-    g.res = (col == N - 1u) ? centre : g.res;
+    const float centre = selm(__ballot(off == 1), g.d1[1], g.d1[2]);
+    g.res = selm(__ballot(col == N - 1u), centre, g.res);
 }
 
 // N, M, R per lane (R in 1..3, N >= M, N >= 2); n_max = the largest N of the wave.  Lanes past their last column keep
@@ -427,9 +447,9 @@ template <bool CLAMP = false>
 __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t R,
                                              const uint32_t n_max)
 {
-    const bool sh = R & 1u;                 // odd radius: P = R, S = R + 1, primaries at slot o + 1 (dtw.cpp:301-303, 459, 479)
+    const lmask sh = __ballot((R & 1u) != 0u); // odd radius: P = R, S = R + 1, primaries at slot o + 1 (dtw.cpp:301-303, 459, 479)
     const int off = (int)((R + 1u) >> 1);   // P/2 + SH, the centre slot: radius 1 -> 1, 2 -> 1, 3 -> 2
-    const bool r1 = R == 1u, r2 = R == 2u;
+    const lmask r1 = __ballot(R == 1u), r2 = __ballot(R == 2u);
     const int iN = (int)N, iM = (int)M;
     GenLane g;
 #pragma unroll
@@ -445,7 +465,7 @@ __device__ __forceinline__ float lane_dp_gen(const float *LA, const float *LB, c
         g.d1[2] = off == 2 ? c : kInf;
     }
     g.res = g.d1[off == 1 ? 1 : 2]; // (N == 1 cannot occur here; kept for completeness)
-    g.rem = 0; g.row = 0; g.prev_adv = false;
+    g.rem = 0; g.row = 0; g.prev_adv = 0;
     g.a_next = LA[CLAMP ? min(1 + off, iN - 1) : 1 + off];
     g.b_next = LB[CLAMP ? min(4 - off, iM - 1) : 4 - off];
     uint32_t col = 1;
@@ -484,40 +504,39 @@ struct QuadLane {
     float a_next, b_next, res;
     uint32_t rem;
     int row;
-    bool prev_adv;
+    lmask prev_adv;
 };
 
 template <bool MASKED>
 __device__ __forceinline__ void quad_r3_step(QuadLane &g, const float *LA, const float *LB, const uint32_t N, const uint32_t M, const int p,
-                                             const uint32_t col)
+                                             const lmask is0, const lmask is1, const lmask is3, const uint32_t col)
 {
-    const bool is0 = p == 0, is1 = p == 1, is3 = p == 3;
     g.rem += M;
-    const bool adv = g.rem >= N;
-    g.rem -= adv ? N : 0u;
-    g.row += adv ? 1 : 0;
+    const lmask adv = __ballot(g.rem >= N);
+    g.rem = wrap_sub(g.rem, N);
+    g.row = (int)selm(adv, (uint32_t)g.row + 1u, (uint32_t)g.row);
     // b-window: one step when the row advances
     const float b_up = quad_up(g.bp);
-    const float bn = adv ? (is3 ? g.b_next : b_up) : g.bp;
+    const float bn = selm(adv, selm(is3, g.b_next, b_up), g.bp);
     g.b_next = LB[g.row + 2];
     // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
     const float d1_up = quad_up(g.d1);
-    float sec = min3f(is0 ? kInf : g.d1, is3 ? kInf : d1_up, (is0 && !g.prev_adv) ? kInf : g.d0) + dist(g.ap, bn);
-    if (MASKED && (p < 2 - g.row || p > (int)col + 1)) sec = kInf; // low side: j = row - 2 + p >= 0 and i = col + 1 - p >= 0
-    const float X = adv ? sec : g.d1; // the antidiagonal just before this column's primary
+    float sec = min3f(selm(is0, kInf, g.d1), selm(is3, kInf, d1_up), selm(is0 & ~g.prev_adv, kInf, g.d0)) + dist(g.ap, bn);
+    if (MASKED) sec = selm(__ballot(p < 2 - g.row || p > (int)col + 1), kInf, sec); // low side: j = row - 2 + p >= 0 and i = col + 1 - p >= 0
+    const float X = selm(adv, sec, g.d1); // the antidiagonal just before this column's primary
     // a-window: one step per column
     const float a_dn = quad_dn(g.ap);
-    g.ap = is0 ? g.a_next : a_dn;
+    g.ap = selm(is0, g.a_next, a_dn);
     g.a_next = LA[col + 3u];
     // primary antidiagonal (dtw.cpp:416-485)
     const float X_dn = quad_dn(X), d0_dn = quad_dn(g.d0);
-    const float top = (is0 || (is1 && !adv)) ? kInf : X_dn;
-    const float stay = (is0 || (is1 && !g.prev_adv)) ? kInf : d0_dn;
-    float pr = min3f(top, X, adv ? g.d1 : stay) + dist(g.ap, bn);
-    if (MASKED && p < 2 - g.row) pr = kInf; // low side: j = row - 2 + p >= 0
+    const float top = selm(is0 | (is1 & ~adv), kInf, X_dn);
+    const float stay = selm(is0 | (is1 & ~g.prev_adv), kInf, d0_dn);
+    float pr = min3f(top, X, selm(adv, g.d1, stay)) + dist(g.ap, bn);
+    if (MASKED) pr = selm(__ballot(p < 2 - g.row), kInf, pr); // low side: j = row - 2 + p >= 0
     g.d0 = X; g.d1 = pr; g.bp = bn;
     g.prev_adv = adv;
-    g.res = (col == N - 1u) ? pr : g.res; // (dtw.cpp:506-512: the centre of the last primary, in the quad's lane 2)
+    g.res = selm(__ballot(col == N - 1u), pr, g.res); // (dtw.cpp:506-512: the centre of the last primary, in the quad's lane 2)
 }
 
 // N, M of the quad's job in all four of its lanes (R = 3: N >= M, N >= 20); n_max = the largest N of the wave.  The result is
@@ -526,6 +545,7 @@ __device__ __forceinline__ float quad_dp_r3(const float *LA, const float *LB, co
                                             const uint32_t n_max)
 {
     const int p = lane & 3;
+    const lmask is0 = __ballot(p == 0), is1 = __ballot(p == 1), is3 = __ballot(p == 3);
     const int iN = (int)N, iM = (int)M;
     QuadLane g;
     g.d0 = kInf;
@@ -536,17 +556,17 @@ __device__ __forceinline__ float quad_dp_r3(const float *LA, const float *LB, co
     }
     g.d1 = p == 2 ? dist(LA[0], LB[0]) : kInf; // column 0: only the corner (dtw.cpp:317-347), at the centre slot
     g.res = g.d1;
-    g.rem = 0; g.row = 0; g.prev_adv = false;
+    g.rem = 0; g.row = 0; g.prev_adv = 0;
     g.a_next = LA[3];
     g.b_next = LB[2];
     uint32_t col = 1;
     // first columns: some job still has cells above row 0 (or left of column 0) inside its band
-    for (; col < n_max && __any((g.row < 2 || col < 3u) && col < N); col++) quad_r3_step<true>(g, LA, LB, N, M, p, col);
+    for (; col < n_max && __any((g.row < 2 || col < 3u) && col < N); col++) quad_r3_step<true>(g, LA, LB, N, M, p, is0, is1, is3, col);
     for (; col + 1u < n_max; col += 2u) {
-        quad_r3_step<false>(g, LA, LB, N, M, p, col);
-        quad_r3_step<false>(g, LA, LB, N, M, p, col + 1u);
+        quad_r3_step<false>(g, LA, LB, N, M, p, is0, is1, is3, col);
+        quad_r3_step<false>(g, LA, LB, N, M, p, is0, is1, is3, col + 1u);
     }
-    if (col < n_max) quad_r3_step<false>(g, LA, LB, N, M, p, col);
+    if (col < n_max) quad_r3_step<false>(g, LA, LB, N, M, p, is0, is1, is3, col);
     return g.res;
 }
 
@@ -662,7 +682,7 @@ __device__ __forceinline__ float lane_dp_k8(const float *A, const float *B, cons
 __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, const uint32_t N, const uint32_t M, const uint32_t R,
                                              const uint32_t n_max)
 {
-    const bool r1 = R == 1u;
+    const lmask r1 = __ballot(R == 1u);
     const int iM = (int)M;
     float d00 = kInf, d01 = kInf;                       // the antidiagonal before the latest: slots 0, 1
     float d10 = kInf, d11 = dist(LA[0], LB[0]), d12 = kInf; // the latest: the corner at the centre slot (dtw.cpp:317-347)
@@ -671,37 +691,37 @@ __device__ __forceinline__ float lane_dp_r12(const float *LA, const float *LB, c
     float a_next = LA[2], b_next = LB[2];
     float res = d11;
     uint32_t rem = 0, row = 0;
-    bool prev_adv = false;
+    lmask prev_adv = 0;
     auto step = [&](const uint32_t col) {
         rem += M;
-        const bool adv = rem >= N;
-        rem -= adv ? N : 0u;
-        row += adv ? 1u : 0u;
-        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? bp2 : bp1, bn2 = adv ? b_next : bp2;
+        const lmask adv = __ballot(rem >= N);
+        rem = wrap_sub(rem, N);
+        row = selm(adv, row + 1u, row);
+        const float bn0 = selm(adv, bp1, bp0), bn1 = selm(adv, bp2, bp1), bn2 = selm(adv, b_next, bp2);
         b_next = LB[row + 2];
         // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
-        const float top0 = r1 ? kInf : d10;                       // is_first (odd radius)
-        const float tl0s = (r1 && !prev_adv) ? kInf : d00;        // previous_increment_center_row
-        const float left1 = r1 ? kInf : d12;                      // is_last (odd radius)
+        const float top0 = selm(r1, kInf, d10);                   // is_first (odd radius)
+        const float tl0s = selm(r1 & ~prev_adv, kInf, d00);       // previous_increment_center_row
+        const float left1 = selm(r1, kInf, d12);                  // is_last (odd radius)
         const float sec0 = min3f(top0, d11, tl0s) + dist(ap0, bn0);
         const float sec1 = min3f(d11, left1, d01) + dist(ap1, bn1);
-        const float X0 = adv ? sec0 : d10, X1 = adv ? sec1 : d11;
+        const float X0 = selm(adv, sec0, d10), X1 = selm(adv, sec1, d11);
         ap2 = ap1; ap1 = ap0; ap0 = a_next;
         a_next = LA[col + 2];
         // primary antidiagonal (dtw.cpp:416-485)
-        const float top1 = (r1 && !adv) ? kInf : X0;
-        const float left2 = (!r1 && adv) ? kInf : d12;
-        const float tl0 = adv ? d10 : kInf;
-        const float tl1 = adv ? d11 : tl0s;                       // (odd radius, row stays: d0[0] only after an advance)
-        const float tl2 = adv ? d12 : d01;
+        const float top1 = selm(r1 & ~adv, kInf, X0);
+        const float left2 = selm(~r1 & adv, kInf, d12);
+        const float tl0 = selm(adv, d10, kInf);
+        const float tl1 = selm(adv, d11, tl0s);                   // (odd radius, row stays: d0[0] only after an advance)
+        const float tl2 = selm(adv, d12, d01);
         float pr0 = min3f(kInf, X0, tl0) + dist(ap0, bn0);
         const float pr1 = min3f(top1, X1, tl1) + dist(ap1, bn1);
         const float pr2 = min3f(X1, left2, tl2) + dist(ap2, bn2);
-        pr0 = row == 0u ? kInf : pr0;                             // (col + 1, -1): above the matrix
+        pr0 = selm(__ballot(row == 0u), kInf, pr0);               // (col + 1, -1): above the matrix
         d00 = X0; d01 = X1; d10 = pr0; d11 = pr1; d12 = pr2;
         bp0 = bn0; bp1 = bn1; bp2 = bn2;
         prev_adv = adv;
-        res = (col == N - 1u) ? d11 : res;
+        res = selm(__ballot(col == N - 1u), d11, res);
     };
     uint32_t col = 1;
     for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
@@ -725,29 +745,29 @@ __device__ __forceinline__ float lane_dp_r2(const float *LA, const float *LB, co
     uint32_t rem = 0, row = 0;
     auto step = [&](const uint32_t col) {
         rem += M;
-        const bool adv = rem >= N;
-        rem -= adv ? N : 0u;
-        row += adv ? 1u : 0u;
-        const float bn0 = adv ? bp1 : bp0, bn1 = adv ? bp2 : bp1, bn2 = adv ? b_next : bp2;
+        const lmask adv = __ballot(rem >= N);
+        rem = wrap_sub(rem, N);
+        row = selm(adv, row + 1u, row);
+        const float bn0 = selm(adv, bp1, bp0), bn1 = selm(adv, bp2, bp1), bn2 = selm(adv, b_next, bp2);
         b_next = LB[row + 2];
         // secondary antidiagonal (dtw.cpp:361-414): a-window of the previous column
         const float sec0 = min3f(d10, d11, d00) + dist(ap0, bn0);
         const float sec1 = min3f(d11, d12, d01) + dist(ap1, bn1);
-        const float X0 = adv ? sec0 : d10, X1 = adv ? sec1 : d11;
+        const float X0 = selm(adv, sec0, d10), X1 = selm(adv, sec1, d11);
         ap2 = ap1; ap1 = ap0; ap0 = a_next;
         a_next = LA[col + 2];
         // primary antidiagonal (dtw.cpp:416-485)
-        const float left2 = adv ? kInf : d12;
-        const float tl0 = adv ? d10 : kInf;
-        const float tl1 = adv ? d11 : d00;
-        const float tl2 = adv ? d12 : d01;
+        const float left2 = selm(adv, kInf, d12);
+        const float tl0 = selm(adv, d10, kInf);
+        const float tl1 = selm(adv, d11, d00);
+        const float tl2 = selm(adv, d12, d01);
         float pr0 = min3f(kInf, X0, tl0) + dist(ap0, bn0);
         const float pr1 = min3f(X0, X1, tl1) + dist(ap1, bn1);
         const float pr2 = min3f(X1, left2, tl2) + dist(ap2, bn2);
-        pr0 = row == 0u ? kInf : pr0;                             // (col + 1, -1): above the matrix
+        pr0 = selm(__ballot(row == 0u), kInf, pr0);               // (col + 1, -1): above the matrix
         d00 = X0; d01 = X1; d10 = pr0; d11 = pr1; d12 = pr2;
         bp0 = bn0; bp1 = bn1; bp2 = bn2;
-        res = (col == N - 1u) ? d11 : res;
+        res = selm(__ballot(col == N - 1u), d11, res);
     };
     uint32_t col = 1;
     for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
@@ -781,7 +801,7 @@ __device__ __forceinline__ float lane_dp_r1(const float *LA, const float *LB, co
         a_next = LA[col + 2];
         const float pr1 = min3f(sec0, sec1, prim) + dist(ap1, bn1);  // (col, col)
         x0 = sec0; x1 = sec1; prim = pr1; bp1 = bn1;
-        res = (col == N - 1u) ? prim : res;
+        res = selm(__ballot(col == N - 1u), prim, res);
     };
     uint32_t col = 1;
     for (; col + 1u < n_max; col += 2u) { step(col); step(col + 1u); } // (two columns a round: the moves of one fold into the other's operands)
