@@ -956,7 +956,7 @@ __device__ __forceinline__ void lane_global_wave(const DevJob *__restrict__ jobs
 // Tile queue: one returning atomic on a single word saturates near 88 dequeues per microsecond (MI355X_MICROARCH.md),
 // which a batch's ten thousand tiles would reach; eight heads on lines of their own, each dealing every eighth tile.
 // A workgroup starts on the head of its block index and moves on when a head runs dry.
-__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_t dbg, uint32_t &head, uint32_t n_tiles)
+__device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_t dbg, uint32_t &head, uint32_t n_tiles, const uint32_t base = 0u)
 {
     if (dbg & 8u) { // timing experiments: tiles dealt by block index, no queue
         const uint32_t t = head;
@@ -966,7 +966,7 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_
     for (uint32_t tries = 0; tries < 8; tries++) {
         const uint32_t h = (head + tries) & 7u;
         const uint32_t k = (uint32_t)atomicAdd(&a.cnt[kCntHeads + 16 * h], 1ull);
-        const uint64_t t = (uint64_t)k * 8u + h;
+        const uint64_t t = (uint64_t)base + (uint64_t)k * 8u + h; // (the list's first `base` entries are dealt by block index: k_runs)
         if (t < n_tiles) { head = h; return (uint32_t)t; }
     }
     return 0xffffffffu;
@@ -1053,16 +1053,14 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     uint4 *rtab = reinterpret_cast<uint4 *>(rec + 2u * kStreamTile);      // 2 x kRT copy orders
     __shared__ uint4 s_ent[2];                 // the passes' list entries, by parity (x = 0xffffffff: none)
     __shared__ uint32_t s_seq;
-    __shared__ uint32_t s_declined;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
 
     // a batch the scan declined (invalid anchors, a chain without anchors, a band nobody takes) is redone through the job
     // list: nothing to do here, and nothing may be derived from its records
-    if (tid == 0)
-        s_declined = (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) ? 1u : 0u;
-    __syncthreads();
-    if (s_declined) return;
+    // (every wave reads the counters itself -- uniform loads, asked for together with the list's sizes below: one round trip
+    // and no barrier in front of a workgroup's first pass)
+    if (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) return;
 
     // LDS-DMA: one wave instruction moves 16 bytes a lane straight into LDS at `dst` + 16 * lane; inactive lanes move
     // nothing.  `dst` must be the same in every lane.
@@ -1101,18 +1099,30 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     // The queue, three passes deep, so that no pass waits for a round trip at its start.  At the top of pass t thread 0 turns
     // the ticket it drew a pass ago into the list index of pass t + 2 and draws the ticket of pass t + 3; wave 0 asks for
     // the entry of pass t + 2 (it has the whole pass to arrive) and publishes the entry of pass t + 1 (asked for a pass ago).
+    // A workgroup's first two passes are dealt by block index (list entries b and b + grid): their entries can be asked for at
+    // once -- two queue tickets in front of the first pass were two dependent round trips.  The queue deals the entries from
+    // 2 * grid on.
     uint32_t head = (dbg & 8u) ? blockIdx.x : (blockIdx.x & 7u);
+    const uint32_t q_base = (dbg & 8u) ? 0u : 2u * gridDim.x;
     unsigned long long ticket = 0;
     bool more = false; // (thread 0) a ticket is out
     const uint4 none = make_uint4(0xffffffffu, 0u, 0u, 0u);
     uint4 e_next = none, e_load = none;
     if (wv == 0) {
         uint32_t i0 = 0xffffffffu, i1 = 0xffffffffu;
-        if (tid == 0) {
-            i0 = next_tile(a, dbg, head, n_pass);
-            i1 = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_pass) : 0xffffffffu;
-            more = i1 != 0xffffffffu;
-            if (more && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull); // pass 2's
+        if (dbg & 8u) {
+            if (tid == 0) {
+                i0 = next_tile(a, dbg, head, n_pass);
+                i1 = i0 != 0xffffffffu ? next_tile(a, dbg, head, n_pass) : 0xffffffffu;
+                more = i1 != 0xffffffffu;
+            }
+        } else {
+            i0 = blockIdx.x < n_pass ? blockIdx.x : 0xffffffffu;
+            i1 = blockIdx.x + gridDim.x < n_pass ? blockIdx.x + gridDim.x : 0xffffffffu;
+            if (tid == 0) {
+                more = i1 != 0xffffffffu;
+                if (more) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull); // pass 2's
+            }
         }
         i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
         i1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i1);
@@ -1179,8 +1189,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
             if (more) {
                 if (dbg & 8u) i2 = next_tile(a, dbg, head, n_pass);
                 else {
-                    const unsigned long long t = ticket * 8ull + head;
-                    i2 = t < n_pass ? (uint32_t)t : next_tile(a, dbg, head, n_pass); // (this head is dry: try the others)
+                    const unsigned long long t = (unsigned long long)q_base + ticket * 8ull + head;
+                    i2 = t < n_pass ? (uint32_t)t : next_tile(a, dbg, head, n_pass, q_base); // (this head is dry: try the others)
                 }
                 more = i2 != 0xffffffffu;
                 if (more && !(dbg & 8u)) ticket = atomicAdd(&a.cnt[kCntHeads + 16 * head], 1ull);
