@@ -69,10 +69,10 @@ constexpr int kMaxLaneRadiusHi = 8;    // second tile-kernel instance: radii kMa
 constexpr int kLaneMaxN = 73;          // ... and for jobs whose longer side is at most this
 // tile kernel: a tile = consecutive lane-eligible jobs whose windows fit this much LDS
 constexpr uint32_t kTileLdsFloats = 4800;  // job-list tile kernel: 8 workgroups per CU
-constexpr uint32_t kStreamTileFloats = 5800; // k_runs: 4 workgroups per CU (image + two passes' records and copy orders = 33 KB), and 27 KB of
-                                             // the CU's 160 KB stay free: a planner and a fold workgroup of the batches behind fit beside them
-                                             // (7000 left 5 KB -- nothing fitted: the bench pipeline 762 -> 775 GCUPS; the bench batch's tiles
-                                             // average 5 200 floats: below 5 400 every other tile takes two passes and the planning doubles)
+constexpr uint32_t kStreamTileFloats = 5800; // k_runs: image + the pass's records + two passes' copy orders = 29 KB a workgroup: five workgroups per
+                                             // CU, and 13 KB of the CU's 160 KB stay free for a planner workgroup of the batches behind (at 7000 floats
+                                             // and two record buffers it was four workgroups and 5 KB: nothing fitted beside them; the bench batch's
+                                             // tiles average 5 200 floats: below 5 400 every other tile takes two passes and the planning doubles)
 constexpr uint32_t kTileMaxJobs = 1024;
 constexpr uint32_t kTileHiLdsFloats = 14336, kTileHiMaxJobs = 64; // wide-band instance: one wave per tile
 constexpr uint32_t kTileMaxSpans = 96;

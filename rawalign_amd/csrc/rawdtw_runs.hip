@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     constexpr uint32_t kWaves = TT / 64, kRT = 2u * kStreamMaxSeg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *win = smem;                                                    // the pass's LDS image
-    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);            // 2 x kStreamTile job records
-    uint4 *rtab = reinterpret_cast<uint4 *>(rec + 2u * kStreamTile);      // 2 x kRT copy orders
+    uint2 *rec = reinterpret_cast<uint2 *>(smem + lds_floats);            // kStreamTile job records: the pass's (they come in with its image)
+    uint4 *rtab = reinterpret_cast<uint4 *>(rec + kStreamTile);           // 2 x kRT copy orders: the pass's and the next one's
     __shared__ uint4 s_ent[2];                 // the passes' list entries, by parity (x = 0xffffffff: none)
     __shared__ uint32_t s_seq;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1067,13 +1067,18 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     auto dma16 = [](const void *src, void *dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    // a pass's records (all waves: two records a piece) and, by the last wave, its copy orders, into buffer `buf`
-    auto fetch_pass = [&](const uint4 e, const uint32_t buf, const bool one_wave) {
-        const uint32_t n_jobs = e.z & 0xffffu, n_ord = 2u * (e.z >> 16), pieces = (n_jobs + 1u) >> 1;
+    // a pass's records (all waves: two records a piece): asked for with the pass's image and landed with it -- the lanes read
+    // them behind B1 only, so they need no buffer of their own a pass ahead (4 KB of LDS a workgroup: a fifth workgroup a CU)
+    auto fetch_recs = [&](const uint4 e) {
+        const uint32_t n_jobs = e.z & 0xffffu, pieces = (n_jobs + 1u) >> 1;
         const uint2 *src = a.recs + (uint64_t)e.x * kStreamRecStride + (e.w >> 16);
-        for (uint32_t q0 = one_wave ? 0u : wv * 64u; q0 < pieces; q0 += one_wave ? 64u : (uint32_t)TT)
-            if (q0 + (uint32_t)lane < pieces) dma16(src + 2u * (q0 + (uint32_t)lane), rec + buf * kStreamTile + 2u * q0);
-        if ((one_wave || wv == kWaves - 1u) && (uint32_t)lane < n_ord) dma16(a.runtab + (uint64_t)e.y * kRT + lane, rtab + buf * kRT);
+        for (uint32_t q0 = wv * 64u; q0 < pieces; q0 += (uint32_t)TT)
+            if (q0 + (uint32_t)lane < pieces) dma16(src + 2u * (q0 + (uint32_t)lane), rec + 2u * q0);
+    };
+    // ... and its copy orders, which the staging itself reads: a pass ahead, into buffer `buf` (one wave)
+    auto fetch_orders = [&](const uint4 e, const uint32_t buf) {
+        const uint32_t n_ord = 2u * (e.z >> 16);
+        if ((uint32_t)lane < n_ord) dma16(a.runtab + (uint64_t)e.y * kRT + lane, rtab + buf * kRT);
     };
 
     // diagnostic build of the launch ("stream_debug" 256): where a wave's cycles go, phase by phase (s_memtime around the
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
     }
     __syncthreads();
     if (s_ent[0].x == 0xffffffffu) return;
-    fetch_pass(s_ent[0], 0u, false); // the first pass's records: nobody to fetch them ahead
+    if (wv == kWaves - 1u) fetch_orders(s_ent[0], 0u); // the first pass's copy orders: nobody to fetch them ahead
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     // the DP of one pass: waves pull chunks of the sorted records (the heavy class first), so the waves of the workgroup
@@ -1199,12 +1204,11 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         if (wv == 0) {
             i2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i2);
             e_load = i2 != 0xffffffffu ? entry_of(i2) : none;
-            // the next pass's records and copy orders into the other buffer (read last in the pass before this one: every wave
-            // is past that DP): wave 0 holds the entry -- five DMA instructions, in flight beside this pass's staging and
-            // landed with it (the wait in front of B1), so that nothing has to be waited for behind the DP: the costs' stores
-            // need no acknowledgement before the next pass
-            if (e_next.x != 0xffffffffu) fetch_pass(e_next, cur ^ 1u, true);
+            // the next pass's copy orders into the other buffer (read last in the pass before this one's staging): wave 0 holds
+            // the entry -- one DMA instruction, in flight beside this pass's staging and landed with it (the wait in front of B1)
+            if (e_next.x != 0xffffffffu) fetch_orders(e_next, cur ^ 1u);
         }
+        fetch_recs(e); // (every wave is past B2: the records of the pass before are read)
         stamp(0);
         // ---- staging: a wave's share of the copy orders, 16 bytes a lane, consecutive lanes consecutive pieces; nothing
         // waits between a wave's pieces: all of them are in flight at once ----
@@ -1229,7 +1233,7 @@ __global__ __launch_bounds__(TT, 4) void k_runs(const StreamArgs a, const uint32
         stamp(2);
         __syncthreads(); // B1: the image is staged; the next pass's entry is published
         stamp(3);
-        run_dp(rec + cur * kStreamTile, n_jobs, (e.x + 1u) * kStreamTile);
+        run_dp(rec, n_jobs, (e.x + 1u) * kStreamTile);
         stamp(4);
         if (wv == 0) e_next = e_load; // (asked for at this pass's start)
         stamp(5);
@@ -1450,7 +1454,7 @@ inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kT - 1) / kT); }
 static uint32_t stream_lds_bytes_t(uint32_t lds_floats, int threads)
 {
     (void)threads;
-    return lds_floats * 4u + 2u * kStreamTile * 8u + 2u * 2u * kStreamMaxSeg * 16u; // image, two passes' records and copy orders
+    return lds_floats * 4u + kStreamTile * 8u + 2u * 2u * kStreamMaxSeg * 16u; // image, the pass's records, two passes' copy orders
 }
 
 // everything rawdtw_batch_create enqueues for a sparse + banded batch: the scan of the anchor list (side list, checks,
