@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_full_wave(const DevJob *__restri
         // virtual row above row 0 is +inf, its corner D[-1][-1] is 0 so that D[0][0] = dist
         float diag_in = (s == 0 && lane == 0) ? 0.0f : kInf;
         float last_out = kInf, xval = 0.0f, xchunk = 0.0f, bchunk = kInf, wchunk = 0.0f;
-        const int sh_up = swapped ? 1 : 0, sh_lf = swapped ? 0 : 1; // bit of the 2-bit code each plane sets
+        // (bit of the 2-bit code each plane sets: "up" bit 0 and "lf" bit 1, the other way round for a swapped job)
 
         for (uint32_t t = 0; t < steps; t++) {
             if ((t & 63u) == 0) {
@@ -445,15 +445,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_full_wave(const DevJob *__restri
                         // In kernel coordinates: up = ab (row-1), lf = left (column-1).  "up strictly best"
                         // and "lf strictly best" exclude each other, so the code is two bit planes; Y rows
                         // are a-indices unless swapped, which only decides which plane is bit 0.
-                        const uint32_t c_up = ab < __builtin_fminf(left, d) ? 1u : 0u;
-                        const uint32_t c_lf = left < __builtin_fminf(ab, d) ? 1u : 0u;
-                        code |= (c_up << (2 * k + sh_up)) | (c_lf << (2 * k + sh_lf));
+                        // Six instructions a cell: per plane v_min_f32 (as the instruction: through fminf the compiler quiets
+                        // signalling NaNs first, two more instructions an operand), v_cmp_lt_f32 into VCC and v_addc_co_u32
+                        // code = 2 code + VCC -- the compare's bit shifts in from below, no select, no shift-or.  The word grows
+                        // most significant cell first, "up" before "lf": turned round behind the loop (below).
+                        float t_up, t_lf;
+                        asm("v_min_f32 %0, %1, %2" : "=v"(t_up) : "v"(left), "v"(d));
+                        asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(code) : "v"(ab), "v"(t_up) : "vcc");
+                        asm("v_min_f32 %0, %1, %2" : "=v"(t_lf) : "v"(ab), "v"(d));
+                        asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(code) : "v"(left), "v"(t_lf) : "vcc");
                     }
                     d = left; ab = nv; v[k] = nv;
                 }
                 diag_in = up_in;
                 last_out = v[RPL - 1];
-                if (TB) tbuf[lane * SPB + (t % SPB)] = (word_t)code;
+                if (TB) {
+                    // bit reversal puts cell k at bits 2k ("up", shifted in first) and 2k + 1 ("lf"): the layout of sh_up = 0,
+                    // sh_lf = 1; a swapped job has the planes the other way round -- its adjacent bits change places
+                    uint32_t w = __builtin_bitreverse32(code) >> (32 - 2 * RPL);
+                    if (swapped) w = ((w & 0x55555555u) << 1) | ((w >> 1) & 0x55555555u);
+                    tbuf[lane * SPB + (t % SPB)] = (word_t)w;
+                }
             }
             if (TB && ((t % SPB) == SPB - 1 || t + 1 == steps)) {
                 // same wave wrote and reads the buffer; LDS operations of a wave complete in order, the
