@@ -1165,20 +1165,8 @@ int rawdtw_create(int device_ordinal, rawdtw_ctx **out)
     rawdtw_ctx *ctx = new (std::nothrow) rawdtw_ctx;
     if (!ctx) return RAWDTW_ERR_OOM;
     ctx->device = device_ordinal;
-    bool stream_ok = hipSetDevice(device_ordinal) == hipSuccess;
-    if (stream_ok) {
-        // EXPERIMENT (RAWDTW_CU_MASK_STREAM=1): a stream with a (full) CU mask gets a hardware queue of its own instead of one
-        // out of the runtime's shared pool
-        const char *cm = getenv("RAWDTW_CU_MASK_STREAM");
-        if (cm && atoi(cm) != 0) {
-            hipDeviceProp_t prop;
-            stream_ok = hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess;
-            std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
-            if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
-            stream_ok = stream_ok && hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-        } else stream_ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
-    }
-    if (!stream_ok) {
+    if (hipSetDevice(device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return RAWDTW_ERR_DEVICE;
     }
