@@ -24,7 +24,7 @@ Figures of one run (all in the one JSON line):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 The timed region is exactly K steps between barrier + synchronize pairs; because K steps can be a few milliseconds, the
-region is repeated (`repeats` in the line, at least 100 ms in total) and the MEDIAN repetition is reported (max over
+region is repeated (`repeats` in the line, at least 400 ms in total) and the MEDIAN repetition is reported (max over
 ranks per repetition).  Multi-GPU: reads shard across ranks, reference replicated, no data-path collective; RCCL only
 reduces the final counters and the times.  Weak scaling.
 """
@@ -56,7 +56,10 @@ def parse():
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="contexts = mini-batches in flight per GPU (the reference's kt_pipeline keeps 2, rmap.cpp:1033)")
-    ap.add_argument("--min-region-ms", type=float, default=100.0, help="repeat the K-step region until this much is timed")
+    ap.add_argument("--min-region-ms", type=float, default=400.0,
+                    help="repeat the K-step region until this much is timed (the pipeline's regions come in two modes, 6.5 and 7.2-7.5 ms for "
+                         "40 steps, in bursts: at 100 ms the median of one run in four fell into the slow one, at 400 ms five runs in five "
+                         "read within 1 %)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU baseline budget per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
@@ -564,7 +567,12 @@ def main():
 
     def repeat_region(fn):
         first = timed_region(fn)
-        reps = int(min(200, max(3, np.ceil(args.min_region_ms * 1e-3 / max(first, 1e-6)))))
+        first_all = first
+        if dist is not None:  # every rank repeats the region the same number of times (each repetition has two barriers)
+            f = torch.tensor([first], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            first_all = float(f.item())
+        reps = int(min(200, max(3, np.ceil(args.min_region_ms * 1e-3 / max(first_all, 1e-6)))))
         ts = [first] + [timed_region(fn) for _ in range(reps - 1)]
         return ts
 
