@@ -50,12 +50,17 @@ SEED = 20231005 + 2  # seed = 20231005 + config id
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=160, help="steps of one timed region (a region starts and ends with an idle pipeline: at 40 steps its start-up and drain are 4 %% of it, at 160 1 %%)")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="contexts = mini-batches in flight per GPU (the reference's kt_pipeline keeps 2, rmap.cpp:1033)")
+    ap.add_argument("--stagger-us", type=float, default=100.0,
+                    help="pause between the first submissions of a region's contexts (inside the timed region).  A region starts from an "
+                         "idle, synchronised device; four contexts submitted in the same instant run their launches in step with each other "
+                         "-- a state that lasts the whole region and costs 11 %% (one region in three) -- while a caller's contexts are out "
+                         "of phase by themselves; 60-120 us apart the regions all run in the fast mode, at no cost to the region's time")
     ap.add_argument("--min-region-ms", type=float, default=400.0,
                     help="repeat the K-step region until this much is timed (the pipeline's regions come in two modes, 6.5 and 7.2-7.5 ms for "
                          "40 steps, in bursts: at 100 ms the median of one run in four fell into the slow one, at 400 ms five runs in five "
@@ -544,6 +549,10 @@ def main():
                 create(sl, not pcie)
                 e._check(lib.rawdtw_batch_enqueue(e._ctx, handles[sl], 1))
             issued["dtw"] += 1
+            if args.stagger_us > 0 and k < slots - 1:  # (see --stagger-us)
+                t_s = pc()
+                while (pc() - t_s) * 1e6 < args.stagger_us:
+                    pass
             if host is not None:
                 host["fetch"] += t1 - t0; host["submit"] += pc() - t1; host["steps"] += 1
         for sl in range(slots):
@@ -574,6 +583,8 @@ def main():
             first_all = float(f.item())
         reps = int(min(200, max(3, np.ceil(args.min_region_ms * 1e-3 / max(first_all, 1e-6)))))
         ts = [first] + [timed_region(fn) for _ in range(reps - 1)]
+        if os.environ.get("RAWDTW_BENCH_DUMP"):  # every repetition's time, for a look at their spread
+            print("regions_ms", " ".join("%.2f" % (x * 1e3) for x in ts), file=sys.stderr)
         return ts
 
     K = args.steps
