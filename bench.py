@@ -62,9 +62,7 @@ def parse():
                          "-- a state that lasts the whole region and costs 11 %% (one region in three) -- while a caller's contexts are out "
                          "of phase by themselves; 60-120 us apart the regions all run in the fast mode, at no cost to the region's time")
     ap.add_argument("--min-region-ms", type=float, default=400.0,
-                    help="repeat the K-step region until this much is timed (the pipeline's regions come in two modes, 6.5 and 7.2-7.5 ms for "
-                         "40 steps, in bursts: at 100 ms the median of one run in four fell into the slow one, at 400 ms five runs in five "
-                         "read within 1 %)")
+                    help="repeat the K-step region until this much is timed; the median repetition counts")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU baseline budget per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
