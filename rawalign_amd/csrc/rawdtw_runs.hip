@@ -1327,7 +1327,9 @@ __global__ __launch_bounds__(kT) void k_events_scatter(const float *__restrict__
 // (The lane-per-chain fold over the arena read 4 bytes a lane from 64 different lines per instruction and needed the chains
 // sorted by length -- a one-workgroup sort on the scan's critical path; this one needs no order.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFoldReads = 8, kFoldWin = 4096, kFoldCap = 256;
+// (windows of 2 048 floats: 10 KB of LDS a workgroup -- a fold workgroup of the batch in front fits into the 13 KB five workgroups of
+// k_runs leave on a CU; at 4 096 the launch alone is a quarter faster and the pipeline half a per cent slower, at 1 024 both are slower)
+constexpr uint32_t kFoldReads = 8, kFoldWin = 2048, kFoldCap = 256;
 __global__ __launch_bounds__(64) void k_fold_select(const StreamArgs a, const ChainDesc *__restrict__ chains, const uint64_t *__restrict__ chain_off,
                                                     const uint64_t n_reads, const float bonus, const int fused, const float min_score,
                                                     float *__restrict__ full_score, float *__restrict__ att_last, float *__restrict__ score,
