@@ -288,6 +288,43 @@ def test_windows_that_end_with_the_arenas(oracle, ref_len, tail):
     _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
 
 
+def test_wave_per_job_bands_at_the_register_layouts_edges(oracle):
+    """k_wide's wave-per-job bodies hold a band of K slots in C = 1, 2 or 4 registers a lane (wreg_gen<C>: K <= 64 C).  Parts
+    whose radius puts K on both sides of every change of layout -- radius 63 / 64 (K = 64 fills the one-register wave: its last
+    lane's neighbour is the DPP shift's fill; K = 65 is the first two-register band), 127 / 128, and 255 (K = 256, the widest
+    band the sync-free path takes) -- square and slanted, with the longer side on either arena, between small parts: every part cost and every
+    chain score bit for bit against the oracle (dtw.cpp:298-303 for P and S, rmap.cpp:276 for the radius)."""
+    rng = np.random.default_rng(4242)
+    ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
+    eng = ra.Engine(0)
+    eng.upload_reference([ref[0]], [ref[1]])
+    # (dq, dt): n = dq + 1, m = dt + 1, r0 = int(0.1 n), R = r0 + ceil((N - M) r0 / N) with N the longer side (dtw.cpp:298-300)
+    edges = [(629, 629), (639, 639), (571, 630), (1269, 1269), (1279, 1279), (1160, 1280), (2549, 2549), (2320, 2570), (700, 630)]
+
+    def radius(dq, dt):
+        n, m = dq + 1, dt + 1
+        r0, N, M = max(1, int(np.float32(n) * np.float32(0.1))), max(n, m), min(n, m)
+        return r0 + ((N - M) * r0 + N - 1) // N
+    assert [radius(*e) for e in edges][:8] == [63, 64, 63, 127, 128, 127, 255, 255]
+    state = {"k": 0}
+
+    def shapes(r):
+        state["k"] += 1
+        return edges[(state["k"] // 9) % len(edges)] if state["k"] % 9 == 4 else _tiny(r)
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 40, 60000, shapes, (1, 14))
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    cb = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    eng.upload_events(events)
+    opt = ra.MapOpt(dtw_min_score=5.0)
+    b = ra.Batch(eng, opt, cb)
+    assert b.verify_plan() is True
+    b.run()
+    score, keep, jc = b.fetch(with_job_costs=True)
+    _oracle_check(oracle, cb, {1: ref[0], 0: ref[1]}, strand_of, score, keep, jc, opt)
+    assert b.info()["n_wave_band_jobs"] >= len(edges)
+
+
 def test_band_too_wide_for_the_stream_path_is_redone_through_the_job_list(oracle):
     """A part whose band needs more than 256 offsets: the sync-free path declines the batch at fetch and the job-list
     path (register-resident wave kernel with more chunks) produces the same answers the oracle gives."""
