@@ -23,9 +23,10 @@ Figures of one run (all in the one JSON line):
     python bench.py --gpus N ...          # launches N ranks itself (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-The timed region is exactly K steps between barrier + synchronize pairs; because K steps can be a few milliseconds, the
-region is repeated (`repeats` in the line, at least 400 ms in total) and the MEDIAN repetition is reported (max over
-ranks per repetition).  Multi-GPU: reads shard across ranks, reference replicated, no data-path collective; RCCL only
+A K-step region is a few milliseconds and starts and ends with an idle pipeline, so one timed bracket (barrier +
+synchronize on both sides) holds `repeats` consecutive K-step regions of the same loop with no drain between them;
+ms_per_step = bracket / (repeats * K); three brackets (at least 400 ms in total), the MEDIAN one is reported (max over
+ranks per bracket) -- the figure does not depend on --steps.  Multi-GPU: reads shard across ranks, reference replicated, no data-path collective; RCCL only
 reduces the final counters and the times.  Weak scaling.
 """
 import argparse
@@ -50,7 +51,7 @@ SEED = 20231005 + 2  # seed = 20231005 + config id
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=160, help="steps of one timed region (a region starts and ends with an idle pipeline: at 40 steps its start-up and drain are 4 %% of it, at 160 1 %%)")
+    ap.add_argument("--steps", type=int, default=160, help="steps of one region; a timed bracket holds `repeats` regions back to back (see repeat_region)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--reads", type=int, default=16384, help="reads per GPU in one batch (chunk round)")
     ap.add_argument("--genome", type=int, default=4_600_000, help="reference length in bases (E. coli K-12)")
@@ -62,7 +63,7 @@ def parse():
                          "-- a state that lasts the whole region and costs 11 %% (one region in three) -- while a caller's contexts are out "
                          "of phase by themselves; 60-120 us apart the regions all run in the fast mode, at no cost to the region's time")
     ap.add_argument("--min-region-ms", type=float, default=400.0,
-                    help="repeat the K-step region until this much is timed; the median repetition counts")
+                    help="the three timed brackets of a loop hold this much in total; the median bracket counts")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU baseline budget per thread count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hit-prob", type=float, default=None, help="workload sensitivity: anchor density of the true chains")
@@ -210,67 +211,103 @@ def vp(a):
     return C.c_void_p(a.ctypes.data)
 
 
-def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank):
-    """SURVEY.md 8(f-4) at the bench batch's scale: `n_rounds` chunk rounds of one batch of reads (synth.make_rounds), each
-    submitted with the batch of the round before (rawdtw_batch_submit_round: parts whose anchors did not change take over
-    their cost on the device) and, for comparison, from scratch as the reference does (rmap.cpp:516-517).  One context,
-    rounds in sequence (a round needs the one before); wall time per round from submit to fetched scores."""
-    from rawalign_amd import synth
+CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
 
-    rounds = synth.make_rounds(cb, info, n_rounds)
-    arrs = [[np.ascontiguousarray(r.chain_off, np.uint64), np.ascontiguousarray(r.anchor_off, np.uint64), np.ascontiguousarray(r.anchors),
-             np.ascontiguousarray(r.ref_base, np.uint64), np.ascontiguousarray(r.read_base, np.uint32)] for r in rounds]
-    ident = np.arange(cb.n_chains, dtype=np.uint64)
+
+def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
+    """SURVEY.md 8(f-4) at the bench batch's scale: `n_rounds` chunk rounds of one batch of reads (synth.make_rounds), each
+    submitted from scratch as the reference does (rmap.cpp:516-517: rawdtw_batch_submit, the whole anchor lists) and carried
+    (rawdtw_batch_submit_carry: per chain the host names the chain it continues and the leading parts that did not change --
+    rawdtw_round_match_chains, timed on its own -- only the NEW anchors are handed over, the device copies one stretch of
+    anchors and costs per chain out of the previous batch's workspace and scores the rest).  One context, rounds in sequence
+    (a round needs the one before); wall time per round from submit to fetched scores, (a) with the hand-over arrays in
+    pinned host memory -- what a mapper's round is -- and (b) with them resident in HBM, as in the `value` loop."""
+    from rawalign_amd import synth
     import torch
 
-    dev = []   # the three big arrays of every round resident in HBM (as in the `value` loop): no PCIe in either mode
-    for a in arrs:
-        dev.append([torch.from_numpy(x.view(np.uint8).copy()).cuda(local_rank) for x in (a[2], a[3], a[4])])
-    torch.cuda.synchronize()
-    engine.set_option("resident_arrays", 1)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-    out = {"rounds": n_rounds, "per_round": []}
-    same = True
-    for mode in ("warm", "scratch", "carried"):
-        prev = None
-        for k, a in enumerate(arrs):
-            h = C.c_void_p()
-            score, keep = np.zeros(cb.n_chains, np.float32), np.zeros(cb.n_chains, np.uint8)
-            engine.sync()
+    rounds = synth.make_rounds(cb, info, n_rounds)
+    ident = np.arange(cb.n_reads, dtype=np.uint64)
+    R = []
+    for k, r in enumerate(rounds):
+        d = {"chain_off": pin.copy(np.ascontiguousarray(r.chain_off, np.uint64)), "anchor_off": pin.copy(np.ascontiguousarray(r.anchor_off, np.uint64)),
+             "anchors": pin.copy(np.ascontiguousarray(r.anchors)), "ref_base": pin.copy(np.ascontiguousarray(r.ref_base, np.uint64)),
+             "read_base": pin.copy(np.ascontiguousarray(r.read_base, np.uint32))}
+        if k:
+            p = R[k - 1]
+            carry = np.zeros(cb.n_chains, CARRY_DTYPE)
+            new_off = np.zeros(cb.n_chains + 1, np.uint64)
+            new_anchors = np.zeros(len(r.anchors) + 1, r.anchors.dtype)
             t0 = time.perf_counter()
-            if mode == "carried":
-                engine._check(lib.rawdtw_batch_submit_round(engine._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), P(dev[k][0]), P(dev[k][1]), P(dev[k][2]),
-                                                            prev, vp(ident), C.byref(h)))
-            else:
-                engine._check(lib.rawdtw_batch_submit(engine._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), P(dev[k][0]), P(dev[k][1]), P(dev[k][2]), C.byref(h)))
-            engine._check(lib.rawdtw_batch_fetch(engine._ctx, h, vp(score), vp(keep), None))
-            dt = time.perf_counter() - t0
-            if mode == "warm":
-                lib.rawdtw_batch_destroy(h)
-                continue
-            if mode == "scratch":
-                out["per_round"].append({"parts": int(max(int(a[1][-1]) - cb.n_chains, 0)), "scratch_ms": round(dt * 1e3, 4), "score": score.copy(), "keep": keep.copy()})
-                lib.rawdtw_batch_destroy(h)
-                continue
-            sc, ru = C.c_uint64(), C.c_uint64()
-            engine._check(lib.rawdtw_batch_round_stats(engine._ctx, h, C.byref(sc), C.byref(ru)))
-            rec = out["per_round"][k]
-            s0, k0 = rec.pop("score"), rec.pop("keep")
-            same = same and np.array_equal(s0.view(np.uint32), score.view(np.uint32)) and np.array_equal(k0, keep)
-            rec.update({"parts": int(sc.value + ru.value), "parts_scored": int(sc.value), "parts_reused": int(ru.value), "carried_ms": round(dt * 1e3, 4)})
+            engine._check(lib.rawdtw_round_match_chains(cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["anchors"]), vp(d["ref_base"]), vp(d["read_base"]),
+                                                        vp(ident), vp(p["chain_off"]), vp(p["anchor_off"]), vp(p["anchors"]), vp(p["ref_base"]), vp(p["read_base"]),
+                                                        vp(carry), vp(new_off), vp(new_anchors)))
+            d["match_ms"] = (time.perf_counter() - t0) * 1e3
+            d["carry"], d["new_off"] = pin.copy(carry), pin.copy(new_off)
+            d["new_anchors"] = pin.copy(new_anchors[:max(int(new_off[-1]), 1)])
+            d["n_new"] = int(new_off[-1])
+            d["t_new"] = torch.from_numpy(d["new_anchors"].view(np.uint8).copy()).cuda(local_rank)
+        d["t"] = [torch.from_numpy(d[x].view(np.uint8).copy()).cuda(local_rank) for x in ("anchors", "ref_base", "read_base")]
+        R.append(d)
+    torch.cuda.synchronize()
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    out = {"rounds": n_rounds, "per_round": [{"parts": int(max(int(d["anchor_off"][-1]) - cb.n_chains, 0)), "anchors": int(d["anchor_off"][-1])} for d in R]}
+    same = True
+    want = [None] * n_rounds
+    for resident in (0, 1):
+        engine.set_option("resident_arrays", resident)
+        sfx = "" if resident else "_host"
+        for mode in ("warm", "scratch", "carried"):
+            prev = None
+            for k, d in enumerate(R):
+                h = C.c_void_p()
+                score, keep = np.zeros(cb.n_chains, np.float32), np.zeros(cb.n_chains, np.uint8)
+                A = (P(d["t"][0]), P(d["t"][1]), P(d["t"][2])) if resident else (vp(d["anchors"]), vp(d["ref_base"]), vp(d["read_base"]))
+                engine.sync()
+                t0 = time.perf_counter()
+                if mode == "carried" and prev is not None:
+                    engine._check(lib.rawdtw_batch_submit_carry(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["new_off"]),
+                                                                P(d["t_new"]) if resident else vp(d["new_anchors"]), A[1], A[2], prev, vp(d["carry"]), C.byref(h)))
+                else:
+                    engine._check(lib.rawdtw_batch_submit(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), A[0], A[1], A[2], C.byref(h)))
+                engine._check(lib.rawdtw_batch_fetch(engine._ctx, h, vp(score), vp(keep), None))
+                dt = time.perf_counter() - t0
+                rec = out["per_round"][k]
+                if mode == "scratch":
+                    rec["scratch%s_ms" % sfx] = round(dt * 1e3, 4)
+                    if want[k] is None:
+                        want[k] = (score.copy(), keep.copy())
+                    same = same and np.array_equal(want[k][0].view(np.uint32), score.view(np.uint32)) and np.array_equal(want[k][1], keep)
+                if mode == "carried":
+                    sc, ru = C.c_uint64(), C.c_uint64()
+                    engine._check(lib.rawdtw_batch_round_stats(engine._ctx, h, C.byref(sc), C.byref(ru)))
+                    same = same and np.array_equal(want[k][0].view(np.uint32), score.view(np.uint32)) and np.array_equal(want[k][1], keep)
+                    rec.update({"parts_scored": int(sc.value), "parts_reused": int(ru.value), "carried%s_ms" % sfx: round(dt * 1e3, 4),
+                                "anchors_handed_over": int(d.get("n_new", rec["anchors"])), "match_ms_host_1_thread": round(d.get("match_ms", 0.0), 3)})
+                    if prev is not None:
+                        lib.rawdtw_batch_destroy(prev)
+                    prev = h
+                else:
+                    lib.rawdtw_batch_destroy(h)
             if prev is not None:
                 lib.rawdtw_batch_destroy(prev)
-            prev = h
-        if prev is not None:
-            lib.rawdtw_batch_destroy(prev)
-    tot = sum(r["parts"] for r in out["per_round"])
-    out.update({"parts_total": tot, "parts_scored": sum(r["parts_scored"] for r in out["per_round"]),
-                "jobs_reused": sum(r["parts_reused"] for r in out["per_round"]),
-                "scratch_ms_total": round(sum(r["scratch_ms"] for r in out["per_round"]), 4),
-                "carried_ms_total": round(sum(r["carried_ms"] for r in out["per_round"]), 4),
+    engine.set_option("resident_arrays", 1)
+    pr = out["per_round"]
+    tot = lambda key, lo=0: round(sum(r[key] for r in pr[lo:]), 4)  # noqa: E731
+    out.update({"parts_total": sum(r["parts"] for r in pr), "parts_scored": sum(r["parts_scored"] for r in pr),
+                "jobs_reused": sum(r["parts_reused"] for r in pr),
+                "scratch_ms_total": tot("scratch_ms"), "carried_ms_total": tot("carried_ms"),
+                "scratch_host_ms_total": tot("scratch_host_ms"), "carried_host_ms_total": tot("carried_host_ms"),
+                "carried_rounds": {"scratch_ms": tot("scratch_ms", 1), "carried_ms": tot("carried_ms", 1), "scratch_host_ms": tot("scratch_host_ms", 1),
+                                   "carried_host_ms": tot("carried_host_ms", 1),
+                                   "anchor_list_bytes_scratch": 8 * sum(r["anchors"] for r in pr[1:]),
+                                   "anchor_list_bytes_carried": 8 * sum(r["anchors_handed_over"] for r in pr[1:]),
+                                   "note": "rounds 2.. only (round 1 has no predecessor and is the same submission in both modes)"},
                 "scores_identical_to_scratch": bool(same),
-                "note": "inputs resident in HBM in both modes; the carried rounds score only the parts whose anchors are new (their "
-                        "scan looks every other part up in the round before)"})
+                "note": "`*_ms`: hand-over arrays resident in HBM (no PCIe in either mode); `*_host_ms`: from pinned host memory, as a "
+                        "mapper's round hands them over.  A carried round sends its new anchors only (anchors_handed_over) and scores "
+                        "only the parts they bring (k_carry copies the rest's costs, one stretch a chain); the host's matching of the "
+                        "chains (match_ms_host_1_thread, rawdtw_round_match_chains on one thread; the mapper does it per read on "
+                        "its pool) is outside these times"})
     return out
 
 
@@ -572,18 +609,26 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
-    def repeat_region(fn):
-        first = timed_region(fn)
+    def repeat_region(fn_of_steps):
+        """The timed figure of one loop.  A region of exactly K steps starts and ends with an idle pipeline, and at K = 20 its
+        fill, drain and the contexts' staggered start are a tenth of it (round 3: 755 GCUPS at --steps 20 against 826 at 160).
+        So one BRACKET (barrier + synchronize on both sides, as ever) times `reps` consecutive K-step regions with no drain
+        between them -- reps * K steps of the same loop, the stagger once at its start -- and a step's time is the bracket's
+        divided by reps * K.  Three brackets; the median counts.  Returns (bracket seconds, reps)."""
+        first = timed_region(lambda: fn_of_steps(K))
         first_all = first
-        if dist is not None:  # every rank repeats the region the same number of times (each repetition has two barriers)
+        if dist is not None:  # every rank runs the same number of steps (each bracket has two barriers)
             f = torch.tensor([first], dtype=torch.float64, device=red_dev)
             dist.all_reduce(f, op=dist.ReduceOp.MAX)
             first_all = float(f.item())
-        reps = int(min(200, max(3, np.ceil(args.min_region_ms * 1e-3 / max(first_all, 1e-6)))))
-        ts = [first] + [timed_region(fn) for _ in range(reps - 1)]
-        if os.environ.get("RAWDTW_BENCH_DUMP"):  # every repetition's time, for a look at their spread
-            print("regions_ms", " ".join("%.2f" % (x * 1e3) for x in ts), file=sys.stderr)
-        return ts
+        n_br = 3
+        reps = int(min(400, max(1, np.ceil(args.min_region_ms * 1e-3 / n_br / max(first_all, 1e-6)))))
+        while (reps * K) % slots:  # whole turns of the contexts: every bracket holds every batch equally often
+            reps += 1
+        ts = [timed_region(lambda: fn_of_steps(reps * K)) for _ in range(n_br)]
+        if os.environ.get("RAWDTW_BENCH_DUMP"):  # every bracket's time, for a look at their spread
+            print("first_region_ms %.3f  brackets_ms (%d x %d steps)" % (first * 1e3, reps, K), " ".join("%.2f" % (x * 1e3) for x in ts), file=sys.stderr)
+        return ts, reps
 
     K = args.steps
     # ---- warm-up (workspace pools, code objects), then the three timed loops ----
@@ -594,9 +639,9 @@ def main():
         return
     pipeline(slots, pcie=True)
     pipeline(slots, pcie="compact")
-    t_fresh = repeat_region(lambda: pipeline(K, pcie=False, host=host_s))
-    t_pcie = repeat_region(lambda: pipeline(K, pcie="compact"))
-    t_pcie_plain = repeat_region(lambda: pipeline(K, pcie=True))
+    t_fresh, reps_fresh = repeat_region(lambda n: pipeline(n, pcie=False, host=host_s))
+    t_pcie, reps_pcie = repeat_region(lambda n: pipeline(n, pcie="compact"))
+    t_pcie_plain, reps_pcie_plain = repeat_region(lambda n: pipeline(n, pcie=True))
     # host cost of one create call, steady state (inputs resident / from pinned host memory)
     create_ms = {}
     for mode, pc in (("resident", False), ("from_host", True)):
@@ -657,15 +702,16 @@ def main():
     # the tiles' launch (k_runs) moves the tile-class jobs' bytes; the side list's are k_wide's (counter words: rawdtw_internal.h)
     cntw = (C.c_uint64 * 64)(); ncw = C.c_uint32()
     engines[0]._check(lib.rawdtw_batch_stream_counters(engines[0]._ctx, handles[0], cntw, 64, C.byref(ncw)))
-    K_TILE_JOBS, K_TILE_BYTES = 47, 48
+    K_TILE_JOBS, K_TILE_BYTES = lib.rawdtw_batch_stream_counter_index(b"tile_jobs"), lib.rawdtw_batch_stream_counter_index(b"tile_bytes")
+    assert K_TILE_JOBS >= 0 and K_TILE_BYTES >= 0
     tile_jobs0, tile_bytes0 = (int(cntw[K_TILE_JOBS]), int(cntw[K_TILE_BYTES])) if ncw.value else (infos[0]["n_jobs"], infos[0]["algorithmic_bytes"])
 
-    def replay():
-        for k in range(K):
+    def replay(n=K):
+        for k in range(n):
             sl = k % slots
             engines[sl]._check(lib.rawdtw_batch_enqueue(engines[sl]._ctx, handles[sl], 0))
     replay()
-    t_replay = repeat_region(replay)
+    t_replay, reps_replay = repeat_region(replay)
     # one context alone, launches back to back: the dominant kernel without neighbours
     ms = np.zeros(8, np.float32); kind = np.zeros(8, np.uint32); nl = C.c_uint32()
     engines[0]._check(lib.rawdtw_batch_run_reps(engines[0]._ctx, handles[0], 10, vp(ms), vp(kind), 8, C.byref(nl)))
@@ -680,11 +726,12 @@ def main():
         mapped.append(int(len(np.unique(roc[B[sl]["keep"].astype(bool)]))))  # reads with >= 1 surviving chain
 
     # ---- reduce: counters summed, each repetition's time = max over ranks ----
-    steps_of_slot = [len(range(sl, K, slots)) for sl in range(slots)]
+    n_f = reps_fresh * K  # steps of one bracket of the fresh-batch loop: what the totals below are over
+    steps_of_slot = [len(range(sl, n_f, slots)) for sl in range(slots)]
 
     def total(vals):
         return int(sum(v * r for v, r in zip(vals, steps_of_slot)))
-    counters = [args.reads * K, total([d["n_chains"] for d in B]), total([i["n_jobs"] for i in infos]),
+    counters = [args.reads * n_f, total([d["n_chains"] for d in B]), total([i["n_jobs"] for i in infos]),
                 total([i["cells"] for i in infos]), total(mapped), total([i["algorithmic_bytes"] for i in infos])]
 
     def reduce_times(ts):
@@ -700,8 +747,11 @@ def main():
     r_pcie_plain = reduce_times(t_pcie_plain)
 
     if rank == 0:
-        T, Tp, Tr = float(np.median(r_fresh)), float(np.median(r_pcie)), float(np.median(r_replay))
-        Tpp = float(np.median(r_pcie_plain))
+        T = float(np.median(r_fresh))  # one bracket of the fresh-batch loop: n_f steps
+        # the other loops' brackets hold their own numbers of steps: brought to n_f steps' worth (every bracket is whole turns of the contexts)
+        Tp = float(np.median(r_pcie)) * n_f / (reps_pcie * K)
+        Tr = float(np.median(r_replay)) * n_f / (reps_replay * K)
+        Tpp = float(np.median(r_pcie_plain)) * n_f / (reps_pcie_plain * K)
         lp = np.array(launches_in_pipeline)  # rows: steps, columns: [k_wide, k_runs, fold + select, (select: in the launch before)]
         dms = float(lp[:, 1].mean())
         plan_pipe, plan_al = float(np.median(plan_ms)), float(np.median(plan_alone))
@@ -723,7 +773,7 @@ def main():
                 pass
         out = {
             "metric": "DTW GCUPS", "value": cells_t / T / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": T / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": T / n_f * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD, "reads_per_gpu": args.reads, "genome_bp": args.genome,
                        "border_constraint": "sparse", "fill_method": "banded=0.10", "batches_in_flight": slots,
@@ -735,14 +785,18 @@ def main():
             "value_resident": cells_t / T / 1e9, "value_pcie": cells_t / Tp / 1e9,
             "value_pcie_is": "the same loop with the step's host hand-over inside (new events + anchor lists from pinned host memory over "
                              "PCIe): what a caller whose anchors are produced on the host gets end to end",
-            "repeats": len(r_fresh), "timed_region_ms_total": round(sum(r_fresh) * 1e3, 3),
-            "region_ms": {"median": round(T * 1e3, 4), "min": round(min(r_fresh) * 1e3, 4), "max": round(max(r_fresh) * 1e3, 4)},
+            "repeats": reps_fresh, "brackets": len(r_fresh), "timed_region_ms_total": round(sum(r_fresh) * 1e3, 3),
+            "region_is": "one timed bracket (barrier + synchronize on both sides) = `repeats` consecutive regions of `steps` steps of the same "
+                         "loop with no drain between them (the contexts' staggered start once per bracket); ms_per_step = bracket / (repeats * "
+                         "steps); `brackets` brackets, the median counts -- so that the figure does not depend on --steps (round 3: a 20-step "
+                         "region was 9 % pipeline fill, drain and stagger)",
+            "region_ms": {"median": round(T * 1e3, 4), "min": round(min(r_fresh) * 1e3, 4), "max": round(max(r_fresh) * 1e3, 4), "steps": n_f},
             "reads_per_s": reads_t / T, "dtw_stage_rounds_per_s": mapped_t / T, "jobs_per_s": jobs_t / T,
             "dtw_stage_rounds_is": "chunk rounds of the DTW stage per second in which >= 1 candidate chain of the (synthetic) read survives "
                                    "dtw_min_score -- a capacity of this stage alone, not RawAlign's mapped reads/s: event detection, seeding "
                                    "and chaining are imitated by their output (rawalign_amd/synth.py)",
-            "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "dtw_stage_rounds_per_s": mapped_t / Tp, "ms_per_step": Tp / K * 1e3,
-                              "repeats": len(r_pcie),
+            "pipeline_pcie": {"gcups": cells_t / Tp / 1e9, "dtw_stage_rounds_per_s": mapped_t / Tp, "ms_per_step": Tp / n_f * 1e3,
+                              "repeats": reps_pcie,
                               "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["compact_bytes"] + B[0]["ref_base"].nbytes + B[0]["read_base"].nbytes +
                                                         B[0]["anchor_off"].nbytes + B[0]["chain_off"].nbytes),
                               "h2d_bytes": {"new_events": int(B[0]["new_events"].nbytes), "anchor_lists_compact": int(B[0]["compact_bytes"]),
@@ -750,10 +804,10 @@ def main():
                               "note": "same loop with the step's host hand-over inside: the round's new events (last chunk of "
                                       "every read, rawdtw_events_append) and the anchor lists cross PCIe from pinned memory; the lists in "
                                       "the compact form (rawdtw_batch_submit_compact: 2-byte steps, decoded inside k_scan)",
-                              "plain_anchor_lists": {"gcups": cells_t / Tpp / 1e9, "ms_per_step": Tpp / K * 1e3,
+                              "plain_anchor_lists": {"gcups": cells_t / Tpp / 1e9, "ms_per_step": Tpp / n_f * 1e3,
                                                      "h2d_bytes_per_step": int(B[0]["new_events"].nbytes + B[0]["anchors"].nbytes + B[0]["ref_base"].nbytes +
                                                                                B[0]["read_base"].nbytes + B[0]["anchor_off"].nbytes + B[0]["chain_off"].nbytes)}},
-            "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / K * 1e3, "repeats": len(r_replay),
+            "kernel_replay": {"gcups": cells_t / Tr / 1e9, "ms_per_step": Tr / n_f * 1e3, "repeats": reps_replay,
                               "note": "launches of already submitted resident batches only (round 1's headline)"},
             "host_ms_per_step": {k: round(host_s[k] / max(host_s["steps"], 1) * 1e3, 4) for k in ("fetch", "submit")} | {
                 "note": "host wall time inside the two calls of one step of the timed fresh-batch loop: `fetch` "
@@ -766,7 +820,7 @@ def main():
                                         "device: alone on the chip / with all contexts submitting at once",
                                 "planning_gpu_ms": round(plan_al, 4), "planning_gpu_ms_in_pipeline": round(plan_pipe, 4)},
             "kernel_ms_sum_per_batch": {"alone": round(sum_alone, 4), "in_pipeline": round(sum_pipe, 4),
-                                        "overlap_factor": round(sum_pipe / (T / K * 1e3), 3),
+                                        "overlap_factor": round(sum_pipe / (T / n_f * 1e3), 3),
                                         "note": "sum of a batch's launch durations (planning, k_wide, k_runs, fold + select; HIP events): each "
                                                 "alone on the chip, and bracketed inside the pipeline, where the batches in flight stretch "
                                                 "each other -- overlap_factor = that sum / ms_per_step = batches effectively in flight"},
@@ -798,7 +852,7 @@ def main():
                                  "(k_runs), fold + select"},
         }
         if world == 1 and args.rounds > 0:
-            out["chunk_rounds"] = rounds_block(engines[0], lib, copt, B[0]["cb"], B[0]["inf"], args.rounds, local_rank)
+            out["chunk_rounds"] = rounds_block(engines[0], lib, copt, B[0]["cb"], B[0]["inf"], args.rounds, local_rank, pin)
         if world == 1 and args.modes_reads > 0:
             out["modes"] = modes_block(local_rank, args.modes_reads)
         if world == 1 and not args.no_cpu_baseline:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RAWDTW_ABI_VERSION 1
+#define RAWDTW_ABI_VERSION 2
 
 typedef enum {
     RAWDTW_OK = 0,
@@ -92,6 +92,8 @@ int rawdtw_sync(rawdtw_ctx *ctx);
 int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value);
 /* the ctx's hipStream_t, as void* (for event timing on the stream kernels run on) */
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream);
+/* the device ordinal the context was created on */
+int rawdtw_context_device(const rawdtw_ctx *ctx, int *device_ordinal);
 
 /* ---- reference signals: replaces ri_idx_t.forward_signals / reverse_signals
  * (src/rawindex.h:32-34) as the `b` operand.  Uploaded once, resident in HBM.
@@ -392,10 +394,14 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
  * between them for the batch's first run is DTW work: rawdtw_batch_wide_ms. */
 int rawdtw_batch_plan_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
 int rawdtw_batch_wide_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms);
-/* Diagnostics of a device-planned batch (waits for its planning kernels): the planner's counters, in the order of
- * rawdtw_internal.h's StreamCounter -- 0 first invalid job (~0 none), 1 first tile over a capacity (~0 none), 2 jobs with
- * a band the side list does not take, 3 tile jobs, 4 their algorithmic bytes, 5 the side list's bytes, 6 side-list jobs,
- * 7 tiles, 9.. jobs per side-list class.  *n_out = 0 for a batch planned on the host. */
+/* Diagnostics of a device-planned batch (waits for its planning kernels): the planner's counter block (rawdtw_internal.h,
+ * StreamCounter).  The layout is the library's own and moves between versions: look a word up by NAME with
+ * rawdtw_batch_stream_counter_index -- "bad" first invalid part (~0 none), "overflow" first tile over a capacity (~0 none),
+ * "unsupported" parts with a band nobody takes, "side_jobs" side-list entries, "class0" the first of the per-class totals,
+ * "cells", "tile_jobs" / "tile_bytes" / "side_bytes" (reporting, filled on request), "todo" listed tiles, "reused" parts
+ * taken over from the round before, "pool" passes beyond one a tile, "stamp0" the first of ten phase-stamp words -- which
+ * returns -1 for a name it does not know.  *n_out = 0 for a batch planned on the host. */
+int rawdtw_batch_stream_counter_index(const char *name);
 int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out);
 int rawdtw_batch_destroy(rawdtw_batch *batch);
 /* ---- compact hand-over of the anchor lists.  A mini-batch's anchors are its largest array (8 bytes an anchor: as much
@@ -430,26 +436,49 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
 /* ---- chunk rounds.  A read is consumed chunk by chunk (rmap.cpp:685-693) and every round re-aligns every surviving chain
  * from scratch over all its anchors (rmap.cpp:516-517), although a part between two anchors that were there the round before
  * has the same operands (events are append-only, rmap.cpp:554-567; the read keeps its place in the event arena) and
- * therefore the same cost.  rawdtw_batch_submit_round = rawdtw_batch_submit, given the batch of the round before
- * (`prev`: same context, not destroyed yet, fetched or not) and per chain the chain of `prev` it continues
- * (carry_chain[c], or RAWDTW_NO_CHAIN).  A part whose two anchors and two bases equal those of the same part -- counted
- * from the chain's START -- of that chain takes over its cost instead of being scored again; the device checks the
- * equality itself, the hint only says where to look, so a wrong hint costs time, never correctness.  Results are
- * bit-identical to scoring everything again: a part that was its chain's last then and is not now loses its last
- * cell's distance exactly as the DTW functions take it off (dtw.cpp:514-519); the other way round it is scored again.
- * `prev` and carry_chain may be let go of as soon as the call returns.  rawdtw_round_match_chains builds the hint on the
- * host: for every chain the previous chain of the same read (same bases) that starts on the same anchor.
+ * therefore the same cost.  A chain grows at its END from round to round (rmap.cpp:344-357 re-seeds the chaining with the
+ * previous chains' anchors), i.e. at the FRONT of its end-first list: what a chain shares with the chain it continues is a
+ * run of leading parts counted from its START = the tail of its list.
+ *
+ * rawdtw_round_match_chains (pure host code) finds, per chain of the new round, the chain of the round before it continues
+ * (same read, same bases, same start anchor, the longest common tail) and VALIDATES the common tail anchor by anchor:
+ * carry[c] = {that chain, the number of leading parts taken over}; it also packs the anchors that are NOT taken over --
+ * per chain the first n_anchors - (parts + 1) entries of its list (all of them when parts == 0) -- into new_anchors
+ * (chain c owns new_anchors[new_off[c] .. new_off[c + 1])).  A part that was not its chain's last then and is now cannot be
+ * taken over (exclude_last_element, rmap.cpp:270: there is no exact way back) and is counted out; a part that was the last
+ * then and is not now loses its last cell's distance on the device exactly as the DTW functions take it off (dtw.cpp:514-519).
+ *
+ * rawdtw_batch_submit_carry = rawdtw_batch_submit for such a round: ONLY the new anchors cross the bus; the device copies,
+ * per chain, one contiguous stretch of anchors and one of costs out of `prev`'s workspace (k_carry), and scans, plans and
+ * scores the new parts only.  Results are bit-identical to scoring everything again.  Preconditions (else
+ * RAWDTW_ERR_UNSUPPORTED, nothing enqueued: submit the round whole with rawdtw_batch_submit): `prev` is a batch of this
+ * context that was scored on the device-planned path with the same options (rawdtw_batch_can_carry tells), has been run
+ * and is not destroyed.  carry[] is trusted as rawdtw_round_match_chains wrote it -- the device only checks that the counts
+ * add up and that the named chain has the same bases (a mismatch makes the batch fall back to scoring everything from the
+ * assembled lists); a caller that invents it gets wrong costs.  All host arrays must stay valid until the batch is fetched;
+ * `prev` until this batch is fetched or destroyed (its device arrays are read by this batch's first launch).
  * rawdtw_batch_round_stats (waits for the scan): the parts scored and the parts taken over. ---- */
 #define RAWDTW_NO_CHAIN (~(uint64_t)0)
-int rawdtw_batch_submit_round(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
-                              const uint32_t *read_base, const rawdtw_batch *prev, const uint64_t *carry_chain, rawdtw_batch **out);
-int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *parts_scored, uint64_t *parts_reused);
-/* read r of the new round is read prev_read[r] of the previous one (or RAWDTW_NO_CHAIN: a new read) */
+typedef struct {
+    uint64_t prev_chain; /* chain of the previous batch, or RAWDTW_NO_CHAIN */
+    uint32_t parts;      /* leading parts (from the chain's start) whose costs are taken over; 0: none */
+    uint32_t reserved;   /* 0 */
+} rawdtw_carry_t;
+/* read r of the new round is read prev_read[r] of the previous one (or RAWDTW_NO_CHAIN: a new read); new_anchors must have
+ * room for anchor_off[n_chains] entries, new_off for n_chains + 1 */
 int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain_off, const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
                               const uint64_t *ref_base, const uint32_t *read_base, const uint64_t *prev_read,
                               const uint64_t *prev_chain_off, const uint64_t *prev_anchor_off, const rawdtw_anchor_t *prev_anchors,
-                              const uint64_t *prev_ref_base, const uint32_t *prev_read_base, uint64_t *carry_chain);
+                              const uint64_t *prev_ref_base, const uint32_t *prev_read_base, rawdtw_carry_t *carry, uint64_t *new_off,
+                              rawdtw_anchor_t *new_anchors);
+/* 1 when `prev` can serve as the previous batch of a rawdtw_batch_submit_carry with options `opt` (waits for nothing; a batch
+ * not fetched yet may still turn out declined: the carried batch then falls back by itself) */
+int rawdtw_batch_can_carry(const rawdtw_ctx *ctx, const rawdtw_batch *prev, const rawdtw_align_opt_t *opt);
+int rawdtw_batch_submit_carry(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                              const uint64_t *anchor_off, const uint64_t *new_off, const rawdtw_anchor_t *new_anchors,
+                              const uint64_t *ref_base, const uint32_t *read_base, const rawdtw_batch *prev,
+                              const rawdtw_carry_t *carry, rawdtw_batch **out);
+int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *parts_scored, uint64_t *parts_reused);
 
 /* The two calls a pipelined host makes per mini-batch: submit = rawdtw_batch_create +
  * rawdtw_batch_run (everything enqueued, nothing waited for; O(1) host work for sparse + banded batches), and, when the
@@ -479,8 +508,15 @@ typedef struct {
     uint32_t min_chain_anchor;                  /* roptions.c:25 */
     uint32_t bp_per_sec, sample_rate, chunk_size, max_num_chunk; /* roptions.c:9-11, 24 */
     uint32_t slot_events;      /* events a read may reach: its slot in the event arena */
-    uint32_t max_reads;        /* reads the mapper holds at a time */
-    int carry;                 /* 1: a round takes the unchanged parts' costs over from the round before (rawdtw_batch_submit_round) */
+    uint32_t max_reads;        /* reads the mapper holds at a time (rawdtw_mapper_release_read gives a finished read's slot back) */
+    int carry;                 /* 1: a round takes the unchanged parts' costs over from the round before (rawdtw_batch_submit_carry) */
+    uint32_t min_events;       /* roptions.c:23 (50): a chunk with fewer events is appended to the read's events, but the round leaves
+                                  the read's chains and its offset alone (rmap.cpp:569-575) */
+    int threads;               /* host threads of a round's per-read work (re-seeding, sort, chaining DP, carry matching, primary
+                                  chains): the reference runs kt_for over n_threads reads (rmap.cpp:916).  <= 1: the calling thread */
+    int groups;                /* 1 or 2 read groups, each on a context of its own (the second is created by the mapper and shares
+                                  the reference arena): one group's host phase runs while the other's batch is on the device, as the
+                                  reference's two pipeline workers overlap (rmap.cpp:1015,1033) */
 } rawdtw_mapper_opt_t;
 typedef struct {
     uint32_t ref_seq;
@@ -488,11 +524,16 @@ typedef struct {
     uint32_t target_position;
     uint32_t query_position;   /* inside the chunk */
 } rawdtw_seed_hit_t;
+/* `ctx` may be NULL for a mapper that scores through rawdtw_mapper_set_scorer only (no device is touched then) */
 int rawdtw_mapper_create(rawdtw_ctx *ctx, const rawdtw_mapper_opt_t *opt, uint32_t n_seq, const char *const *seq_names,
                          const uint32_t *seq_len, rawdtw_mapper **out);
 int rawdtw_mapper_add_read(rawdtw_mapper *m, const char *name, uint32_t qlen /* samples */, uint32_t n_chunks_available,
                            uint32_t *read_id);
-/* one chunk round: read read_ids[k] gets events[event_off[k] .. event_off[k+1]) and hits[hit_off[k] .. hit_off[k+1]) */
+/* a finished read whose line has been written: its slot in the event arena goes to the next rawdtw_mapper_add_read */
+int rawdtw_mapper_release_read(rawdtw_mapper *m, uint32_t read_id);
+/* one chunk round: read read_ids[k] gets events[event_off[k] .. event_off[k+1]) and hits[hit_off[k] .. hit_off[k+1]).
+ * All reads are checked before anything changes; when the device round fails afterwards, the reads are put back as they
+ * were (a failed round can be repeated). */
 int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read_ids, const uint64_t *event_off,
                         const float *events, const uint64_t *hit_off, const rawdtw_seed_hit_t *hits);
 int rawdtw_mapper_read_state(const rawdtw_mapper *m, uint32_t read_id, int *finished, uint32_t *chunks_done);
@@ -502,6 +543,20 @@ int rawdtw_mapper_paf(const rawdtw_mapper *m, uint32_t read_id, char *buf, uint3
 /* the lines --dtw-log-scores writes to stderr (rmap.cpp:308-312), in order */
 int rawdtw_mapper_log(const rawdtw_mapper *m, const char **text);
 int rawdtw_mapper_stats(const rawdtw_mapper *m, uint64_t *rounds, uint64_t *parts_scored, uint64_t *parts_reused);
+/* where a round's time went, accumulated over the mapper's rounds, in milliseconds of host wall time: 0 the per-read host
+ * phase (events, re-seeding, sort, chaining, evaluation order, carry matching), 1 laying the round's arrays out, 2 the
+ * submissions (enqueue only), 3 waiting for the device in fetch, 4 the round's end per read (primary chains, MAPQ, stop
+ * rule); 5 bytes handed to the device for anchor lists, 6 for events, 7 for everything else (offsets, bases, carry records) */
+int rawdtw_mapper_timing(const rawdtw_mapper *m, double out[8]);
+/* Harness hook: score a round's chains with `fn` instead of on the device -- for timing or checking the SAME control flow
+ * with another DTW implementation (bench.py's cpu_baseline, the CPU-only tests).  fn receives the round's chains read by
+ * read, each read's chains in evaluation order (rmap.cpp:512), and must write score[c] / keep[c] for every chain exactly as
+ * the DTW block of gen_chains would (rmap.cpp:515-524); a non-zero return fails the round.  The product's own path never
+ * sets one. */
+typedef int (*rawdtw_scorer_fn)(void *user, uint64_t n_reads, const uint64_t *chain_off, const uint64_t *anchor_off,
+                                const rawdtw_anchor_t *anchors, const uint32_t *chain_seq, const int32_t *chain_strand,
+                                const float *const *read_events, const uint32_t *read_n_events, float *score, uint8_t *keep);
+int rawdtw_mapper_set_scorer(rawdtw_mapper *m, rawdtw_scorer_fn fn, void *user);
 const char *rawdtw_mapper_last_error(const rawdtw_mapper *m);
 int rawdtw_mapper_destroy(rawdtw_mapper *m);
 

@@ -78,6 +78,27 @@ class ChainOut(C.Structure):
                 ("n_anchors", C.c_uint32)]
 
 
+class MapperOpt(C.Structure):
+    """rawdtw_mapper_opt_t"""
+    _fields_ = [
+        ("flag", C.c_int), ("align", AlignOpt), ("chain", ChainOpt),
+        ("min_bestmap_ratio", C.c_float), ("min_meanmap_ratio", C.c_float), ("min_chain_anchor", C.c_uint32),
+        ("bp_per_sec", C.c_uint32), ("sample_rate", C.c_uint32), ("chunk_size", C.c_uint32), ("max_num_chunk", C.c_uint32),
+        ("slot_events", C.c_uint32), ("max_reads", C.c_uint32), ("carry", C.c_int), ("min_events", C.c_uint32),
+        ("threads", C.c_int), ("groups", C.c_int),
+    ]
+
+
+class SeedHit(C.Structure):
+    """rawdtw_seed_hit_t"""
+    _fields_ = [("ref_seq", C.c_uint32), ("strand", C.c_int32), ("target_position", C.c_uint32), ("query_position", C.c_uint32)]
+
+
+# rawdtw_scorer_fn (rawdtw_mapper_set_scorer)
+SCORER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                        C.c_void_p, C.c_void_p)
+
+
 class PlanInfo(C.Structure):
     _fields_ = [
         ("n_jobs", C.c_uint64),
@@ -159,9 +180,11 @@ SYMBOLS = {
     "rawdtw_batch_destroy": (I32, [VP]),
     "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_fetch_destroy": (I32, [VP, VP, VP, VP]),
-    "rawdtw_batch_submit_round": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_submit_carry": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_can_carry": (I32, [VP, VP, VP]),
     "rawdtw_batch_round_stats": (I32, [VP, VP, VP, VP]),
-    "rawdtw_round_match_chains": (I32, [U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_round_match_chains": (I32, [U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_stream_counter_index": (I32, [C.c_char_p]),
     "rawdtw_mapper_create": (I32, [VP, VP, U32, VP, VP, VP]),
     "rawdtw_mapper_add_read": (I32, [VP, C.c_char_p, U32, U32, VP]),
     "rawdtw_mapper_round": (I32, [VP, U32, VP, VP, VP, VP, VP]),
@@ -172,6 +195,10 @@ SYMBOLS = {
     "rawdtw_mapper_stats": (I32, [VP, VP, VP, VP]),
     "rawdtw_mapper_last_error": (C.c_char_p, [VP]),
     "rawdtw_mapper_destroy": (I32, [VP]),
+    "rawdtw_mapper_release_read": (I32, [VP, U32]),
+    "rawdtw_mapper_timing": (I32, [VP, VP]),
+    "rawdtw_mapper_set_scorer": (I32, [VP, VP, VP]),
+    "rawdtw_context_device": (I32, [VP, C.POINTER(I32)]),
     "rawdtw_anchors_pack": (I32, [U64, VP, VP, VP, VP, VP, VP, U64, VP]),
     "rawdtw_anchors_unpack": (I32, [U64, VP, VP, VP, VP, VP, U64, VP]),
     "rawdtw_batch_submit_compact": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, U64, VP, VP, VP]),

@@ -216,9 +216,13 @@ struct rawdtw_batch {
     const uint16_t *in_steps = nullptr;
     const rawdtw_wide_step_t *in_wide = nullptr;
     uint64_t in_n_wide = 0;
-    // chunk rounds (rawdtw_batch_submit_round): the batch of the round before and the per-chain hint (read at create only)
+    // chunk rounds (rawdtw_batch_submit_carry): the batch of the round before, the per-chain carry records and the round's new
+    // anchors (the full list exists on the device only: k_carry assembles it)
     const rawdtw_batch *in_prev = nullptr;
-    const uint64_t *in_carry_chain = nullptr;
+    const rawdtw_carry_t *in_carry = nullptr;
+    const uint64_t *in_new_off = nullptr;
+    const rawdtw_anchor_t *in_new_anchors = nullptr;
+    bool in_carried = false;             // the batch's anchor list was assembled on the device (a fallback reads it back from there)
     // "resident_arrays": the three big arrays are device pointers; host copies are made only if the job list is needed
     bool in_resident = false;
     std::vector<rawdtw_anchor_t> host_anchors;
@@ -1300,6 +1304,13 @@ int rawdtw_set_option(rawdtw_ctx *ctx, const char *name, int64_t value)
     return fail(ctx, RAWDTW_ERR_INVALID, std::string("unknown option ") + name);
 }
 
+int rawdtw_context_device(const rawdtw_ctx *ctx, int *device_ordinal)
+{
+    if (!ctx || !device_ordinal) return RAWDTW_ERR_INVALID;
+    *device_ordinal = ctx->device;
+    return RAWDTW_OK;
+}
+
 int rawdtw_stream(rawdtw_ctx *ctx, void **stream)
 {
     if (!ctx || !stream) return RAWDTW_ERR_INVALID;
@@ -1859,8 +1870,9 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const uint64_t n_units = (na + RAWDTW_COMPACT_STRIDE - 1) / RAWDTW_COMPACT_STRIDE;
     const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
     const rawdtw_batch *prev = b->in_prev;
-    const bool round = prev && b->in_carry_chain && prev->ctx == ctx && prev->stream && !(prev->cnt_valid && stream_declined(prev));
-    const size_t round_bytes = round ? al(nc * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
+    const bool round = prev != nullptr; // (rawdtw_batch_submit_carry checked that it can serve: rawdtw_batch_can_carry)
+    const uint64_t n_new = round ? b->in_new_off[nc] : 0;
+    const size_t round_bytes = round ? al(nc * sizeof(rawdtw_carry_t)) + al((nc + 1) * 8) + al(n_new * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
     const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
                              al((size_t)a.n_tiles * 8) + al((size_t)a.n_slots * 16) + al((size_t)a.n_tiles * 24) +               // tile list, work list, statistics
@@ -1891,7 +1903,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.out = carve<float>(p, na);
     a.debug = ctx->stream_debug;
     a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
-    if (b->in_resident) { a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
+    if (b->in_resident) { if (!b->in_prev) a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place (a chunk round's list is assembled in d_anchors)
     rawdtw_anchor_t *d_heads = nullptr, *d_unit_abs = nullptr;
     uint16_t *d_steps = nullptr;
     rawdtw_wide_step_t *d_wide = nullptr;
@@ -1901,11 +1913,13 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         a.heads = d_heads; a.unit_abs = d_unit_abs; a.steps = d_steps; a.wide = d_wide; a.n_wide = b->in_n_wide; a.anchors_w = d_anchors;
     }
     a.ev = ctx->d_ev; a.ref = ctx->d_ref;
-    uint64_t *d_carry = nullptr;
-    if (round) { // (the previous batch's arrays are read by this batch's k_scan: stream order keeps them alive that long)
-        d_carry = carve<uint64_t>(p, nc);
+    rawdtw_carry_t *d_carry = nullptr;
+    uint64_t *d_new_off = nullptr;
+    rawdtw_anchor_t *d_new = nullptr;
+    if (round) { // (the previous batch's arrays are read by this batch's k_carry: stream order keeps them alive that long)
+        d_carry = carve<rawdtw_carry_t>(p, nc); d_new_off = carve<uint64_t>(p, nc + 1); d_new = carve<rawdtw_anchor_t>(p, n_new);
         a.carried = carve<uint8_t>(p, (uint64_t)a.n_tiles * (a.tile_anchors / 8));
-        a.carry_chain = d_carry;
+        a.carry = d_carry; a.new_off = d_new_off; a.new_anchors = d_new; a.anchors_w = d_anchors;
         a.prev_n_chains = prev->n_chains; a.prev_anchor_off = prev->sa.anchor_off; a.prev_anchors = prev->sa.anchors;
         a.prev_ref_base = prev->sa.ref_base; a.prev_read_base = prev->sa.read_base; a.prev_out = prev->sa.out;
         a.prev_cnt = prev->sa.cnt; a.prev_others_cap = prev->sa.others_cap;
@@ -1927,16 +1941,25 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         if (b->in_n_wide) HIP_TRY(ctx, hipMemcpyAsync(d_wide, b->in_wide, b->in_n_wide * sizeof(rawdtw_wide_step_t), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+    } else if (round) { // only the round's NEW anchors cross the bus: the rest of the list is on the device already
+        HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry, nc * sizeof(rawdtw_carry_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_new_off, b->in_new_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        if (b->in_resident) a.new_anchors = b->in_new_anchors; // ("resident_arrays": the three big arrays are device pointers, used in place)
+        else {
+            if (n_new) HIP_TRY(ctx, hipMemcpyAsync(d_new, b->in_new_anchors, n_new * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
+        }
     } else if (!b->in_resident) {
         HIP_TRY(ctx, hipMemcpyAsync(d_anchors, anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
-    if (round) HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry_chain, nc * 8, hipMemcpyHostToDevice, s));
     b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s)); // ("time_plan": the planning LAUNCHES, behind the hand-over's copies)
-    hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
+    hipError_t e = round ? stream_carry(a, s) : hipSuccess;
+    if (e == hipSuccess) e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
     // The side list's launch goes out here, between the scan and the pass planning, for the batch's first run (a batch that
     // runs again launches it again in front of the tiles' launch): measured, the fresh-batch pipeline runs 6 % faster with
     // the wide bands' long tail in front of the planning launch than behind it.
@@ -1995,6 +2018,21 @@ int materialise_host_arrays(rawdtw_ctx *ctx, rawdtw_batch *b)
             return fail(ctx, RAWDTW_ERR_INVALID, "malformed compact anchor lists");
         b->in_anchors = b->host_anchors.data();
         b->in_steps = nullptr;
+        return RAWDTW_OK;
+    }
+    if (b->in_carried) { // a chunk round: the list exists on the device only (k_carry assembled it)
+        const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
+        try { b->host_anchors.resize(na); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+        if (na) HIP_TRY(ctx, hipMemcpy(b->host_anchors.data(), b->sa.anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost));
+        b->in_anchors = b->host_anchors.data();
+        b->in_carried = false;
+        if (b->in_resident) { // (the bases are the caller's device arrays)
+            try { b->host_ref_base.resize(nc); b->host_read_base.resize(nc); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+            if (nc) HIP_TRY(ctx, hipMemcpy(b->host_ref_base.data(), b->in_ref_base, nc * 8, hipMemcpyDeviceToHost));
+            if (nc) HIP_TRY(ctx, hipMemcpy(b->host_read_base.data(), b->in_read_base, nc * 4, hipMemcpyDeviceToHost));
+            b->in_ref_base = b->host_ref_base.data(); b->in_read_base = b->host_read_base.data();
+            b->in_resident = false;
+        }
         return RAWDTW_OK;
     }
     if (!b->in_resident) return RAWDTW_OK;
@@ -2157,7 +2195,8 @@ struct CompactIn {
 
 static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
                             const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const CompactIn *cin, const uint64_t *ref_base,
-                            const uint32_t *read_base, rawdtw_batch **out, const rawdtw_batch *prev = nullptr, const uint64_t *carry_chain = nullptr)
+                            const uint32_t *read_base, rawdtw_batch **out, const rawdtw_batch *prev = nullptr, const rawdtw_carry_t *carry = nullptr,
+                            const uint64_t *new_off = nullptr)
 {
     if (!out) return RAWDTW_ERR_INVALID;
     *out = nullptr;
@@ -2176,7 +2215,8 @@ static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint
     ctx->live_batches.push_back(b);
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
     b->in_resident = ctx->resident_arrays && !cin;
-    b->in_prev = prev; b->in_carry_chain = carry_chain;
+    b->in_prev = prev; b->in_carry = carry; b->in_new_off = new_off;
+    if (prev) { b->in_new_anchors = anchors; b->in_anchors = nullptr; b->in_carried = true; } // (`anchors` = the round's new entries only)
     if (cin) { b->in_heads = cin->heads; b->in_unit_abs = cin->unit_abs; b->in_steps = cin->steps; b->in_wide = cin->wide; b->in_n_wide = cin->n_wide; }
     if (stream_eligible(ctx, opt, anchor_off[n_chains]))
         st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base);
@@ -2191,7 +2231,7 @@ static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint
         if (st == RAWDTW_OK)
             st = batch_create_joblist(ctx, b, chain_off, anchor_off, b->in_anchors, b->in_ref_base, b->in_read_base, job_off, n_jobs);
     }
-    b->in_prev = nullptr; b->in_carry_chain = nullptr; // (read at create only: the caller may let go of both)
+    b->in_prev = nullptr; // (read at create only)
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(b); return st; }
     *out = b;
     return RAWDTW_OK;
@@ -2221,13 +2261,33 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
     return st;
 }
 
-int rawdtw_batch_submit_round(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
-                              const uint32_t *read_base, const rawdtw_batch *prev, const uint64_t *carry_chain, rawdtw_batch **out)
+// can `prev` serve as the previous batch of a chunk round with options `opt`?  (include/rawdtw.h)
+int rawdtw_batch_can_carry(const rawdtw_ctx *ctx, const rawdtw_batch *prev, const rawdtw_align_opt_t *opt)
 {
-    if (ctx) ctx->in_submit = true;
-    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, anchors, nullptr, ref_base, read_base, out, prev, carry_chain);
-    if (ctx) ctx->in_submit = false;
+    if (!ctx || !prev || !opt || prev->ctx != ctx || !prev->stream || prev->stream_runs == 0) return 0;
+    if (prev->cnt_valid && stream_declined(prev)) return 0;
+    // (a part's radius, and with it its cost, follows from these; the fold's options may differ)
+    if (prev->opt.border_constraint != opt->border_constraint || prev->opt.fill_method != opt->fill_method ||
+        memcmp(&prev->opt.band_radius_frac, &opt->band_radius_frac, sizeof(float)) != 0)
+        return 0;
+    return 1; // (the kernel-selection options only decide which body scores a part: costs do not depend on them)
+}
+
+int rawdtw_batch_submit_carry(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                              const uint64_t *anchor_off, const uint64_t *new_off, const rawdtw_anchor_t *new_anchors,
+                              const uint64_t *ref_base, const uint32_t *read_base, const rawdtw_batch *prev,
+                              const rawdtw_carry_t *carry, rawdtw_batch **out)
+{
+    if (out) *out = nullptr;
+    if (!ctx || !opt || !out || !chain_off || !anchor_off || !new_off || !carry || !prev) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    const uint64_t nc = chain_off[n_reads];
+    if (!rawdtw_batch_can_carry(ctx, prev, opt) || !stream_eligible(ctx, opt, anchor_off[nc]))
+        return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "the previous batch cannot serve this round (another context or options, never run, or not on the device-planned path): submit the round whole");
+    if (new_off[nc] > anchor_off[nc] || (!new_anchors && new_off[nc])) return fail(ctx, RAWDTW_ERR_INVALID, "more new anchors than anchors");
+    static const rawdtw_anchor_t none{0, 0};
+    ctx->in_submit = true;
+    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, new_anchors ? new_anchors : &none, nullptr, ref_base, read_base, out, prev, carry, new_off);
+    ctx->in_submit = false;
     if (st != RAWDTW_OK) return st;
     st = batch_enqueue_one(ctx, *out, nullptr);
     if (st != RAWDTW_OK) { rawdtw_batch_destroy(*out); *out = nullptr; }
@@ -2758,6 +2818,17 @@ int rawdtw_batch_wide_ms(rawdtw_ctx *ctx, rawdtw_batch *batch, float *ms)
     HIP_TRY(ctx, hipEventSynchronize(batch->ev_plan[2]));
     HIP_TRY(ctx, hipEventElapsedTime(ms, batch->ev_plan[1], batch->ev_plan[2]));
     return RAWDTW_OK;
+}
+
+int rawdtw_batch_stream_counter_index(const char *name)
+{
+    static const struct { const char *name; int index; } table[] = {
+        {"bad", kCntBad}, {"overflow", kCntOverflow}, {"unsupported", kCntUnsupported}, {"side_jobs", kCntOthers}, {"class0", kCntCls0},
+        {"cells", kCntCells}, {"tile_jobs", kCntTileJobs}, {"tile_bytes", kCntTileBytes}, {"side_bytes", kCntOtherBytes}, {"todo", kCntTodo},
+        {"reused", kCntReused}, {"pool", kCntPool}, {"stamp0", kCntStamp0}};
+    if (!name) return -1;
+    for (const auto &t : table) if (strcmp(name, t.name) == 0) return t.index;
+    return -1;
 }
 
 int rawdtw_batch_stream_counters(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *out, uint32_t cap, uint32_t *n_out)

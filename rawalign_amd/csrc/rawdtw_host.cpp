@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -435,29 +436,43 @@ extern "C" int rawdtw_anchors_unpack(uint64_t n_chains, const uint64_t *anchor_o
 extern "C" int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain_off, const uint64_t *anchor_off, const rawdtw_anchor_t *anchors,
                                          const uint64_t *ref_base, const uint32_t *read_base, const uint64_t *prev_read,
                                          const uint64_t *prev_chain_off, const uint64_t *prev_anchor_off, const rawdtw_anchor_t *prev_anchors,
-                                         const uint64_t *prev_ref_base, const uint32_t *prev_read_base, uint64_t *carry_chain)
+                                         const uint64_t *prev_ref_base, const uint32_t *prev_read_base, rawdtw_carry_t *carry, uint64_t *new_off,
+                                         rawdtw_anchor_t *new_anchors)
 {
     if (!chain_off || !anchor_off || !ref_base || !read_base || !prev_read || !prev_chain_off || !prev_anchor_off || !prev_ref_base ||
-        !prev_read_base || !carry_chain)
+        !prev_read_base || !carry || !new_off || (!new_anchors && anchor_off[chain_off[n_reads]]))
         return RAWDTW_ERR_INVALID;
+    uint64_t at = 0;
     for (uint64_t r = 0; r < n_reads; r++) {
         const uint64_t pr = prev_read[r];
         for (uint64_t c = chain_off[r]; c < chain_off[r + 1]; c++) {
-            carry_chain[c] = RAWDTW_NO_CHAIN;
+            carry[c] = rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u};
             const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
-            if (pr == RAWDTW_NO_CHAIN || a1 < a0 + 2) continue;
-            // the previous chain on the same strand array that starts on the same anchor and shares the longest run of parts
-            uint64_t best = 0;
-            for (uint64_t pc = prev_chain_off[pr]; pc < prev_chain_off[pr + 1]; pc++) {
-                const uint64_t b0 = prev_anchor_off[pc], b1 = prev_anchor_off[pc + 1];
-                if (b1 < b0 + 2 || prev_ref_base[pc] != ref_base[c] || prev_read_base[pc] != read_base[c]) continue;
-                uint64_t same = 0; // anchors equal, counted from the chains' starts (= the lists' ends)
-                while (same < a1 - a0 && same < b1 - b0 && anchors[a1 - 1 - same].target_position == prev_anchors[b1 - 1 - same].target_position &&
-                       anchors[a1 - 1 - same].query_position == prev_anchors[b1 - 1 - same].query_position)
-                    same++;
-                if (same >= 2 && same > best) { best = same; carry_chain[c] = pc; }
+            uint64_t best = 0; // anchors of the longest common tail
+            if (pr != RAWDTW_NO_CHAIN && a1 >= a0 + 2) {
+                // the previous chain on the same strand array that starts on the same anchor and shares the longest run of parts
+                for (uint64_t pc = prev_chain_off[pr]; pc < prev_chain_off[pr + 1]; pc++) {
+                    const uint64_t b0 = prev_anchor_off[pc], b1 = prev_anchor_off[pc + 1];
+                    if (b1 < b0 + 2 || prev_ref_base[pc] != ref_base[c] || prev_read_base[pc] != read_base[c]) continue;
+                    uint64_t same = 0; // anchors equal, counted from the chains' starts (= the lists' ends)
+                    while (same < a1 - a0 && same < b1 - b0 && anchors[a1 - 1 - same].target_position == prev_anchors[b1 - 1 - same].target_position &&
+                           anchors[a1 - 1 - same].query_position == prev_anchors[b1 - 1 - same].query_position)
+                        same++;
+                    // exclude_last_element (rmap.cpp:270): a part that is this chain's last and was not the other's cannot be taken
+                    // over -- there is no exact way back from a cost without its last cell's distance (dtw.cpp:514-519)
+                    if (same == a1 - a0 && same < b1 - b0) same--;
+                    if (same >= 2 && same > best) { best = same; carry[c].prev_chain = pc; }
+                }
             }
+            if (best >= 2) carry[c].parts = (uint32_t)std::min<uint64_t>(best - 1, 0xffffffffull);
+            else carry[c].prev_chain = RAWDTW_NO_CHAIN;
+            // the entries that are not taken over: the list's first n - (parts + 1)
+            const uint64_t n_new = (a1 - a0) - (carry[c].parts ? (uint64_t)carry[c].parts + 1 : 0);
+            new_off[c] = at;
+            if (n_new) memcpy(new_anchors + at, anchors + a0, n_new * sizeof(rawdtw_anchor_t));
+            at += n_new;
         }
     }
+    new_off[chain_off[n_reads]] = at;
     return RAWDTW_OK;
 }

@@ -131,7 +131,7 @@ enum StreamCounter : int {
     kCntCells = kCntCur0 + 21,
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
     kCntTodo,           // entries of the DTW launch's work list
-    kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_round)
+    kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_carry)
     kCntPool,           // record slots handed out beyond one a tile (tiles whose image takes several passes)
     kCntStamp0,         // 10 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
@@ -167,10 +167,14 @@ struct StreamArgs {
     const rawdtw_wide_step_t *wide;
     uint64_t n_wide;
     rawdtw_anchor_t *anchors_w;
-    // chunk rounds (rawdtw_batch_submit_round; `carry_chain` null otherwise): the batch of the round before.  A part whose two
-    // anchors and bases equal those of the same part (counted from the chain's start) of the chain `carry_chain` names takes
-    // that part's cost instead of being scored again (k_scan checks the equality itself: the hint only says where to look)
-    const uint64_t *carry_chain;      // per chain: a chain of the previous batch, or ~0
+    // chunk rounds (rawdtw_batch_submit_carry; `carry` null otherwise): the batch of the round before.  Per chain the host names
+    // the chain it continues and the number of leading parts (from the chain's start = the tail of its end-first list) that are
+    // unchanged -- validated there, anchor by anchor (rawdtw_round_match_chains).  k_carry assembles the round's anchor list in
+    // `anchors_w` (= `anchors`): a chain's new entries from `new_anchors`, its unchanged tail from `prev_anchors`; and copies
+    // the tail's costs from `prev_out` -- one contiguous stretch a chain.  The scan then leaves those parts out.
+    const rawdtw_carry_t *carry;      // per chain: {chain of the previous batch or ~0, parts taken over}
+    const uint64_t *new_off;          // chain c's new entries: new_anchors[new_off[c] .. new_off[c + 1])
+    const rawdtw_anchor_t *new_anchors;
     uint64_t prev_n_chains;
     const uint64_t *prev_anchor_off;
     const rawdtw_anchor_t *prev_anchors;
@@ -201,6 +205,7 @@ struct StreamArgs {
 };
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
+hipError_t stream_carry(const StreamArgs &a, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
 hipError_t stream_plan_passes(const StreamArgs &a, hipStream_t s);
 hipError_t stream_wide(const StreamArgs &a, uint32_t blocks, hipStream_t s);

@@ -1,23 +1,41 @@
 // rawdtw_mapper.cpp -- the chunk-round mapping loop on the library's host side (include/rawdtw.h, rawdtw_mapper_*).
 //
 // What it restates: the control flow of map_worker_for / ri_map_frag / gen_chains (src/rmap.cpp:667-822, 545-578, 315-541)
-// turned inside out so that every chunk round makes ONE device submission for all active reads (option A),
-// and the PAF line of a read (src/rmap.cpp:696-801, 950-965).  Per round and active read: append the chunk's events
-// (rmap.cpp:554-567), re-seed with the previous chains' anchors plus the chunk's seed hits (344-391), sort (396-401), the
-// chaining DP per (sequence, strand) (430-507: rawdtw_chain_anchors), evaluation order (512).  Then one batch scores
-// every chain of every read on the device (rawdtw_batch_submit_round: DTW + fold + accept/cut, unchanged parts taken over
-// from the round before), and the host finishes the round: gen_primary_chains, comp_mapq, the stop rule (532-541, 692).
-// Event detection and seeding stay in RawAlign (revent.c, rsketch.c, rawindex.cpp): the caller hands in each chunk's
-// events and seed hits.  rawalign_amd/mapper.py is the Python mirror of this file; tests/test_abi_shim.py compares the two
-// and the oracle-scored flow line by line.  Pure host code above the C ABI: no kernel is launched from here directly.
+// turned inside out so that every chunk round makes ONE device submission per read group (option A), and the
+// PAF line of a read (src/rmap.cpp:696-801, 950-965).
+//
+// A round, per read group (the reads are dealt over one or two groups, each with a context of its own):
+//   host phase   a pool of threads over the group's reads, as the reference runs kt_for over n_threads reads
+//                (rmap.cpp:916): append the chunk's events (rmap.cpp:554-567), re-seed with the previous chains' anchors plus the
+//                chunk's seed hits (344-391), sort (396-401), the chaining DP per (sequence, strand) (430-507:
+//                rawdtw_chain_anchors), evaluation order (512), and -- chunk rounds with carry -- per chain the chain of the
+//                round before it continues and the number of leading parts that did not change, compared anchor by anchor
+//   lay-out      the round's arrays in pinned memory: chain and anchor offsets, bases, the NEW anchors and the carry records
+//                (or the whole lists for a round without a predecessor), the new events' segments
+//   submit       rawdtw_events_append + rawdtw_batch_submit_carry / rawdtw_batch_submit: enqueued, not waited for
+// then, group by group: fetch (the only wait), and the round's end per read on the pool: gen_primary_chains, comp_mapq, the
+// stop rule (532-541, 692).  With two groups one group's host phase runs while the other's batch is on the device, and one
+// group's round end while the other's batch finishes -- the overlap the reference gets from its two pipeline workers
+// (rmap.cpp:1015,1033).
+//
+// Event detection and seeding stay in RawAlign (revent.c, rsketch.c, rawindex.cpp): the caller hands in each chunk's events
+// and seed hits.  rawalign_amd/mapper.py is the Python mirror of the control flow; tests/test_mapper.py and
+// tests/test_abi_shim.py compare the two and the oracle-scored flow line by line.  Pure host code above the C ABI: no kernel
+// is launched from here directly.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
-#include <map>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -38,18 +56,151 @@ struct MChain {
 struct MRead {
     std::string name;
     uint32_t qlen = 0, n_chunks = 0, chunks_done = 0;
-    bool finished = false, broke_early = false;
+    bool finished = false, broke_early = false, released = false;
     std::vector<float> events;   // p->events[read].values
+    uint32_t offset = 0;         // reg->offset: events of the chunks that were chained (rmap.cpp:574; a chunk below min_events does not count)
     std::vector<MChain> chains;  // reg0->chains: the primary chains, best first
-    uint32_t slot = 0;
+    uint32_t slot = 0;           // its place in the mapper's event arenas: group = slot % groups, place there = slot / groups
+    uint64_t last_round = 0;     // the round it was last scored in, and its position among its group's reads then
+    uint64_t last_pos = 0;
+    uint64_t seen_round = 0;     // (duplicate check)
 };
 
-struct PrevRound {
+// growable array in page-locked memory (plain memory for a mapper without a device); contents are NOT kept over a growth
+template <typename T> struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { release(); }
+    void release()
+    {
+        if (p) { if (pinned) rawdtw_host_free(p); else free(p); }
+        p = nullptr; cap = 0;
+    }
+    bool ensure(size_t n, bool want_pinned)
+    {
+        if (n <= cap) return true;
+        release();
+        const size_t c = n + n / 4 + 64;
+        void *q = nullptr;
+        if (want_pinned && rawdtw_host_alloc(c * sizeof(T), &q) == RAWDTW_OK && q) pinned = true;
+        else { q = malloc(c * sizeof(T)); pinned = false; }
+        if (!q) return false;
+        p = static_cast<T *>(q); cap = c;
+        return true;
+    }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// one round's arrays of one read group, as handed to the device (and kept for the next round's matching)
+struct RoundArrays {
+    std::vector<uint32_t> ks;  // the group's reads: indices into the round's read list, in order
+    PinBuf<uint64_t> chain_off, anchor_off, ref_base, new_off, seg_src;
+    PinBuf<uint32_t> read_base, seg_dst;
+    PinBuf<rawdtw_anchor_t> anchors, new_anchors;
+    PinBuf<rawdtw_carry_t> carry;
+    PinBuf<float> new_events, score;
+    PinBuf<uint8_t> keep;
+    std::vector<uint32_t> chain_seq; // (the external scorer's view)
+    std::vector<int32_t> chain_strand;
+    uint64_t n_reads = 0, n_chains = 0, n_anchors = 0, n_new = 0, n_new_events = 0, n_seg = 0;
     rawdtw_batch *batch = nullptr;
-    std::vector<uint64_t> chain_off, anchor_off, ref_base;
-    std::vector<rawdtw_anchor_t> anchors;
-    std::vector<uint32_t> read_base;
-    std::map<uint32_t, uint64_t> index_of; // read id -> its index in that round
+    uint64_t round_id = 0;
+    bool carried = false;
+};
+
+struct Group {
+    rawdtw_ctx *ctx = nullptr;
+    bool own_ctx = false;
+    RoundArrays buf[2];
+    int cur = 0;          // buf[cur]: the round at hand; buf[cur ^ 1]: the round before (when has_prev)
+    bool has_prev = false;
+};
+
+// what the host phase leaves per read of the round
+struct RoundRead {
+    std::vector<MChain> chains;          // the round's candidate chains in evaluation order
+    std::vector<rawdtw_carry_t> carry;   // per chain
+    std::vector<uint64_t> ref_base;      // per chain
+    std::vector<uint8_t> keep;
+    std::string log;
+    uint64_t ne = 0;
+    uint32_t ev_before = 0, off_before = 0;
+    bool skipped = false;                // a chunk below min_events: no chaining, chains and offset stay (rmap.cpp:569-575)
+    uint64_t chain0 = 0, anchor0 = 0, new0 = 0, ev0 = 0; // its first chain / anchor / new anchor / new event in the group's arrays
+    int err = RAWDTW_OK;
+};
+
+// a pool of threads running one loop at a time; the calling thread works too
+class Pool {
+public:
+    explicit Pool(int threads)
+    {
+        for (int t = 1; t < threads; t++) th_.emplace_back([this] { worker(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // fn(i) for i in [0, n), dealt in pieces of `grain` from a shared counter (as kt_for deals reads: kthread.c:54-72)
+    void run(size_t n, size_t grain, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0) return;
+        if (th_.empty() || n <= grain) { for (size_t i = 0; i < n; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; n_ = n; grain_ = grain; next_.store(0); busy_ = (int)th_.size(); gen_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+    int threads() const { return (int)th_.size() + 1; }
+
+private:
+    void work()
+    {
+        for (;;) {
+            const size_t s = next_.fetch_add(grain_);
+            if (s >= n_) break;
+            const size_t e = std::min(n_, s + grain_);
+            for (size_t i = s; i < e; i++) (*fn_)(i);
+        }
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--busy_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0, grain_ = 1;
+    std::atomic<size_t> next_{0};
+    int busy_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 rawdtw_chain_t record_of(const MChain &c, uint32_t tag)
@@ -64,6 +215,11 @@ std::string fmt_f(double x) // std::to_string(float/double) == printf("%f")
     return b;
 }
 
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 } // namespace
 
 struct rawdtw_mapper {
@@ -71,10 +227,18 @@ struct rawdtw_mapper {
     rawdtw_mapper_opt_t opt{};
     std::vector<std::string> seq_names;
     std::vector<uint32_t> seq_len;
+    std::vector<uint64_t> ref_off; // [seq * 2 + strand]: the strand array's offset in the reference arena (a scorer-only mapper: its index)
     std::vector<MRead> reads;
-    PrevRound prev;
+    std::vector<uint32_t> free_slots;
+    uint32_t slots_used = 0;
+    Group groups_store[2];
+    struct GroupSpan { Group *b; size_t n; Group *begin() const { return b; } Group *end() const { return b + n; } size_t size() const { return n; } Group &operator[](size_t i) const { return b[i]; } } groups{groups_store, 1};
+    Pool *pool = nullptr;
     std::string log;
     uint64_t rounds = 0, parts_scored = 0, parts_reused = 0;
+    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    rawdtw_scorer_fn scorer = nullptr;
+    void *scorer_user = nullptr;
     std::string err;
 };
 
@@ -115,10 +279,106 @@ int fail(rawdtw_mapper *m, int st, const std::string &msg)
     return st;
 }
 
-void drop_prev(rawdtw_mapper *m)
+void drop_batches(rawdtw_mapper *m)
 {
-    if (m->prev.batch) rawdtw_batch_destroy(m->prev.batch);
-    m->prev = PrevRound{};
+    for (Group &g : m->groups)
+        for (RoundArrays &ra : g.buf) {
+            if (ra.batch) rawdtw_batch_destroy(ra.batch);
+            ra.batch = nullptr;
+        }
+}
+
+struct Seed { uint32_t key, t, q; };
+
+// The host phase of one read: the chunk's events, the round's anchors, chaining, evaluation order, carry records.
+// `pv` = the arrays of the round before of the read's group (null: none, or the read was not in it).
+void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev, uint64_t ne, const rawdtw_seed_hit_t *hits, uint64_t n_hits,
+                     const RoundArrays *pv, bool runs_dtw)
+{
+    rr.ne = ne;
+    rr.ev_before = (uint32_t)rd.events.size();
+    rr.off_before = rd.offset;
+    rd.events.insert(rd.events.end(), ev, ev + ne); // rmap.cpp:554-567
+    if (ne < m->opt.min_events) { rr.skipped = true; return; } // rmap.cpp:569-572: no gen_chains, reg->offset stays
+    const uint32_t chunk_start = rd.offset; // reg->offset (rmap.cpp:574)
+    rd.offset += (uint32_t)ne;               // rmap.cpp:575
+    // rmap.cpp:344-357: re-seed with the previous chains' anchors; rmap.cpp:371-391: the chunk's seed hits
+    std::vector<Seed> seeds;
+    size_t n_prev = 0;
+    for (const MChain &ch : rd.chains) n_prev += ch.anchors.size();
+    seeds.reserve(n_prev + n_hits);
+    for (const MChain &ch : rd.chains)
+        for (const rawdtw_anchor_t &a : ch.anchors) seeds.push_back(Seed{ch.ref * 2u + (uint32_t)ch.strand, a.target_position, a.query_position});
+    for (uint64_t h = 0; h < n_hits; h++)
+        seeds.push_back(Seed{hits[h].ref_seq * 2u + (uint32_t)(hits[h].strand ? 1 : 0), hits[h].target_position, hits[h].query_position + chunk_start});
+    // by (sequence, strand), then (target, query): rmap.cpp:396-401 sorts every list; rmap.cpp:432-433 walks them sequence-major,
+    // strand 0 then 1
+    std::sort(seeds.begin(), seeds.end(), [](const Seed &a, const Seed &b) {
+        if (a.key != b.key) return a.key < b.key;
+        if (a.t != b.t) return a.t < b.t;
+        return a.q < b.q;
+    });
+    std::vector<MChain> chains;
+    float maxs = 0.0f;
+    const uint32_t cap = (uint32_t)std::max(1, m->opt.chain.num_best_chains);
+    std::vector<rawdtw_chain_out_t> outc(cap);
+    std::vector<uint64_t> off(cap + 1);
+    std::vector<rawdtw_anchor_t> a, outa;
+    for (size_t s0 = 0; s0 < seeds.size();) {
+        size_t s1 = s0;
+        while (s1 < seeds.size() && seeds[s1].key == seeds[s0].key) s1++;
+        a.resize(s1 - s0);
+        for (size_t q = s0; q < s1; q++) a[q - s0] = rawdtw_anchor_t{seeds[q].t, seeds[q].q};
+        outa.resize(std::max<size_t>(a.size(), 1));
+        const int nc = rawdtw_chain_anchors(&m->opt.chain, a.data(), (uint32_t)a.size(), &maxs, outc.data(), off.data(), outa.data(), cap, outa.size());
+        if (nc < 0) { rr.err = RAWDTW_ERR_RANGE; return; }
+        for (int c = 0; c < nc; c++) {
+            MChain ch;
+            ch.chaining_score = outc[c].chaining_score; ch.ref = seeds[s0].key >> 1; ch.strand = (int32_t)(seeds[s0].key & 1u);
+            ch.start_position = outc[c].start_position; ch.end_position = outc[c].end_position;
+            ch.anchors.assign(outa.begin() + off[c], outa.begin() + off[c + 1]);
+            chains.push_back(std::move(ch));
+        }
+        s0 = s1;
+    }
+    if (!chains.empty() && runs_dtw) { // rmap.cpp:512: std::sort by chaining score, descending (its permutation)
+        std::vector<float> cs(chains.size());
+        for (size_t c = 0; c < chains.size(); c++) cs[c] = chains[c].chaining_score;
+        std::vector<uint32_t> perm(chains.size());
+        if (rawdtw_sort_by_chaining_score(cs.data(), (uint32_t)cs.size(), perm.data()) != RAWDTW_OK) { rr.err = RAWDTW_ERR_INVALID; return; }
+        std::vector<MChain> sorted;
+        sorted.reserve(chains.size());
+        for (uint32_t p : perm) sorted.push_back(std::move(chains[p]));
+        chains.swap(sorted);
+    }
+    rr.chains = std::move(chains);
+    if (!runs_dtw) return;
+    rr.ref_base.resize(rr.chains.size());
+    rr.carry.assign(rr.chains.size(), rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u});
+    for (size_t c = 0; c < rr.chains.size(); c++) rr.ref_base[c] = m->ref_off[rr.chains[c].ref * 2u + (uint32_t)rr.chains[c].strand];
+    if (!pv) return;
+    // chunk rounds: the chain of the round before this chain continues -- same strand array, same start anchor, the longest
+    // common tail, compared anchor by anchor -- and the leading parts taken over (as rawdtw_round_match_chains)
+    const uint64_t pr = rd.last_pos;
+    for (size_t c = 0; c < rr.chains.size(); c++) {
+        const std::vector<rawdtw_anchor_t> &an = rr.chains[c].anchors;
+        const uint64_t na = an.size();
+        if (na < 2) continue;
+        uint64_t best = 0;
+        for (uint64_t pc = pv->chain_off[pr]; pc < pv->chain_off[pr + 1]; pc++) {
+            const uint64_t b0 = pv->anchor_off[pc], b1 = pv->anchor_off[pc + 1];
+            if (b1 < b0 + 2 || pv->ref_base[pc] != rr.ref_base[c]) continue;
+            const rawdtw_anchor_t *pa = pv->anchors.p;
+            uint64_t same = 0;
+            while (same < na && same < b1 - b0 && an[na - 1 - same].target_position == pa[b1 - 1 - same].target_position &&
+                   an[na - 1 - same].query_position == pa[b1 - 1 - same].query_position)
+                same++;
+            if (same == na && same < b1 - b0) same--; // (its last part was not the last then: rmap.cpp:270, no exact way back)
+            if (same >= 2 && same > best) { best = same; rr.carry[c].prev_chain = pc; }
+        }
+        if (best >= 2) rr.carry[c].parts = (uint32_t)(best - 1);
+        else rr.carry[c].prev_chain = RAWDTW_NO_CHAIN;
+    }
 }
 
 } // namespace
@@ -130,14 +390,36 @@ int rawdtw_mapper_create(rawdtw_ctx *ctx, const rawdtw_mapper_opt_t *opt, uint32
 {
     if (!out) return RAWDTW_ERR_INVALID;
     *out = nullptr;
-    if (!ctx || !opt || (n_seq && (!seq_names || !seq_len)) || opt->slot_events == 0 || opt->max_reads == 0) return RAWDTW_ERR_INVALID;
+    if (!opt || (n_seq && (!seq_names || !seq_len)) || opt->slot_events == 0 || opt->max_reads == 0) return RAWDTW_ERR_INVALID;
     if (opt->align.border_constraint != 0 && opt->align.border_constraint != 1) return RAWDTW_ERR_INVALID; // rmap.cpp:301-304
     rawdtw_mapper *m = new (std::nothrow) rawdtw_mapper;
     if (!m) return RAWDTW_ERR_OOM;
     m->ctx = ctx; m->opt = *opt;
+    m->opt.groups = (ctx && opt->groups >= 2) ? 2 : 1;
+    m->opt.threads = std::max(1, std::min(opt->threads, 256));
     for (uint32_t s = 0; s < n_seq; s++) { m->seq_names.emplace_back(seq_names[s]); m->seq_len.push_back(seq_len[s]); }
-    const int st = rawdtw_events_reserve(ctx, (uint64_t)opt->slot_events * opt->max_reads);
-    if (st != RAWDTW_OK) { delete m; return st; }
+    m->ref_off.resize(2ull * n_seq);
+    for (uint32_t s = 0; s < n_seq; s++)
+        for (int st = 0; st < 2; st++) {
+            uint64_t off = 2ull * s + (uint64_t)st;
+            if (ctx && rawdtw_reference_offset(ctx, s, st, &off) != RAWDTW_OK) { delete m; return RAWDTW_ERR_INVALID; } // (no reference array for a sequence)
+            m->ref_off[2ull * s + (uint64_t)st] = off;
+        }
+    m->groups.n = (size_t)m->opt.groups;
+    m->groups[0].ctx = ctx;
+    int st = RAWDTW_OK;
+    if (m->opt.groups == 2) { // the second group's context: same device, the same resident reference
+        int dev = 0;
+        st = rawdtw_context_device(ctx, &dev);
+        if (st == RAWDTW_OK) st = rawdtw_create(dev, &m->groups[1].ctx);
+        if (st == RAWDTW_OK) { m->groups[1].own_ctx = true; st = rawdtw_share_reference(m->groups[1].ctx, ctx); }
+    }
+    const uint64_t per_group = ((uint64_t)opt->max_reads + (uint64_t)m->opt.groups - 1) / (uint64_t)m->opt.groups;
+    for (Group &g : m->groups)
+        if (st == RAWDTW_OK && g.ctx) st = rawdtw_events_reserve(g.ctx, (uint64_t)opt->slot_events * per_group);
+    if (st != RAWDTW_OK) { rawdtw_mapper_destroy(m); return st; }
+    m->pool = new (std::nothrow) Pool(m->opt.threads);
+    if (!m->pool) { rawdtw_mapper_destroy(m); return RAWDTW_ERR_OOM; }
     *out = m;
     return RAWDTW_OK;
 }
@@ -145,21 +427,55 @@ int rawdtw_mapper_create(rawdtw_ctx *ctx, const rawdtw_mapper_opt_t *opt, uint32
 int rawdtw_mapper_destroy(rawdtw_mapper *m)
 {
     if (!m) return RAWDTW_OK;
-    drop_prev(m);
+    drop_batches(m);
+    for (Group &g : m->groups) {
+        for (RoundArrays &ra : g.buf) { // (pinned memory goes before the context that may own the device)
+            ra.chain_off.release(); ra.anchor_off.release(); ra.ref_base.release(); ra.new_off.release(); ra.seg_src.release();
+            ra.read_base.release(); ra.seg_dst.release(); ra.anchors.release(); ra.new_anchors.release(); ra.carry.release();
+            ra.new_events.release(); ra.score.release(); ra.keep.release();
+        }
+        if (g.own_ctx && g.ctx) rawdtw_destroy(g.ctx);
+    }
+    delete m->pool;
     delete m;
     return RAWDTW_OK;
 }
 
 const char *rawdtw_mapper_last_error(const rawdtw_mapper *m) { return m ? m->err.c_str() : "null mapper"; }
 
+int rawdtw_mapper_set_scorer(rawdtw_mapper *m, rawdtw_scorer_fn fn, void *user)
+{
+    if (!m) return RAWDTW_ERR_INVALID;
+    m->scorer = fn; m->scorer_user = user;
+    drop_batches(m); // (a round scored elsewhere leaves nothing to carry from)
+    for (Group &g : m->groups) g.has_prev = false;
+    return RAWDTW_OK;
+}
+
 int rawdtw_mapper_add_read(rawdtw_mapper *m, const char *name, uint32_t qlen, uint32_t n_chunks_available, uint32_t *read_id)
 {
     if (!m || !name || !read_id) return RAWDTW_ERR_INVALID;
-    if (m->reads.size() >= m->opt.max_reads) return fail(m, RAWDTW_ERR_RANGE, "more reads than the mapper has slots for");
+    uint32_t slot;
+    if (!m->free_slots.empty()) { slot = m->free_slots.back(); m->free_slots.pop_back(); }
+    else if (m->slots_used < m->opt.max_reads) slot = m->slots_used++;
+    else return fail(m, RAWDTW_ERR_RANGE, "more reads than the mapper has slots for (rawdtw_mapper_release_read gives a finished read's slot back)");
     MRead r;
-    r.name = name; r.qlen = qlen; r.n_chunks = n_chunks_available; r.slot = (uint32_t)m->reads.size();
-    *read_id = r.slot;
+    r.name = name; r.qlen = qlen; r.n_chunks = n_chunks_available; r.slot = slot;
+    *read_id = (uint32_t)m->reads.size();
     m->reads.push_back(std::move(r));
+    return RAWDTW_OK;
+}
+
+int rawdtw_mapper_release_read(rawdtw_mapper *m, uint32_t read_id)
+{
+    if (!m || read_id >= m->reads.size()) return RAWDTW_ERR_INVALID;
+    MRead &rd = m->reads[read_id];
+    if (rd.released) return RAWDTW_OK;
+    if (!rd.finished) return fail(m, RAWDTW_ERR_INVALID, "only a finished read can be released");
+    rd.released = true;
+    std::vector<float>().swap(rd.events);
+    std::vector<MChain>().swap(rd.chains);
+    m->free_slots.push_back(rd.slot);
     return RAWDTW_OK;
 }
 
@@ -180,6 +496,13 @@ int rawdtw_mapper_stats(const rawdtw_mapper *m, uint64_t *rounds, uint64_t *part
     return RAWDTW_OK;
 }
 
+int rawdtw_mapper_timing(const rawdtw_mapper *m, double out[8])
+{
+    if (!m || !out) return RAWDTW_ERR_INVALID;
+    for (int i = 0; i < 8; i++) out[i] = m->timing[i];
+    return RAWDTW_OK;
+}
+
 int rawdtw_mapper_log(const rawdtw_mapper *m, const char **text)
 {
     if (!m || !text) return RAWDTW_ERR_INVALID;
@@ -194,142 +517,219 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         return RAWDTW_ERR_INVALID;
     if (n_reads == 0) return RAWDTW_OK;
     const uint32_t n_seq = (uint32_t)m->seq_len.size();
-    m->rounds++;
-    // ---- per read: the chunk's events, the round's anchors, chaining, evaluation order ----
-    std::vector<std::vector<MChain>> round_chains(n_reads);
-    std::vector<uint64_t> seg_src{0};
-    std::vector<uint32_t> seg_dst;
-    std::vector<float> new_events;
+    const bool runs_dtw = (m->opt.flag & (0x2 | 0x8)) != 0; // rmap.cpp:509
+    if (runs_dtw && !m->scorer && !m->ctx) return fail(m, RAWDTW_ERR_NO_DEVICE, "a mapper without a context needs a scorer (rawdtw_mapper_set_scorer)");
+    // ---- every read is checked before anything changes ----
+    const uint64_t stamp = m->rounds + 1;
     for (uint32_t k = 0; k < n_reads; k++) {
         if (read_ids[k] >= m->reads.size()) return fail(m, RAWDTW_ERR_INVALID, "unknown read id");
         MRead &rd = m->reads[read_ids[k]];
-        if (rd.finished) return fail(m, RAWDTW_ERR_INVALID, "a finished read in a round");
-        const uint64_t ne = event_off[k + 1] - event_off[k];
-        const uint32_t chunk_start = (uint32_t)rd.events.size(); // reg->offset (rmap.cpp:574)
-        if ((uint64_t)chunk_start + ne > m->opt.slot_events) return fail(m, RAWDTW_ERR_RANGE, "a read outgrew its slot in the event arena");
-        rd.events.insert(rd.events.end(), events + event_off[k], events + event_off[k + 1]); // rmap.cpp:554-567
-        if (ne) {
-            new_events.insert(new_events.end(), events + event_off[k], events + event_off[k + 1]);
-            seg_src.push_back(seg_src.back() + ne);
-            seg_dst.push_back(rd.slot * m->opt.slot_events + chunk_start);
+        bool dup = rd.seen_round == stamp;
+        rd.seen_round = stamp;
+        if (dup || rd.finished || rd.released || event_off[k + 1] < event_off[k] || hit_off[k + 1] < hit_off[k]) {
+            for (uint32_t q = 0; q <= k; q++) m->reads[read_ids[q]].seen_round = 0;
+            return fail(m, RAWDTW_ERR_INVALID, dup ? "a read twice in one round" : rd.finished || rd.released ? "a finished read in a round" : "offsets do not ascend");
         }
-        // rmap.cpp:344-357: re-seed with the previous chains' anchors; rmap.cpp:371-391: the chunk's seed hits
-        std::map<std::pair<uint32_t, int32_t>, std::vector<std::pair<uint32_t, uint32_t>>> per;
-        for (const MChain &ch : rd.chains)
-            for (const rawdtw_anchor_t &a : ch.anchors) per[{ch.ref, ch.strand}].push_back({a.target_position, a.query_position});
-        for (uint64_t h = hit_off[k]; h < hit_off[k + 1]; h++) {
+    }
+    for (uint32_t k = 0; k < n_reads; k++) m->reads[read_ids[k]].seen_round = 0; // (a failed round does not count)
+    for (uint32_t k = 0; k < n_reads; k++) {
+        const MRead &rd = m->reads[read_ids[k]];
+        if ((uint64_t)rd.events.size() + (event_off[k + 1] - event_off[k]) > m->opt.slot_events) return fail(m, RAWDTW_ERR_RANGE, "a read outgrew its slot in the event arena");
+        for (uint64_t h = hit_off[k]; h < hit_off[k + 1]; h++)
             if (hits[h].ref_seq >= n_seq) return fail(m, RAWDTW_ERR_INVALID, "seed hit on an unknown sequence");
-            per[{hits[h].ref_seq, hits[h].strand}].push_back({hits[h].target_position, hits[h].query_position + chunk_start});
-        }
-        std::vector<MChain> chains;
-        float maxs = 0.0f;
-        for (uint32_t s = 0; s < n_seq; s++)       // rmap.cpp:432-433: sequence-major, strand 0 then 1
-            for (int32_t st = 0; st < 2; st++) {
-                auto it = per.find({s, st});
-                if (it == per.end() || it->second.empty()) continue;
-                std::vector<std::pair<uint32_t, uint32_t>> &lst = it->second;
-                std::sort(lst.begin(), lst.end()); // by (target, query): rmap.cpp:396-401
-                std::vector<rawdtw_anchor_t> a(lst.size());
-                for (size_t q = 0; q < lst.size(); q++) a[q] = rawdtw_anchor_t{lst[q].first, lst[q].second};
-                const uint32_t cap = (uint32_t)std::max(1, m->opt.chain.num_best_chains);
-                std::vector<rawdtw_chain_out_t> outc(cap);
-                std::vector<uint64_t> off(cap + 1);
-                std::vector<rawdtw_anchor_t> outa(std::max<size_t>(a.size(), 1));
-                const int nc = rawdtw_chain_anchors(&m->opt.chain, a.data(), (uint32_t)a.size(), &maxs, outc.data(), off.data(), outa.data(), cap, outa.size());
-                if (nc < 0) return fail(m, RAWDTW_ERR_RANGE, "chain output buffers too small");
-                for (int c = 0; c < nc; c++) {
-                    MChain ch;
-                    ch.chaining_score = outc[c].chaining_score; ch.ref = s; ch.strand = st;
-                    ch.start_position = outc[c].start_position; ch.end_position = outc[c].end_position;
-                    ch.anchors.assign(outa.begin() + off[c], outa.begin() + off[c + 1]);
-                    chains.push_back(std::move(ch));
-                }
-            }
-        if (!chains.empty()) { // rmap.cpp:512: std::sort by chaining score, descending (its permutation)
-            std::vector<float> cs(chains.size());
-            for (size_t c = 0; c < chains.size(); c++) cs[c] = chains[c].chaining_score;
-            std::vector<uint32_t> perm(chains.size());
-            if (rawdtw_sort_by_chaining_score(cs.data(), (uint32_t)cs.size(), perm.data()) != RAWDTW_OK) return fail(m, RAWDTW_ERR_INVALID, "sort failed");
-            std::vector<MChain> sorted;
-            sorted.reserve(chains.size());
-            for (uint32_t p : perm) sorted.push_back(std::move(chains[p]));
-            chains.swap(sorted);
-        }
-        round_chains[k] = std::move(chains);
     }
-    // ---- the DTW block of gen_chains for every read of the round (rmap.cpp:509-530), one device submission ----
-    const bool runs_dtw = (m->opt.flag & (0x2 | 0x8)) != 0; // rmap.cpp:509
-    std::vector<std::vector<uint8_t>> keep_of(n_reads);
-    if (runs_dtw) {
-        if (seg_dst.size()) {
-            const int st = rawdtw_events_append(m->ctx, new_events.data(), new_events.size(), (uint32_t)seg_dst.size(), seg_src.data(), seg_dst.data());
-            if (st != RAWDTW_OK) return fail(m, st, rawdtw_last_error(m->ctx));
+    const uint64_t round_id = m->rounds + 1;
+    const uint32_t G = (uint32_t)m->groups.size();
+    const bool on_device = runs_dtw && !m->scorer;
+    std::vector<RoundRead> rr(n_reads);
+    for (Group &g : m->groups) { g.cur ^= 1; g.buf[g.cur].ks.clear(); }
+    for (uint32_t k = 0; k < n_reads; k++) { Group &g = m->groups[m->reads[read_ids[k]].slot % G]; g.buf[g.cur].ks.push_back(k); }
+    int status = RAWDTW_OK;
+    std::string status_msg;
+    auto set_fail = [&](int st, const std::string &msg) { if (status == RAWDTW_OK) { status = st; status_msg = msg; } };
+    double t0 = now_ms();
+    // ---- per group: host phase, lay-out, submit ----
+    for (uint32_t gi = 0; gi < G && status == RAWDTW_OK; gi++) {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur];
+        const RoundArrays *pv = nullptr;
+        ra.carried = false;
+        ra.round_id = round_id;
+        const RoundArrays &pb = g.buf[g.cur ^ 1];
+        if (on_device && m->opt.carry && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) { pv = &pb; ra.carried = true; }
+        const size_t nr = ra.ks.size();
+        ra.n_reads = nr;
+        m->pool->run(nr, 16, [&](size_t i) {
+            const uint32_t k = ra.ks[i];
+            MRead &rd = m->reads[read_ids[k]];
+            const bool in_prev = pv && rd.last_round == pv->round_id;
+            host_phase_read(m, rd, rr[k], events + event_off[k], event_off[k + 1] - event_off[k], hits + hit_off[k], hit_off[k + 1] - hit_off[k],
+                            in_prev ? pv : nullptr, runs_dtw);
+        });
+        double t1 = now_ms();
+        m->timing[0] += t1 - t0; t0 = t1;
+        for (size_t i = 0; i < nr; i++) if (rr[ra.ks[i]].err != RAWDTW_OK) set_fail(rr[ra.ks[i]].err, "chaining failed (chain output buffers too small)");
+        if (status != RAWDTW_OK || !runs_dtw) continue;
+        // ---- lay-out: offsets by a running sum, then every read copies its own stretch ----
+        uint64_t nc = 0, na = 0, nn = 0, nev = 0, nseg = 0;
+        for (size_t i = 0; i < nr; i++) {
+            RoundRead &r = rr[ra.ks[i]];
+            r.chain0 = nc; r.anchor0 = na; r.new0 = nn; r.ev0 = nev;
+            nc += r.chains.size();
+            for (size_t c = 0; c < r.chains.size(); c++) {
+                const uint64_t n = r.chains[c].anchors.size();
+                na += n;
+                nn += n - (r.carry[c].parts ? (uint64_t)r.carry[c].parts + 1 : 0);
+            }
+            nev += r.ne;
+            nseg += r.ne ? 1 : 0;
         }
-        PrevRound cur;
-        cur.chain_off.push_back(0); cur.anchor_off.push_back(0);
-        for (uint32_t k = 0; k < n_reads; k++) {
+        ra.n_chains = nc; ra.n_anchors = na; ra.n_new = nn; ra.n_new_events = nev; ra.n_seg = nseg;
+        const bool pin = on_device;
+        const bool ok = ra.chain_off.ensure(nr + 1, pin) && ra.anchor_off.ensure(nc + 1, pin) && ra.ref_base.ensure(nc + 1, pin) && ra.read_base.ensure(nc + 1, pin) &&
+                        ra.anchors.ensure(na + 1, pin && !ra.carried) && ra.score.ensure(nc + 1, pin) && ra.keep.ensure(nc + 1, pin) &&
+                        (!ra.carried || (ra.new_off.ensure(nc + 1, pin) && ra.new_anchors.ensure(nn + 1, pin) && ra.carry.ensure(nc + 1, pin))) &&
+                        (!on_device || (ra.new_events.ensure(nev + 1, pin) && ra.seg_src.ensure(nseg + 2, pin) && ra.seg_dst.ensure(nseg + 1, pin)));
+        if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); continue; }
+        if (m->scorer) { ra.chain_seq.resize(nc); ra.chain_strand.resize(nc); }
+        ra.chain_off[nr] = nc; ra.anchor_off[nc] = na;
+        if (ra.carried) ra.new_off[nc] = nn;
+        ra.ref_base[nc] = 0; ra.read_base[nc] = 0; // (non-null, initialised arrays for a round without chains)
+        ra.anchors[na] = rawdtw_anchor_t{0, 0};
+        {   // the new events' segments (reads with a chunk this round, in order)
+            uint64_t s = 0, at = 0;
+            for (size_t i = 0; i < nr && on_device; i++) {
+                const RoundRead &r = rr[ra.ks[i]];
+                if (!r.ne) continue;
+                const MRead &rd = m->reads[read_ids[ra.ks[i]]];
+                ra.seg_src[s] = at;
+                ra.seg_dst[s] = (rd.slot / G) * m->opt.slot_events + r.ev_before;
+                at += r.ne; s++;
+            }
+            if (on_device) ra.seg_src[s] = at;
+        }
+        m->pool->run(nr, 32, [&](size_t i) {
+            const uint32_t k = ra.ks[i];
+            const RoundRead &r = rr[k];
             const MRead &rd = m->reads[read_ids[k]];
-            cur.index_of[read_ids[k]] = k;
-            for (const MChain &ch : round_chains[k]) {
-                cur.anchors.insert(cur.anchors.end(), ch.anchors.begin(), ch.anchors.end());
-                cur.anchor_off.push_back(cur.anchors.size());
-                uint64_t rb = 0;
-                if (rawdtw_reference_offset(m->ctx, ch.ref, ch.strand, &rb) != RAWDTW_OK) return fail(m, RAWDTW_ERR_INVALID, "no reference array for a chain");
-                cur.ref_base.push_back(rb);
-                cur.read_base.push_back(rd.slot * m->opt.slot_events);
-            }
-            cur.chain_off.push_back(cur.ref_base.size());
-        }
-        const uint64_t nc = cur.ref_base.size();
-        std::vector<float> score(std::max<uint64_t>(nc, 1));
-        std::vector<uint8_t> keep(std::max<uint64_t>(nc, 1));
-        if (cur.ref_base.empty()) { cur.ref_base.push_back(0); cur.read_base.push_back(0); } // (non-null pointers for a round without chains)
-        if (cur.anchors.empty()) cur.anchors.push_back(rawdtw_anchor_t{0, 0});
-        std::vector<uint64_t> carry(std::max<uint64_t>(nc, 1), RAWDTW_NO_CHAIN);
-        const bool carry_on = m->opt.carry && m->prev.batch && m->opt.align.border_constraint == 1;
-        if (carry_on) {
-            std::vector<uint64_t> prev_read(n_reads, RAWDTW_NO_CHAIN);
-            for (uint32_t k = 0; k < n_reads; k++) {
-                auto it = m->prev.index_of.find(read_ids[k]);
-                if (it != m->prev.index_of.end()) prev_read[k] = it->second;
-            }
-            rawdtw_round_match_chains(n_reads, cur.chain_off.data(), cur.anchor_off.data(), cur.anchors.data(), cur.ref_base.data(), cur.read_base.data(),
-                                      prev_read.data(), m->prev.chain_off.data(), m->prev.anchor_off.data(), m->prev.anchors.data(),
-                                      m->prev.ref_base.data(), m->prev.read_base.data(), carry.data());
-        }
-        rawdtw_batch *b = nullptr;
-        int st = rawdtw_batch_submit_round(m->ctx, &m->opt.align, n_reads, cur.chain_off.data(), cur.anchor_off.data(), cur.anchors.data(),
-                                           cur.ref_base.data(), cur.read_base.data(), carry_on ? m->prev.batch : nullptr, carry.data(), &b);
-        if (st == RAWDTW_OK) st = rawdtw_batch_fetch(m->ctx, b, score.data(), keep.data(), nullptr);
-        if (st != RAWDTW_OK) { if (b) rawdtw_batch_destroy(b); return fail(m, st, rawdtw_last_error(m->ctx)); }
-        uint64_t sc = 0, ru = 0;
-        if (rawdtw_batch_round_stats(m->ctx, b, &sc, &ru) == RAWDTW_OK) { m->parts_scored += sc; m->parts_reused += ru; }
-        drop_prev(m);
-        if (m->opt.carry) { cur.batch = b; m->prev = std::move(cur); }
-        else rawdtw_batch_destroy(b);
-        const std::vector<uint64_t> &coff = m->opt.carry ? m->prev.chain_off : cur.chain_off;
-        for (uint32_t k = 0; k < n_reads; k++) {
-            keep_of[k].assign(round_chains[k].size(), 1);
-            for (size_t c = 0; c < round_chains[k].size(); c++) {
-                MChain &ch = round_chains[k][c];
-                ch.alignment_score = score[coff[k] + c];
-                keep_of[k][c] = keep[coff[k] + c];
-                // --dtw-log-scores (rmap.cpp:308-312): in evaluation order; a cut chain returns before the fprintf
-                if ((m->opt.flag & 0x8) && ch.alignment_score != -1e10f) {
-                    char line[128];
-                    snprintf(line, sizeof line, "chaining_score=%f alignment_score=%f\n", (double)ch.chaining_score, (double)ch.alignment_score);
-                    m->log += line;
+            ra.chain_off[i] = r.chain0;
+            uint64_t at = r.anchor0, nat = r.new0;
+            for (size_t c = 0; c < r.chains.size(); c++) {
+                const std::vector<rawdtw_anchor_t> &an = r.chains[c].anchors;
+                const uint64_t cc = r.chain0 + c;
+                ra.anchor_off[cc] = at;
+                ra.ref_base[cc] = r.ref_base[c];
+                ra.read_base[cc] = (rd.slot / G) * m->opt.slot_events;
+                if (m->scorer) { ra.chain_seq[cc] = r.chains[c].ref; ra.chain_strand[cc] = r.chains[c].strand; }
+                memcpy(ra.anchors.p + at, an.data(), an.size() * sizeof(rawdtw_anchor_t));
+                if (ra.carried) {
+                    const uint64_t n_new = an.size() - (r.carry[c].parts ? (uint64_t)r.carry[c].parts + 1 : 0);
+                    ra.carry[cc] = r.carry[c];
+                    ra.new_off[cc] = nat;
+                    memcpy(ra.new_anchors.p + nat, an.data(), n_new * sizeof(rawdtw_anchor_t));
+                    nat += n_new;
                 }
+                at += an.size();
             }
+            if (on_device && r.ne) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
+        });
+        t1 = now_ms();
+        m->timing[1] += t1 - t0; t0 = t1;
+        // ---- submit: the DTW block of gen_chains for every read of the group (rmap.cpp:509-530), one device submission ----
+        if (on_device) {
+            int st = RAWDTW_OK;
+            if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
+            if (st == RAWDTW_OK) {
+                if (ra.carried)
+                    st = rawdtw_batch_submit_carry(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.new_off.p, ra.new_anchors.p, ra.ref_base.p,
+                                                   ra.read_base.p, pb.batch, ra.carry.p, &ra.batch);
+                else
+                    st = rawdtw_batch_submit(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.anchors.p, ra.ref_base.p, ra.read_base.p, &ra.batch);
+            }
+            if (st != RAWDTW_OK) set_fail(st, rawdtw_last_error(g.ctx));
+            m->timing[5] += (double)((ra.carried ? nn : na) * sizeof(rawdtw_anchor_t));
+            m->timing[6] += (double)(nev * sizeof(float));
+            m->timing[7] += (double)((nr + 1) * 8 + (nc + 1) * 8 + nc * 12 + (ra.carried ? nc * 24 + 8 : 0) + nseg * 12);
+        } else {
+            std::vector<const float *> evp(nr);
+            std::vector<uint32_t> evn(nr);
+            for (size_t i = 0; i < nr; i++) { const MRead &rd = m->reads[read_ids[ra.ks[i]]]; evp[i] = rd.events.data(); evn[i] = (uint32_t)rd.events.size(); }
+            if (m->scorer(m->scorer_user, nr, ra.chain_off.p, ra.anchor_off.p, ra.anchors.p, ra.chain_seq.data(), ra.chain_strand.data(), evp.data(), evn.data(),
+                          ra.score.p, ra.keep.p) != 0)
+                set_fail(RAWDTW_ERR_DEVICE, "the external scorer failed");
+        }
+        t1 = now_ms();
+        m->timing[2] += t1 - t0; t0 = t1;
+    }
+    // ---- per group: fetch, then the round's end per read ----
+    for (uint32_t gi = 0; gi < G; gi++) {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur];
+        const size_t nr = ra.ks.size();
+        if (on_device && ra.batch) {
+            int st = rawdtw_batch_fetch(g.ctx, ra.batch, ra.score.p, ra.keep.p, nullptr); // (also after a failure elsewhere: the arrays it reads go out of use here)
+            if (st != RAWDTW_OK) set_fail(st, rawdtw_last_error(g.ctx));
+            uint64_t sc = 0, ru = 0;
+            if (st == RAWDTW_OK && status == RAWDTW_OK && rawdtw_batch_round_stats(g.ctx, ra.batch, &sc, &ru) == RAWDTW_OK) { m->parts_scored += sc; m->parts_reused += ru; }
+        }
+        double t1 = now_ms();
+        m->timing[3] += t1 - t0; t0 = t1;
+        if (status != RAWDTW_OK) continue;
+        const bool evaluate = (m->opt.flag & 0x2) != 0, log_scores = (m->opt.flag & 0x8) != 0;
+        m->pool->run(nr, 16, [&](size_t i) {
+            const uint32_t k = ra.ks[i];
+            RoundRead &r = rr[k];
+            MRead &rd = m->reads[read_ids[k]];
+            if (r.skipped) return; // rmap.cpp:569-572: the chains stay as they were
+            std::vector<MChain> post;
+            for (size_t c = 0; c < r.chains.size(); c++) {
+                MChain &ch = r.chains[c];
+                bool keep = true;
+                if (runs_dtw) {
+                    ch.alignment_score = ra.score[r.chain0 + c];
+                    keep = ra.keep[r.chain0 + c] != 0;
+                    // --dtw-log-scores (rmap.cpp:308-312): in evaluation order; a cut chain returns before the fprintf
+                    if (log_scores && ch.alignment_score != -1e10f) {
+                        char line[128];
+                        snprintf(line, sizeof line, "chaining_score=%f alignment_score=%f\n", (double)ch.chaining_score, (double)ch.alignment_score);
+                        r.log += line;
+                    }
+                }
+                if (!evaluate || !runs_dtw || keep) post.push_back(std::move(ch)); // rmap.cpp:525: replaced only under EVALUATE_CHAINS
+            }
+            rd.chains = primary_chains(m, post);
+        });
+        t1 = now_ms();
+        m->timing[4] += t1 - t0; t0 = t1;
+    }
+    if (status != RAWDTW_OK) { // put the reads back as they were; nothing of the round stays
+        for (uint32_t k = 0; k < n_reads; k++) {
+            MRead &rd = m->reads[read_ids[k]];
+            if (rd.events.size() >= rr[k].ev_before && rr[k].ne + rr[k].ev_before == rd.events.size()) { rd.events.resize(rr[k].ev_before); rd.offset = rr[k].off_before; }
+        }
+        for (Group &g : m->groups) {
+            RoundArrays &ra = g.buf[g.cur];
+            if (ra.batch) { rawdtw_batch_destroy(ra.batch); ra.batch = nullptr; }
+            g.cur ^= 1; // (the round before stays the round before)
+        }
+        return fail(m, status, status_msg);
+    }
+    // ---- commit ----
+    m->rounds = round_id;
+    for (uint32_t gi = 0; gi < G; gi++) {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur], &pb = g.buf[g.cur ^ 1];
+        if (pb.batch) { rawdtw_batch_destroy(pb.batch); pb.batch = nullptr; }
+        g.has_prev = on_device && m->opt.carry && ra.batch != nullptr;
+        if (!g.has_prev && ra.batch) { rawdtw_batch_destroy(ra.batch); ra.batch = nullptr; }
+        for (size_t i = 0; i < ra.ks.size(); i++) {
+            MRead &rd = m->reads[read_ids[ra.ks[i]]];
+            rd.last_round = round_id; rd.last_pos = i;
         }
     }
-    // ---- the round's end per read: post-alignment chains, primary chains, MAPQ, stop rule ----
     for (uint32_t k = 0; k < n_reads; k++) {
         MRead &rd = m->reads[read_ids[k]];
-        std::vector<MChain> post;
-        for (size_t c = 0; c < round_chains[k].size(); c++)
-            if (!(m->opt.flag & 0x2) || !runs_dtw || keep_of[k][c]) post.push_back(std::move(round_chains[k][c])); // rmap.cpp:525: replaced only under EVALUATE_CHAINS
-        rd.chains = primary_chains(m, post);
+        if (!rr[k].log.empty()) m->log += rr[k].log;
         rd.chunks_done++;
         if (high_confidence(m, rd.chains)) { rd.finished = true; rd.broke_early = true; } // rmap.cpp:692
         else if (rd.chunks_done >= std::min(rd.n_chunks, m->opt.max_num_chunk)) rd.finished = true;
@@ -343,14 +743,16 @@ int rawdtw_mapper_finish(rawdtw_mapper *m)
 {
     if (!m) return RAWDTW_ERR_INVALID;
     if (!(m->opt.flag & 0x4)) return RAWDTW_OK;
+    if (!m->ctx) return fail(m, RAWDTW_ERR_NO_DEVICE, "--dtw-output-cigar needs a device context");
+    drop_batches(m); // (the traceback calls replace the event arena's contents: the mapper's rounds are over)
+    for (Group &g : m->groups) g.has_prev = false;
     for (MRead &rd : m->reads) {
-        if (!high_confidence(m, rd.chains)) continue;
+        if (rd.released || !high_confidence(m, rd.chains)) continue;
         MChain &ch = rd.chains[0];
         const uint32_t na = (uint32_t)ch.anchors.size();
         const uint32_t nj = rawdtw_chain_job_count(&m->opt.align, na);
         std::vector<rawdtw_job_t> jobs(std::max<uint32_t>(nj, 1));
-        uint64_t rb = 0;
-        if (rawdtw_reference_offset(m->ctx, ch.ref, ch.strand, &rb) != RAWDTW_OK) return fail(m, RAWDTW_ERR_INVALID, "no reference array for a chain");
+        const uint64_t rb = m->ref_off[ch.ref * 2u + (uint32_t)ch.strand];
         int st = rawdtw_chain_build_jobs(&m->opt.align, ch.anchors.data(), na, rb, 0, 1, jobs.data());
         if (st != RAWDTW_OK) return fail(m, st, st == RAWDTW_ERR_UNSUPPORTED ? "banded global alignment with --dtw-output-cigar is not implemented (rmap.cpp:223-225)" : "job building failed");
         std::vector<uint64_t> poff(nj + 1, 0);
@@ -384,21 +786,21 @@ int rawdtw_mapper_finish(rawdtw_mapper *m)
             m->log += line;
         }
     }
-    return RAWDTW_OK; // (the traceback calls replaced the event arena's contents: the mapper's rounds are over)
+    return RAWDTW_OK;
 }
 
 // The PAF line of one read (rmap.cpp:696-801 for the fields and tags, 956-965 for the format).  `mt:f:` is wall-clock in the
 // reference and therefore written as 0 here.
 int rawdtw_mapper_paf(const rawdtw_mapper *m, uint32_t read_id, char *buf, uint32_t cap, uint32_t *len)
 {
-    if (!m || read_id >= m->reads.size() || !len) return RAWDTW_ERR_INVALID;
+    if (!m || read_id >= m->reads.size() || !len || m->reads[read_id].released) return RAWDTW_ERR_INVALID;
     const MRead &rd = m->reads[read_id];
     const uint32_t l_chunk = m->opt.chunk_size, max_chunk = m->opt.max_num_chunk;
     uint32_t current_chunk = rd.broke_early ? rd.chunks_done - 1 : rd.chunks_done; // the loop's current_chunk when it exits
     const uint64_t chunk_start = (uint64_t)current_chunk * l_chunk;
     // rmap.cpp:696: step back one chunk when the loop ran out of signal or chunks rather than breaking
     if (!rd.broke_early && current_chunk > 0 && (chunk_start >= rd.qlen || current_chunk == max_chunk)) current_chunk -= 1;
-    const uint32_t offset = (uint32_t)rd.events.size(); // reg0->offset: events consumed so far
+    const uint32_t offset = rd.offset; // reg0->offset: the events of the chunks that were chained (rmap.cpp:574-575)
     // rmap.cpp:698, float arithmetic throughout
     const float scale = offset ? ((float)(current_chunk + 1) * (float)l_chunk / (float)offset) / ((float)m->opt.sample_rate / (float)m->opt.bp_per_sec)
                                : INFINITY;

@@ -425,9 +425,9 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         else an[KI] = base + AT < a.n_anchors ? a.unit_abs[unit + 1] : rawdtw_anchor_t{0, 0}; // (the next unit's first entry travels whole)
     }
 
-    // (the round before must have stood: a batch the scan declined has no costs to take over)
-    const bool carry = CARRY && a.carry_chain && a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
-                       a.prev_cnt[kCntOverflow] == ~0ull;
+    // (chunk rounds: k_carry has assembled the anchor list and copied the carried parts' costs; a round whose previous batch did
+    // not stand has marked itself bad there, and nothing here counts)
+    const bool carry = CARRY && a.carry != nullptr;
     uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0;
     unsigned long long my_obytes = 0;
     uint32_t o_rec[kHalves][KI]; // the thread's side-list parts: slot | class << 16 | radius << 21 (0xffffffff: none)
@@ -440,51 +440,21 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
     uint32_t carried_bits = 0, half_tiles = 0;
     if (carry) {
-        // Chunk rounds, a pass of its own in front of the classification (so that neither loop carries the other's registers):
-        // a part whose two anchors and bases equal those of the same part of the chain it continues takes that part's cost
-        uint64_t cc = ~0ull, c_a1 = 0, pa0 = 0, pa1 = 0;
-        bool c_ok = false;
-        uint64_t c_rb = 0;
-        uint32_t c_qb = 0;
+        // Chunk rounds: a chain's carried parts are the last `parts` of its stretch of the list (counted from the chain's start =
+        // the list's tail): the part that ends at anchor i is carried iff i >= a1 - 1 - parts.  Two loads a chain, nothing a part.
+        uint64_t cc = ~0ull, c_lo = ~0ull; // the chain at hand; its first carried anchor
 #pragma unroll
         for (int k = 0; k < KI; k++) {
             const uint32_t p = h * kHalf + (uint32_t)tid * KI + k;
             const uint64_t i = base + p;
             if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue;
-            // part p_idx of chain c (counted from the chain's start, rmap.cpp:248-293) = the part that ends at anchor a1 - 2 - p_idx
             const uint64_t c = chain_at(p);
             if (c != cc) {
                 cc = c;
-                c_a1 = a.anchor_off[c + 1];
-                const uint64_t pc = a.carry_chain[c];
-                c_ok = pc < a.prev_n_chains;
-                if (c_ok) {
-                    pa0 = a.prev_anchor_off[pc]; pa1 = a.prev_anchor_off[pc + 1];
-                    c_rb = a.ref_base[c]; c_qb = a.read_base[c];
-                    c_ok = pa1 > pa0 + 1 && a.prev_ref_base[pc] == c_rb && a.prev_read_base[pc] == c_qb;
-                }
+                const uint32_t parts = a.carry[c].parts;
+                c_lo = parts ? a.anchor_off[c + 1] - 1ull - parts : ~0ull;
             }
-            const uint64_t p_idx = c_a1 - 2 - i;
-            if (c_ok && p_idx + 1 < pa1 - pa0) {
-                const uint64_t pi = pa1 - 2 - p_idx; // the same part of the chain before
-                const rawdtw_anchor_t pe = a.prev_anchors[pi], ps = a.prev_anchors[pi + 1];
-                const rawdtw_anchor_t e = an[k], s = an[k + 1];
-                if (pe.target_position == e.target_position && pe.query_position == e.query_position && ps.target_position == s.target_position &&
-                    ps.query_position == s.query_position) {
-                    // same operands, same radius: the same cost -- up to exclude_last_element (rmap.cpp:270), which only the
-                    // chain's LAST part goes without: a part that was the last one then and is not now loses its last cell's
-                    // distance exactly as the DTW functions take it off (dtw.cpp:514-519); the other way round there is no
-                    // exact way back, and the part is scored again
-                    const bool was_last = pi == pa0, is_last = mask_bit(s_mask, p);
-                    if (was_last == is_last || was_last) {
-                        float cost = a.prev_out[pi];
-                        if (was_last != is_last) cost = cost - dist(a.ev[(uint64_t)c_qb + e.query_position], a.ref[c_rb + e.target_position]);
-                        a.out[i] = cost;
-                        carried_bits |= 1u << k;
-                        my_reused++;
-                    }
-                }
-            }
+            if (i >= c_lo) { carried_bits |= 1u << k; my_reused++; }
         }
     }
 #pragma unroll
@@ -582,6 +552,56 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
 }
 
+// k_carry: a chunk round's first launch (rawdtw_batch_submit_carry).  A wave a chain: the chain's stretch of the round's anchor
+// list is its new entries (from the hand-over) followed by the tail it shares with the chain it continues (from the previous
+// batch's list, on the device since the round before); the costs of the tail's parts come with it, one contiguous stretch.
+// The host validated the tail anchor by anchor (rawdtw_round_match_chains); here only the counts and the bases are checked.
+// A part that was its chain's last then and is not now loses its last cell's distance exactly as the DTW functions take it
+// off (dtw.cpp:514-519): that can only be the tail's first entry.
+constexpr int kCarryT = 256;
+__global__ __launch_bounds__(kCarryT) void k_carry(const StreamArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t c = (uint64_t)blockIdx.x * (kCarryT / 64) + (threadIdx.x >> 6);
+    if (c >= a.n_chains) return;
+    const uint64_t a0 = a.anchor_off[c], a1 = a.anchor_off[c + 1], nb = a.new_off[c], n_new = a.new_off[c + 1] - nb;
+    const rawdtw_carry_t rec = a.carry[c];
+    const uint64_t L = rec.parts;
+    // (the round before must have stood: a batch the scan declined has no costs to take over)
+    const bool prev_ok = a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
+                         a.prev_cnt[kCntOverflow] == ~0ull;
+    // idx_ok: the stretches exist (the list can be assembled); cost_ok: ... and their costs may be taken over.  Anything else
+    // marks the batch bad: rawdtw_batch_fetch then scores everything from the assembled list through the job-list path.
+    uint64_t src = 0;
+    bool idx_ok = n_new + (L ? L + 1 : 0) == a1 - a0, cost_ok = false, fix = false;
+    if (L) {
+        idx_ok = idx_ok && rec.prev_chain < a.prev_n_chains;
+        if (idx_ok) {
+            const uint64_t pa0 = a.prev_anchor_off[rec.prev_chain], pa1 = a.prev_anchor_off[rec.prev_chain + 1];
+            idx_ok = pa1 - pa0 >= L + 1;
+            src = pa1 - (L + 1);
+            cost_ok = idx_ok && prev_ok && a.prev_ref_base[rec.prev_chain] == a.ref_base[c] && a.prev_read_base[rec.prev_chain] == a.read_base[c] &&
+                      !(n_new == 0 && src > pa0); // (its last part was not the last then: no exact way back -- the host counts it out)
+            fix = src == pa0 && n_new != 0;       // the tail's first part was the last one then and is not now
+        }
+    }
+    if (!idx_ok || (L && !cost_ok)) { if (lane == 0) atomicMin(&a.cnt[kCntBad], (unsigned long long)a0); }
+    for (uint64_t k = (uint64_t)lane; k < n_new && k < a1 - a0; k += 64) a.anchors_w[a0 + k] = a.new_anchors[nb + k];
+    if (!L || !idx_ok) return;
+    const uint64_t dst = a0 + n_new;
+    const uint64_t rb = a.ref_base[c];
+    const uint32_t qb = a.read_base[c];
+    for (uint64_t k = (uint64_t)lane; k <= L; k += 64) {
+        const rawdtw_anchor_t e = a.prev_anchors[src + k];
+        a.anchors_w[dst + k] = e;
+        if (k < L && cost_ok) {
+            float cost = a.prev_out[src + k];
+            if (fix && k == 0) cost = cost - dist(a.ev[(uint64_t)qb + e.query_position], a.ref[rb + e.target_position]);
+            a.out[dst + k] = cost;
+        }
+    }
+}
+
 // grid: workgroup 0 the fold order (one workgroup's latency chain, ~30 us: dispatched first, it runs beside everything
 // else instead of behind it), then the chain records, then the scan units
 __global__ __launch_bounds__(kScanT, 8) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
@@ -591,8 +611,8 @@ __global__ __launch_bounds__(kScanT, 8) void k_scan(const StreamArgs a, ChainDes
     else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
     else scan_unit_body<false, false>(a, b - 1 - n_desc);
 }
-// (a chunk round that takes costs over from the round before: the units look every part up there first)
-__global__ __launch_bounds__(kScanT, 6) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
+// (a chunk round that takes costs over from the round before -- k_carry ran in front: the units leave the carried parts out)
+__global__ __launch_bounds__(kScanT, 8) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
     if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
@@ -1469,9 +1489,18 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     if (a.steps) {
         hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanTC), 0, s, a, d_fold_order);
         if (n_desc) hipLaunchKernelGGL(k_scan_desc, dim3(n_desc), dim3(kScanT), 0, s, a, d_chains);
-    } else if (a.carry_chain) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    } else if (a.carry) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// a chunk round's first launch: the round's anchor list and the carried costs out of the previous batch's workspace
+hipError_t stream_carry(const StreamArgs &a, hipStream_t s)
+{
+    if (!a.carry || a.n_chains == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_carry, dim3((uint32_t)((a.n_chains + kCarryT / 64 - 1) / (kCarryT / 64))), dim3(kCarryT), 0, s, a);
     return hipGetLastError();
 }
 

@@ -24,6 +24,8 @@ from .align import (RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_LOG_SCORES, RI_M_DTW_OUTP
                     MapOpt, align_chain)
 from .dtw import ANCHOR_DTYPE
 
+CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
+
 
 @dataclass
 class ReadJob:
@@ -31,6 +33,7 @@ class ReadJob:
     qlen: int                      # samples in the read
     n_chunks_available: int        # chunks the read has signal for
     events: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))  # p->events[read].values
+    offset: int = 0                # reg->offset: events of the chunks that were chained (rmap.cpp:574-575)
     chains: list = field(default_factory=list)     # reg0->chains (primary chains, best first)
     chunks_done: int = 0
     finished: bool = False
@@ -248,10 +251,10 @@ class DeviceScorer:
 
 class RoundScorer:
     """Chunk rounds scored on the device with the part costs carried over from round to round ON the device (SURVEY.md 8 f-4,
-    rawdtw_batch_submit_round): every read keeps a slot in the event arena and only its new events are uploaded
+    rawdtw_batch_submit_carry): every read keeps a slot in the event arena and only its new events are uploaded
     (rawdtw_events_append, rmap.cpp:554-567 is append-only); the batch of the round before stays resident until the next one
-    has taken what it can from it; per chain the host only names the previous chain it continues
-    (rawdtw_round_match_chains).  Results are bit-identical to scoring every round from scratch (rmap.cpp:516-517)."""
+    has taken what it can from it; per chain the host names the previous chain it continues and the leading parts that
+    did not change (rawdtw_round_match_chains), and only the NEW anchors are handed over (rawdtw_batch_submit_carry).  Results are bit-identical to scoring every round from scratch (rmap.cpp:516-517)."""
 
     memoise = True
 
@@ -265,6 +268,7 @@ class RoundScorer:
         self.prev = None         # (Batch handle, arrays, {read key: read index})
         self.jobs_scored = 0
         self.jobs_reused = 0
+        self.anchors_sent = 0    # anchors handed to the device over all rounds (a carried round sends its new ones only)
         engine._check(engine.lib.rawdtw_events_reserve(engine._ctx, self.slot_events * self.n_slots))
 
     def align_cigar(self, chain, read_events, opt: MapOpt):
@@ -318,17 +322,31 @@ class RoundScorer:
         n_chains = len(flat)
         copt = opt.c_struct()
         h = C.c_void_p()
-        carry = np.full(max(n_chains, 1), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
-        prev_h = None
-        if self.prev is not None and opt.dtw_border_constraint == 1:
+        carried = False
+        if self.prev is not None and n_chains and lib.rawdtw_batch_can_carry(eng._ctx, self.prev[0], C.byref(copt)):
             prev_h, pa, pidx = self.prev
             prev_read = np.array([pidx.get(k, 0xFFFFFFFFFFFFFFFF) for k in keys], np.uint64)
+            carry = np.zeros(n_chains, CARRY_DTYPE)
+            new_off = np.zeros(n_chains + 1, np.uint64)
+            new_anchors = np.zeros(max(len(arrays["anchors"]), 1), ANCHOR_DTYPE)
             eng._check(lib.rawdtw_round_match_chains(len(reads), _vp(arrays["chain_off"]), _vp(arrays["anchor_off"]), _vp(arrays["anchors"]),
                                                      _vp(arrays["ref_base"]), _vp(arrays["read_base"]), _vp(prev_read), _vp(pa["chain_off"]),
-                                                     _vp(pa["anchor_off"]), _vp(pa["anchors"]), _vp(pa["ref_base"]), _vp(pa["read_base"]), _vp(carry)))
-        eng._check(lib.rawdtw_batch_submit_round(eng._ctx, C.byref(copt), len(reads), _vp(arrays["chain_off"]), _vp(arrays["anchor_off"]),
-                                                 _vp(arrays["anchors"]), _vp(arrays["ref_base"]), _vp(arrays["read_base"]), prev_h, _vp(carry),
-                                                 C.byref(h)))
+                                                     _vp(pa["anchor_off"]), _vp(pa["anchors"]), _vp(pa["ref_base"]), _vp(pa["read_base"]), _vp(carry),
+                                                     _vp(new_off), _vp(new_anchors)))
+            eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), len(reads), _vp(arrays["chain_off"]), _vp(arrays["anchor_off"]),
+                                                     _vp(new_off), _vp(new_anchors), _vp(arrays["ref_base"]), _vp(arrays["read_base"]), prev_h,
+                                                     _vp(carry), C.byref(h)))
+            keep_alive = (keep_alive, carry, new_off, new_anchors)
+            self.anchors_sent += int(new_off[-1])
+            carried = True
+        if not carried:
+            a_ = arrays["anchors"] if len(arrays["anchors"]) else np.zeros(1, ANCHOR_DTYPE)
+            rb_ = arrays["ref_base"] if n_chains else np.zeros(1, np.uint64)
+            qb_ = arrays["read_base"] if n_chains else np.zeros(1, np.uint32)
+            eng._check(lib.rawdtw_batch_submit(eng._ctx, C.byref(copt), len(reads), _vp(arrays["chain_off"]), _vp(arrays["anchor_off"]), _vp(a_),
+                                               _vp(rb_), _vp(qb_), C.byref(h)))
+            keep_alive = (keep_alive, a_, rb_, qb_)
+            self.anchors_sent += len(arrays["anchors"])
         score = np.zeros(max(n_chains, 1), np.float32)
         keep = np.zeros(max(n_chains, 1), np.uint8)
         eng._check(lib.rawdtw_batch_fetch(eng._ctx, h, _vp(score), _vp(keep), None))
@@ -337,7 +355,7 @@ class RoundScorer:
         eng._check(lib.rawdtw_batch_round_stats(eng._ctx, h, C.byref(sc), C.byref(ru)))
         self.jobs_scored += sc.value
         self.jobs_reused += ru.value
-        if prev_h is not None or self.prev is not None:
+        if self.prev is not None:
             lib.rawdtw_batch_destroy(self.prev[0])
         self.prev = (h, arrays, {k: i for i, k in enumerate(keys)})
         out = []
@@ -381,11 +399,17 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
             break
         rounds += 1
         submission = []
+        skipped = set()
         for r in active:
             rj = jobs[r]
             ev, hits = seeds.chunk(r, rj.chunks_done)
-            chunk_start = len(rj.events)                       # reg->offset (rmap.cpp:574)
             rj.events = np.concatenate([rj.events, ev])        # rmap.cpp:554-567
+            if len(ev) < stop.min_events:                      # rmap.cpp:569-572: no gen_chains, chains and offset stay
+                skipped.add(r)
+                submission.append((rj.events, []))
+                continue
+            chunk_start = rj.offset                            # reg->offset (rmap.cpp:574)
+            rj.offset += len(ev)                               # rmap.cpp:575
             per = {}
             for ch in rj.chains:                               # rmap.cpp:344-357: re-seed with previous anchors
                 per.setdefault((ch.reference_sequence_index, ch.strand), []).extend(
@@ -418,7 +442,8 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
             kept = [chains for _, chains in submission]                                # rmap.cpp:525: list not replaced
         for r, post in zip(active, kept):
             rj = jobs[r]
-            rj.chains = M.gen_primary_chains(post, opt, stop) if post else []
+            if r not in skipped:
+                rj.chains = M.gen_primary_chains(post, opt, stop) if post else []
             rj.chunks_done += 1
             if M.is_mapped_with_high_confidence(rj.chains, opt, stop):   # rmap.cpp:692
                 rj.finished, rj.broke_early = True, True
@@ -431,7 +456,7 @@ def map_reads(seeds, read_ids, scorer, opt: MapOpt, stop: M.StopOpt = M.StopOpt(
             scorer.align_cigar(rj.chains[0], rj.events, opt)                            # rmap.cpp:715-717
             if log is not None and (opt.flag & RI_M_DTW_LOG_SCORES):
                 log.append(score_log_line(rj.chains[0]))
-        rs = M.ReadState(rj.name, rj.qlen, len(rj.events), rj.chunks_done if not rj.broke_early else rj.chunks_done - 1,
+        rs = M.ReadState(rj.name, rj.qlen, rj.offset, rj.chunks_done if not rj.broke_early else rj.chunks_done - 1,
                          rj.broke_early, 0.0, rj.chains)
         lines.append(M.paf_line(rs, names, [int(x) for x in seeds.lens], opt, stop))
     return lines, rounds
@@ -454,3 +479,174 @@ class _SortHelper:
                     assert st == 0
             cls._inst = _E()
         return cls._inst
+
+
+HIT_DTYPE = np.dtype([("ref_seq", "<u4"), ("strand", "<i4"), ("target_position", "<u4"), ("query_position", "<u4")])  # rawdtw_seed_hit_t
+
+
+class CMapper:
+    """The chunk-round mapper inside the library (rawdtw_mapper_*, rawalign_amd/csrc/rawdtw_mapper.cpp) behind ctypes: what a
+    RawAlign maintainer's binding calls.  `engine` may be None for a mapper that scores through
+    `set_scorer` only (CPU harnesses)."""
+
+    def __init__(self, engine, opt: MapOpt, stop: M.StopOpt, seq_names, seq_lens, slot_events: int, max_reads: int, carry: bool = True,
+                 threads: int = 1, groups: int = 1, e: int = 6):
+        import ctypes as C
+
+        from ._lib import MapperOpt, load_library
+
+        self.lib = engine.lib if engine is not None else load_library()
+        self.engine = engine
+        mo = MapperOpt()
+        mo.flag = opt.flag
+        mo.align = opt.c_struct()
+        mo.chain = M.default_chain_opt(e)
+        mo.min_bestmap_ratio, mo.min_meanmap_ratio, mo.min_chain_anchor = stop.min_bestmap_ratio, stop.min_meanmap_ratio, stop.min_chain_anchor
+        mo.bp_per_sec, mo.sample_rate, mo.chunk_size, mo.max_num_chunk = stop.bp_per_sec, stop.sample_rate, stop.chunk_size, stop.max_num_chunk
+        mo.slot_events, mo.max_reads, mo.carry, mo.min_events = int(slot_events), int(max_reads), int(bool(carry)), int(stop.min_events)
+        mo.threads, mo.groups = int(threads), int(groups)
+        names = (C.c_char_p * len(seq_names))(*[n.encode() for n in seq_names])
+        lens = np.ascontiguousarray(seq_lens, np.uint32)
+        self._h = C.c_void_p()
+        st = self.lib.rawdtw_mapper_create(engine._ctx if engine is not None else None, C.byref(mo), len(seq_names), names, _vp(lens), C.byref(self._h))
+        if st != 0:
+            raise RuntimeError(f"rawdtw_mapper_create -> {st}")
+        self._cb = None
+
+    def _check(self, st):
+        if st != 0:
+            raise RuntimeError(f"rawdtw_mapper status {st}: {self.lib.rawdtw_mapper_last_error(self._h).decode()}")
+
+    def add_read(self, name: str, qlen: int, n_chunks: int) -> int:
+        import ctypes as C
+
+        rid = C.c_uint32()
+        self._check(self.lib.rawdtw_mapper_add_read(self._h, name.encode(), int(qlen), int(n_chunks), C.byref(rid)))
+        return rid.value
+
+    def release_read(self, rid: int):
+        self._check(self.lib.rawdtw_mapper_release_read(self._h, int(rid)))
+
+    def round_arrays(self, read_ids, event_off, events, hit_off, hits):
+        """one chunk round from flat arrays (read_ids u32, event_off / hit_off u64, events f32, hits HIT_DTYPE)"""
+        self._check(self.lib.rawdtw_mapper_round(self._h, len(read_ids), _vp(read_ids), _vp(event_off), _vp(events), _vp(hit_off), _vp(hits)))
+
+    def round(self, read_ids, chunks):
+        """chunks[k] = (events, hits as (seq, strand, target, query) tuples) of read read_ids[k]"""
+        ids = np.ascontiguousarray(read_ids, np.uint32)
+        eoff = np.zeros(len(ids) + 1, np.uint64)
+        hoff = np.zeros(len(ids) + 1, np.uint64)
+        for k, (ev, hits) in enumerate(chunks):
+            eoff[k + 1] = eoff[k] + len(ev)
+            hoff[k + 1] = hoff[k] + len(hits)
+        ev = np.concatenate([np.ascontiguousarray(c[0], np.float32) for c in chunks] + [np.zeros(1, np.float32)])
+        hits = np.zeros(int(hoff[-1]) + 1, HIT_DTYPE)
+        at = 0
+        for _, hs in chunks:
+            for s, st, t, q in hs:
+                hits[at] = (s, st, t, q)
+                at += 1
+        self.round_arrays(ids, eoff, ev, hoff, hits)
+
+    def state(self, rid: int):
+        import ctypes as C
+
+        fin, done = C.c_int(), C.c_uint32()
+        self._check(self.lib.rawdtw_mapper_read_state(self._h, int(rid), C.byref(fin), C.byref(done)))
+        return bool(fin.value), done.value
+
+    def finish(self):
+        return self.lib.rawdtw_mapper_finish(self._h)
+
+    def paf(self, rid: int) -> str:
+        import ctypes as C
+
+        n = C.c_uint32()
+        buf = C.create_string_buffer(1 << 16)
+        st = self.lib.rawdtw_mapper_paf(self._h, int(rid), buf, len(buf), C.byref(n))
+        if st == 4:  # RAWDTW_ERR_RANGE: the line is longer
+            buf = C.create_string_buffer(n.value + 1)
+            st = self.lib.rawdtw_mapper_paf(self._h, int(rid), buf, len(buf), C.byref(n))
+        self._check(st)
+        return buf.value.decode()
+
+    def log(self):
+        import ctypes as C
+
+        p = C.c_char_p()
+        self._check(self.lib.rawdtw_mapper_log(self._h, C.byref(p)))
+        return (p.value or b"").decode()
+
+    def stats(self):
+        import ctypes as C
+
+        r, s, u = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.rawdtw_mapper_stats(self._h, C.byref(r), C.byref(s), C.byref(u)))
+        return r.value, s.value, u.value
+
+    def timing(self):
+        t = np.zeros(8, np.float64)
+        self._check(self.lib.rawdtw_mapper_timing(self._h, _vp(t)))
+        return dict(host_phase_ms=t[0], layout_ms=t[1], submit_ms=t[2], fetch_wait_ms=t[3], round_end_ms=t[4], anchor_bytes=int(t[5]),
+                    event_bytes=int(t[6]), other_bytes=int(t[7]))
+
+    def set_scorer(self, fn):
+        """fn(chain_off, anchor_off, anchors, chain_seq, chain_strand, read_events: list of arrays) -> (score f32, keep u8);
+        harnesses only (bench.py's cpu_baseline, the CPU tests) -- see rawdtw_mapper_set_scorer"""
+        import ctypes as C
+
+        from ._lib import SCORER_FN
+
+        def cb(_user, n_reads, p_coff, p_aoff, p_anch, p_seq, p_strand, p_ev, p_nev, p_score, p_keep):
+            try:
+                n_reads = int(n_reads)
+                coff = np.ctypeslib.as_array(C.cast(p_coff, C.POINTER(C.c_uint64)), (n_reads + 1,)).copy()
+                nc = int(coff[-1])
+                aoff = np.ctypeslib.as_array(C.cast(p_aoff, C.POINTER(C.c_uint64)), (nc + 1,)).copy()
+                na = int(aoff[-1])
+                anch = np.frombuffer((C.c_char * (max(na, 1) * 8)).from_address(p_anch), ANCHOR_DTYPE, na).copy()
+                seq = np.ctypeslib.as_array(C.cast(p_seq, C.POINTER(C.c_uint32)), (max(nc, 1),))[:nc].copy() if nc else np.zeros(0, np.uint32)
+                strand = np.ctypeslib.as_array(C.cast(p_strand, C.POINTER(C.c_int32)), (max(nc, 1),))[:nc].copy() if nc else np.zeros(0, np.int32)
+                nev = np.ctypeslib.as_array(C.cast(p_nev, C.POINTER(C.c_uint32)), (n_reads,))
+                evp = C.cast(p_ev, C.POINTER(C.c_void_p))
+                evs = [np.ctypeslib.as_array(C.cast(evp[r], C.POINTER(C.c_float)), (max(int(nev[r]), 1),))[:int(nev[r])] for r in range(n_reads)]
+                score, keep = fn(coff, aoff, anch, seq, strand, evs)
+                if nc:
+                    np.ctypeslib.as_array(C.cast(p_score, C.POINTER(C.c_float)), (nc,))[:] = score
+                    np.ctypeslib.as_array(C.cast(p_keep, C.POINTER(C.c_uint8)), (nc,))[:] = keep
+                return 0
+            except Exception:  # noqa: BLE001 -- nothing may propagate through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+        self._cb = SCORER_FN(cb) if fn is not None else None
+        self._check(self.lib.rawdtw_mapper_set_scorer(self._h, self._cb, None))
+
+    def close(self):
+        if self._h:
+            self.lib.rawdtw_mapper_destroy(self._h)
+            self._h = None
+
+
+def map_reads_c(seeds, read_ids, cm: CMapper):
+    """map_reads through the library's mapper: chunk rounds until every read stopped; the PAF lines in read order, the rounds."""
+    jobs = {r: seeds.read_job(r) for r in read_ids}
+    ids = {r: cm.add_read(jobs[r].name, jobs[r].qlen, jobs[r].n_chunks_available) for r in read_ids}
+    rounds = 0
+    while True:
+        act, chunks = [], []
+        for r in read_ids:
+            fin, done = cm.state(ids[r])
+            if fin or done >= jobs[r].n_chunks_available:
+                continue
+            act.append(ids[r])
+            chunks.append(seeds.chunk(r, done))
+        if not act:
+            break
+        cm.round(act, chunks)
+        rounds += 1
+    st = cm.finish()
+    if st != 0:
+        raise RuntimeError(f"rawdtw_mapper_finish -> {st}")
+    return [cm.paf(ids[r]) for r in read_ids], rounds

@@ -32,6 +32,7 @@ class StopOpt:
     sample_rate: int = 4000
     chunk_size: int = 4000
     max_num_chunk: int = 30
+    min_events: int = 50      # roptions.c:23: a chunk with fewer events is not chained (rmap.cpp:569-575)
 
     def c_struct(self, opt: MapOpt) -> SelectOpt:
         return SelectOpt(1 if (opt.flag & RI_M_DTW_EVALUATE_CHAINS) else 0, self.min_bestmap_ratio,

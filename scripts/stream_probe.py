@@ -39,12 +39,14 @@ for cfg in configs:
     ncnt = C.c_uint32()
     eng.lib.rawdtw_batch_stream_counters(eng._ctx, b._h, cnt, 64, C.byref(ncnt))
     if cfg == configs[0]:
-        print("counters: side list %d  classes %s" % (cnt[3], list(cnt[4:25])), flush=True)
+        ix = lambda n: eng.lib.rawdtw_batch_stream_counter_index(n)  # noqa: E731
+        print("counters: side list %d  classes %s" % (cnt[ix(b"side_jobs")], list(cnt[ix(b"class0"):ix(b"class0") + 21])), flush=True)
     # launches: k_wide, k_runs, fold + select (one launch), -
     print("%-28s create %.3f ms  plan(gpu) %.3f ms  launches %s" % (cfg or "default", t_create, pm.value, ["%.4f" % m[2] for m in ms]), flush=True)
-    if any(cnt[53:63]):  # "stream_debug" 256: cycles per phase of k_runs (kCntStamp0 = 53), summed over waves and runs
-        tot = float(sum(cnt[53:63]))
+    s0 = eng.lib.rawdtw_batch_stream_counter_index(b"stamp0")
+    if any(cnt[s0:s0 + 10]):  # "stream_debug" 256: cycles per phase of k_runs, summed over waves and runs
+        tot = float(sum(cnt[s0:s0 + 10]))
         names = ["entry", "stage issue", "stage wait", "B1", "DP + next records", "ticket + wait", "B2"]
-        print("   phase shares: " + "  ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, cnt[53:63])), flush=True)
+        print("   phase shares: " + "  ".join("%s %.1f%%" % (n, 100.0 * c / tot) for n, c in zip(names, cnt[s0:s0 + 10])), flush=True)
     b.close()
     eng.close()

@@ -147,6 +147,11 @@ static int run_map(const char *path)
     mo.min_bestmap_ratio = ratio[0]; mo.min_meanmap_ratio = ratio[1]; mo.min_chain_anchor = min_chain_anchor;        // roptions.c:25-31 (1.2, 5, 2)
     mo.bp_per_sec = 450; mo.sample_rate = 4000; mo.chunk_size = 4000; mo.max_num_chunk = 30;                          // roptions.c:9-11, 24
     mo.slot_events = slot; mo.max_reads = n_reads ? n_reads : 1; mo.carry = carry;
+    // (host threads, read groups and --min-events of the run: roptions.c:23, rmap.cpp:916,1033)
+    if (const char *e = getenv("RAWDTW_SHIM_THREADS")) mo.threads = atoi(e);
+    if (const char *e = getenv("RAWDTW_SHIM_GROUPS")) mo.groups = atoi(e);
+    mo.min_events = 50;
+    if (const char *e = getenv("RAWDTW_SHIM_MIN_EVENTS")) mo.min_events = (uint32_t)atoi(e);
     rawdtw_mapper *mp = nullptr;
     CHECK(rawdtw_mapper_create(dtw, &mo, n_seq, pn.data(), len.data(), &mp));
     std::vector<uint32_t> ids(n_reads);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/rawdtw.h but not exported"
         assert n in SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.rawdtw_abi_version() == 1
+    assert lib.rawdtw_abi_version() == 2
     assert lib.rawdtw_status_string(4) == b"job window out of range"
 
 

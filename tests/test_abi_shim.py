@@ -251,22 +251,25 @@ def _write_map_blob(path, ref, seeds, n_reads, opt, carry, stop):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("border,fill,flag,carry,never", [(1, 1, 0x2, 1, 0), (1, 1, 0x2, 0, 0), (1, 1, 0x2 | 0x4, 1, 0), (1, 0, 0x2 | 0x4, 0, 0),
-                                                          (0, 0, 0x2 | 0x4, 0, 0), (1, 1, 0x8, 1, 0), (1, 1, 0x2 | 0x4 | 0x8, 1, 0), (0, 1, 0x2, 0, 0),
-                                                          (1, 1, 0x2, 1, 1), (1, 1, 0x8, 1, 1)])
-def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_path, border, fill, flag, carry, never):
+@pytest.mark.parametrize("border,fill,flag,carry,never,threads,groups,min_events",
+                         [(1, 1, 0x2, 1, 0, 1, 1, 50), (1, 1, 0x2, 0, 0, 4, 2, 50), (1, 1, 0x2 | 0x4, 1, 0, 3, 2, 50), (1, 0, 0x2 | 0x4, 0, 0, 1, 1, 50),
+                          (0, 0, 0x2 | 0x4, 0, 0, 2, 1, 50), (1, 1, 0x8, 1, 0, 1, 2, 50), (1, 1, 0x2 | 0x4 | 0x8, 1, 0, 4, 1, 50), (0, 1, 0x2, 0, 0, 1, 1, 50),
+                          (1, 1, 0x2, 1, 1, 4, 2, 50), (1, 1, 0x8, 1, 1, 2, 2, 50), (1, 1, 0x2, 1, 1, 1, 1, 300), (1, 1, 0x2, 1, 0, 4, 2, 300)])
+def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_path, border, fill, flag, carry, never, threads, groups, min_events):
     """f-2 in C++: the chunk-round loop, chaining, primary chains / MAPQ / stop rule and the PAF line run inside the library
     (rawdtw_mapper_*, rawalign_amd/csrc/rawdtw_mapper.cpp), driven by the compiled shim.  Its PAF lines and --dtw-log-scores
     lines must equal, character for character, those of the Python mirror (rawalign_amd.mapper.map_reads) scored on the
     device AND scored by the oracle's sequential loop -- sparse and global, banded and full, with traceback tags, with
     log-scores alone, with and without costs carried from round to round, under the reference's stop rule and with reads
-    that never stop early (every read through all of its chunks: the rounds in which carried costs are taken over).
-    d1-scale reference (configs[0])."""
+    that never stop early (every read through all of its chunks: the rounds in which carried costs are taken over), on one
+    host thread and several, with one read group and two (two contexts, one group's host phase beside the other's batch),
+    and with --min-events at the reference's 50 and at 300 (chunks that are appended but not chained, rmap.cpp:569-575: most
+    reads' last chunk).  d1-scale reference (configs[0])."""
     from rawalign_amd import mapper
     from rawalign_amd.mapping import StopOpt
     from tests.util import OracleScorer
 
-    stop = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6) if never else StopOpt()
+    stop = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6, min_events=min_events) if never else StopOpt(min_events=min_events)
 
     exe = _build(tmp_path, "host_shim", ["-L", os.path.join(ROOT, "rawalign_amd"), "-lrawdtw"])
     ref = synth.make_reference([29903], seed=20231005 + 1)
@@ -275,7 +278,8 @@ def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_p
     opt = ra.MapOpt(dtw_border_constraint=border, dtw_fill_method=fill, flag=flag)
     blob = os.path.join(str(tmp_path), "map.bin")
     _write_map_blob(blob, ref, seeds, n, opt, carry, stop)
-    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               RAWDTW_SHIM_THREADS=str(threads), RAWDTW_SHIM_GROUPS=str(groups), RAWDTW_SHIM_MIN_EVENTS=str(min_events))
     run = subprocess.run([exe, blob, "--map"], capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0, run.stderr
     got = run.stdout.rstrip("\n").split("\n")
@@ -294,6 +298,9 @@ def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_p
     assert paf == dev
     kv = dict(x.split("=") for x in stats[0].split(" ")[1:])
     assert int(kv["rounds"]) == rounds and float(kv["rounds_per_s"]) > 0
+    if min_events > 50:   # (the case is there: chunks that were appended but not chained)
+        skipped = sum(1 for r in range(n) for c in range(seeds.read_job(r).n_chunks_available) if len(seeds.chunk(r, c)[0]) < min_events)
+        assert skipped > 0
     if never:
         assert rounds >= 3
         if carry and border == 1 and fill == 1:   # (sparse + banded: the sync-free path, the one that carries)

@@ -448,11 +448,78 @@ def test_compact_hand_over_equals_plain(oracle, shapes, n_reads, parts_range):
     b.close()
 
 
+CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
+
+
+def _two_rounds(rng, eng, n_reads=300):
+    """Round 2 = round 1's chains: 0 grown at the end (the usual case), 1 unchanged, 2 an interior anchor moved, 3 a chain round 1
+    did not have, 4 cut back at the end (its last part was not the last one then).  Returns (cb1, cb2, prev_read, expected
+    parts taken over per chain of round 2, events)."""
+    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, n_reads, 90000, _medium, (3, 90))
+    strand_of = [1 if s == 0 else 0 for s in slot]
+    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
+    nc = len(anchor_off) - 1
+    kinds = rng.integers(0, 5, nc)
+    a1, off1, a2, off2, expect, sel = [], [0], [], [0], np.zeros(nc, np.int64), []
+    for c in range(nc):
+        a = anchors[int(anchor_off[c]):int(anchor_off[c + 1])].copy()
+        parts = len(a) - 1
+        r2 = a
+        if kinds[c] == 3:
+            r1 = None
+        elif kinds[c] == 0 and parts >= 2:
+            cut = int(rng.integers(1, parts))        # round 1 lacks the last `cut` parts (end-first: the list's first entries)
+            r1 = a[cut:]
+            expect[c] = parts - cut
+        elif kinds[c] == 2 and parts >= 3:
+            k = int(rng.integers(1, len(a) - 1))     # an interior anchor that differs: the parts from the chain's start up to it stay
+            r1 = a.copy()
+            r1[k]["query_position"] -= 0 if r1[k]["query_position"] == r1[k + 1]["query_position"] else 1
+            moved = r1[k]["query_position"] != a[k]["query_position"]
+            same = len(a) - 1 - k if moved else len(a)   # anchors of the common tail
+            expect[c] = same - 1 if same >= 2 else 0
+        elif kinds[c] == 4 and parts >= 3:
+            r1 = a
+            r2 = a[1:]                                # round 2 lacks round 1's last part: its own last part is scored again
+            expect[c] = len(r2) - 2
+        else:
+            r1 = a
+            expect[c] = parts
+        a2.append(r2); off2.append(off2[-1] + len(r2))
+        if r1 is not None:
+            sel.append(c); a1.append(r1); off1.append(off1[-1] + len(r1))
+    # round 1 keeps the reads' structure: read r holds the chains of round 2's read r that existed then
+    keep1 = np.zeros(nc, bool); keep1[sel] = True
+    ch_read = np.repeat(np.arange(n_reads), np.diff(chain_off.astype(np.int64)))
+    chain_off1 = np.concatenate([[0], np.cumsum(np.bincount(ch_read[keep1], minlength=n_reads))]).astype(np.uint64)
+    cb1 = CandidateBatch(events, chain_off1, np.array(off1, np.uint64), np.concatenate(a1), ref_base[sel], read_base[sel])
+    cb2 = CandidateBatch(events, chain_off, np.array(off2, np.uint64), np.concatenate(a2), ref_base, read_base)
+    return cb1, cb2, np.arange(n_reads, dtype=np.uint64), expect
+
+
+def _match(lib, cb2, cb1, prev_read):
+    import ctypes as C
+
+    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    a2 = [np.ascontiguousarray(cb2.chain_off, np.uint64), np.ascontiguousarray(cb2.anchor_off, np.uint64), np.ascontiguousarray(cb2.anchors),
+          np.ascontiguousarray(cb2.ref_base, np.uint64), np.ascontiguousarray(cb2.read_base, np.uint32)]
+    a1 = [np.ascontiguousarray(cb1.chain_off, np.uint64), np.ascontiguousarray(cb1.anchor_off, np.uint64), np.ascontiguousarray(cb1.anchors),
+          np.ascontiguousarray(cb1.ref_base, np.uint64), np.ascontiguousarray(cb1.read_base, np.uint32)]
+    carry = np.zeros(cb2.n_chains, CARRY_DTYPE)
+    new_off = np.zeros(cb2.n_chains + 1, np.uint64)
+    new_anchors = np.zeros(len(cb2.anchors) + 1, ra.ANCHOR_DTYPE)
+    st = lib.rawdtw_round_match_chains(cb2.n_reads, vp(a2[0]), vp(a2[1]), vp(a2[2]), vp(a2[3]), vp(a2[4]), vp(prev_read), vp(a1[0]), vp(a1[1]), vp(a1[2]),
+                                       vp(a1[3]), vp(a1[4]), vp(carry), vp(new_off), vp(new_anchors))
+    assert st == 0
+    return a2, carry, new_off, new_anchors
+
+
 def test_round_carry_takes_over_unchanged_parts(oracle):
-    """rawdtw_batch_submit_round: round 2 = round 1's chains, some grown at their ends (the usual case), some unchanged, some
-    with a changed interior anchor, some new.  Every part whose two anchors were there before must be taken over (the
-    reused count says so), a chain's former last part loses its last cell's distance when it is no longer last, and all
-    scores, keeps and part costs equal a from-scratch batch of round 2 (which the cases above pin to the oracle)."""
+    """rawdtw_batch_submit_carry: every leading part (from the chain's start) whose anchors were there the round before is taken
+    over -- the host's matcher says how many (checked against an independent count), only the new anchors are handed over, the
+    device assembles the list and copies the costs; a chain's former last part loses its last cell's distance when it is no
+    longer last; a part that is the last now and was not then is scored again.  All scores, keeps and part costs equal a
+    from-scratch batch of round 2 (which the cases above pin to the oracle)."""
     import ctypes as C
 
     rng = np.random.default_rng(99)
@@ -460,63 +527,66 @@ def test_round_carry_takes_over_unchanged_parts(oracle):
     eng = ra.Engine(0)
     eng.upload_reference([ref[0]], [ref[1]])
     lib = eng.lib
-    # round 2 first (the longer chains), round 1 = its chains cut back at their ends
-    events, chain_off, anchor_off, anchors, slot, read_base = _chains(rng, 300, 90000, _medium, (3, 90))
-    strand_of = [1 if s == 0 else 0 for s in slot]
-    ref_base = np.array([eng.reference_offset(0, st) for st in strand_of], np.uint64)
-    cb2 = CandidateBatch(events, chain_off, anchor_off, anchors, ref_base, read_base)
+    cb1, cb2, prev_read, expect = _two_rounds(rng, eng)
     nc = cb2.n_chains
-    a1, off1 = [], [0]
-    kinds = rng.integers(0, 4, nc)   # 0 grown at the end, 1 unchanged, 2 an interior anchor moved, 3 a chain round 1 did not have
-    expect_reused = 0
-    carry = np.full(nc, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
-    n1 = 0
-    for c in range(nc):
-        a = anchors[int(anchor_off[c]):int(anchor_off[c + 1])].copy()
-        parts = len(a) - 1
-        if kinds[c] == 3:
-            continue
-        if kinds[c] == 0 and parts >= 2:
-            cut = int(rng.integers(1, parts))        # round 1 lacks the last `cut` parts (end-first: the list's first entries)
-            a = a[cut:]
-            expect_reused += parts - cut
-        elif kinds[c] == 2 and parts >= 3:
-            k = int(rng.integers(1, len(a) - 1))     # an interior anchor that differs: the two parts around it are scored again
-            a[k]["query_position"] -= 0 if a[k]["query_position"] == a[k + 1]["query_position"] else 1
-            moved = a[k]["query_position"] != anchors[int(anchor_off[c]) + k]["query_position"]
-            expect_reused += parts - (2 if moved else 0)
-        else:
-            expect_reused += parts
-        carry[c] = n1
-        n1 += 1
-        a1.append(a)
-        off1.append(off1[-1] + len(a))
-    sel = [c for c in range(nc) if kinds[c] != 3]
-    # round 1's chains all in one read per original read is not needed: one read holds them all
-    cb1 = CandidateBatch(events, np.array([0, len(sel)], np.uint64), np.array(off1, np.uint64), np.concatenate(a1), ref_base[sel], read_base[sel])
-    eng.upload_events(events)
+    eng.upload_events(cb2.events)
     opt = ra.MapOpt(dtw_min_score=5.0)
+    copt = opt.c_struct()
+    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
     b1 = ra.Batch(eng, opt, cb1)
+    assert lib.rawdtw_batch_can_carry(eng._ctx, b1._h, C.byref(copt)) == 0   # never run: nothing to take over
+    h = C.c_void_p()
+    arr, carry, new_off, new_anchors = _match(lib, cb2, cb1, prev_read)
+    assert np.array_equal(carry["parts"].astype(np.int64), expect)
+    assert int(new_off[-1]) == len(cb2.anchors) - int((expect + (expect > 0)).sum())
+    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]), vp(arr[4]),
+                                       b1._h, vp(carry), C.byref(h))
+    assert st == 5 and not h.value                                            # RAWDTW_ERR_UNSUPPORTED, nothing enqueued
     b1.run()
     b1.fetch()
+    other = ra.MapOpt(dtw_min_score=5.0, dtw_band_radius_frac=0.2).c_struct()
+    assert lib.rawdtw_batch_can_carry(eng._ctx, b1._h, C.byref(other)) == 0   # another radius: other costs
+    assert lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(other), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]),
+                                         vp(arr[4]), b1._h, vp(carry), C.byref(h)) == 5
+    assert lib.rawdtw_batch_can_carry(eng._ctx, b1._h, C.byref(copt)) == 1
     plain = ra.Batch(eng, opt, cb2)
     plain.run()
     want = plain.fetch(with_job_costs=True)
     plain.close()
-    copt = opt.c_struct()
-    h = C.c_void_p()
-    arr = [np.ascontiguousarray(cb2.chain_off, np.uint64), np.ascontiguousarray(cb2.anchor_off, np.uint64), np.ascontiguousarray(cb2.anchors),
-           np.ascontiguousarray(cb2.ref_base, np.uint64), np.ascontiguousarray(cb2.read_base, np.uint32)]
-    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
-    eng._check(lib.rawdtw_batch_submit_round(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(arr[3]), vp(arr[4]),
-                                             b1._h, vp(carry), C.byref(h)))
-    b1.close()   # (the round before may go as soon as the call has returned)
+    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]),
+                                             vp(arr[4]), b1._h, vp(carry), C.byref(h)))
     score, keep = np.zeros(nc, np.float32), np.zeros(nc, np.uint8)
     jc = np.zeros(len(want[2]), np.float32)
     eng._check(lib.rawdtw_batch_fetch(eng._ctx, h, vp(score), vp(keep), vp(jc)))
+    b1.close()
     sc, ru = C.c_uint64(), C.c_uint64()
     eng._check(lib.rawdtw_batch_round_stats(eng._ctx, h, C.byref(sc), C.byref(ru)))
-    lib.rawdtw_batch_destroy(h)
     assert np.array_equal(jc.view(np.uint32), want[2].view(np.uint32))
     assert np.array_equal(score.view(np.uint32), want[0].view(np.uint32)) and np.array_equal(keep, want[1])
-    assert ru.value == expect_reused and sc.value + ru.value == len(jc) and ru.value > 1000
+    assert ru.value == int(expect.sum()) and sc.value + ru.value == len(jc) and ru.value > 1000
+    # a third round on top of the carried one (its costs were copied, not computed): round 2 again, everything taken over
+    arr3, carry3, new_off3, new_anchors3 = _match(lib, cb2, cb2, prev_read)
+    assert int(new_off3[-1]) == 0 or int(carry3["parts"].sum()) == len(jc)
+    h3 = C.c_void_p()
+    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr3[0]), vp(arr3[1]), vp(new_off3), vp(new_anchors3), vp(arr3[3]),
+                                             vp(arr3[4]), h, vp(carry3), C.byref(h3)))
+    score3, keep3, jc3 = np.zeros(nc, np.float32), np.zeros(nc, np.uint8), np.zeros(len(jc), np.float32)
+    eng._check(lib.rawdtw_batch_fetch(eng._ctx, h3, vp(score3), vp(keep3), vp(jc3)))
+    eng._check(lib.rawdtw_batch_round_stats(eng._ctx, h3, C.byref(sc), C.byref(ru)))
+    assert ru.value == len(jc) and sc.value == 0
+    assert np.array_equal(jc3.view(np.uint32), want[2].view(np.uint32)) and np.array_equal(score3.view(np.uint32), want[0].view(np.uint32))
+    lib.rawdtw_batch_destroy(h3)
+    # an invented record (more parts than the named chain has): the counts do not add up on the device -- the batch is not
+    # scored from it (an error or a from-scratch fallback, never a wrong cost)
+    bad = carry.copy()
+    c_bad = int(np.argmax(bad["parts"] > 0))
+    bad["parts"][c_bad] += 1
+    hb = C.c_void_p()
+    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]), vp(arr[4]),
+                                       h, vp(bad), C.byref(hb))
+    if st == 0:
+        st = lib.rawdtw_batch_fetch(eng._ctx, hb, vp(score3), vp(keep3), None)
+        assert st != 0 or np.array_equal(score3.view(np.uint32), want[0].view(np.uint32))
+        lib.rawdtw_batch_destroy(hb)
+    lib.rawdtw_batch_destroy(h)
+    eng.close()
