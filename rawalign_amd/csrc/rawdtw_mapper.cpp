@@ -640,10 +640,12 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             int st = RAWDTW_OK;
             if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
             if (st == RAWDTW_OK) {
-                if (ra.carried)
+                if (ra.carried) {
                     st = rawdtw_batch_submit_carry(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.new_off.p, ra.new_anchors.p, ra.ref_base.p,
                                                    ra.read_base.p, pb.batch, ra.carry.p, &ra.batch);
-                else
+                    if (st == RAWDTW_ERR_UNSUPPORTED) { ra.carried = false; st = RAWDTW_OK; } // (e.g. a round without a chain: nothing to plan on the device)
+                }
+                if (st == RAWDTW_OK && !ra.carried)
                     st = rawdtw_batch_submit(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.anchors.p, ra.ref_base.p, ra.read_base.p, &ra.batch);
             }
             if (st != RAWDTW_OK) set_fail(st, rawdtw_last_error(g.ctx));
