@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--decoys-per-read", type=float, default=None)
     ap.add_argument("--rounds", type=int, default=4, help="chunk rounds of the cross-round cache block (0: skip it)")
     ap.add_argument("--modes-reads", type=int, default=8192, help="reads of the configs[2] block (0: skip it)")
+    ap.add_argument("--mapper-reads", type=int, default=16384, help="reads of the mapper block: mapped reads/s through the chunk-round loop (0: skip it)")
+    ap.add_argument("--mapper-threads", type=int, default=0, help="host threads of the mapper block (0: the cores this process may use)")
     ap.add_argument("--trace-fresh", type=int, default=0,
                     help="profiling runs: only the fresh-batch loop (inputs resident), this many steps, no JSON line")
     ap.add_argument("--dry-run", action="store_true",
@@ -308,6 +310,145 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
                         "only the parts they bring (k_carry copies the rest's costs, one stretch a chain); the host's matching of the "
                         "chains (match_ms_host_1_thread, rawdtw_round_match_chains on one thread; the mapper does it per read on "
                         "its pool) is outside these times"})
+    return out
+
+
+def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
+    """The metric's second half: MAPPED READS per second through the chunk-round mapping loop of the library
+    (rawdtw_mapper_*, rawalign_amd/csrc/rawdtw_mapper.cpp: src/rmap.cpp:667-822 turned into rounds) -- per round and read the
+    chunk's events and seed hits go in (event detection and seeding stay in RawAlign: imitated by synth.make_seed_chunks,
+    outside the timed calls), the mapper re-seeds, sorts, chains (rmap.cpp:344-507) on `threads` host threads, scores every
+    chain of every read on the device in one submission per read group, and finishes the round (primary chains, MAPQ, stop
+    rule).  Timed: the rawdtw_mapper_round calls.  Variants: one read group / two (two contexts: one group's host phase beside
+    the other's batch), costs carried from round to round or every round from scratch, the reference's stop rule and every read
+    through all of its chunks (>= 4 rounds: where carried costs matter).  PAF lines must be identical across all of them.
+    `cpu_baseline`: the SAME flow with the DTW block on the host cores through the reference's own dtw.cpp
+    (oracle/_ref, plugged in through rawdtw_mapper_set_scorer) on a bounded sample of the reads."""
+    import hashlib
+
+    import rawalign_amd as ra
+    from rawalign_amd import mapper, synth
+    from rawalign_amd.mapping import StopOpt
+
+    sc = synth.make_seed_chunks(ref, n_reads, seed=SEED + 17)
+    opt = ra.MapOpt()
+    names = [f"seq{s}" for s in range(ref.n_seq)]
+    lens = [len(x) for x in ref.forward]
+    slot = int(sc["n_ev"].max()) + 8
+    first, nch = sc["chunk_first"], sc["n_chunks"]
+    ev_off, hit_off = sc["ev_off"].astype(np.int64), sc["hit_off"].astype(np.int64)
+
+    def run(cm, reads, label):
+        ids = np.array([cm.add_read("read_%d" % r, int(sc["qlen"][r]), int(nch[r])) for r in reads], np.uint32)
+        done = np.zeros(len(reads), np.int64)
+        active = np.ones(len(reads), bool)
+        t_rounds, n_rounds, read_rounds = 0.0, 0, 0
+        per_round = []
+        while active.any():
+            sel = np.nonzero(active)[0]
+            ci = first[reads[sel]] + done[sel]                      # this round's chunk of every active read
+            ecnt, hcnt = ev_off[ci + 1] - ev_off[ci], hit_off[ci + 1] - hit_off[ci]
+            eo = np.concatenate([[0], np.cumsum(ecnt)]).astype(np.uint64)
+            ho = np.concatenate([[0], np.cumsum(hcnt)]).astype(np.uint64)
+            eidx = np.repeat(ev_off[ci], ecnt) + (np.arange(int(eo[-1])) - np.repeat(eo[:-1].astype(np.int64), ecnt))
+            hidx = np.repeat(hit_off[ci], hcnt) + (np.arange(int(ho[-1])) - np.repeat(ho[:-1].astype(np.int64), hcnt))
+            ev = np.ascontiguousarray(sc["events"][eidx]) if len(eidx) else np.zeros(1, np.float32)
+            hits = np.ascontiguousarray(sc["hits"][hidx]) if len(hidx) else np.zeros(1, sc["hits"].dtype)
+            rid = np.ascontiguousarray(ids[sel])
+            t0 = time.perf_counter()
+            cm.round_arrays(rid, eo, ev, ho, hits)
+            dt = time.perf_counter() - t0
+            t_rounds += dt; n_rounds += 1; read_rounds += len(sel)
+            per_round.append({"reads": int(len(sel)), "ms": round(dt * 1e3, 3)})
+            done[sel] += 1
+            for k in sel:  # (the mapper's own stop rule decides)
+                fin, _ = cm.state(int(ids[k]))
+                if fin or done[k] >= nch[reads[k]]:
+                    active[k] = False
+        assert cm.finish() == 0
+        lines = [cm.paf(int(i)) for i in ids]
+        mapped = sum(1 for ln in lines if ln.split("\t")[4] in "+-")
+        h = hashlib.sha1("\n".join(lines).encode()).hexdigest()
+        tm = cm.timing()
+        rounds, scored, reused = cm.stats()
+        return {"label": label, "reads": int(len(reads)), "mapped_reads": mapped, "rounds": n_rounds, "read_rounds": read_rounds,
+                "seconds_in_rounds": round(t_rounds, 4), "reads_per_s": len(reads) / t_rounds, "mapped_reads_per_s": mapped / t_rounds,
+                "read_rounds_per_s": read_rounds / t_rounds, "parts_scored": scored, "parts_reused": reused,
+                "ms_per_round": {k: round(v / max(n_rounds, 1), 3) for k, v in tm.items() if k.endswith("_ms")},
+                "h2d_bytes_per_round": {k: int(v / max(n_rounds, 1)) for k, v in tm.items() if k.endswith("_bytes")},
+                "per_round": per_round, "paf_sha1": h}
+
+    all_reads = np.arange(n_reads)
+    never = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
+    out = {"workload": WORKLOAD + ", synthetic seed hits (hit probability 0.2 per event, 25 false hits a chunk), chunks of 520 events",
+           "reads": n_reads, "host_threads": threads, "runs": [], "all_chunks": []}
+
+    def device_run(stop, carry, groups, label, thr=threads):
+        eng = ra.Engine(local_rank)
+        eng.upload_reference(ref.forward, ref.reverse)
+        cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n_reads, carry=carry, threads=thr, groups=groups)
+        r = run(cm, all_reads, label)
+        cm.close()
+        eng.close()
+        return r
+    for carry, groups in ((1, 2), (1, 1), (0, 2), (0, 1)):
+        out["runs"].append(device_run(StopOpt(), carry, groups, "stop rule of the reference, carry=%d groups=%d" % (carry, groups)))
+    out["runs"].append(device_run(StopOpt(), 1, 2, "stop rule of the reference, carry=1 groups=2, ONE host thread", thr=1))
+    for carry, groups in ((1, 2), (0, 2), (1, 1), (0, 1)):
+        out["all_chunks"].append(device_run(never, carry, groups, "every read through all of its chunks, carry=%d groups=%d" % (carry, groups)))
+    out["paf_identical_across_runs"] = len({r["paf_sha1"] for r in out["runs"]}) == 1 and len({r["paf_sha1"] for r in out["all_chunks"]}) == 1
+    best = max(out["runs"], key=lambda r: r["reads_per_s"])
+    out["reads_per_s"], out["mapped_reads_per_s"], out["best_run"] = best["reads_per_s"], best["mapped_reads_per_s"], best["label"]
+    ac = {r["label"].split(", ")[1]: r for r in out["all_chunks"]}
+    out["all_chunks_summary"] = {k: {"seconds_in_rounds": r["seconds_in_rounds"], "read_rounds_per_s": r["read_rounds_per_s"],
+                                     "anchor_bytes_per_round": r["h2d_bytes_per_round"]["anchor_bytes"],
+                                     "fetch_wait_ms_per_round": r["ms_per_round"]["fetch_wait_ms"]} for k, r in ac.items()}
+    if with_cpu:
+        from oracle.loader import RefDTW
+        if RefDTW.available():
+            rl = RefDTW().lib
+
+            class ScorerCtx(C.Structure):
+                _fields_ = [("fwd", C.c_void_p), ("rev", C.c_void_p), ("border_constraint", C.c_int), ("fill_method", C.c_int),
+                            ("band_radius_frac", C.c_float), ("match_bonus", C.c_float), ("min_score", C.c_float), ("fused_score", C.c_int),
+                            ("threads", C.c_int), ("dtw_calls", C.c_uint64)]
+            fwd = (C.c_void_p * ref.n_seq)(*[x.ctypes.data for x in ref.forward])
+            rev = (C.c_void_p * ref.n_seq)(*[x.ctypes.data for x in ref.reverse])
+            sctx = ScorerCtx(C.cast(fwd, C.c_void_p), C.cast(rev, C.c_void_p), opt.dtw_border_constraint, opt.dtw_fill_method, opt.dtw_band_radius_frac,
+                             opt.dtw_match_bonus, opt.dtw_min_score, int(opt.fused_score), threads, 0)
+            fn = C.cast(rl.ref_scorer, C.c_void_p)
+            # a bounded sample of the same reads: sized from a first small run
+            n_s = min(n_reads, 512)
+            base = None
+            for _ in range(3):
+                cm = mapper.CMapper(None, opt, StopOpt(), names, lens, slot_events=slot, max_reads=n_s, carry=False, threads=threads)
+                cm.set_scorer_c(fn, C.cast(C.pointer(sctx), C.c_void_p))
+                base = run(cm, all_reads[:n_s], "stop rule of the reference, DTW on the host cores (reference dtw.cpp)")
+                cm.close()
+                if base["seconds_in_rounds"] >= 0.25 * cpu_seconds or n_s >= n_reads:
+                    break
+                n_s = int(min(n_reads, max(n_s * 2, n_s * cpu_seconds / max(base["seconds_in_rounds"], 1e-3))))
+            dev_same = next(r for r in out["runs"] if r["label"].endswith("carry=0 groups=1"))
+            base.pop("per_round")
+            out["cpu_baseline"] = {"value": base["reads_per_s"], "unit": "reads/s", "cores": threads, "kind": "reference",
+                                   "sample": "the first %d of the %d reads through the same mapper (same host threads, same chaining) with the DTW block "
+                                             "on the host cores: align_chain's score-only form around the reference's own dtw.cpp (oracle/_ref: "
+                                             "ref_scorer, one task per read as kt_for deals them), %.2f s in its rounds" % (base["reads"], n_reads, base["seconds_in_rounds"]),
+                                   "mapped_reads_per_s": base["mapped_reads_per_s"], "ms_per_round": base["ms_per_round"], "dtw_calls": int(sctx.dtw_calls),
+                                   "note": "submit_ms holds the scorer's time here (the DTW block runs inside the submission)"}
+            # the sample's lines must be the device flow's lines
+            out["cpu_baseline"]["paf_prefix_identical_to_device_flow"] = None
+            eng = ra.Engine(local_rank)
+            eng.upload_reference(ref.forward, ref.reverse)
+            cm = mapper.CMapper(eng, opt, StopOpt(), names, lens, slot_events=slot, max_reads=base["reads"], carry=True, threads=threads, groups=2)
+            dev_s = run(cm, all_reads[:base["reads"]], "device, same sample")
+            cm.close(); eng.close()
+            out["cpu_baseline"]["paf_identical_to_device_flow_on_the_sample"] = dev_s["paf_sha1"] == base["paf_sha1"]
+            out["cpu_baseline"]["device_reads_per_s_on_the_sample"] = dev_s["reads_per_s"]
+            del dev_same
+    for r in out["runs"] + out["all_chunks"]:
+        if len(r["per_round"]) > 8:
+            r["per_round"] = r["per_round"][:8] + [{"more": len(r["per_round"]) - 8}]
     return out
 
 
@@ -855,6 +996,16 @@ def main():
             out["chunk_rounds"] = rounds_block(engines[0], lib, copt, B[0]["cb"], B[0]["inf"], args.rounds, local_rank, pin)
         if world == 1 and args.modes_reads > 0:
             out["modes"] = modes_block(local_rank, args.modes_reads)
+        if world == 1 and args.mapper_reads > 0:
+            for e in engines:   # (the loops above are over: their contexts' workspaces go, the mapper makes its own)
+                e.close()
+            engines = []
+            thr = args.mapper_threads
+            if thr <= 0:
+                quota = cgroup_cpu_quota()
+                aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                thr = max(1, min(aff, int(quota + 0.999))) if quota else min(aff, 16)
+            out["mapper"] = mapper_block(lib, ref, local_rank, args.mapper_reads, thr, args.cpu_seconds * 3, not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             cb = B[0]["cb"]
             job_off = np.zeros(cb.n_chains + 1, np.uint64)

@@ -623,6 +623,10 @@ class CMapper:
         self._cb = SCORER_FN(cb) if fn is not None else None
         self._check(self.lib.rawdtw_mapper_set_scorer(self._h, self._cb, None))
 
+    def set_scorer_c(self, fn_ptr, user_ptr):
+        """a scorer that is C code itself (address of a rawdtw_scorer_fn, its user pointer): no Python between the mapper and it"""
+        self._check(self.lib.rawdtw_mapper_set_scorer(self._h, fn_ptr, user_ptr))
+
     def close(self):
         if self._h:
             self.lib.rawdtw_mapper_destroy(self._h)

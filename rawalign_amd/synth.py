@@ -244,3 +244,73 @@ def make_rounds(cb: CandidateBatch, info: dict, n_rounds: int):
         idx = np.repeat(first - new_off[:-1], cnt) + np.arange(int(new_off[-1]))
         rounds.append(CandidateBatch(cb.events, cb.chain_off, new_off.astype(np.uint64), cb.anchors[idx], cb.ref_base, cb.read_base))
     return rounds
+
+
+def make_seed_chunks(ref: Reference, n_reads: int, seed: int, events_per_chunk: int = 520, hit_prob: float = 0.2, false_hits: int = 25,
+                     noise_sd: float = 0.25, max_chunks: int = 6, unmappable_frac: float = 0.05):
+    """What detect_events + ri_sketch + ri_idx_get hand the mapper, for many reads at once (vectorised; mapper.SyntheticSeeds is the
+    small per-read form the parity tests use): per read and chunk the chunk's events (z-normalised per chunk, revent.c:178-184) and
+    its seed hits -- true hits on the read's real path with probability `hit_prob` per event, `false_hits` random ones per chunk.
+    Returns a dict of flat arrays: `n_chunks[r]`, `qlen[r]`; chunk (r, c) has index ci = chunk_first[r] + c, events
+    events[ev_off[ci] .. ev_off[ci + 1]) and hits hits[hit_off[ci] .. hit_off[ci + 1]) (mapper.HIT_DTYPE, query positions inside
+    the chunk)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(x) for x in ref.forward], np.int64)
+    seq = rng.choice(len(lens), size=n_reads, p=lens / lens.sum())
+    strand = rng.integers(0, 2, n_reads)
+    chunks_k = rng.integers(1, max_chunks + 1, n_reads)
+    n_k = np.minimum(chunks_k * int(events_per_chunk / 1.28), lens[seq] - 1).astype(np.int64)
+    start = (rng.random(n_reads) * (lens[seq] - n_k)).astype(np.int64)
+    mappable = rng.random(n_reads) >= unmappable_frac
+    read_of_k = np.repeat(np.arange(n_reads), n_k)
+    kpos = np.repeat(start, n_k) + _segment_arange(n_k)
+    mult = rng.choice(4, size=len(kpos), p=(0.06, 0.66, 0.22, 0.06))
+    mult[np.cumsum(n_k) - n_k] = np.maximum(mult[np.cumsum(n_k) - n_k], 1)
+    t_of_ev = np.repeat(kpos, mult)
+    read_of_ev = np.repeat(read_of_k, mult)
+    n_ev = np.bincount(read_of_ev, minlength=n_reads).astype(np.int64)
+    rd_off = np.concatenate([[0], np.cumsum(n_ev)])
+    q_in_read = np.arange(len(t_of_ev), dtype=np.int64) - rd_off[read_of_ev]
+    clean = np.empty(len(t_of_ev), np.float32)
+    for s in range(ref.n_seq):
+        for st in (0, 1):
+            sel = (seq[read_of_ev] == s) & (strand[read_of_ev] == st)
+            arr = ref.forward[s] if st == 1 else ref.reverse[s]
+            clean[sel] = arr[t_of_ev[sel]]
+    vals = clean.astype(np.float64) + rng.normal(0.0, noise_sd, len(clean))
+    unm = ~mappable[read_of_ev]
+    vals[unm] = rng.normal(0.0, 1.0, int(unm.sum()))
+    # chunks: events_per_chunk events each, the last one what is left
+    n_chunks = (n_ev + events_per_chunk - 1) // events_per_chunk
+    chunk_first = np.concatenate([[0], np.cumsum(n_chunks)]).astype(np.int64)
+    chunk_of_ev = chunk_first[read_of_ev] + q_in_read // events_per_chunk
+    n_tot = int(chunk_first[-1])
+    ev_cnt = np.bincount(chunk_of_ev, minlength=n_tot).astype(np.int64)
+    ev_off = np.concatenate([[0], np.cumsum(ev_cnt)]).astype(np.uint64)
+    s1 = np.add.reduceat(vals, ev_off[:-1].astype(np.int64))
+    s2 = np.add.reduceat(vals * vals, ev_off[:-1].astype(np.int64))
+    mean = s1 / ev_cnt
+    sd = np.maximum(np.sqrt(np.maximum(s2 / ev_cnt - mean * mean, 0.0)), 1e-9)
+    events = ((vals - mean[chunk_of_ev]) / sd[chunk_of_ev]).astype(np.float32)
+    q_in_chunk = q_in_read % events_per_chunk
+    # hits: true ones (events on the path of a mappable read), then the chunk's false ones
+    hit = (rng.random(len(t_of_ev)) < hit_prob) & mappable[read_of_ev]
+    hi = np.nonzero(hit)[0]
+    n_false = n_tot * false_hits
+    f_chunk = np.repeat(np.arange(n_tot), false_hits)
+    f_seq = rng.integers(0, len(lens), n_false)
+    f_hits = np.zeros(n_false, [("chunk", "<i8"), ("ref_seq", "<u4"), ("strand", "<i4"), ("target_position", "<u4"), ("query_position", "<u4")])
+    f_hits["chunk"], f_hits["ref_seq"], f_hits["strand"] = f_chunk, f_seq, rng.integers(0, 2, n_false)
+    f_hits["target_position"] = (rng.random(n_false) * lens[f_seq]).astype(np.int64)
+    f_hits["query_position"] = (rng.random(n_false) * ev_cnt[f_chunk]).astype(np.int64)
+    t_hits = np.zeros(len(hi), f_hits.dtype)
+    t_hits["chunk"], t_hits["ref_seq"], t_hits["strand"] = chunk_of_ev[hi], seq[read_of_ev[hi]], strand[read_of_ev[hi]]
+    t_hits["target_position"], t_hits["query_position"] = t_of_ev[hi], q_in_chunk[hi]
+    allh = np.concatenate([t_hits, f_hits])
+    allh = allh[np.argsort(allh["chunk"], kind="stable")]
+    hit_off = np.concatenate([[0], np.cumsum(np.bincount(allh["chunk"], minlength=n_tot))]).astype(np.uint64)
+    hits = np.zeros(len(allh), [("ref_seq", "<u4"), ("strand", "<i4"), ("target_position", "<u4"), ("query_position", "<u4")])
+    for f in hits.dtype.names:
+        hits[f] = allh[f]
+    return {"n_reads": n_reads, "n_chunks": n_chunks.astype(np.int64), "qlen": (n_chunks * 4000).astype(np.int64), "chunk_first": chunk_first,
+            "ev_off": ev_off, "events": events, "hit_off": hit_off, "hits": hits, "mappable": mappable, "n_ev": n_ev, "seq_lens": lens}

@@ -187,3 +187,41 @@ def test_device_side_carry_over_three_rounds_and_more(oracle):
     b, _ = mapper.map_reads(seeds, list(range(40)), carry, ra.MapOpt())
     carry.close()
     assert a == b
+
+
+@pytest.mark.gpu
+def test_cpp_mapper_lines_do_not_depend_on_threads_groups_or_carry(oracle):
+    """The library's mapper (rawdtw_mapper_*) over 600 reads of a 200 kb reference: the PAF lines' hash is the same on one host
+    thread and eight, with one read group and two (two contexts), with costs carried from round to round and without, under
+    the reference's stop rule and with every read through all of its chunks -- and equals the Python mirror's on the plain
+    device path (the flow the rounds above pin to the oracle)."""
+    import hashlib
+
+    from rawalign_amd.mapping import StopOpt
+
+    ref = synth.make_reference([200_000], seed=77)
+    n = 600
+    seeds = mapper.SyntheticSeeds(ref, n, seed=5, max_chunks=5)
+    names, lens = ["seq0"], [len(ref.forward[0])]
+    slot = max(rd["n_ev"] for rd in seeds.reads) + 8
+    for stop in (StopOpt(), StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)):
+        hashes, reused = {}, {}
+        for threads, groups, carry in ((1, 1, 1), (8, 2, 1), (8, 1, 0), (3, 2, 0), (8, 2, 1)):
+            eng = ra.Engine(0)
+            eng.upload_reference(ref.forward, ref.reverse)
+            cm = mapper.CMapper(eng, ra.MapOpt(), stop, names, lens, slot_events=slot, max_reads=n, carry=carry, threads=threads, groups=groups)
+            lines, rounds = mapper.map_reads_c(seeds, list(range(n)), cm)
+            hashes[(threads, groups, carry)] = hashlib.sha1("\n".join(lines).encode()).hexdigest()
+            reused[(threads, groups, carry)] = cm.stats()[2]
+            tm = cm.timing()
+            assert tm["anchor_bytes"] > 0 and tm["event_bytes"] > 0
+            cm.close()
+            eng.close()
+        assert len(set(hashes.values())) == 1, hashes
+        eng = ra.Engine(0)
+        eng.upload_reference(ref.forward, ref.reverse)
+        want, _ = mapper.map_reads(seeds, list(range(n)), mapper.DeviceScorer(eng), ra.MapOpt(), stop)
+        eng.close()
+        assert hashlib.sha1("\n".join(want).encode()).hexdigest() == hashes[(1, 1, 1)]
+        if stop.min_chain_anchor > 2:   # every read through all of its chunks: the rounds in which costs are taken over
+            assert reused[(8, 2, 1)] > 0 and reused[(1, 1, 1)] == reused[(8, 2, 1)] and reused[(8, 1, 0)] == 0
