@@ -1133,6 +1133,172 @@ __device__ __forceinline__ void wreg_gen(const DevJob &jb, const int lane, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// wband_gen<C>: the wave-per-job band of wreg_gen with its two operand windows read from LDS.
+//
+// What a column of wreg_gen costs is not its cells: the band's arithmetic is ~10 VALU instructions, the column took 350-390
+// clocks (profiles/r03_wreg_probe.txt: 144 ns with one register a lane, 162 with two) -- a wave that is alone on its SIMD issues
+// an instruction every ~7 clocks WHATEVER it is, and two thirds of the column's ~45 instructions kept the windows moving:
+// two v_readlane -> SGPR -> v_mov -> DPP round trips for the fresh operands, the cursors' increments, refill tests and
+// branches, a fill move in front of every shift, the register copies of the blocked layout.  Here the job's two operand
+// stretches are staged ONCE into a wave-private piece of LDS (A reversed, so that both windows ascend with the slot), and a
+// column's windows are one LDS read each -- 4 C bytes a lane, whatever C is -- asked for a column ahead; the row-advance
+// test is the only branch; the two DPP shifts of the DP values write into registers whose fill lane (1e10) is never
+// overwritten, so nothing has to be moved in front of them.
+//   per column with a row advance: 2 LDS reads + their two address adds, 2 DPP shifts, 8 C VALU for the 2 C cells, ~5 SALU.
+// Same cells, same neighbours, same masks as wreg_gen_step (the argument there): bit-identical costs.
+// Staging: lds_a[k] = A[clamp(i_hi - k)], lds_b[k] = B[clamp(j_lo + k)] for the columns [col, ce) of a segment; a job longer
+// than the wave's piece of LDS takes several segments.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_shl_keep(float &keep, const float v)
+{
+    // lane l receives lane l+1's value; lane 63 keeps what `keep` holds there (1e10, written once: no lane ever writes it)
+    keep = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return keep;
+}
+__device__ __forceinline__ float dpp_shr_keep(float &keep, const float v)
+{
+    keep = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return keep;
+}
+
+template <int C> struct WinVec { float v[C]; };
+template <int C> __device__ __forceinline__ WinVec<C> lds_window(const float *p) // C consecutive floats at p (any 4-byte boundary: ds_read2_b32 pairs)
+{
+    WinVec<C> w;
+    __builtin_memcpy(w.v, p, sizeof(float) * C);
+    return w;
+}
+
+// one column.  X = the secondary antidiagonal (row advance) or the primary before this one; see wreg_gen_step.
+template <int C, bool MASKED>
+__device__ __forceinline__ void wband_step(float (&d0)[C], float (&d1)[C], const float (&ap_prev)[C], const float (&ap)[C], const float (&bp)[C],
+                                           const bool adv, const lmask (&m_sec)[C], const lmask (&m_prim)[C], float &keep_hi, float &keep_lo, float &keep_lo2,
+                                           const int lane, const int off, const int row, const int col)
+{
+    const int p0 = lane * C;
+    float X[C];
+    if (adv) {
+        const float d1_up = dpp_shl_keep(keep_hi, d1[0]); // the next lane's first slot
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float left = (c + 1 < C) ? d1[c + 1 < C ? c + 1 : c] : d1_up;
+            const float v = min3f(d1[c], left, d0[c]) + dist(ap_prev[c], bp[c]);
+            if (MASKED) X[c] = (((m_sec[c] >> lane) & 1ull) && !(p0 + c < off - row || p0 + c > col - 1 + off)) ? v : kInf;
+            else X[c] = selm(m_sec[c], v, kInf);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) X[c] = d1[c];
+    }
+    const float X_dn = dpp_shr_keep(keep_lo, X[C - 1]); // the previous lane's last slot
+    float d0_dn = kInf;
+    if (!adv) d0_dn = dpp_shr_keep(keep_lo2, d0[C - 1]);
+    float pr[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float top = c > 0 ? X[c > 0 ? c - 1 : 0] : X_dn;
+        const float tl = adv ? d1[c] : (c > 0 ? d0[c > 0 ? c - 1 : 0] : d0_dn);
+        const float v = min3f(top, X[c], tl) + dist(ap[c], bp[c]);
+        if (MASKED) pr[c] = (((m_prim[c] >> lane) & 1ull) && !(p0 + c < off - row)) ? v : kInf;
+        else pr[c] = selm(m_prim[c], v, kInf);
+    }
+#pragma unroll
+    for (int c = 0; c < C; c++) { d0[c] = X[c]; d1[c] = pr[c]; }
+}
+
+} // namespace rawdtw
+#include "rawdtw_wband_asm.h" // wband_loop_asm: the main loop below, hand-scheduled (scripts/gen_wband_asm.py); opens the namespace itself
+namespace rawdtw {
+
+template <int C>
+__device__ __forceinline__ void wband_gen(const DevJob &jb, const int lane, const float *__restrict__ ev, const float *__restrict__ ref,
+                                          float *__restrict__ out, float *lds, const uint32_t lds_floats)
+{
+    // (the job is the wave's: its shape in scalar registers, whatever the caller derived its index from)
+    const float *A = ev + (uint32_t)__builtin_amdgcn_readfirstlane((int)jb.read_off);
+    const float *B = ref + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(jb.ref_off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)jb.ref_off));
+    uint32_t N = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb.n), M = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb.m);
+    if (N < M) {
+        const float *tp = A; A = B; B = tp;
+        uint32_t tn = N; N = M; M = tn;
+    }
+    const int R = __builtin_amdgcn_readfirstlane(jb.R);
+    const int P = R + ((R % 2 == 0) ? 1 : 0);
+    const int S = R + ((R % 2 == 1) ? 1 : 0);
+    const int SH = P > S ? 0 : 1;
+    const int off = P / 2 + SH, K = P > S ? P : S;
+    const int iN = (int)N, iM = (int)M;
+    constexpr int W = 64 * C; // slots the wave holds
+    float d0[C], d1[C];
+    lmask m_sec[C], m_prim[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int p = lane * C + c;
+        d0[c] = kInf;
+        d1[c] = p == off ? dist(A[0], B[0]) : kInf; // the corner (dtw.cpp:317-347)
+        m_sec[c] = __ballot(p < S);
+        m_prim[c] = __ballot(p >= SH && p < SH + P);
+    }
+    float keep_hi = kInf, keep_lo = kInf, keep_lo2 = kInf;
+    // a segment's columns: both stretches (+ a window each, + a few floats of slack: the loop asks for the windows of the
+    // column behind its last one) in half of the wave's piece of LDS each
+    const int half = (int)(lds_floats / 2u) & ~3;
+    const int seg = half - W - 12;
+    float *lds_a = lds + 4, *lds_b = lds + half;
+    int row = 0;
+    uint32_t rem = 0;
+    int col = 1;
+    while (col < iN) {
+        const int ce = min(iN, col + seg);
+        // A: the windows of columns col - 1 .. ce - 1 (the secondary of a column reads the window of the column before):
+        // slot p of column c holds A[c + off - p]  =>  lds_a[k] = A[i_hi - k], window of column c from k = ce - 1 - c on
+        const int i_hi = ce - 1 + off, na = ce - col + W;
+        for (int k = lane; k < na; k += 64) { const int i = i_hi - k; lds_a[k] = A[i < 0 ? 0 : (i >= iN ? iN - 1 : i)]; }
+        // B: slot p at centre row r holds B[r - off + p]; the rows of this segment: row .. row + (ce - col) at most
+        const int row0 = row, j_lo = row - off, nb = min(ce - col, iM - 1 - row) + W;
+        for (int k = lane; k < nb; k += 64) { const int j = j_lo + k; lds_b[k] = B[j < 0 ? 0 : (j >= iM ? iM - 1 : j)]; }
+        // (the wave's own LDS writes are ordered with its reads; the compiler must not move the reads up)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float *wa = lds_a + (ce - 1) + lane * C; // window of column c: wa - c
+        const float *wb = lds_b + lane * C - row0;     // window at centre row r: wb + r
+        auto columns = [&](const int upto) { // columns [col, upto), windows straight from LDS
+            for (; col < upto; col++) {
+                rem += M;
+                const bool adv = rem >= N;
+                if (adv) { rem -= N; row++; }
+                const WinVec<C> ap_prev = lds_window<C>(wa - (col - 1)), ap = lds_window<C>(wa - col), bp = lds_window<C>(wb + row);
+                // first columns: cells above row 0 or left of column 0 exist while row < off or col - 1 + off < K - 1
+                if (row < off || col < K - off + 1) wband_step<C, true>(d0, d1, ap_prev.v, ap.v, bp.v, adv, m_sec, m_prim, keep_hi, keep_lo, keep_lo2, lane, off, row, col);
+                else wband_step<C, false>(d0, d1, ap_prev.v, ap.v, bp.v, adv, m_sec, m_prim, keep_hi, keep_lo, keep_lo2, lane, off, row, col);
+            }
+        };
+        while (col < ce && (row < off || col < K - off + 1)) columns(col + 1); // (the masks' conditions only ever go from true to false)
+        const uint32_t iters = (uint32_t)(ce - col) / 6u;
+        if (iters) { // the rest, six columns a turn: the hand-scheduled loop
+            uint32_t va = (uint32_t)(size_t)(__attribute__((address_space(3))) const float *)(wa - (col + 6));
+            uint32_t vb = (uint32_t)(size_t)(__attribute__((address_space(3))) const float *)(wb + row);
+            const uint32_t vb0 = vb;
+            wband_loop_asm(d0, d1, va, vb, rem, iters, M, N, m_sec, m_prim);
+            col += 6 * (int)iters;
+            row += (int)(__builtin_amdgcn_readfirstlane((int)(vb - vb0)) / 4);
+        }
+        columns(ce);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the next segment's staging overwrites what this one read)
+        __builtin_amdgcn_wave_barrier();
+    }
+    float res = 0.0f; // dtw.cpp:506-512: the centre of the last primary
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        if (off % C == c) res = read_lane(d1[c], off / C);
+    if (lane == 0) {
+        if (jb.flags & kFlagExcludeLast) res = res - dist(A[N - 1], B[M - 1]);
+        out[jb.aux] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Four jobs per wave: the same register-resident scheme as wreg_body<1>, but for bands that fit 16
 // lanes (radius + 1 <= 16) each job takes one 16-lane DPP row, so a wave advances four jobs per
 // instruction instead of one.  Control values (lengths, centre row, remainder) are per-row vector
@@ -1261,13 +1427,14 @@ __device__ __forceinline__ void grp_wave(const DevJob *__restrict__ jobs, uint32
 // variant is picked per job (wave-uniform).  Jobs are sorted longest first, so the few long jobs
 // that bound the launch's duration start first and the many short ones fill in around them --
 // as separate launches they were separate long poles on separate streams.
+constexpr uint32_t kWbandLdsFloats = 1536; // a wave's piece of LDS (6 KB): segments of 500 columns for one-register bands, 252 for four
 __device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const float *__restrict__ ev,
-                                               const float *__restrict__ ref, float *__restrict__ out)
+                                               const float *__restrict__ ref, float *__restrict__ out, float *lds, uint32_t lds_floats = kWbandLdsFloats)
 {
     const int K = jb.R + 1;
-    if (K <= 64) wreg_gen<1>(jb, lane, ev, ref, out);
-    else if (K <= 128) wreg_gen<2>(jb, lane, ev, ref, out);
-    else wreg_gen<4>(jb, lane, ev, ref, out);
+    if (K <= 64) wband_gen<1>(jb, lane, ev, ref, out, lds, lds_floats);
+    else if (K <= 128) wband_gen<2>(jb, lane, ev, ref, out, lds, lds_floats);
+    else wband_gen<4>(jb, lane, ev, ref, out, lds, lds_floats);
 }
 
 } // namespace rawdtw

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict
                                                         const float *__restrict__ ref,
                                                         float *__restrict__ out)
 {
-    wreg_small_job(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
+    __shared__ __attribute__((aligned(16))) float s_w[kWbandLdsFloats];
+    wreg_small_job(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out, s_w);
 }
 
 // One launch for the three kernels every sparse batch needs -- the tile kernel (bulk), the 16-lane-row kernel
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void k_band_merged(const TileDesc *__restrict_
                                                      const DevJob *__restrict__ gjobs, uint32_t n_g,
                                                      const DevJob *__restrict__ hjobs, uint32_t n_h,
                                                      const float *__restrict__ ev, const float *__restrict__ ref,
-                                                     float *__restrict__ out)
+                                                     float *__restrict__ out, const uint32_t wave_floats)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     const uint32_t nbw = (n_w + 3u) / 4u, nbg = (n_g + 15u) / 16u, nbh = (n_h + 31u) / 32u;
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(256) void k_band_merged(const TileDesc *__restrict_
     const int lane = threadIdx.x & 63;
     if (b < nbw) {
         const uint32_t j = b * 4u + wv;
-        if (j < n_w) wreg_small_job(wjobs[j], lane, ev, ref, out);
+        // (the tiles' image is these workgroups' to use: a quarter a wave, launch_band_merged sees to its size)
+        if (j < n_w) wreg_small_job(wjobs[j], lane, ev, ref, out, win + wv * wave_floats, wave_floats);
         return;
     }
     b -= nbw;
@@ -829,6 +831,8 @@ hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const Til
 {
     const uint64_t blocks = (n_w + 3) / 4 + (n_g + 15) / 16 + (n_h + 31) / 32 + n_tiles;
     if (blocks == 0) return hipSuccess;
+    if (n_w) lds_floats = std::max(lds_floats, 4u * kWbandLdsFloats); // (the wave-per-job bands keep their operand windows there)
+    const uint32_t wave_floats = (lds_floats / 4u) & ~3u;
     const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_merged),
@@ -836,7 +840,7 @@ hipError_t launch_band_merged(const TileDesc *tiles, uint64_t n_tiles, const Til
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_band_merged, dim3((uint32_t)blocks), dim3(256), lds_bytes, s, tiles, spans, tjobs, masks, wjobs,
-                       (uint32_t)n_w, gjobs, (uint32_t)n_g, hjobs, (uint32_t)n_h, ev, ref, out);
+                       (uint32_t)n_w, gjobs, (uint32_t)n_g, hjobs, (uint32_t)n_h, ev, ref, out, wave_floats);
     return hipGetLastError();
 }
 

@@ -1004,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 {
     const uint32_t dbg = a.debug;
     constexpr uint32_t kWaves = 4;
+    __shared__ __attribute__((aligned(16))) float s_w[kWaves][kWbandLdsFloats]; // the wave-per-job bands' operand windows (wband_gen)
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
     // (a batch the scan declined is redone through the job list)
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
                 if (len >= 256u) __builtin_amdgcn_s_setprio(3);
                 else if (len >= 96u) __builtin_amdgcn_s_setprio(2);
                 else __builtin_amdgcn_s_setprio(1);
-                wreg_small_job(jb, lane, a.ev, a.ref, a.out);
+                wreg_small_job(jb, lane, a.ev, a.ref, a.out, s_w[wv]);
                 __builtin_amdgcn_s_setprio(0);
             }
             else if (dbg & 64u) continue;

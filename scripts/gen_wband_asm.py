@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Writes rawalign_amd/csrc/rawdtw_wband_asm.h: the main loop of the wave-per-job band body (wband_gen<C>, rawdtw_dp.h) as
+hand-scheduled gfx950 assembly, for C = 1, 2, 4 registers a lane.
+
+Why assembly: the loop is one wave's dependency chain, alone on its SIMD -- every instruction costs an issue slot of ~7 clocks
+whatever it is, so the column's time is its instruction COUNT.  Left to the compiler the loop carried a dozen register copies
+a column (the three roles of the a-window, the two of the b-window and the two DP buffers meet in phi nodes), turned the
+uniform row-advance branch into per-lane selects and put a fill move in front of every DPP shift.  Here:
+
+  * six columns a loop iteration: the a-window's roles (previous / this / next column) rotate over three register sets, the
+    b-window's (this / next) over two -- after six columns every value is back in the register it started in: no copies;
+  * the DP buffers are updated in place: the secondary antidiagonal X overwrites d0 (its own top-left operand), the primary
+    overwrites d1; a column without a row advance computes its primary into d0 and swaps the two (v_swap_b32);
+  * the windows of column c + 1 are asked for (ds_read, immediate offsets within the six columns) while column c is computed;
+    s_waitcnt lgkmcnt(n) leaves exactly those in flight;
+  * the two DPP shifts a column write into registers whose fill lane holds 1e10 for good (bound_ctrl off: a lane without a
+    source keeps the destination's value);
+  * the instructions between a value's last write and its DPP read are chosen to cover the two wait states the hardware wants
+    there (the assembler does not insert them inside inline assembly).
+
+Cells, neighbours and masks are those of wband_step<C, false> / wreg_gen_step (dtw.cpp:361-485): bit-identical costs
+(tests/test_gpu_parity.py::test_random_wave_band, tests/test_stream_path.py: the wave-per-job bands at the register layouts'
+edges)."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VBASE = 96  # first scratch VGPR of the block (clobbered; the kernels that inline it use fewer than this many otherwise)
+
+
+def gen(C):
+    nd = 1 if C <= 2 else C // 2          # ds_read instructions per window
+    P = [[VBASE + s * C + c for c in range(C)] for s in range(3)]          # a-window register sets
+    B = [[VBASE + 3 * C + s * C + c for c in range(C)] for s in range(2)]  # b-window register sets
+    t = VBASE + 5 * C
+    DIFF = [t + c for c in range(C)]
+    KHI, KLO, KLO2, VINF = t + C, t + C + 1, t + C + 2, t + C + 3
+    last = VINF
+    # operands: %0.. d0[C], d1[C] (+v) ; then va, vb (+v) ; rem (+s), iters (+s) ; M, N (s) ; masks sec[C], prim[C] (s, 64-bit) ; temps adv0, adv1, st (=&s)
+    op = {}
+    k = 0
+    for name in [f"d0_{c}" for c in range(C)] + [f"d1_{c}" for c in range(C)] + ["va", "vb", "rem", "it"]:
+        op[name] = f"%{k}"; k += 1
+    n_io = k
+    for name in ["adv0", "adv1", "st"]:
+        op[name] = f"%{k}"; k += 1
+    n_out = k
+    for name in ["M", "N", "step"] + [f"ms{c}" for c in range(C)] + [f"mp{c}" for c in range(C)]:
+        op[name] = f"%{k}"; k += 1
+    L = []
+    e = L.append
+    v = lambda r: f"v{r}"  # noqa: E731
+    d0 = [op[f"d0_{c}"] for c in range(C)]
+    d1 = [op[f"d1_{c}"] for c in range(C)]
+
+    def read_window(dst, addr, dw_off):
+        """C consecutive dwords at LDS byte address `addr` + 4 * dw_off into registers dst[0..C)"""
+        if C == 1:
+            e(f"ds_read_b32 {v(dst[0])}, {addr} offset:{4 * dw_off}")
+        else:
+            for q in range(C // 2):
+                e(f"ds_read2_b32 v[{dst[2 * q]}:{dst[2 * q + 1]}], {addr} offset0:{dw_off + 2 * q} offset1:{dw_off + 2 * q + 1}")
+
+    def next_adv(dst):
+        """row advance of the NEXT column: rem += M; adv = rem >= N; rem -= adv ? N : 0; dst = adv ? step : 0 (bytes the b-window moves)"""
+        e(f"s_add_u32 {op['rem']}, {op['rem']}, {op['M']}")
+        e(f"s_cmp_ge_u32 {op['rem']}, {op['N']}")
+        e(f"s_cselect_b32 {op['st']}, {op['N']}, 0")
+        e(f"s_cselect_b32 {dst}, {op['step']}, 0")
+        e(f"s_sub_u32 {op['rem']}, {op['rem']}, {op['st']}")
+
+    # ---- prologue: constants, the windows of the first column ----
+    e("s_waitcnt lgkmcnt(0)")  # (nothing else of this wave's may be counted by the waits below)
+    e(f"v_mov_b32 {v(VINF)}, 0x501502f9")
+    e(f"v_mov_b32 {v(KHI)}, {v(VINF)}")
+    e(f"v_mov_b32 {v(KLO)}, {v(VINF)}")
+    e(f"v_mov_b32 {v(KLO2)}, {v(VINF)}")
+    # va = address of the window of column c0 + 6 (what the group's last column asks for): window(c) = va + 4 * (c0 + 6 - c)
+    read_window(P[0], op["va"], 7)      # window(c0 - 1)
+    read_window(P[1], op["va"], 6)      # window(c0)
+    next_adv(op["adv0"])                # the first column's own advance
+    e(f"v_add_u32 {op['vb']}, {op['adv0']}, {op['vb']}")
+    read_window(B[0], op["vb"], 0)
+    e("1:")
+    for kcol in range(6):
+        pp, pc, pn = P[kcol % 3], P[(kcol + 1) % 3], P[(kcol + 2) % 3]
+        bc, bn = B[kcol % 2], B[(kcol + 1) % 2]
+        adv, advn = op[f"adv{kcol % 2}"], op[f"adv{(kcol + 1) % 2}"]
+        # the next column: its advance, its windows
+        next_adv(advn)
+        e(f"v_add_u32 {op['vb']}, {advn}, {op['vb']}")
+        read_window(bn, op["vb"], 0)
+        read_window(pn, op["va"], 5 - kcol)
+        e(f"s_waitcnt lgkmcnt({2 * nd})")
+        e(f"s_cmp_eq_u32 {adv}, 0")
+        e(f"s_cbranch_scc1 2{kcol}f")
+        # ---- a column with a row advance: secondary X into d0, primary into d1 ----
+        e(f"v_mov_b32_dpp {v(KHI)}, {d1[0]} wave_shl:1 row_mask:0xf bank_mask:0xf")
+        for c in range(C):
+            e(f"v_sub_f32 {v(DIFF[c])}, {v(pp[c])}, {v(bc[c])}")
+        for c in range(C):  # ascending: X[c] reads d1[c], d1[c + 1] (untouched) and its own d0[c]
+            left = d1[c + 1] if c + 1 < C else v(KHI)
+            e(f"v_min3_f32 {d0[c]}, {d1[c]}, {left}, {d0[c]}")
+        for c in range(C):
+            e(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
+        for c in reversed(range(C)):  # (the last slot first: the shift below reads it)
+            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {op[f'ms{c}']}")
+        for c in range(C):
+            e(f"v_sub_f32 {v(DIFF[c])}, {v(pc[c])}, {v(bc[c])}")
+        if C == 1:
+            e("s_nop 0")  # (two wait states between the select that wrote d0[C-1] and the DPP that reads it: the subtraction is one)
+        e(f"v_mov_b32_dpp {v(KLO)}, {d0[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
+        for c in range(C):  # primary[c] reads X[c - 1], X[c] (d0: untouched here) and its own d1[c]
+            top = d0[c - 1] if c > 0 else v(KLO)
+            e(f"v_min3_f32 {d1[c]}, {top}, {d0[c]}, {d1[c]}")
+        for c in range(C):
+            e(f"v_add_f32 {d1[c]}, |{v(DIFF[c])}|, {d1[c]}")
+        for c in reversed(range(C)):
+            e(f"v_cndmask_b32_e64 {d1[c]}, {v(VINF)}, {d1[c]}, {op[f'mp{c}']}")
+        e(f"s_branch 3{kcol}f")
+        # ---- a column without: X = d1; the primary (X[p-1], X[p], d0[p-1]) into d0, then d0 <-> d1 ----
+        e(f"2{kcol}:")
+        e(f"v_mov_b32_dpp {v(KLO)}, {d1[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {v(KLO2)}, {d0[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
+        for c in range(C):
+            e(f"v_sub_f32 {v(DIFF[c])}, {v(pc[c])}, {v(bc[c])}")
+        for c in reversed(range(C)):  # descending: primary[c] reads d0[c - 1], not yet overwritten
+            top = d1[c - 1] if c > 0 else v(KLO)
+            tl = d0[c - 1] if c > 0 else v(KLO2)
+            e(f"v_min3_f32 {d0[c]}, {top}, {d1[c]}, {tl}")
+        for c in range(C):
+            e(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
+        for c in range(C):
+            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {op[f'mp{c}']}")
+        for c in range(C):
+            e(f"v_swap_b32 {d0[c]}, {d1[c]}")
+        e(f"3{kcol}:")
+    e(f"v_subrev_u32 {op['va']}, 24, {op['va']}")
+    e(f"s_sub_u32 {op['it']}, {op['it']}, 1")
+    e(f"s_cmp_lg_u32 {op['it']}, 0")
+    e("s_cbranch_scc1 1b")
+    e("s_waitcnt lgkmcnt(0)")
+    # (the advance computed for the column behind the last one is taken back: rem and vb describe the last column done)
+    e(f"v_subrev_u32 {op['vb']}, {op['adv0']}, {op['vb']}")
+    e(f"s_cmp_lg_u32 {op['adv0']}, 0")
+    e(f"s_cselect_b32 {op['st']}, {op['N']}, 0")
+    e(f"s_add_u32 {op['rem']}, {op['rem']}, {op['st']}")
+    e(f"s_sub_u32 {op['rem']}, {op['rem']}, {op['M']}")
+    body = "\n".join(f'        "{ln}\\n"' for ln in L)
+    outs = ", ".join([f'"+v"(d0[{c}])' for c in range(C)] + [f'"+v"(d1[{c}])' for c in range(C)] + ['"+v"(va)', '"+v"(vb)', '"+s"(rem)', '"+s"(iters)',
+                                                                                                     '"=&s"(t_adv0)', '"=&s"(t_adv1)', '"=&s"(t_st)'])
+    ins = ", ".join(['"s"(M)', '"s"(N)', '"s"(step)'] + [f'"s"(m_sec[{c}])' for c in range(C)] + [f'"s"(m_prim[{c}])' for c in range(C)])
+    clob = ", ".join(f'"v{r}"' for r in range(VBASE, last + 1)) + ', "scc", "memory"'
+    return f"""// {C} register(s) a lane: 6 * iters columns from column c0 on.  va: LDS byte address (this lane's) of the a-window of column c0 + 6; vb: of the
+// b-window at the centre row BEFORE column c0; rem: the Bresenham remainder before c0.  On return rem and vb describe the last column done.
+__device__ __forceinline__ void wband_loop_asm(float (&d0)[{C}], float (&d1)[{C}], uint32_t &va, uint32_t &vb, uint32_t &rem, uint32_t iters, const uint32_t M,
+                                               const uint32_t N, const lmask (&m_sec)[{C}], const lmask (&m_prim)[{C}])
+{{
+    uint32_t t_adv0, t_adv1, t_st;
+    const uint32_t step = 4u; // (a row advance moves the b-window by one element, whatever C is)
+    asm volatile(
+{body}
+        : {outs}
+        : {ins}
+        : {clob});
+}}
+"""
+
+
+def main():
+    out = ["// rawdtw_wband_asm.h -- GENERATED by scripts/gen_wband_asm.py (edit that, not this): the main loop of wband_gen<C> (rawdtw_dp.h).",
+           "#pragma once", "namespace rawdtw {", ""]
+    for C in (1, 2, 4):
+        out.append(gen(C))
+    out.append("} // namespace rawdtw")
+    path = os.path.join(ROOT, "rawalign_amd", "csrc", "rawdtw_wband_asm.h")
+    with open(path, "w") as f:
+        f.write("\n".join(out))
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
