@@ -1240,11 +1240,25 @@ __device__ __forceinline__ void wband_gen(const DevJob &jb, const int lane, cons
         m_prim[c] = __ballot(p >= SH && p < SH + P);
     }
     float keep_hi = kInf, keep_lo = kInf, keep_lo2 = kInf;
-    // a segment's columns: both stretches (+ a window each, + a few floats of slack: the loop asks for the windows of the
-    // column behind its last one) in half of the wave's piece of LDS each
-    const int half = (int)(lds_floats / 2u) & ~3;
+    // the wave's piece of LDS: the DP state's way into and out of the hand-scheduled loop (2 C floats a lane), then a segment's
+    // columns: both stretches (+ a window each, + a few floats of slack: the loop asks for the windows of the column behind its
+    // last one) in half of the rest each
+    float *lds_st = lds + lane * 2 * C;
+    const int half = (int)((lds_floats - 128u * C) / 2u) & ~3;
     const int seg = half - W - 12;
-    float *lds_a = lds + 4, *lds_b = lds + half;
+    float *lds_a = lds + 128 * C + 4, *lds_b = lds + 128 * C + half;
+    WbandMasks wm;
+    {   // register c's lanes inside [0, H): l C + c < H  <=>  l <= H / C for c < H % C, l < H / C otherwise
+        auto lanes_below = [](const int n) { // (in scalar registers: the loop takes them as such)
+            const unsigned long long m = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+            return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+        };
+        const int Hp = SH + P;
+        wm.sec_lo = lanes_below(S / C); wm.sec_hi = lanes_below(S / C + 1); wm.sec_c0 = (uint32_t)(S % C);
+        wm.prim_lo = lanes_below(Hp / C); wm.prim_hi = lanes_below(Hp / C + 1); wm.prim_c0 = (uint32_t)(Hp % C);
+        wm.prim_0 = lanes_below(0 < Hp % C ? Hp / C + 1 : Hp / C) & (SH ? ~1ull : ~0ull); // (the primaries start at slot SH)
+        wm.prim_0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wm.prim_0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wm.prim_0);
+    }
     int row = 0;
     uint32_t rem = 0;
     int col = 1;
@@ -1279,8 +1293,12 @@ __device__ __forceinline__ void wband_gen(const DevJob &jb, const int lane, cons
         if (iters) { // the rest, six columns a turn: the hand-scheduled loop
             uint32_t va = (uint32_t)(size_t)(__attribute__((address_space(3))) const float *)(wa - (col + 6));
             uint32_t vb = (uint32_t)(size_t)(__attribute__((address_space(3))) const float *)(wb + row);
-            const uint32_t vb0 = vb;
-            wband_loop_asm(d0, d1, va, vb, rem, iters, M, N, m_sec, m_prim);
+            const uint32_t vb0 = vb, vst = (uint32_t)(size_t)(__attribute__((address_space(3))) const float *)lds_st;
+#pragma unroll
+            for (int c = 0; c < C; c++) { lds_st[c] = d0[c]; lds_st[C + c] = d1[c]; }
+            wband_loop_asm<C>(va, vb, vst, rem, iters, M, N, wm);
+#pragma unroll
+            for (int c = 0; c < C; c++) { d0[c] = lds_st[c]; d1[c] = lds_st[C + c]; }
             col += 6 * (int)iters;
             row += (int)(__builtin_amdgcn_readfirstlane((int)(vb - vb0)) / 4);
         }
@@ -1427,7 +1445,7 @@ __device__ __forceinline__ void grp_wave(const DevJob *__restrict__ jobs, uint32
 // variant is picked per job (wave-uniform).  Jobs are sorted longest first, so the few long jobs
 // that bound the launch's duration start first and the many short ones fill in around them --
 // as separate launches they were separate long poles on separate streams.
-constexpr uint32_t kWbandLdsFloats = 1536; // a wave's piece of LDS (6 KB): segments of 500 columns for one-register bands, 252 for four
+constexpr uint32_t kWbandLdsFloats = 2048; // a wave's piece of LDS (8 KB): the DP state's 128 C floats + segments of 940 columns for one-register bands, 500 for four
 __device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const float *__restrict__ ev,
                                                const float *__restrict__ ref, float *__restrict__ out, float *lds, uint32_t lds_floats = kWbandLdsFloats)
 {

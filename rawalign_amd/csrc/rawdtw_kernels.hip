@@ -295,6 +295,15 @@ __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ job
     wreg_body<C>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
 }
 
+// bands of 257 .. 512 slots (global-mode chains of a few thousand events at banded=0.10): the LDS-window body with eight registers a lane
+constexpr uint32_t kWband8LdsFloats = 128u * 8u + 2u * 1200u;
+__global__ __launch_bounds__(64) void k_band_wband8(const DevJob *__restrict__ jobs, const float *__restrict__ ev, const float *__restrict__ ref,
+                                                    float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float s_w[kWband8LdsFloats];
+    wband_gen<8>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out, s_w, kWband8LdsFloats);
+}
+
 __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict__ jobs,
                                                         const float *__restrict__ ev,
                                                         const float *__restrict__ ref,
@@ -883,7 +892,9 @@ hipError_t launch_band_wreg(int chunks, const DevJob *jobs, uint64_t count, cons
     case 1: return launch_wreg_c<1>(jobs, count, ev, ref, out, s);
     case 2: return launch_wreg_c<2>(jobs, count, ev, ref, out, s);
     case 4: return launch_wreg_c<4>(jobs, count, ev, ref, out, s);
-    case 8: return launch_wreg_c<8>(jobs, count, ev, ref, out, s);
+    case 8:
+        hipLaunchKernelGGL(k_band_wband8, dim3((uint32_t)count), dim3(64), 0, s, jobs, ev, ref, out);
+        return hipGetLastError();
     case 16: return launch_wreg_c<16>(jobs, count, ev, ref, out, s);
     case 32: return launch_wreg_c<32>(jobs, count, ev, ref, out, s);
     default: return hipErrorInvalidValue;

@@ -1005,6 +1005,7 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
     const uint32_t dbg = a.debug;
     constexpr uint32_t kWaves = 4;
     __shared__ __attribute__((aligned(16))) float s_w[kWaves][kWbandLdsFloats]; // the wave-per-job bands' operand windows (wband_gen)
+    __shared__ uint32_t s_next;                                                 // the workgroup's next item
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = (uint32_t)tid >> 6;
     // (a batch the scan declined is redone through the job list)
@@ -1023,16 +1024,23 @@ __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
         for (uint32_t c = kClsM0; c < kClsM0 + kClsMCount; c++) n_m += a.cnt[kCntCls0 + c];
         // item order = list order: wave-per-job (longest first), 16-lane groups, lane-per-job (4 slots, then 8; by length)
         const uint64_t it_g16 = (n_g16 + 3) / 4, it_l = (n_l + 63) / 64, it_m = (n_m + 63) / 64, items = n_w + it_g16 + it_l + it_m;
-        // The waves that draw the long items (a wave-per-job or 16-lane item: 30..150 us) take the short ones as well, in
-        // further rounds: their workgroups start on tiles late anyway, and every other workgroup starts at once.
-        // (debug 2048: all waves of the grid share the items, one round.)
-        const uint32_t all_waves = gridDim.x * kWaves, widx = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + wv);
-        const uint32_t side_waves = (dbg & 2048u) ? all_waves : (uint32_t)min<uint64_t>(all_waves, max<uint64_t>((n_w + it_g16 + 3) & ~3ull, 64));
+        // Items are dealt to the workgroups like a snake (workgroup b: items b, 2 G - 1 - b, 2 G + b, ...: the one that drew the
+        // longest item of a turn draws the shortest of the next) and inside a workgroup its four waves pull the workgroup's items
+        // from a counter in LDS: the wave that sits on a long job (one job of 950 columns is 70 us, a short item 1-2 us) takes no
+        // other, its three neighbours share what the workgroup was dealt.  (Dealt to the WAVES by index, the wave with the
+        // batch's longest job also owned some twenty-five short items: 35 us behind a 70 us job.)
+        const uint32_t G = gridDim.x;
         const uint32_t n_items = (uint32_t)min<uint64_t>(items, 0xffffffffull);
-        // dealt like a snake: the wave that drew the longest item of a round draws the shortest of the next
-        // (item r * S + w in even rounds, r * S + S - 1 - w in odd ones: the stride alternates between 2S - 1 - 2w and 1 + 2w)
-        for (uint32_t it = widx < side_waves ? widx : n_items, step = (dbg & 4096u) ? side_waves : 2u * side_waves - 1u - 2u * widx; it < n_items;
-             it += step, step = 2u * side_waves - step) {
+        if (tid == 0) s_next = 0;
+        __syncthreads();
+        for (;;) {
+            uint32_t kq = 0;
+            if (lane == 0) kq = atomicAdd(&s_next, 1u);
+            kq = (uint32_t)__builtin_amdgcn_readfirstlane((int)kq);
+            const uint64_t first = (uint64_t)kq * G;
+            if (first >= n_items) break;
+            const uint64_t it = first + ((kq & 1u) ? G - 1u - blockIdx.x : blockIdx.x);
+            if (it >= n_items) continue; // (the last, partial turn)
             if (it < n_w) {
                 if (dbg & 32u) continue;
                 // the longest jobs bound the launch: a job of hundreds of columns is one dependent chain, and shares its

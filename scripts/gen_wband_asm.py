@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
 """Writes rawalign_amd/csrc/rawdtw_wband_asm.h: the main loop of the wave-per-job band body (wband_gen<C>, rawdtw_dp.h) as
-hand-scheduled gfx950 assembly, for C = 1, 2, 4 registers a lane.
+hand-scheduled gfx950 assembly, for C = 1, 2, 4, 8 registers a lane (bands of up to 64 C slots).
 
-Why assembly: the loop is one wave's dependency chain, alone on its SIMD -- every instruction costs an issue slot of ~7 clocks
-whatever it is, so the column's time is its instruction COUNT.  Left to the compiler the loop carried a dozen register copies
-a column (the three roles of the a-window, the two of the b-window and the two DP buffers meet in phi nodes), turned the
-uniform row-advance branch into per-lane selects and put a fill move in front of every DPP shift.  Here:
+Why assembly: a long band is one wave's dependency chain, alone on its SIMD -- every instruction costs an issue slot of ~5
+clocks whatever it is, so the column's time is its instruction COUNT.  Left to the compiler the loop carried a dozen register
+copies a column (the three roles of the a-window, the two of the b-window and the two DP buffers meet in phi nodes), turned
+the uniform row-advance branch into per-lane selects and put a fill move in front of every DPP shift.  Here:
 
   * six columns a loop iteration: the a-window's roles (previous / this / next column) rotate over three register sets, the
     b-window's (this / next) over two -- after six columns every value is back in the register it started in: no copies;
   * the DP buffers are updated in place: the secondary antidiagonal X overwrites d0 (its own top-left operand), the primary
-    overwrites d1; a column without a row advance computes its primary into d0 and swaps the two (v_swap_b32);
+    overwrites d1; a column without a row advance (the rare kind: out of line, behind the loop) computes its primary into d0
+    and swaps the two (v_swap_b32);
   * the windows of column c + 1 are asked for (ds_read, immediate offsets within the six columns) while column c is computed;
     s_waitcnt lgkmcnt(n) leaves exactly those in flight;
   * the two DPP shifts a column write into registers whose fill lane holds 1e10 for good (bound_ctrl off: a lane without a
     source keeps the destination's value);
-  * the instructions between a value's last write and its DPP read are chosen to cover the two wait states the hardware wants
-    there (the assembler does not insert them inside inline assembly).
+  * two slots' operand differences are one packed subtract (v_pk_add_f32 with the second operand negated);
+  * the instructions between a value's last write and its DPP read cover the two wait states the hardware wants there (the
+    assembler does not insert them inside inline assembly).
+
+The DP state (d0, d1: 2 C floats a lane) enters and leaves through the wave's piece of LDS -- inline assembly takes at most
+thirty operands -- and the extent masks of the 2 C slot registers are made inside from three lane masks a kind: with the
+blocked layout (lane l holds slots l C .. l C + C - 1) a register's lanes inside an extent [lo, hi) are `lanes <= hi / C` for
+the registers below hi % C and `lanes < hi / C` for the others (and the primaries' lo = 1 takes lane 0 out of register 0).
 
 Cells, neighbours and masks are those of wband_step<C, false> / wreg_gen_step (dtw.cpp:361-485): bit-identical costs
 (tests/test_gpu_parity.py::test_random_wave_band, tests/test_stream_path.py: the wave-per-job bands at the register layouts'
-edges)."""
+edges, scripts/experiments/wband_dbg.py)."""
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VBASE = 96  # first scratch VGPR of the block (clobbered; the kernels that inline it use fewer than this many otherwise)
+VBASE = 64   # first scratch VGPR of the block (clobbered): above what the C++ around it needs, so that the kernels' register count stays low
+SBASE = 36   # first scratch SGPR of the block (clobbered): the 2 C extent masks
 
 
 def gen(C):
@@ -33,26 +41,22 @@ def gen(C):
     B = [[VBASE + 3 * C + s * C + c for c in range(C)] for s in range(2)]  # b-window register sets
     t = VBASE + 5 * C
     DIFF = [t + c for c in range(C)]
-    KHI, KLO, KLO2, VINF = t + C, t + C + 1, t + C + 2, t + C + 3
-    last = VINF
-    # operands: %0.. d0[C], d1[C] (+v) ; then va, vb (+v) ; rem (+s), iters (+s) ; M, N (s) ; masks sec[C], prim[C] (s, 64-bit) ; temps adv0, adv1, st (=&s)
-    op = {}
-    k = 0
-    for name in [f"d0_{c}" for c in range(C)] + [f"d1_{c}" for c in range(C)] + ["va", "vb", "rem", "it"]:
-        op[name] = f"%{k}"; k += 1
-    n_io = k
-    for name in ["adv0", "adv1", "st"]:
-        op[name] = f"%{k}"; k += 1
-    n_out = k
-    for name in ["M", "N", "step"] + [f"ms{c}" for c in range(C)] + [f"mp{c}" for c in range(C)]:
-        op[name] = f"%{k}"; k += 1
-    L = []
-    e = L.append
+    D0 = [t + C + c for c in range(C)]
+    D1 = [t + 2 * C + c for c in range(C)]
+    KHI, KLO, KLO2, VINF = t + 3 * C, t + 3 * C + 1, t + 3 * C + 2, t + 3 * C + 3
+    last_v = VINF
+    MS = [SBASE + 2 * c for c in range(C)]              # s[MS[c] : MS[c] + 1]: the secondaries' mask of register c
+    MP = [SBASE + 2 * C + 2 * c for c in range(C)]
+    last_s = SBASE + 4 * C - 1
+    names = ["va", "vb", "rem", "it", "adv0", "adv1", "st", "vst", "M", "N", "step", "s_lo", "s_hi", "s_c0", "p_lo", "p_hi", "p_c0", "p_0"]
+    op = {n: f"%{k}" for k, n in enumerate(names)}
     v = lambda r: f"v{r}"  # noqa: E731
-    d0 = [op[f"d0_{c}"] for c in range(C)]
-    d1 = [op[f"d1_{c}"] for c in range(C)]
+    d0 = [v(r) for r in D0]
+    d1 = [v(r) for r in D1]
+    sm = lambda r: f"s[{r}:{r + 1}]"  # noqa: E731
+    main, tail = [], []
 
-    def read_window(dst, addr, dw_off):
+    def read_window(e, dst, addr, dw_off):
         """C consecutive dwords at LDS byte address `addr` + 4 * dw_off into registers dst[0..C)"""
         if C == 1:
             e(f"ds_read_b32 {v(dst[0])}, {addr} offset:{4 * dw_off}")
@@ -60,52 +64,69 @@ def gen(C):
             for q in range(C // 2):
                 e(f"ds_read2_b32 v[{dst[2 * q]}:{dst[2 * q + 1]}], {addr} offset0:{dw_off + 2 * q} offset1:{dw_off + 2 * q + 1}")
 
-    def next_adv(dst):
-        """row advance of the NEXT column: rem += M; adv = rem >= N; rem -= adv ? N : 0; dst = adv ? step : 0 (bytes the b-window moves)"""
+    def diffs(e, a, b):
+        """DIFF[c] = a[c] - b[c]"""
+        if C == 1:
+            e(f"v_sub_f32 {v(DIFF[0])}, {v(a[0])}, {v(b[0])}")
+        else:
+            for q in range(C // 2):
+                e(f"v_pk_add_f32 v[{DIFF[2 * q]}:{DIFF[2 * q + 1]}], v[{a[2 * q]}:{a[2 * q + 1]}], v[{b[2 * q]}:{b[2 * q + 1]}] neg_lo:[0,1] neg_hi:[0,1]")
+
+    def next_adv(e, dst):
+        """row advance of the NEXT column: rem += M; adv = rem >= N; rem -= adv ? N : 0; dst = adv ? 4 : 0 (bytes the b-window moves)"""
         e(f"s_add_u32 {op['rem']}, {op['rem']}, {op['M']}")
         e(f"s_cmp_ge_u32 {op['rem']}, {op['N']}")
         e(f"s_cselect_b32 {op['st']}, {op['N']}, 0")
         e(f"s_cselect_b32 {dst}, {op['step']}, 0")
         e(f"s_sub_u32 {op['rem']}, {op['rem']}, {op['st']}")
 
-    # ---- prologue: constants, the windows of the first column ----
+    e = main.append
+    # ---- prologue: the masks, constants, the DP state, the windows of the first column ----
     e("s_waitcnt lgkmcnt(0)")  # (nothing else of this wave's may be counted by the waits below)
+    for c in range(C):
+        e(f"s_cmp_lt_u32 {c}, {op['s_c0']}")
+        e(f"s_cselect_b64 {sm(MS[c])}, {op['s_hi']}, {op['s_lo']}")
+        if c == 0:
+            e(f"s_mov_b64 {sm(MP[0])}, {op['p_0']}")
+        else:
+            e(f"s_cmp_lt_u32 {c}, {op['p_c0']}")
+            e(f"s_cselect_b64 {sm(MP[c])}, {op['p_hi']}, {op['p_lo']}")
     e(f"v_mov_b32 {v(VINF)}, 0x501502f9")
     e(f"v_mov_b32 {v(KHI)}, {v(VINF)}")
     e(f"v_mov_b32 {v(KLO)}, {v(VINF)}")
     e(f"v_mov_b32 {v(KLO2)}, {v(VINF)}")
+    read_window(e, D0, op["vst"], 0)
+    read_window(e, D1, op["vst"], C)
     # va = address of the window of column c0 + 6 (what the group's last column asks for): window(c) = va + 4 * (c0 + 6 - c)
-    read_window(P[0], op["va"], 7)      # window(c0 - 1)
-    read_window(P[1], op["va"], 6)      # window(c0)
-    next_adv(op["adv0"])                # the first column's own advance
+    read_window(e, P[0], op["va"], 7)      # window(c0 - 1)
+    read_window(e, P[1], op["va"], 6)      # window(c0)
+    next_adv(e, op["adv0"])                # the first column's own advance
     e(f"v_add_u32 {op['vb']}, {op['adv0']}, {op['vb']}")
-    read_window(B[0], op["vb"], 0)
+    read_window(e, B[0], op["vb"], 0)
     e("1:")
     for kcol in range(6):
         pp, pc, pn = P[kcol % 3], P[(kcol + 1) % 3], P[(kcol + 2) % 3]
         bc, bn = B[kcol % 2], B[(kcol + 1) % 2]
         adv, advn = op[f"adv{kcol % 2}"], op[f"adv{(kcol + 1) % 2}"]
         # the next column: its advance, its windows
-        next_adv(advn)
+        next_adv(e, advn)
         e(f"v_add_u32 {op['vb']}, {advn}, {op['vb']}")
-        read_window(bn, op["vb"], 0)
-        read_window(pn, op["va"], 5 - kcol)
+        read_window(e, bn, op["vb"], 0)
+        read_window(e, pn, op["va"], 5 - kcol)
         e(f"s_waitcnt lgkmcnt({2 * nd})")
         e(f"s_cmp_eq_u32 {adv}, 0")
         e(f"s_cbranch_scc1 2{kcol}f")
         # ---- a column with a row advance: secondary X into d0, primary into d1 ----
         e(f"v_mov_b32_dpp {v(KHI)}, {d1[0]} wave_shl:1 row_mask:0xf bank_mask:0xf")
-        for c in range(C):
-            e(f"v_sub_f32 {v(DIFF[c])}, {v(pp[c])}, {v(bc[c])}")
+        diffs(e, pp, bc)
         for c in range(C):  # ascending: X[c] reads d1[c], d1[c + 1] (untouched) and its own d0[c]
             left = d1[c + 1] if c + 1 < C else v(KHI)
             e(f"v_min3_f32 {d0[c]}, {d1[c]}, {left}, {d0[c]}")
         for c in range(C):
             e(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
         for c in reversed(range(C)):  # (the last slot first: the shift below reads it)
-            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {op[f'ms{c}']}")
-        for c in range(C):
-            e(f"v_sub_f32 {v(DIFF[c])}, {v(pc[c])}, {v(bc[c])}")
+            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {sm(MS[c])}")
+        diffs(e, pc, bc)
         if C == 1:
             e("s_nop 0")  # (two wait states between the select that wrote d0[C-1] and the DPP that reads it: the subtraction is one)
         e(f"v_mov_b32_dpp {v(KLO)}, {d0[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
@@ -115,45 +136,58 @@ def gen(C):
         for c in range(C):
             e(f"v_add_f32 {d1[c]}, |{v(DIFF[c])}|, {d1[c]}")
         for c in reversed(range(C)):
-            e(f"v_cndmask_b32_e64 {d1[c]}, {v(VINF)}, {d1[c]}, {op[f'mp{c}']}")
-        e(f"s_branch 3{kcol}f")
-        # ---- a column without: X = d1; the primary (X[p-1], X[p], d0[p-1]) into d0, then d0 <-> d1 ----
-        e(f"2{kcol}:")
-        e(f"v_mov_b32_dpp {v(KLO)}, {d1[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
-        e(f"v_mov_b32_dpp {v(KLO2)}, {d0[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
-        for c in range(C):
-            e(f"v_sub_f32 {v(DIFF[c])}, {v(pc[c])}, {v(bc[c])}")
+            e(f"v_cndmask_b32_e64 {d1[c]}, {v(VINF)}, {d1[c]}, {sm(MP[c])}")
+        e(f"3{kcol}:")
+        # ---- a column without (behind the loop): X = d1; the primary (X[p-1], X[p], d0[p-1]) into d0, then d0 <-> d1 ----
+        T = tail.append
+        T(f"2{kcol}:")
+        T(f"v_mov_b32_dpp {v(KLO)}, {d1[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
+        T(f"v_mov_b32_dpp {v(KLO2)}, {d0[C - 1]} wave_shr:1 row_mask:0xf bank_mask:0xf")
+        diffs(T, pc, bc)
         for c in reversed(range(C)):  # descending: primary[c] reads d0[c - 1], not yet overwritten
             top = d1[c - 1] if c > 0 else v(KLO)
             tl = d0[c - 1] if c > 0 else v(KLO2)
-            e(f"v_min3_f32 {d0[c]}, {top}, {d1[c]}, {tl}")
+            T(f"v_min3_f32 {d0[c]}, {top}, {d1[c]}, {tl}")
         for c in range(C):
-            e(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
+            T(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
         for c in range(C):
-            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {op[f'mp{c}']}")
+            T(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {sm(MP[c])}")
         for c in range(C):
-            e(f"v_swap_b32 {d0[c]}, {d1[c]}")
-        e(f"3{kcol}:")
+            T(f"v_swap_b32 {d0[c]}, {d1[c]}")
+        T(f"s_branch 3{kcol}b")
     e(f"v_subrev_u32 {op['va']}, 24, {op['va']}")
     e(f"s_sub_u32 {op['it']}, {op['it']}, 1")
     e(f"s_cmp_lg_u32 {op['it']}, 0")
     e("s_cbranch_scc1 1b")
+    e("s_branch 9f")
+    main.extend(tail)
+    e("9:")
     e("s_waitcnt lgkmcnt(0)")
+    # the DP state back where it came from
+    if C == 1:
+        e(f"ds_write_b32 {op['vst']}, {d0[0]}")
+        e(f"ds_write_b32 {op['vst']}, {d1[0]} offset:4")
+    else:
+        for q in range(C // 2):
+            e(f"ds_write2_b32 {op['vst']}, {d0[2 * q]}, {d0[2 * q + 1]} offset0:{2 * q} offset1:{2 * q + 1}")
+        for q in range(C // 2):
+            e(f"ds_write2_b32 {op['vst']}, {d1[2 * q]}, {d1[2 * q + 1]} offset0:{C + 2 * q} offset1:{C + 2 * q + 1}")
     # (the advance computed for the column behind the last one is taken back: rem and vb describe the last column done)
     e(f"v_subrev_u32 {op['vb']}, {op['adv0']}, {op['vb']}")
     e(f"s_cmp_lg_u32 {op['adv0']}, 0")
     e(f"s_cselect_b32 {op['st']}, {op['N']}, 0")
     e(f"s_add_u32 {op['rem']}, {op['rem']}, {op['st']}")
     e(f"s_sub_u32 {op['rem']}, {op['rem']}, {op['M']}")
-    body = "\n".join(f'        "{ln}\\n"' for ln in L)
-    outs = ", ".join([f'"+v"(d0[{c}])' for c in range(C)] + [f'"+v"(d1[{c}])' for c in range(C)] + ['"+v"(va)', '"+v"(vb)', '"+s"(rem)', '"+s"(iters)',
-                                                                                                     '"=&s"(t_adv0)', '"=&s"(t_adv1)', '"=&s"(t_st)'])
-    ins = ", ".join(['"s"(M)', '"s"(N)', '"s"(step)'] + [f'"s"(m_sec[{c}])' for c in range(C)] + [f'"s"(m_prim[{c}])' for c in range(C)])
-    clob = ", ".join(f'"v{r}"' for r in range(VBASE, last + 1)) + ', "scc", "memory"'
+    e("s_waitcnt lgkmcnt(0)")
+    body = "\n".join(f'        "{ln}\\n"' for ln in main)
+    outs = '"+v"(va), "+v"(vb), "+s"(rem), "+s"(iters), "=&s"(t_adv0), "=&s"(t_adv1), "=&s"(t_st)'
+    ins = '"v"(vstate), "s"(M), "s"(N), "s"(step), "s"(m.sec_lo), "s"(m.sec_hi), "s"(m.sec_c0), "s"(m.prim_lo), "s"(m.prim_hi), "s"(m.prim_c0), "s"(m.prim_0)'
+    clob = ", ".join(f'"v{r}"' for r in range(VBASE, last_v + 1)) + ", " + ", ".join(f'"s{r}"' for r in range(SBASE, last_s + 1)) + ', "scc", "memory"'
     return f"""// {C} register(s) a lane: 6 * iters columns from column c0 on.  va: LDS byte address (this lane's) of the a-window of column c0 + 6; vb: of the
-// b-window at the centre row BEFORE column c0; rem: the Bresenham remainder before c0.  On return rem and vb describe the last column done.
-__device__ __forceinline__ void wband_loop_asm(float (&d0)[{C}], float (&d1)[{C}], uint32_t &va, uint32_t &vb, uint32_t &rem, uint32_t iters, const uint32_t M,
-                                               const uint32_t N, const lmask (&m_sec)[{C}], const lmask (&m_prim)[{C}])
+// b-window at the centre row BEFORE column c0; vstate: of this lane's DP state (d0[0..{C}), d1[0..{C}): read at the start, written back at the end);
+// rem: the Bresenham remainder before c0.  On return rem and vb describe the last column done.
+template <> __device__ __forceinline__ void wband_loop_asm<{C}>(uint32_t &va, uint32_t &vb, const uint32_t vstate, uint32_t &rem, uint32_t iters, const uint32_t M,
+                                                              const uint32_t N, const WbandMasks &m)
 {{
     uint32_t t_adv0, t_adv1, t_st;
     const uint32_t step = 4u; // (a row advance moves the b-window by one element, whatever C is)
@@ -168,8 +202,13 @@ __device__ __forceinline__ void wband_loop_asm(float (&d0)[{C}], float (&d1)[{C}
 
 def main():
     out = ["// rawdtw_wband_asm.h -- GENERATED by scripts/gen_wband_asm.py (edit that, not this): the main loop of wband_gen<C> (rawdtw_dp.h).",
-           "#pragma once", "namespace rawdtw {", ""]
-    for C in (1, 2, 4):
+           "#pragma once", "namespace rawdtw {", "",
+           "// the extents of a band's antidiagonals as lane masks of the blocked layout (lane l holds slots l C .. l C + C - 1): register c's lanes",
+           "// inside the secondaries' [0, S) are sec_hi for c < sec_c0 and sec_lo otherwise; the primaries' [SH, SH + P) likewise, register 0 apart",
+           "struct WbandMasks { unsigned long long sec_lo, sec_hi, prim_lo, prim_hi, prim_0; uint32_t sec_c0, prim_c0; };",
+           "template <int C> __device__ __forceinline__ void wband_loop_asm(uint32_t &va, uint32_t &vb, const uint32_t vstate, uint32_t &rem, uint32_t iters,",
+           "                                                              const uint32_t M, const uint32_t N, const WbandMasks &m);", ""]
+    for C in (1, 2, 4, 8):
         out.append(gen(C))
     out.append("} // namespace rawdtw")
     path = os.path.join(ROOT, "rawalign_amd", "csrc", "rawdtw_wband_asm.h")
