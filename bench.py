@@ -213,15 +213,16 @@ def vp(a):
     return C.c_void_p(a.ctypes.data)
 
 
-CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
+CARRY_DTYPE = np.dtype([("prev_src", "<u8"), ("parts", "<u4"), ("flags", "<u4"), ("start_t", "<u4"), ("start_q", "<u4")])  # rawdtw_carry_t
 
 
 def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
     """SURVEY.md 8(f-4) at the bench batch's scale: `n_rounds` chunk rounds of one batch of reads (synth.make_rounds), each
     submitted from scratch as the reference does (rmap.cpp:516-517: rawdtw_batch_submit, the whole anchor lists) and carried
-    (rawdtw_batch_submit_carry: per chain the host names the chain it continues and the leading parts that did not change --
-    rawdtw_round_match_chains, timed on its own -- only the NEW anchors are handed over, the device copies one stretch of
-    anchors and costs per chain out of the previous batch's workspace and scores the rest).  One context, rounds in sequence
+    (rawdtw_batch_submit_carry: per chain the host says how many leading parts did not change and where their costs lie
+    in the batch before -- rawdtw_round_match_chains, timed on its own -- only the NEW anchors and one junction a chain are
+    handed over, the device's scan, planning and DTW launches run on that short list, and one gather launch lays every
+    chain's costs out in full for the fold).  One context, rounds in sequence
     (a round needs the one before); wall time per round from submit to fetched scores, (a) with the hand-over arrays in
     pinned host memory -- what a mapper's round is -- and (b) with them resident in HBM, as in the `value` loop."""
     from rawalign_amd import synth
@@ -267,8 +268,9 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
                 engine.sync()
                 t0 = time.perf_counter()
                 if mode == "carried" and prev is not None:
-                    engine._check(lib.rawdtw_batch_submit_carry(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["new_off"]),
-                                                                P(d["t_new"]) if resident else vp(d["new_anchors"]), A[1], A[2], prev, vp(d["carry"]), C.byref(h)))
+                    engine._check(lib.rawdtw_batch_submit_carry(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["anchors"]),
+                                                                vp(d["new_off"]), P(d["t_new"]) if resident else vp(d["new_anchors"]), A[1], A[2], prev,
+                                                                vp(d["carry"]), C.byref(h)))
                 else:
                     engine._check(lib.rawdtw_batch_submit(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), A[0], A[1], A[2], C.byref(h)))
                 engine._check(lib.rawdtw_batch_fetch(engine._ctx, h, vp(score), vp(keep), None))
@@ -306,8 +308,9 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
                                    "note": "rounds 2.. only (round 1 has no predecessor and is the same submission in both modes)"},
                 "scores_identical_to_scratch": bool(same),
                 "note": "`*_ms`: hand-over arrays resident in HBM (no PCIe in either mode); `*_host_ms`: from pinned host memory, as a "
-                        "mapper's round hands them over.  A carried round sends its new anchors only (anchors_handed_over) and scores "
-                        "only the parts they bring (k_carry copies the rest's costs, one stretch a chain); the host's matching of the "
+                        "mapper's round hands them over.  A carried round sends its new anchors and a junction a chain "
+                        "(anchors_handed_over), plans and scores only the parts they bring, and gathers the rest's costs out of the batch before "
+                        "(k_gather: one stretch a chain); the host's matching of the "
                         "chains (match_ms_host_1_thread, rawdtw_round_match_chains on one thread; the mapper does it per read on "
                         "its pool) is outside these times"})
     return out

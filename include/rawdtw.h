@@ -442,27 +442,33 @@ int rawdtw_batch_submit_compact(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, 
  *
  * rawdtw_round_match_chains (pure host code) finds, per chain of the new round, the chain of the round before it continues
  * (same read, same bases, same start anchor, the longest common tail) and VALIDATES the common tail anchor by anchor:
- * carry[c] = {that chain, the number of leading parts taken over}; it also packs the anchors that are NOT taken over --
- * per chain the first n_anchors - (parts + 1) entries of its list (all of them when parts == 0) -- into new_anchors
- * (chain c owns new_anchors[new_off[c] .. new_off[c + 1])).  A part that was not its chain's last then and is now cannot be
- * taken over (exclude_last_element, rmap.cpp:270: there is no exact way back) and is counted out; a part that was the last
- * then and is not now loses its last cell's distance on the device exactly as the DTW functions take it off (dtw.cpp:514-519).
+ * carry[c] says how many leading parts are taken over and where their costs lie in the previous batch.  It also packs what
+ * the device still needs of the chain's list -- its first n_anchors - (parts + 1) entries (the NEW anchors) followed, when
+ * parts > 0, by ONE more entry, the junction (the end anchor of the carried stretch: the new part behind it starts there) --
+ * into new_anchors (chain c owns new_anchors[new_off[c] .. new_off[c + 1])).  A part that was not its chain's last then
+ * and is now cannot be taken over (exclude_last_element, rmap.cpp:270: there is no exact way back) and is counted out; a part
+ * that was the last then and is not now loses its last cell's distance on the device exactly as the DTW functions take it off
+ * (dtw.cpp:514-519).
  *
- * rawdtw_batch_submit_carry = rawdtw_batch_submit for such a round: ONLY the new anchors cross the bus; the device copies,
- * per chain, one contiguous stretch of anchors and one of costs out of `prev`'s workspace (k_carry), and scans, plans and
- * scores the new parts only.  Results are bit-identical to scoring everything again.  Preconditions (else
- * RAWDTW_ERR_UNSUPPORTED, nothing enqueued: submit the round whole with rawdtw_batch_submit): `prev` is a batch of this
- * context that was scored on the device-planned path with the same options (rawdtw_batch_can_carry tells), has been run
- * and is not destroyed.  carry[] is trusted as rawdtw_round_match_chains wrote it -- the device only checks that the counts
- * add up and that the named chain has the same bases (a mismatch makes the batch fall back to scoring everything from the
- * assembled lists); a caller that invents it gets wrong costs.  All host arrays must stay valid until the batch is fetched;
- * `prev` until this batch is fetched or destroyed (its device arrays are read by this batch's first launch).
- * rawdtw_batch_round_stats (waits for the scan): the parts scored and the parts taken over. ---- */
+ * rawdtw_batch_submit_carry = rawdtw_batch_submit for such a round.  ONLY the new anchors and the junctions cross the bus, and
+ * the device's whole planning and scoring pipeline (scan, side list, passes, DTW launches) runs on that SHORT list -- a carried
+ * round costs what its new parts cost; one gather launch then lays every chain's costs out in full (the carried stretch out
+ * of `prev`'s cost array, one contiguous copy a chain, then the new parts') for the unchanged fold and accept/cut loop.
+ * Results are bit-identical to scoring everything again.  Preconditions (else RAWDTW_ERR_UNSUPPORTED, nothing enqueued:
+ * submit the round whole with rawdtw_batch_submit): `prev` is a batch of this context that was scored on the device-planned
+ * path with the same options (rawdtw_batch_can_carry tells), has been run and is not destroyed.  carry[] is trusted as
+ * rawdtw_round_match_chains wrote it -- the device only checks that the counts add up and stay inside `prev`'s cost array; a
+ * caller that invents it gets wrong costs.  `anchor_off` are the offsets of the FULL lists (n_chains + 1 entries); `anchors` the
+ * full lists themselves on the host, read only if the batch has to be redone through the job-list path (a band nobody takes,
+ * a list over a capacity): they may be NULL, the fetch then fails with RAWDTW_ERR_UNSUPPORTED instead.  All host arrays must
+ * stay valid until the batch is fetched; `prev` until this batch is fetched or destroyed (its cost array is read by this
+ * batch's gather launch).  rawdtw_batch_round_stats: the parts scored and the parts taken over. ---- */
 #define RAWDTW_NO_CHAIN (~(uint64_t)0)
 typedef struct {
-    uint64_t prev_chain; /* chain of the previous batch, or RAWDTW_NO_CHAIN */
-    uint32_t parts;      /* leading parts (from the chain's start) whose costs are taken over; 0: none */
-    uint32_t reserved;   /* 0 */
+    uint64_t prev_src;     /* index in the previous batch's (full) anchor list of the carried stretch's first entry; RAWDTW_NO_CHAIN: none */
+    uint32_t parts;        /* leading parts (from the chain's start) whose costs are taken over; 0: none */
+    uint32_t flags;        /* bit 0: the stretch's first part was its chain's last then and is not now (loses its last cell's distance) */
+    rawdtw_anchor_t start; /* the chain's start anchor (the last entry of its full list): the fold's span needs it (rmap.cpp:245) */
 } rawdtw_carry_t;
 /* read r of the new round is read prev_read[r] of the previous one (or RAWDTW_NO_CHAIN: a new read); new_anchors must have
  * room for anchor_off[n_chains] entries, new_off for n_chains + 1 */
@@ -475,9 +481,9 @@ int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain_off, const
  * not fetched yet may still turn out declined: the carried batch then falls back by itself) */
 int rawdtw_batch_can_carry(const rawdtw_ctx *ctx, const rawdtw_batch *prev, const rawdtw_align_opt_t *opt);
 int rawdtw_batch_submit_carry(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                              const uint64_t *anchor_off, const uint64_t *new_off, const rawdtw_anchor_t *new_anchors,
-                              const uint64_t *ref_base, const uint32_t *read_base, const rawdtw_batch *prev,
-                              const rawdtw_carry_t *carry, rawdtw_batch **out);
+                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors /* full lists: fallback only, may be NULL */,
+                              const uint64_t *new_off, const rawdtw_anchor_t *new_anchors, const uint64_t *ref_base,
+                              const uint32_t *read_base, const rawdtw_batch *prev, const rawdtw_carry_t *carry, rawdtw_batch **out);
 int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *parts_scored, uint64_t *parts_reused);
 
 /* The two calls a pipelined host makes per mini-batch: submit = rawdtw_batch_create +

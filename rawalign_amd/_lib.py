@@ -180,7 +180,7 @@ SYMBOLS = {
     "rawdtw_batch_destroy": (I32, [VP]),
     "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_fetch_destroy": (I32, [VP, VP, VP, VP]),
-    "rawdtw_batch_submit_carry": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_submit_carry": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_can_carry": (I32, [VP, VP, VP]),
     "rawdtw_batch_round_stats": (I32, [VP, VP, VP, VP]),
     "rawdtw_round_match_chains": (I32, [U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),

@@ -216,13 +216,14 @@ struct rawdtw_batch {
     const uint16_t *in_steps = nullptr;
     const rawdtw_wide_step_t *in_wide = nullptr;
     uint64_t in_n_wide = 0;
-    // chunk rounds (rawdtw_batch_submit_carry): the batch of the round before, the per-chain carry records and the round's new
-    // anchors (the full list exists on the device only: k_carry assembles it)
+    // chunk rounds (rawdtw_batch_submit_carry): the batch of the round before, the per-chain carry records and the round's SHORT
+    // lists (new entries + junction); in_anchor_off / in_anchors stay the FULL lists' (in_anchors: the fallback's, may be null)
     const rawdtw_batch *in_prev = nullptr;
     const rawdtw_carry_t *in_carry = nullptr;
     const uint64_t *in_new_off = nullptr;
     const rawdtw_anchor_t *in_new_anchors = nullptr;
-    bool in_carried = false;             // the batch's anchor list was assembled on the device (a fallback reads it back from there)
+    bool in_carried = false;             // a chunk round: the device works on the short lists
+    uint64_t parts_carried = 0;          // (summed from the carry records at create)
     // "resident_arrays": the three big arrays are device pointers; host copies are made only if the job list is needed
     bool in_resident = false;
     std::vector<rawdtw_anchor_t> host_anchors;
@@ -1848,7 +1849,11 @@ static hipError_t stream_wide_fork(rawdtw_ctx *ctx, const StreamArgs &a)
 int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_off, const uint64_t *anchor_off,
                         const rawdtw_anchor_t *anchors, const uint64_t *ref_base, const uint32_t *read_base)
 {
-    const uint64_t nc = b->n_chains, nr = b->n_reads, na = anchor_off[nc];
+    // (a chunk round: the device's lists are the SHORT ones -- new entries + junction -- and `na` their length; the full lists only
+    // give the fold its offsets)
+    const rawdtw_batch *prev = b->in_prev;
+    const bool round = prev != nullptr; // (rawdtw_batch_submit_carry checked that it can serve: rawdtw_batch_can_carry)
+    const uint64_t nc = b->n_chains, nr = b->n_reads, n_full = anchor_off[nc], na = round ? b->in_new_off[nc] : n_full;
     const uint32_t lds_floats = stream_tile_floats(ctx);
     StreamArgs &a = b->sa;
     a = StreamArgs{};
@@ -1869,10 +1874,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     const bool compact = b->in_steps != nullptr;
     const uint64_t n_units = (na + RAWDTW_COMPACT_STRIDE - 1) / RAWDTW_COMPACT_STRIDE;
     const size_t compact_bytes = compact ? al(nc * 8) + al(n_units * 8) + al(n_units * RAWDTW_COMPACT_STRIDE * 2) + al(b->in_n_wide * sizeof(rawdtw_wide_step_t)) : 0;
-    const rawdtw_batch *prev = b->in_prev;
-    const bool round = prev != nullptr; // (rawdtw_batch_submit_carry checked that it can serve: rawdtw_batch_can_carry)
-    const uint64_t n_new = round ? b->in_new_off[nc] : 0;
-    const size_t round_bytes = round ? al(nc * sizeof(rawdtw_carry_t)) + al((nc + 1) * 8) + al(n_new * 8) + al((size_t)a.n_tiles * (a.tile_anchors / 8)) : 0;
+    const size_t round_bytes = round ? al(nc * sizeof(rawdtw_carry_t)) + al((nc + 1) * 8) + al(n_full * 4) : 0;
     const size_t dev_bytes = compact_bytes + round_bytes +
                              al(kStreamCounters * 8) + al((nc + 1) * 8) + al(na * 8) + al(nc * 8) + al(nc * 4) + al((nr + 1) * 8) + // counters, inputs
                              al((size_t)a.n_tiles * 8) + al((size_t)a.n_slots * 16) + al((size_t)a.n_tiles * 24) +               // tile list, work list, statistics
@@ -1903,7 +1905,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     a.out = carve<float>(p, na);
     a.debug = ctx->stream_debug;
     a.anchor_off = d_anchor_off; a.anchors = d_anchors; a.ref_base = d_ref_base; a.read_base = d_read_base;
-    if (b->in_resident) { if (!b->in_prev) a.anchors = anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place (a chunk round's list is assembled in d_anchors)
+    if (b->in_resident) { a.anchors = round ? b->in_new_anchors : anchors; a.ref_base = ref_base; a.read_base = read_base; } // used in place
     rawdtw_anchor_t *d_heads = nullptr, *d_unit_abs = nullptr;
     uint16_t *d_steps = nullptr;
     rawdtw_wide_step_t *d_wide = nullptr;
@@ -1914,14 +1916,13 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     }
     a.ev = ctx->d_ev; a.ref = ctx->d_ref;
     rawdtw_carry_t *d_carry = nullptr;
-    uint64_t *d_new_off = nullptr;
-    rawdtw_anchor_t *d_new = nullptr;
-    if (round) { // (the previous batch's arrays are read by this batch's k_carry: stream order keeps them alive that long)
-        d_carry = carve<rawdtw_carry_t>(p, nc); d_new_off = carve<uint64_t>(p, nc + 1); d_new = carve<rawdtw_anchor_t>(p, n_new);
-        a.carried = carve<uint8_t>(p, (uint64_t)a.n_tiles * (a.tile_anchors / 8));
-        a.carry = d_carry; a.new_off = d_new_off; a.new_anchors = d_new; a.anchors_w = d_anchors;
-        a.prev_n_chains = prev->n_chains; a.prev_anchor_off = prev->sa.anchor_off; a.prev_anchors = prev->sa.anchors;
-        a.prev_ref_base = prev->sa.ref_base; a.prev_read_base = prev->sa.read_base; a.prev_out = prev->sa.out;
+    uint64_t *d_full_off = nullptr;
+    a.full_off = d_anchor_off; a.n_full = n_full; a.out_full = a.out; // (no predecessor: the lists are the full ones)
+    if (round) { // (the previous batch's cost array is read by this batch's k_gather: stream order keeps it alive that long)
+        d_carry = carve<rawdtw_carry_t>(p, nc); d_full_off = carve<uint64_t>(p, nc + 1);
+        a.out_full = carve<float>(p, n_full);
+        a.carry = d_carry; a.full_off = d_full_off;
+        a.prev_out_full = prev->sa.out_full; a.prev_n_full = prev->sa.n_full;
         a.prev_cnt = prev->sa.cnt; a.prev_others_cap = prev->sa.others_cap;
     }
     char *hp = b->ws.h;
@@ -1933,7 +1934,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     hipStream_t s = ctx->stream;
     if (ctx->time_plan) for (hipEvent_t &pe : b->ev_plan) if (!pe) HIP_TRY(ctx, hipEventCreate(&pe));
     HIP_TRY(ctx, hipMemcpyAsync(a.cnt, h_init, kStreamCounters * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_anchor_off, round ? b->in_new_off : anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
     if (compact) {
         HIP_TRY(ctx, hipMemcpyAsync(d_heads, b->in_heads, nc * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_unit_abs, b->in_unit_abs, n_units * 8, hipMemcpyHostToDevice, s));
@@ -1941,12 +1942,12 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
         if (b->in_n_wide) HIP_TRY(ctx, hipMemcpyAsync(d_wide, b->in_wide, b->in_n_wide * sizeof(rawdtw_wide_step_t), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
-    } else if (round) { // only the round's NEW anchors cross the bus: the rest of the list is on the device already
+    } else if (round) { // only the round's NEW anchors (and the junctions) cross the bus
         HIP_TRY(ctx, hipMemcpyAsync(d_carry, b->in_carry, nc * sizeof(rawdtw_carry_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(d_new_off, b->in_new_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
-        if (b->in_resident) a.new_anchors = b->in_new_anchors; // ("resident_arrays": the three big arrays are device pointers, used in place)
+        HIP_TRY(ctx, hipMemcpyAsync(d_full_off, anchor_off, (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        if (b->in_resident) a.anchors = b->in_new_anchors; // ("resident_arrays": the three big arrays are device pointers, used in place)
         else {
-            if (n_new) HIP_TRY(ctx, hipMemcpyAsync(d_new, b->in_new_anchors, n_new * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
+            if (na) HIP_TRY(ctx, hipMemcpyAsync(d_anchors, b->in_new_anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, hipMemcpyAsync(d_ref_base, ref_base, nc * 8, hipMemcpyHostToDevice, s));
             HIP_TRY(ctx, hipMemcpyAsync(d_read_base, read_base, nc * 4, hipMemcpyHostToDevice, s));
         }
@@ -1958,8 +1959,7 @@ int batch_create_stream(rawdtw_ctx *ctx, rawdtw_batch *b, const uint64_t *chain_
     HIP_TRY(ctx, hipMemcpyAsync(b->d_chain_off, chain_off, (nr + 1) * 8, hipMemcpyHostToDevice, s));
     b->fold_fused = ctx->fold_mode == 4; // (no fold order then: the one-workgroup sort stays off the scan's critical path)
     if (ctx->time_plan) HIP_TRY(ctx, hipEventRecord(b->ev_plan[0], s)); // ("time_plan": the planning LAUNCHES, behind the hand-over's copies)
-    hipError_t e = round ? stream_carry(a, s) : hipSuccess;
-    if (e == hipSuccess) e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
+    hipError_t e = stream_plan(a, b->d_chains, b->fold_fused ? nullptr : b->d_fold_order, s);
     // The side list's launch goes out here, between the scan and the pass planning, for the batch's first run (a batch that
     // runs again launches it again in front of the tiles' launch): measured, the fresh-batch pipeline runs 6 % faster with
     // the wide bands' long tail in front of the planning launch than behind it.
@@ -2020,13 +2020,11 @@ int materialise_host_arrays(rawdtw_ctx *ctx, rawdtw_batch *b)
         b->in_steps = nullptr;
         return RAWDTW_OK;
     }
-    if (b->in_carried) { // a chunk round: the list exists on the device only (k_carry assembled it)
-        const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
-        try { b->host_anchors.resize(na); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-        if (na) HIP_TRY(ctx, hipMemcpy(b->host_anchors.data(), b->sa.anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost));
-        b->in_anchors = b->host_anchors.data();
+    if (b->in_carried) { // a chunk round: the device only has the short lists; the full ones are the caller's, for exactly this
+        if (!b->in_anchors) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "a carried round the device-planned path declined, and no full anchor lists to redo it from: submit the round whole");
         b->in_carried = false;
         if (b->in_resident) { // (the bases are the caller's device arrays)
+            const uint64_t nc = b->n_chains;
             try { b->host_ref_base.resize(nc); b->host_read_base.resize(nc); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
             if (nc) HIP_TRY(ctx, hipMemcpy(b->host_ref_base.data(), b->in_ref_base, nc * 8, hipMemcpyDeviceToHost));
             if (nc) HIP_TRY(ctx, hipMemcpy(b->host_read_base.data(), b->in_read_base, nc * 4, hipMemcpyDeviceToHost));
@@ -2196,11 +2194,11 @@ struct CompactIn {
 static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
                             const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const CompactIn *cin, const uint64_t *ref_base,
                             const uint32_t *read_base, rawdtw_batch **out, const rawdtw_batch *prev = nullptr, const rawdtw_carry_t *carry = nullptr,
-                            const uint64_t *new_off = nullptr)
+                            const uint64_t *new_off = nullptr, const rawdtw_anchor_t *new_anchors = nullptr)
 {
     if (!out) return RAWDTW_ERR_INVALID;
     *out = nullptr;
-    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && !cin && n_reads) || !ref_base || !read_base)
+    if (!ctx || !opt || !chain_off || !anchor_off || (!anchors && !cin && !prev && n_reads) || !ref_base || !read_base)
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     if (cin && (!cin->heads || !cin->unit_abs || !cin->steps || (!cin->wide && cin->n_wide)))
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
@@ -2216,7 +2214,10 @@ static int batch_create_any(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint
     b->in_chain_off = chain_off; b->in_anchor_off = anchor_off; b->in_anchors = anchors; b->in_ref_base = ref_base; b->in_read_base = read_base;
     b->in_resident = ctx->resident_arrays && !cin;
     b->in_prev = prev; b->in_carry = carry; b->in_new_off = new_off;
-    if (prev) { b->in_new_anchors = anchors; b->in_anchors = nullptr; b->in_carried = true; } // (`anchors` = the round's new entries only)
+    if (prev) {
+        b->in_new_anchors = new_anchors; b->in_carried = true;
+        for (uint64_t c = 0; c < n_chains; c++) b->parts_carried += carry[c].parts;
+    }
     if (cin) { b->in_heads = cin->heads; b->in_unit_abs = cin->unit_abs; b->in_steps = cin->steps; b->in_wide = cin->wide; b->in_n_wide = cin->n_wide; }
     if (stream_eligible(ctx, opt, anchor_off[n_chains]))
         st = batch_create_stream(ctx, b, chain_off, anchor_off, anchors, ref_base, read_base);
@@ -2274,19 +2275,17 @@ int rawdtw_batch_can_carry(const rawdtw_ctx *ctx, const rawdtw_batch *prev, cons
 }
 
 int rawdtw_batch_submit_carry(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
-                              const uint64_t *anchor_off, const uint64_t *new_off, const rawdtw_anchor_t *new_anchors,
-                              const uint64_t *ref_base, const uint32_t *read_base, const rawdtw_batch *prev,
-                              const rawdtw_carry_t *carry, rawdtw_batch **out)
+                              const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *new_off, const rawdtw_anchor_t *new_anchors,
+                              const uint64_t *ref_base, const uint32_t *read_base, const rawdtw_batch *prev, const rawdtw_carry_t *carry, rawdtw_batch **out)
 {
     if (out) *out = nullptr;
     if (!ctx || !opt || !out || !chain_off || !anchor_off || !new_off || !carry || !prev) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
     const uint64_t nc = chain_off[n_reads];
-    if (!rawdtw_batch_can_carry(ctx, prev, opt) || !stream_eligible(ctx, opt, anchor_off[nc]))
+    if (!rawdtw_batch_can_carry(ctx, prev, opt) || !stream_eligible(ctx, opt, new_off[nc]))
         return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "the previous batch cannot serve this round (another context or options, never run, or not on the device-planned path): submit the round whole");
     if (new_off[nc] > anchor_off[nc] || (!new_anchors && new_off[nc])) return fail(ctx, RAWDTW_ERR_INVALID, "more new anchors than anchors");
-    static const rawdtw_anchor_t none{0, 0};
     ctx->in_submit = true;
-    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, new_anchors ? new_anchors : &none, nullptr, ref_base, read_base, out, prev, carry, new_off);
+    int st = batch_create_any(ctx, opt, n_reads, chain_off, anchor_off, anchors, nullptr, ref_base, read_base, out, prev, carry, new_off, new_anchors);
     ctx->in_submit = false;
     if (st != RAWDTW_OK) return st;
     st = batch_enqueue_one(ctx, *out, nullptr);
@@ -2303,7 +2302,7 @@ int rawdtw_batch_round_stats(rawdtw_ctx *ctx, rawdtw_batch *batch, uint64_t *par
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         const int st = stream_counters(ctx, batch);
         if (st != RAWDTW_OK) return st;
-        if (!stream_declined(batch)) reused = batch->h_cnt[kCntReused];
+        if (!stream_declined(batch)) reused = batch->parts_carried;
     }
     if (parts_reused) *parts_reused = reused;
     if (parts_scored) *parts_scored = batch->n_jobs - reused;
@@ -2533,10 +2532,13 @@ static int batch_tail(rawdtw_ctx *ctx, rawdtw_batch *b, int which)
     hipError_t e;
     if (ctx->debug_skip_kinds & (1u << (which == 0 ? kKindChainFold : kKindReadSelect))) return RAWDTW_OK;
     if (ctx->debug_skip_tail & (1u << which)) return RAWDTW_OK;
-    const float *job_cost = b->stream ? b->sa.out : b->plan->d_cost;
+    const float *job_cost = b->stream ? b->sa.out_full : b->plan->d_cost;
     if (b->stream && b->fold_fused) {
         if (which == 1) return RAWDTW_OK; // (done by the launch before)
-        e = stream_fold_select(b->sa, b->d_chains, b->d_chain_off, b->n_reads, b->opt.match_bonus, b->opt.fused_score, b->opt.min_score, b->d_full,
+        StreamArgs f = b->sa; // (the fold walks the FULL lists: a chunk round's costs were gathered into out_full)
+        f.anchor_off = b->sa.full_off; f.out = b->sa.out_full; f.n_anchors = b->sa.n_full;
+        e = stream_gather(b->sa, b->d_chains, ctx->stream);
+        if (e == hipSuccess) e = stream_fold_select(f, b->d_chains, b->d_chain_off, b->n_reads, b->opt.match_bonus, b->opt.fused_score, b->opt.min_score, b->d_full,
                                b->d_gate, b->d_score, b->d_keep, ctx->stream);
     } else if (which == 0)
         e = launch_chain_fold(std::min(ctx->fold_mode, 3), b->d_chains, b->d_fold_order, b->n_chains, job_cost, b->opt.match_bonus, b->opt.fused_score,
@@ -2754,7 +2756,7 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
     if (!ctx || !batch || batch->ctx != ctx || batch_dead(batch)) return fail(ctx, RAWDTW_ERR_INVALID, "batch does not belong to this context");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int attempt = 0; attempt < 2; attempt++) {
-        const float *d_cost = batch->stream ? batch->sa.out : batch->plan->d_cost;
+        const float *d_cost = batch->stream ? batch->sa.out_full : batch->plan->d_cost;
         // a sync-free batch: counters, scores and keep flags in one copy into the batch's pinned block, and from there into the
         // caller's arrays (200 KB of host copying against two more operations on the stream)
         const bool block = batch->stream && batch->n_chains && (score || keep);
@@ -2765,9 +2767,9 @@ int rawdtw_batch_fetch(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8
         }
         // (a sync-free batch keeps one cost per ANCHOR: the part that ends there; they are put into job order below)
         std::vector<float> per_anchor;
-        if (job_cost && batch->stream && batch->sa.n_anchors) {
-            try { per_anchor.resize(batch->sa.n_anchors); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
-            HIP_TRY(ctx, hipMemcpyAsync(per_anchor.data(), d_cost, batch->sa.n_anchors * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (job_cost && batch->stream && batch->sa.n_full) {
+            try { per_anchor.resize(batch->sa.n_full); } catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
+            HIP_TRY(ctx, hipMemcpyAsync(per_anchor.data(), d_cost, batch->sa.n_full * 4, hipMemcpyDeviceToHost, ctx->stream));
         } else if (job_cost && !batch->stream && batch->n_jobs)
             HIP_TRY(ctx, hipMemcpyAsync(job_cost, d_cost, batch->n_jobs * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (batch->stream && !batch->cnt_valid && !block)

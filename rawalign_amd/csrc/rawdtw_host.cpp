@@ -446,7 +446,7 @@ extern "C" int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain
     for (uint64_t r = 0; r < n_reads; r++) {
         const uint64_t pr = prev_read[r];
         for (uint64_t c = chain_off[r]; c < chain_off[r + 1]; c++) {
-            carry[c] = rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u};
+            carry[c] = rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u, rawdtw_anchor_t{0u, 0u}};
             const uint64_t a0 = anchor_off[c], a1 = anchor_off[c + 1];
             uint64_t best = 0; // anchors of the longest common tail
             if (pr != RAWDTW_NO_CHAIN && a1 >= a0 + 2) {
@@ -461,16 +461,23 @@ extern "C" int rawdtw_round_match_chains(uint64_t n_reads, const uint64_t *chain
                     // exclude_last_element (rmap.cpp:270): a part that is this chain's last and was not the other's cannot be taken
                     // over -- there is no exact way back from a cost without its last cell's distance (dtw.cpp:514-519)
                     if (same == a1 - a0 && same < b1 - b0) same--;
-                    if (same >= 2 && same > best) { best = same; carry[c].prev_chain = pc; }
+                    if (same >= 2 && same > best) { best = same; carry[c].prev_src = pc; }
                 }
             }
-            if (best >= 2) carry[c].parts = (uint32_t)std::min<uint64_t>(best - 1, 0xffffffffull);
-            else carry[c].prev_chain = RAWDTW_NO_CHAIN;
-            // the entries that are not taken over: the list's first n - (parts + 1)
-            const uint64_t n_new = (a1 - a0) - (carry[c].parts ? (uint64_t)carry[c].parts + 1 : 0);
+            const uint64_t na = a1 - a0;
+            if (best >= 2) {
+                const uint64_t pc = carry[c].prev_src; // (the chain found above)
+                const uint64_t b0 = prev_anchor_off[pc], b1 = prev_anchor_off[pc + 1];
+                carry[c].parts = (uint32_t)(best - 1);
+                carry[c].prev_src = b1 - best;                                 // the stretch's first entry in the previous full list
+                carry[c].flags = (best == b1 - b0 && na > best) ? 1u : 0u;      // its first part was the last one then and is not now
+            } else carry[c].prev_src = RAWDTW_NO_CHAIN;
+            if (na) carry[c].start = anchors[a1 - 1];
+            // what the device still needs: the new entries, then the junction (the carried stretch's end anchor)
+            const uint64_t n_keep = carry[c].parts ? na - carry[c].parts : na;
             new_off[c] = at;
-            if (n_new) memcpy(new_anchors + at, anchors + a0, n_new * sizeof(rawdtw_anchor_t));
-            at += n_new;
+            if (n_keep) memcpy(new_anchors + at, anchors + a0, n_keep * sizeof(rawdtw_anchor_t));
+            at += n_keep;
         }
     }
     new_off[chain_off[n_reads]] = at;

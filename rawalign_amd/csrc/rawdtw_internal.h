@@ -131,7 +131,8 @@ enum StreamCounter : int {
     kCntCells = kCntCur0 + 21,
     kCntTileJobs, kCntTileBytes, kCntOtherBytes, // (reporting: summed from the tiles' statistics on request)
     kCntTodo,           // entries of the DTW launch's work list
-    kCntReused,         // parts whose cost came from the round before (rawdtw_batch_submit_carry)
+    kCntReused,         // (unused: the parts taken over are counted from the carry records on the host -- a counter every chain's wave adds to
+                        // is forty thousand same-address atomics, 0.3 ms)
     kCntPool,           // record slots handed out beyond one a tile (tiles whose image takes several passes)
     kCntStamp0,         // 10 words: cycles per phase of k_runs, summed over waves ("stream_debug" 256: diagnostic runs only)
     kCntHeads = 64,     // tile queue: 8 heads, one per 128-byte line (head h deals the tiles t with t % 8 == h)
@@ -167,23 +168,21 @@ struct StreamArgs {
     const rawdtw_wide_step_t *wide;
     uint64_t n_wide;
     rawdtw_anchor_t *anchors_w;
-    // chunk rounds (rawdtw_batch_submit_carry; `carry` null otherwise): the batch of the round before.  Per chain the host names
-    // the chain it continues and the number of leading parts (from the chain's start = the tail of its end-first list) that are
-    // unchanged -- validated there, anchor by anchor (rawdtw_round_match_chains).  k_carry assembles the round's anchor list in
-    // `anchors_w` (= `anchors`): a chain's new entries from `new_anchors`, its unchanged tail from `prev_anchors`; and copies
-    // the tail's costs from `prev_out` -- one contiguous stretch a chain.  The scan then leaves those parts out.
-    const rawdtw_carry_t *carry;      // per chain: {chain of the previous batch or ~0, parts taken over}
-    const uint64_t *new_off;          // chain c's new entries: new_anchors[new_off[c] .. new_off[c + 1])
-    const rawdtw_anchor_t *new_anchors;
-    uint64_t prev_n_chains;
-    const uint64_t *prev_anchor_off;
-    const rawdtw_anchor_t *prev_anchors;
-    const uint64_t *prev_ref_base;
-    const uint32_t *prev_read_base;
-    const float *prev_out;
+    // chunk rounds (rawdtw_batch_submit_carry; `carry` null otherwise).  The lists above (anchor_off, anchors, n_anchors) are then the
+    // round's SHORT lists: per chain its new entries and the junction (the end anchor of the stretch taken over) -- everything from
+    // the scan to the DTW launches runs on them and leaves the new parts' costs in `out`, one per short-list anchor.  The fold
+    // wants every chain's costs in full: k_gather lays them out in `out_full` by the FULL lists' offsets `full_off` -- a chain's
+    // new parts from `out`, the stretch taken over from the previous batch's full cost array, one contiguous copy a chain (the
+    // host validated it anchor by anchor: rawdtw_round_match_chains).  A batch without a predecessor has out_full = out and
+    // full_off = anchor_off.
+    const rawdtw_carry_t *carry;      // per chain: {first entry of the stretch in the previous full list, parts taken over, flags, start anchor}
+    const uint64_t *full_off;         // n_chains + 1 offsets of the full lists
+    uint64_t n_full;                  // full_off[n_chains]
+    float *out_full;                  // n_full costs: part p of chain c (rmap.cpp:248-293) at full_off[c + 1] - 2 - p
+    const float *prev_out_full;       // the previous batch's
+    uint64_t prev_n_full;
     const unsigned long long *prev_cnt; // its counter block (a batch the scan declined has no costs to take over)
     uint64_t prev_others_cap;
-    uint8_t *carried;                 // one bit per anchor (byte i / 8, bit i % 8): its part's cost was carried over
     // workspace and outputs (device)
     uint2 *tlist;                // the scan's tile list: (tile, the chain its first anchor belongs to) of every tile that has a part for the
                                  // lane bodies; cnt[kCntTodo] entries, at most n_tiles
@@ -205,7 +204,7 @@ struct StreamArgs {
 };
 int stream_blocks_per_cu(uint32_t lds_floats, int threads);
 hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fold_order, hipStream_t s);
-hipError_t stream_carry(const StreamArgs &a, hipStream_t s);
+hipError_t stream_gather(const StreamArgs &a, ChainDesc *d_chains, hipStream_t s);
 hipError_t stream_run(const StreamArgs &a, uint32_t blocks, uint32_t lds_floats, int threads, bool reset_queue, hipStream_t s);
 hipError_t stream_plan_passes(const StreamArgs &a, hipStream_t s);
 hipError_t stream_wide(const StreamArgs &a, uint32_t blocks, hipStream_t s);

@@ -354,7 +354,7 @@ void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev
     rr.chains = std::move(chains);
     if (!runs_dtw) return;
     rr.ref_base.resize(rr.chains.size());
-    rr.carry.assign(rr.chains.size(), rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u});
+    rr.carry.assign(rr.chains.size(), rawdtw_carry_t{RAWDTW_NO_CHAIN, 0u, 0u, rawdtw_anchor_t{0u, 0u}});
     for (size_t c = 0; c < rr.chains.size(); c++) rr.ref_base[c] = m->ref_off[rr.chains[c].ref * 2u + (uint32_t)rr.chains[c].strand];
     if (!pv) return;
     // chunk rounds: the chain of the round before this chain continues -- same strand array, same start anchor, the longest
@@ -363,8 +363,9 @@ void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev
     for (size_t c = 0; c < rr.chains.size(); c++) {
         const std::vector<rawdtw_anchor_t> &an = rr.chains[c].anchors;
         const uint64_t na = an.size();
+        if (na) rr.carry[c].start = an[na - 1];
         if (na < 2) continue;
-        uint64_t best = 0;
+        uint64_t best = 0, best_b0 = 0, best_b1 = 0;
         for (uint64_t pc = pv->chain_off[pr]; pc < pv->chain_off[pr + 1]; pc++) {
             const uint64_t b0 = pv->anchor_off[pc], b1 = pv->anchor_off[pc + 1];
             if (b1 < b0 + 2 || pv->ref_base[pc] != rr.ref_base[c]) continue;
@@ -374,10 +375,13 @@ void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev
                    an[na - 1 - same].query_position == pa[b1 - 1 - same].query_position)
                 same++;
             if (same == na && same < b1 - b0) same--; // (its last part was not the last then: rmap.cpp:270, no exact way back)
-            if (same >= 2 && same > best) { best = same; rr.carry[c].prev_chain = pc; }
+            if (same >= 2 && same > best) { best = same; best_b0 = b0; best_b1 = b1; }
         }
-        if (best >= 2) rr.carry[c].parts = (uint32_t)(best - 1);
-        else rr.carry[c].prev_chain = RAWDTW_NO_CHAIN;
+        if (best >= 2) {
+            rr.carry[c].parts = (uint32_t)(best - 1);
+            rr.carry[c].prev_src = best_b1 - best;                                    // the stretch's first entry in the previous full list
+            rr.carry[c].flags = (best == best_b1 - best_b0 && na > best) ? 1u : 0u;    // its first part was the last one then and is not now
+        }
     }
 }
 
@@ -579,7 +583,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             for (size_t c = 0; c < r.chains.size(); c++) {
                 const uint64_t n = r.chains[c].anchors.size();
                 na += n;
-                nn += n - (r.carry[c].parts ? (uint64_t)r.carry[c].parts + 1 : 0);
+                nn += n - r.carry[c].parts; // (the new entries and, when a stretch is taken over, the junction)
             }
             nev += r.ne;
             nseg += r.ne ? 1 : 0;
@@ -623,7 +627,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                 if (m->scorer) { ra.chain_seq[cc] = r.chains[c].ref; ra.chain_strand[cc] = r.chains[c].strand; }
                 memcpy(ra.anchors.p + at, an.data(), an.size() * sizeof(rawdtw_anchor_t));
                 if (ra.carried) {
-                    const uint64_t n_new = an.size() - (r.carry[c].parts ? (uint64_t)r.carry[c].parts + 1 : 0);
+                    const uint64_t n_new = an.size() - r.carry[c].parts; // (with the junction)
                     ra.carry[cc] = r.carry[c];
                     ra.new_off[cc] = nat;
                     memcpy(ra.new_anchors.p + nat, an.data(), n_new * sizeof(rawdtw_anchor_t));
@@ -641,8 +645,8 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
             if (st == RAWDTW_OK) {
                 if (ra.carried) {
-                    st = rawdtw_batch_submit_carry(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.new_off.p, ra.new_anchors.p, ra.ref_base.p,
-                                                   ra.read_base.p, pb.batch, ra.carry.p, &ra.batch);
+                    st = rawdtw_batch_submit_carry(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, ra.anchors.p, ra.new_off.p, ra.new_anchors.p,
+                                                   ra.ref_base.p, ra.read_base.p, pb.batch, ra.carry.p, &ra.batch);
                     if (st == RAWDTW_ERR_UNSUPPORTED) { ra.carried = false; st = RAWDTW_OK; } // (e.g. a round without a chain: nothing to plan on the device)
                 }
                 if (st == RAWDTW_OK && !ra.carried)
@@ -651,7 +655,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             if (st != RAWDTW_OK) set_fail(st, rawdtw_last_error(g.ctx));
             m->timing[5] += (double)((ra.carried ? nn : na) * sizeof(rawdtw_anchor_t));
             m->timing[6] += (double)(nev * sizeof(float));
-            m->timing[7] += (double)((nr + 1) * 8 + (nc + 1) * 8 + nc * 12 + (ra.carried ? nc * 24 + 8 : 0) + nseg * 12);
+            m->timing[7] += (double)((nr + 1) * 8 + (nc + 1) * 8 + nc * 12 + (ra.carried ? nc * 32 + 8 : 0) + nseg * 12);
         } else {
             std::vector<const float *> evp(nr);
             std::vector<uint32_t> evn(nr);

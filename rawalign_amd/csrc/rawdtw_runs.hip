@@ -319,14 +319,14 @@ constexpr uint32_t kScanUnit = 8192, kScanKI = 8;
 // The compact form (kScanTC threads, one pass) decodes a unit with one scan over all of its entries.
 constexpr uint32_t kScanT = 512, kScanTC = 1024;
 static_assert(kScanUnit == RAWDTW_COMPACT_STRIDE, "the compact hand-over is decoded unit by unit");
-template <bool COMPACT, bool CARRY>
+template <bool COMPACT>
 __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32_t unit)
 {
     constexpr int NT = COMPACT ? (int)kScanTC : (int)kScanT, KI = (int)kScanKI;
     constexpr uint32_t AT = kScanUnit, kWords = AT / 32 + 1, kHalf = (uint32_t)NT * KI, kHalves = AT / kHalf;
     static_assert(kHalves * kHalf == AT && (!COMPACT || kHalves == 1), "a unit in whole passes; the compact form in one");
     __shared__ uint32_t s_mask[kWords], s_pre[kWords];
-    __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses + 1]; // (the last word: parts carried over from the round before)
+    __shared__ uint32_t s_ocnt, s_obase, s_cls[kStreamClasses];
     __shared__ unsigned long long s_stats[3];
     __shared__ uint64_t s_c0;
     __shared__ uint32_t s_todo; // bit t: tile t of the unit has a part for the lane-per-job bodies to score
@@ -337,7 +337,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     for (uint32_t w = tid; w < kWords; w += NT) s_mask[w] = 0;
     if (tid == 0) { s_ocnt = 0; s_todo = 0; }
     if (tid < 3) s_stats[tid] = 0;
-    if (tid <= (int)kStreamClasses) s_cls[tid] = 0;
+    if (tid < (int)kStreamClasses) s_cls[tid] = 0;
     // the anchors: KI + 1 consecutive entries a thread (the last one is the next thread's first: the start of this thread's
     // last part), requested before the chain search waits for anything
     const uint64_t i0 = base + (uint64_t)tid * KI; // the thread's first anchor (of the first half)
@@ -425,10 +425,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         else an[KI] = base + AT < a.n_anchors ? a.unit_abs[unit + 1] : rawdtw_anchor_t{0, 0}; // (the next unit's first entry travels whole)
     }
 
-    // (chunk rounds: k_carry has assembled the anchor list and copied the carried parts' costs; a round whose previous batch did
-    // not stand has marked itself bad there, and nothing here counts)
-    const bool carry = CARRY && a.carry != nullptr;
-    uint32_t my_tiles = 0, my_bytes = 0, my_reused = 0;
+    uint32_t my_tiles = 0, my_bytes = 0;
     unsigned long long my_obytes = 0;
     uint32_t o_rec[kHalves][KI]; // the thread's side-list parts: slot | class << 16 | radius << 21 (0xffffffff: none)
 #pragma unroll
@@ -438,25 +435,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
 #pragma unroll
         for (int k = 0; k <= KI; k++) an[k] = ih + k < a.n_anchors ? a.anchors[ih + k] : rawdtw_anchor_t{0, 0};
     }
-    uint32_t carried_bits = 0, half_tiles = 0;
-    if (carry) {
-        // Chunk rounds: a chain's carried parts are the last `parts` of its stretch of the list (counted from the chain's start =
-        // the list's tail): the part that ends at anchor i is carried iff i >= a1 - 1 - parts.  Two loads a chain, nothing a part.
-        uint64_t cc = ~0ull, c_lo = ~0ull; // the chain at hand; its first carried anchor
-#pragma unroll
-        for (int k = 0; k < KI; k++) {
-            const uint32_t p = h * kHalf + (uint32_t)tid * KI + k;
-            const uint64_t i = base + p;
-            if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue;
-            const uint64_t c = chain_at(p);
-            if (c != cc) {
-                cc = c;
-                const uint32_t parts = a.carry[c].parts;
-                c_lo = parts ? a.anchor_off[c + 1] - 1ull - parts : ~0ull;
-            }
-            if (i >= c_lo) { carried_bits |= 1u << k; my_reused++; }
-        }
-    }
+    uint32_t half_tiles = 0;
 #pragma unroll
     for (int k = 0; k < KI; k++) {
         o_rec[h][k] = 0xffffffffu;
@@ -465,7 +444,6 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         if (i >= a.n_anchors || mask_bit(s_mask, p + 1)) continue; // the chain's first entry (or the list's end): no part ends here
         const Part pt = classify(a, an[k + 1], an[k]);
         if (!pt.asc || pt.n >= 0x7fffffffu || pt.m >= 0x7fffffffu) { atomicMin(&a.cnt[kCntBad], (unsigned long long)i); continue; }
-        if (carry && ((carried_bits >> k) & 1u)) continue; // (its cost came from the round before: the pass above)
         if (pt.tile) { my_tiles++; half_tiles++; my_bytes += 4u * (pt.n + pt.m) + 36u; continue; }
         // the side list: rare.  The radius by the reference's formula, the class, a slot in the workgroup's share of the list
         int r0 = (int)((float)pt.n * a.frac);
@@ -488,15 +466,10 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
         }
         atomicAdd(&s_cls[cls], 1u);
     }
-    if (CARRY && a.carried && ih < a.n_anchors) a.carried[ih >> 3] = (uint8_t)carried_bits; // (eight anchors a thread: one byte of its own)
     {
         const unsigned long long any_tile = __ballot(half_tiles != 0u); // (every lane votes: taken before the branch on the lane)
         if (lane == 0 && any_tile) atomicOr(&s_todo, 1u << ((h * kHalf + (uint32_t)tid * KI) / a.tile_anchors)); // (a wave's anchors lie in one tile)
     }
-    }
-    if (carry) {
-        for (int off = 32; off > 0; off >>= 1) my_reused += (uint32_t)__shfl_down((int)my_reused, off);
-        if (lane == 0 && my_reused) atomicAdd(&s_cls[kStreamClasses], my_reused);
     }
     {   // statistics: tile parts (<= KI a thread) and their bytes (< 2^13 a thread) through one wave reduction
         unsigned long long packed = (unsigned long long)my_tiles | ((unsigned long long)my_bytes << 20);
@@ -507,7 +480,7 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     __syncthreads();
     if (tid == 0 && s_ocnt) s_obase = (uint32_t)atomicAdd(&a.cnt[kCntOthers], (unsigned long long)s_ocnt);
     // The DTW launch's work list: the unit's tiles that have something to score, each with its first chain.  (Tiles without a
-    // tile-class part -- all of their parts carried over from the round before, or on the side list -- are never touched.)
+    // tile-class part -- all of their parts on the side list -- are never touched.)
     if (tid == 0 && s_todo) {
         const uint32_t tiles_per_unit = AT / a.tile_anchors, todo = s_todo;
         uint64_t at = atomicAdd(&a.cnt[kCntTodo], (unsigned long long)__popc(todo));
@@ -516,7 +489,6 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
     if (tid < 3) a.tile_stats[3ull * unit + tid] = s_stats[tid];
     if (tid < (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntCls0 + tid], (unsigned long long)s_cls[tid]);
-    if (tid == (int)kStreamClasses && s_cls[tid]) atomicAdd(&a.cnt[kCntReused], (unsigned long long)s_cls[tid]);
     __syncthreads();
     auto side_record = [&](const uint32_t p, const uint32_t cls, const uint32_t R, const uint64_t q) {
         if (q >= a.others_cap) return; // (beyond the capacity: kCntOthers > others_cap tells rawdtw_batch_fetch to take the job-list path)
@@ -552,53 +524,63 @@ __device__ __forceinline__ void scan_unit_body(const StreamArgs &a, const uint32
     }
 }
 
-// k_carry: a chunk round's first launch (rawdtw_batch_submit_carry).  A wave a chain: the chain's stretch of the round's anchor
-// list is its new entries (from the hand-over) followed by the tail it shares with the chain it continues (from the previous
-// batch's list, on the device since the round before); the costs of the tail's parts come with it, one contiguous stretch.
-// The host validated the tail anchor by anchor (rawdtw_round_match_chains); here only the counts and the bases are checked.
-// A part that was its chain's last then and is not now loses its last cell's distance exactly as the DTW functions take it
-// off (dtw.cpp:514-519): that can only be the tail's first entry.
-constexpr int kCarryT = 256;
-__global__ __launch_bounds__(kCarryT) void k_carry(const StreamArgs a)
+// Chunk rounds (rawdtw_batch_submit_carry): the lists the launches above and below work on are the round's SHORT lists -- per
+// chain its new entries and the junction.  Two things remain to be said about the FULL chains:
+//   chain_desc_carry  the fold's chain records: parts and span of the full chain (its start anchor comes with the carry record,
+//                     its end anchor is the short list's first entry), the one bounds check a batch needs (chain_desc_body);
+//   k_gather          every chain's costs in full, where the fold looks for them (out_full by the full lists' offsets): the new
+//                     parts' from `out` (short-list order), the stretch taken over from the previous batch's full cost array --
+//                     one contiguous copy a chain, a wave a chain.  A part that was its chain's last then and is not now loses
+//                     its last cell's distance exactly as the DTW functions take it off (dtw.cpp:514-519): the stretch's first.
+__device__ __forceinline__ void chain_desc_carry(const StreamArgs &a, ChainDesc *__restrict__ chains, const uint64_t c)
+{
+    if (c >= a.n_chains) return;
+    const uint64_t f0 = a.full_off[c], f1 = a.full_off[c + 1], r0 = a.anchor_off[c], r1 = a.anchor_off[c + 1];
+    const rawdtw_carry_t rec = a.carry[c];
+    ChainDesc d;
+    d.job_first = f1 >= 2 ? f1 - 2 : 0;
+    d.n_jobs = f1 > f0 ? (uint32_t)(f1 - f0 - 1) : 0u;
+    d.descending = 1; d.span = 0; d.num_aligned = 0;
+    // (the short list: the new entries, then the junction when a stretch is taken over)
+    const bool counts_ok = (r1 - r0) + rec.parts == f1 - f0 && (rec.parts == 0 || (rec.prev_src != ~0ull && rec.prev_src + rec.parts <= a.prev_n_full));
+    if (f1 > f0 && r1 > r0 && counts_ok) {
+        const rawdtw_anchor_t last = a.anchors[r0], first = rec.parts ? rec.start : a.anchors[r1 - 1];
+        d.span = last.query_position - first.query_position + 1;                       // rmap.cpp:245
+        d.num_aligned = (last.query_position - first.query_position) + d.n_jobs;         // rmap.cpp:292
+        if (d.n_jobs && ((uint64_t)a.read_base[c] + last.query_position + 1ull > a.n_ev || a.ref_base[c] + last.target_position + 1ull > a.n_ref ||
+                         first.query_position > last.query_position || first.target_position > last.target_position))
+            atomicMin(&a.cnt[kCntBad], (unsigned long long)r0);
+    } else if (f1 > f0) atomicMin(&a.cnt[kCntBad], (unsigned long long)r0); // (a record that does not add up)
+    else atomicAdd(&a.cnt[kCntUnsupported], 1ull);                          // a chain without anchors: align_chain would read anchors[-1]
+    chains[c] = d;
+}
+
+constexpr int kGatherT = 256;
+__global__ __launch_bounds__(kGatherT) void k_gather(const StreamArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t c = (uint64_t)blockIdx.x * (kCarryT / 64) + (threadIdx.x >> 6);
+    const uint64_t c = (uint64_t)blockIdx.x * (kGatherT / 64) + (threadIdx.x >> 6);
     if (c >= a.n_chains) return;
-    const uint64_t a0 = a.anchor_off[c], a1 = a.anchor_off[c + 1], nb = a.new_off[c], n_new = a.new_off[c + 1] - nb;
+    // (a batch the scan declined is redone through the job list)
+    if (a.cnt[kCntBad] != ~0ull || a.cnt[kCntOverflow] != ~0ull || a.cnt[kCntUnsupported] != 0ull || a.cnt[kCntOthers] > a.others_cap) return;
+    const uint64_t f0 = a.full_off[c], r0 = a.anchor_off[c], r1 = a.anchor_off[c + 1];
     const rawdtw_carry_t rec = a.carry[c];
-    const uint64_t L = rec.parts;
+    const uint64_t L = rec.parts, n_new = r1 > r0 ? r1 - r0 - 1 : 0; // the short list's parts: all of them new
+    for (uint64_t k = (uint64_t)lane; k < n_new; k += 64) a.out_full[f0 + k] = a.out[r0 + k];
+    if (!L) return;
     // (the round before must have stood: a batch the scan declined has no costs to take over)
     const bool prev_ok = a.prev_cnt[kCntBad] == ~0ull && a.prev_cnt[kCntUnsupported] == 0ull && a.prev_cnt[kCntOthers] <= a.prev_others_cap &&
                          a.prev_cnt[kCntOverflow] == ~0ull;
-    // idx_ok: the stretches exist (the list can be assembled); cost_ok: ... and their costs may be taken over.  Anything else
-    // marks the batch bad: rawdtw_batch_fetch then scores everything from the assembled list through the job-list path.
-    uint64_t src = 0;
-    bool idx_ok = n_new + (L ? L + 1 : 0) == a1 - a0, cost_ok = false, fix = false;
-    if (L) {
-        idx_ok = idx_ok && rec.prev_chain < a.prev_n_chains;
-        if (idx_ok) {
-            const uint64_t pa0 = a.prev_anchor_off[rec.prev_chain], pa1 = a.prev_anchor_off[rec.prev_chain + 1];
-            idx_ok = pa1 - pa0 >= L + 1;
-            src = pa1 - (L + 1);
-            cost_ok = idx_ok && prev_ok && a.prev_ref_base[rec.prev_chain] == a.ref_base[c] && a.prev_read_base[rec.prev_chain] == a.read_base[c] &&
-                      !(n_new == 0 && src > pa0); // (its last part was not the last then: no exact way back -- the host counts it out)
-            fix = src == pa0 && n_new != 0;       // the tail's first part was the last one then and is not now
+    if (!prev_ok) { if (lane == 0) atomicMin(&a.cnt[kCntBad], (unsigned long long)r0); return; }
+    const float *src = a.prev_out_full + rec.prev_src;
+    float *dst = a.out_full + f0 + n_new;
+    for (uint64_t k = (uint64_t)lane; k < L; k += 64) {
+        float cost = src[k];
+        if (k == 0 && (rec.flags & 1u)) { // its last cell's distance: the junction is where it ends
+            const rawdtw_anchor_t e = a.anchors[r1 - 1];
+            cost = cost - dist(a.ev[(uint64_t)a.read_base[c] + e.query_position], a.ref[a.ref_base[c] + e.target_position]);
         }
-    }
-    if (!idx_ok || (L && !cost_ok)) { if (lane == 0) atomicMin(&a.cnt[kCntBad], (unsigned long long)a0); }
-    for (uint64_t k = (uint64_t)lane; k < n_new && k < a1 - a0; k += 64) a.anchors_w[a0 + k] = a.new_anchors[nb + k];
-    if (!L || !idx_ok) return;
-    const uint64_t dst = a0 + n_new;
-    const uint64_t rb = a.ref_base[c];
-    const uint32_t qb = a.read_base[c];
-    for (uint64_t k = (uint64_t)lane; k <= L; k += 64) {
-        const rawdtw_anchor_t e = a.prev_anchors[src + k];
-        a.anchors_w[dst + k] = e;
-        if (k < L && cost_ok) {
-            float cost = a.prev_out[src + k];
-            if (fix && k == 0) cost = cost - dist(a.ev[(uint64_t)qb + e.query_position], a.ref[rb + e.target_position]);
-            a.out[dst + k] = cost;
-        }
+        dst[k] = cost;
     }
 }
 
@@ -607,17 +589,12 @@ __global__ __launch_bounds__(kCarryT) void k_carry(const StreamArgs a)
 __global__ __launch_bounds__(kScanT, 8) void k_scan(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
 {
     const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
-    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
-    else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
-    else scan_unit_body<false, false>(a, b - 1 - n_desc);
-}
-// (a chunk round that takes costs over from the round before -- k_carry ran in front: the units leave the carried parts out)
-__global__ __launch_bounds__(kScanT, 8) void k_scan_round(const StreamArgs a, ChainDesc *__restrict__ chains, uint32_t *__restrict__ order)
-{
-    const uint32_t b = blockIdx.x, n_desc = (uint32_t)((a.n_chains + kScanT - 1) / kScanT);
-    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.anchor_off, order); }
-    else if (b <= n_desc) chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
-    else scan_unit_body<false, true>(a, b - 1 - n_desc);
+    if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanT>(a.n_chains, a.carry ? a.full_off : a.anchor_off, order); }
+    else if (b <= n_desc) {
+        if (a.carry) chain_desc_carry(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x); // (a chunk round: the records describe the FULL chains)
+        else chain_desc_body(a, chains, (uint64_t)(b - 1) * kScanT + threadIdx.x);
+    }
+    else scan_unit_body<false>(a, b - 1 - n_desc);
 }
 
 // The compact hand-over: the units decode their anchors first (rawdtw_batch_submit_compact).  The chain records read the
@@ -627,7 +604,7 @@ __global__ __launch_bounds__(kScanTC) void k_scan_compact(const StreamArgs a, ui
 {
     const uint32_t b = blockIdx.x;
     if (b == 0) { if (a.n_chains && order) fold_order_body<(int)kScanTC>(a.n_chains, a.anchor_off, order); }
-    else scan_unit_body<true, false>(a, b - 1);
+    else scan_unit_body<true>(a, b - 1);
 }
 __global__ __launch_bounds__(kScanT) void k_scan_desc(const StreamArgs a, ChainDesc *__restrict__ chains)
 {
@@ -673,8 +650,6 @@ __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
     const uint64_t i0 = base + (uint64_t)lane * KI;
 #pragma unroll
     for (int k = 0; k <= KI; k++) an[k] = i0 + k < a.n_anchors ? a.anchors[i0 + k] : rawdtw_anchor_t{0, 0};
-    uint32_t carried = 0;
-    if (a.carried && i0 < a.n_anchors) carried = a.carried[i0 >> 3]; // (chunk rounds: these parts took their cost from the round before)
     // chain starts inside [base, base + 512] from the chains' offsets, starting at the chain that owns the tile's first anchor
     // (the end of the anchor list counts as a chain start); chains are few a tile: mostly one round of loads
     if ((uint32_t)lane < kWords) mask[lane] = 0;
@@ -701,7 +676,7 @@ __global__ __launch_bounds__(kPlanT, 3) void k_plan(const StreamArgs a)
     for (int k = 0; k < KI; k++) {
         const uint32_t p = (uint32_t)lane * KI + k;
         tm[k] = 0u;
-        if (base + p >= a.n_anchors || mask_bit(mask, p + 1) || ((carried >> k) & 1u)) continue; // no part ends here, or its cost is there already
+        if (base + p >= a.n_anchors || mask_bit(mask, p + 1)) continue; // no part ends here
         const Part pt = classify(a, an[k + 1], an[k]);
         if (!pt.tile) continue;
         const uint32_t N = pt.n > pt.m ? pt.n : pt.m, M = pt.n > pt.m ? pt.m : pt.n;
@@ -1498,18 +1473,17 @@ hipError_t stream_plan(const StreamArgs &a, ChainDesc *d_chains, uint32_t *d_fol
     if (a.steps) {
         hipLaunchKernelGGL(k_scan_compact, dim3(n_units + 1u), dim3(kScanTC), 0, s, a, d_fold_order);
         if (n_desc) hipLaunchKernelGGL(k_scan_desc, dim3(n_desc), dim3(kScanT), 0, s, a, d_chains);
-    } else if (a.carry) hipLaunchKernelGGL(k_scan_round, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
-    else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
+    } else hipLaunchKernelGGL(k_scan, dim3(n_units + 1u + n_desc), dim3(kScanT), 0, s, a, d_chains, d_fold_order);
     if (a.n_tiles) hipLaunchKernelGGL(k_side, dim3(kSideGroups), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
-// a chunk round's first launch: the round's anchor list and the carried costs out of the previous batch's workspace
-hipError_t stream_carry(const StreamArgs &a, hipStream_t s)
+// a chunk round's last launch in front of the fold: every chain's costs in full (the stretch taken over + the new parts')
+hipError_t stream_gather(const StreamArgs &a, ChainDesc *, hipStream_t s)
 {
     if (!a.carry || a.n_chains == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_carry, dim3((uint32_t)((a.n_chains + kCarryT / 64 - 1) / (kCarryT / 64))), dim3(kCarryT), 0, s, a);
+    hipLaunchKernelGGL(k_gather, dim3((uint32_t)((a.n_chains + kGatherT / 64 - 1) / (kGatherT / 64))), dim3(kGatherT), 0, s, a);
     return hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ from .align import (RI_M_DTW_EVALUATE_CHAINS, RI_M_DTW_LOG_SCORES, RI_M_DTW_OUTP
                     MapOpt, align_chain)
 from .dtw import ANCHOR_DTYPE
 
-CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
+CARRY_DTYPE = np.dtype([("prev_src", "<u8"), ("parts", "<u4"), ("flags", "<u4"), ("start_t", "<u4"), ("start_q", "<u4")])  # rawdtw_carry_t
 
 
 @dataclass
@@ -334,8 +334,8 @@ class RoundScorer:
                                                      _vp(pa["anchor_off"]), _vp(pa["anchors"]), _vp(pa["ref_base"]), _vp(pa["read_base"]), _vp(carry),
                                                      _vp(new_off), _vp(new_anchors)))
             eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), len(reads), _vp(arrays["chain_off"]), _vp(arrays["anchor_off"]),
-                                                     _vp(new_off), _vp(new_anchors), _vp(arrays["ref_base"]), _vp(arrays["read_base"]), prev_h,
-                                                     _vp(carry), C.byref(h)))
+                                                     _vp(arrays["anchors"]), _vp(new_off), _vp(new_anchors), _vp(arrays["ref_base"]),
+                                                     _vp(arrays["read_base"]), prev_h, _vp(carry), C.byref(h)))
             keep_alive = (keep_alive, carry, new_off, new_anchors)
             self.anchors_sent += int(new_off[-1])
             carried = True

@@ -27,7 +27,7 @@ vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
 arrs = [[np.ascontiguousarray(r.chain_off, np.uint64), np.ascontiguousarray(r.anchor_off, np.uint64), np.ascontiguousarray(r.anchors),
          np.ascontiguousarray(r.ref_base, np.uint64), np.ascontiguousarray(r.read_base, np.uint32)] for r in rounds]
 ident = np.arange(cb.n_reads, dtype=np.uint64)
-CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])
+CARRY_DTYPE = np.dtype([("prev_src", "<u8"), ("parts", "<u4"), ("flags", "<u4"), ("start_t", "<u4"), ("start_q", "<u4")])  # rawdtw_carry_t
 keep_alive = []
 
 
@@ -42,8 +42,8 @@ def submit(k, prev):
         eng._check(lib.rawdtw_round_match_chains(cb.n_reads, vp(a[0]), vp(a[1]), vp(a[2]), vp(a[3]), vp(a[4]), vp(ident), vp(p[0]), vp(p[1]), vp(p[2]), vp(p[3]),
                                                  vp(p[4]), vp(carry), vp(new_off), vp(new_anchors)))
         keep_alive.append((carry, new_off, new_anchors))
-        eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), vp(new_off), vp(new_anchors), vp(a[3]), vp(a[4]), prev,
-                                                 vp(carry), C.byref(h)))
+        eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb.n_reads, vp(a[0]), vp(a[1]), vp(a[2]), vp(new_off), vp(new_anchors), vp(a[3]), vp(a[4]),
+                                                 prev, vp(carry), C.byref(h)))
     eng.sync()
     return h
 
@@ -59,7 +59,7 @@ for mode in ("scratch", "carried"):
         sc, ru = C.c_uint64(), C.c_uint64()
         lib.rawdtw_batch_round_stats(eng._ctx, h, C.byref(sc), C.byref(ru))
         if rep:
-            print("%-8s parts scored %d reused %d   planning (k_carry + k_scan + k_side + k_plan) %.4f ms   k_wide %.4f ms  k_runs %.4f ms  fold + select %.4f"
+            print("%-8s parts scored %d reused %d   planning (k_scan + k_side + k_plan) %.4f ms   k_wide %.4f ms  k_runs %.4f ms  fold + select %.4f"
                   % (mode, sc.value, ru.value, pm.value, ms[0], ms[1], ms[2]), flush=True)
         lib.rawdtw_batch_destroy(h)
     lib.rawdtw_batch_destroy(prev)

@@ -448,7 +448,7 @@ def test_compact_hand_over_equals_plain(oracle, shapes, n_reads, parts_range):
     b.close()
 
 
-CARRY_DTYPE = np.dtype([("prev_chain", "<u8"), ("parts", "<u4"), ("reserved", "<u4")])  # rawdtw_carry_t
+CARRY_DTYPE = np.dtype([("prev_src", "<u8"), ("parts", "<u4"), ("flags", "<u4"), ("start_t", "<u4"), ("start_q", "<u4")])  # rawdtw_carry_t
 
 
 def _two_rounds(rng, eng, n_reads=300):
@@ -538,22 +538,22 @@ def test_round_carry_takes_over_unchanged_parts(oracle):
     h = C.c_void_p()
     arr, carry, new_off, new_anchors = _match(lib, cb2, cb1, prev_read)
     assert np.array_equal(carry["parts"].astype(np.int64), expect)
-    assert int(new_off[-1]) == len(cb2.anchors) - int((expect + (expect > 0)).sum())
-    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]), vp(arr[4]),
-                                       b1._h, vp(carry), C.byref(h))
+    assert int(new_off[-1]) == len(cb2.anchors) - int(expect.sum())   # (the new entries and, where a stretch is taken over, the junction)
+    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(new_off), vp(new_anchors), vp(arr[3]),
+                                       vp(arr[4]), b1._h, vp(carry), C.byref(h))
     assert st == 5 and not h.value                                            # RAWDTW_ERR_UNSUPPORTED, nothing enqueued
     b1.run()
     b1.fetch()
     other = ra.MapOpt(dtw_min_score=5.0, dtw_band_radius_frac=0.2).c_struct()
     assert lib.rawdtw_batch_can_carry(eng._ctx, b1._h, C.byref(other)) == 0   # another radius: other costs
-    assert lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(other), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]),
+    assert lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(other), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(new_off), vp(new_anchors), vp(arr[3]),
                                          vp(arr[4]), b1._h, vp(carry), C.byref(h)) == 5
     assert lib.rawdtw_batch_can_carry(eng._ctx, b1._h, C.byref(copt)) == 1
     plain = ra.Batch(eng, opt, cb2)
     plain.run()
     want = plain.fetch(with_job_costs=True)
     plain.close()
-    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]),
+    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(new_off), vp(new_anchors), vp(arr[3]),
                                              vp(arr[4]), b1._h, vp(carry), C.byref(h)))
     score, keep = np.zeros(nc, np.float32), np.zeros(nc, np.uint8)
     jc = np.zeros(len(want[2]), np.float32)
@@ -566,24 +566,24 @@ def test_round_carry_takes_over_unchanged_parts(oracle):
     assert ru.value == int(expect.sum()) and sc.value + ru.value == len(jc) and ru.value > 1000
     # a third round on top of the carried one (its costs were copied, not computed): round 2 again, everything taken over
     arr3, carry3, new_off3, new_anchors3 = _match(lib, cb2, cb2, prev_read)
-    assert int(new_off3[-1]) == 0 or int(carry3["parts"].sum()) == len(jc)
+    assert int(carry3["parts"].sum()) == len(jc) and int(new_off3[-1]) == cb2.n_chains   # (nothing new: a junction a chain)
     h3 = C.c_void_p()
-    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr3[0]), vp(arr3[1]), vp(new_off3), vp(new_anchors3), vp(arr3[3]),
-                                             vp(arr3[4]), h, vp(carry3), C.byref(h3)))
+    eng._check(lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr3[0]), vp(arr3[1]), vp(arr3[2]), vp(new_off3), vp(new_anchors3),
+                                             vp(arr3[3]), vp(arr3[4]), h, vp(carry3), C.byref(h3)))
     score3, keep3, jc3 = np.zeros(nc, np.float32), np.zeros(nc, np.uint8), np.zeros(len(jc), np.float32)
     eng._check(lib.rawdtw_batch_fetch(eng._ctx, h3, vp(score3), vp(keep3), vp(jc3)))
     eng._check(lib.rawdtw_batch_round_stats(eng._ctx, h3, C.byref(sc), C.byref(ru)))
     assert ru.value == len(jc) and sc.value == 0
     assert np.array_equal(jc3.view(np.uint32), want[2].view(np.uint32)) and np.array_equal(score3.view(np.uint32), want[0].view(np.uint32))
     lib.rawdtw_batch_destroy(h3)
-    # an invented record (more parts than the named chain has): the counts do not add up on the device -- the batch is not
-    # scored from it (an error or a from-scratch fallback, never a wrong cost)
+    # an invented record (one part more than there is room for): the counts do not add up on the device -- the batch is not
+    # scored from it: it is redone from the full lists through the job-list path (never a wrong cost)
     bad = carry.copy()
     c_bad = int(np.argmax(bad["parts"] > 0))
     bad["parts"][c_bad] += 1
     hb = C.c_void_p()
-    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(new_off), vp(new_anchors), vp(arr[3]), vp(arr[4]),
-                                       h, vp(bad), C.byref(hb))
+    st = lib.rawdtw_batch_submit_carry(eng._ctx, C.byref(copt), cb2.n_reads, vp(arr[0]), vp(arr[1]), vp(arr[2]), vp(new_off), vp(new_anchors), vp(arr[3]),
+                                       vp(arr[4]), h, vp(bad), C.byref(hb))
     if st == 0:
         st = lib.rawdtw_batch_fetch(eng._ctx, hb, vp(score3), vp(keep3), None)
         assert st != 0 or np.array_equal(score3.view(np.uint32), want[0].view(np.uint32))
