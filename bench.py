@@ -509,10 +509,25 @@ def modes_block(local_rank, reads):
     cost = np.zeros(len(jobs), np.float32); plen = np.zeros(len(jobs), np.uint32)
     pi = np.zeros(int(poff[-1]), np.uint32); pj = np.zeros(int(poff[-1]), np.uint32); pd = np.zeros(int(poff[-1]), np.float32)
 
-    def tb():
+    tpin = Pinned(lib)   # (the steps form lands in page-locked arrays: no copy on the host)
+    pstep = tpin.empty(int(poff[-1]) + 1, np.uint8)
+    pd_pin = tpin.empty(int(poff[-1]) + 1, np.float32)
+    ev_pin = tpin.copy(cb.events)   # (the reads' events from page-locked memory too: their upload runs beside the host's planning)
+
+    def tb():  # the paths as steps + distances: what the library's mapper consumes (rawdtw_mapper_finish writes aln:s: from them)
+        eng._check(lib.rawdtw_traceback_batch_steps(eng._ctx, vp(jobs), len(jobs), vp(ev_pin), len(ev_pin), vp(cost), vp(poff), vp(plen),
+                                                    vp(pstep), vp(pd_pin)))
+
+    def tb_ij():  # ... and expanded into (i, j, distance) arrays on the host: dtw_result as the reference returns it
         eng._check(lib.rawdtw_traceback_batch(eng._ctx, vp(jobs), len(jobs), vp(cb.events), len(cb.events), vp(cost), vp(poff), vp(plen),
                                               vp(pi), vp(pj), vp(pd)))
-    tb()  # first call: code loading, pinned staging and workspace sizing
+    tb_ij()  # first calls: code loading, pinned staging and workspace sizing
+    t_ij = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tb_ij()
+        t_ij = min(t_ij, time.perf_counter() - t0)
+    tb()
     best, timing = 1e9, None
     for _ in range(3):
         t0 = time.perf_counter()
@@ -533,10 +548,15 @@ def modes_block(local_rank, reads):
                         "algorithmic_bytes": alg, "achieved_gbs": alg / max(kms, 1e-9) / 1e6,
                         "hbm_frac": alg / max(kms, 1e-9) / 1e6 / HBM_PEAK_GBS,
                         "call_ms_end_to_end": round(best * 1e3, 3), "gcups_end_to_end": cells / best / 1e9,
+                        "call_ms_end_to_end_ij_arrays": round(t_ij * 1e3, 3),
+                        "call_is": "rawdtw_traceback_batch_steps: plan, fill, walk, the paths home as one step byte + one distance an element "
+                                   "(5 bytes instead of 12) into the caller's arrays; `_ij_arrays`: rawdtw_traceback_batch, which rebuilds (i, j) from "
+                                   "the steps on the host while it writes three arrays",
                         "note": "kernels_ms = HIP events around the fill (k_full_wave<.,true,.>: the matrix fill writing 2-bit "
                                 "directions) and the walk (k_tb_walk_wave + k_tb_finish) inside rawdtw_traceback_batch; the call "
                                 "also plans on the host, brings 12 bytes a path element back over PCIe and copies them into the "
                                 "caller's pageable arrays"}
+    tpin.free()
     eng.close()
     return out
 

@@ -204,6 +204,14 @@ int rawdtw_traceback_batch(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n
                            const uint64_t *path_off, uint32_t *path_len, uint32_t *path_i,
                            uint32_t *path_j, float *path_d);
 
+/* The same with the paths in the form they leave the device in: per element ONE byte, the step from the element before it
+ * (bit 0: i advanced, bit 1: j advanced; element 0 of a global path is (0, 0): dtw.cpp:640-655, its step byte is 0), and its
+ * distance -- 5 bytes an element over the bus and into the caller's arrays instead of 12.  A consumer that walks the path in
+ * order (the aln:s: writer, rmap.cpp:580-592) needs nothing else. */
+int rawdtw_traceback_batch_steps(rawdtw_ctx *ctx, const rawdtw_job_t *jobs, uint64_t n_jobs,
+                                 const float *h_events, uint64_t n_events, float *out_cost,
+                                 const uint64_t *path_off, uint32_t *path_len, uint8_t *path_step, float *path_d);
+
 /* Device time of the most recent rawdtw_traceback_batch on this context (HIP events on its stream, summed over its
  * sub-batches): fill = the full-matrix kernels that write the packed 2-bit directions, walk = the traceback walk and the
  * path finish; direction_bytes = the packed direction buffers of its jobs; path_elements = the elements of all paths. */

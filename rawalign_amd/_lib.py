@@ -150,6 +150,7 @@ SYMBOLS = {
     "rawdtw_plan_run_timed": (I32, [VP, VP, VP, VP, U32]),
     "rawdtw_plan_destroy": (I32, [VP]),
     "rawdtw_traceback_batch": (I32, [VP, VP, U64, VP, U64, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_traceback_batch_steps": (I32, [VP, VP, U64, VP, U64, VP, VP, VP, VP, VP]),
     "rawdtw_dtw_global": (I32, [VP, VP, U32, VP, U32, I32, C.POINTER(F32)]),
     "rawdtw_dtw_global_slantedbanded_antidiagonalwise": (I32, [VP, VP, U32, VP, U32, I32, I32, C.POINTER(F32)]),
     "rawdtw_dtw_global_tb": (I32, [VP, VP, U32, VP, U32, I32, C.POINTER(F32), C.POINTER(U32), VP, VP, VP]),

@@ -231,8 +231,7 @@ hipError_t launch_full_wave(int rows_per_lane, bool traceback, const DevJob *job
                             float *bnd_ws, uint8_t *dir_ws, hipStream_t s);
 hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl, const float *ev,
                                const float *ref, const uint8_t *dir_ws, const uint64_t *path_off, uint32_t *path_len,
-                               uint32_t *tmp_i, uint32_t *tmp_j, uint32_t *path_i, uint32_t *path_j, float *path_d,
-                               hipStream_t s);
+                               uint32_t *tmp_i, uint32_t *tmp_j, uint8_t *path_mv, float *path_d, hipStream_t s);
 
 hipError_t launch_chain_fold(int mode, const ChainDesc *chains, const uint32_t *order, uint64_t n_chains,
                              const float *job_cost, float bonus, int fused, float *full_score, float *att_last, uint32_t long_parts,

@@ -587,14 +587,16 @@ __global__ __launch_bounds__(64) void k_tb_walk_wave(const DevJob *__restrict__ 
     if (lane == 0) path_len[blockIdx.x] = k;
 }
 
-// Start-first order, the exclude-last pop (dtw.cpp:656-663) and the per-step distance: one thread per path element.
+// Start-first order and the per-step distance: one thread per path element.  What leaves the device per element is its
+// distance and ONE byte: the step from the element before it (bit 0: i advanced, bit 1: j advanced; a global path starts at
+// (0, 0): dtw.cpp:640-655) -- the host rebuilds (i, j) while it writes the caller's arrays; 5 bytes an element over the bus
+// instead of 12.
 __global__ __launch_bounds__(256) void k_tb_finish(const DevJob *__restrict__ jobs, uint32_t count,
                                                    const float *__restrict__ ev, const float *__restrict__ ref,
                                                    const uint64_t *__restrict__ path_off,
                                                    const uint32_t *__restrict__ path_len,
                                                    const uint32_t *__restrict__ tmp_i, const uint32_t *__restrict__ tmp_j,
-                                                   uint32_t *__restrict__ path_i, uint32_t *__restrict__ path_j,
-                                                   float *__restrict__ path_d)
+                                                   uint8_t *__restrict__ path_mv, float *__restrict__ path_d)
 {
     const uint32_t g = blockIdx.x;
     if (g >= count) return;
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(256) void k_tb_finish(const DevJob *__restrict__ jo
     const uint32_t len = path_len[g];
     for (uint32_t q = threadIdx.x; q < len; q += 256) {
         const uint32_t i = tmp_i[po + len - 1 - q], j = tmp_j[po + len - 1 - q];
-        path_i[po + q] = i; path_j[po + q] = j; path_d[po + q] = dist(a[i], b[j]);
+        uint32_t mv = 0;
+        if (q) mv = (i - tmp_i[po + len - q]) | ((j - tmp_j[po + len - q]) << 1);
+        path_mv[po + q] = (uint8_t)mv; path_d[po + q] = dist(a[i], b[j]);
     }
 }
 
@@ -939,8 +943,7 @@ hipError_t launch_full_wave(int rpl, bool tb, const DevJob *jobs, uint64_t count
 // wave-per-job walk (end-first (i, j) into tmp_i / tmp_j) followed by k_tb_finish (start-first i, j, d)
 hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux *aux, int rpl, const float *ev,
                                const float *ref, const uint8_t *dir_ws, const uint64_t *path_off, uint32_t *path_len,
-                               uint32_t *tmp_i, uint32_t *tmp_j, uint32_t *path_i, uint32_t *path_j, float *path_d,
-                               hipStream_t s)
+                               uint32_t *tmp_i, uint32_t *tmp_j, uint8_t *path_mv, float *path_d, hipStream_t s)
 {
     if (count == 0) return hipSuccess;
     const dim3 grid((uint32_t)count), block(64);
@@ -953,7 +956,7 @@ hipError_t launch_tb_walk_wave(const DevJob *jobs, uint64_t count, const FullAux
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tb_finish, grid, dim3(256), 0, s, jobs, (uint32_t)count, ev, ref, path_off, path_len, tmp_i, tmp_j,
-                       path_i, path_j, path_d);
+                       path_mv, path_d);
     return hipGetLastError();
 }
 

@@ -744,31 +744,54 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
 }
 
 // --dtw-output-cigar (rmap.cpp:715-717): the best chain of every mapped read through DTW_global_tb once more, its path as the
-// aln:s: string with the reference's two quirks (rmap.cpp:230-233, 283-289)
+// aln:s: string with the reference's two quirks (rmap.cpp:230-233, 283-289).  All reads' jobs go to the device in ONE call;
+// the paths come back as steps and distances (rawdtw_traceback_batch_steps: 5 bytes an element) and every read's string is
+// written on the pool while the steps are walked.
 int rawdtw_mapper_finish(rawdtw_mapper *m)
 {
     if (!m) return RAWDTW_ERR_INVALID;
     if (!(m->opt.flag & 0x4)) return RAWDTW_OK;
     if (!m->ctx) return fail(m, RAWDTW_ERR_NO_DEVICE, "--dtw-output-cigar needs a device context");
-    drop_batches(m); // (the traceback calls replace the event arena's contents: the mapper's rounds are over)
+    drop_batches(m); // (the traceback call replaces the event arena's contents: the mapper's rounds are over)
     for (Group &g : m->groups) g.has_prev = false;
-    for (MRead &rd : m->reads) {
+    struct Item { uint32_t read; uint64_t job0; uint32_t nj; uint64_t ev0; };
+    std::vector<Item> items;
+    std::vector<rawdtw_job_t> jobs;
+    std::vector<float> events;
+    for (uint32_t r = 0; r < m->reads.size(); r++) {
+        MRead &rd = m->reads[r];
         if (rd.released || !high_confidence(m, rd.chains)) continue;
         MChain &ch = rd.chains[0];
         const uint32_t na = (uint32_t)ch.anchors.size();
         const uint32_t nj = rawdtw_chain_job_count(&m->opt.align, na);
-        std::vector<rawdtw_job_t> jobs(std::max<uint32_t>(nj, 1));
+        if ((uint64_t)events.size() + rd.events.size() >= (1ull << 32)) return fail(m, RAWDTW_ERR_RANGE, "the mapped reads' events exceed one event arena");
+        const uint64_t j0 = jobs.size();
+        jobs.resize(j0 + std::max<uint32_t>(nj, 1));
         const uint64_t rb = m->ref_off[ch.ref * 2u + (uint32_t)ch.strand];
-        int st = rawdtw_chain_build_jobs(&m->opt.align, ch.anchors.data(), na, rb, 0, 1, jobs.data());
+        const int st = rawdtw_chain_build_jobs(&m->opt.align, ch.anchors.data(), na, rb, (uint32_t)events.size(), 1, jobs.data() + j0);
         if (st != RAWDTW_OK) return fail(m, st, st == RAWDTW_ERR_UNSUPPORTED ? "banded global alignment with --dtw-output-cigar is not implemented (rmap.cpp:223-225)" : "job building failed");
-        std::vector<uint64_t> poff(nj + 1, 0);
-        for (uint32_t k = 0; k < nj; k++) poff[k + 1] = poff[k] + jobs[k].n + jobs[k].m - 1;
-        std::vector<uint32_t> plen(nj), pi(poff[nj]), pj(poff[nj]);
-        std::vector<float> pd(poff[nj]), cost(nj);
-        st = rawdtw_traceback_batch(m->ctx, jobs.data(), nj, rd.events.data(), rd.events.size(), cost.data(), poff.data(), plen.data(), pi.data(),
-                                    pj.data(), pd.data());
+        jobs.resize(j0 + nj);
+        items.push_back(Item{r, j0, nj, events.size()});
+        events.insert(events.end(), rd.events.begin(), rd.events.end());
+    }
+    if (items.empty()) return RAWDTW_OK;
+    const uint64_t nj_all = jobs.size();
+    std::vector<uint64_t> poff(nj_all + 1, 0);
+    for (uint64_t k = 0; k < nj_all; k++) poff[k + 1] = poff[k] + jobs[k].n + jobs[k].m - 1;
+    std::vector<uint32_t> plen(nj_all);
+    std::vector<uint8_t> step(poff[nj_all] + 1);
+    std::vector<float> pd(poff[nj_all] + 1), cost(nj_all);
+    if (nj_all) {
+        const int st = rawdtw_traceback_batch_steps(m->ctx, jobs.data(), nj_all, events.data(), events.size(), cost.data(), poff.data(), plen.data(), step.data(), pd.data());
         if (st != RAWDTW_OK) return fail(m, st, rawdtw_last_error(m->ctx));
-        ch.alignment_score = rawdtw_chain_replay(&m->opt.align, ch.anchors.data(), na, cost.data(), -1e10f); // rmap.cpp:306 on the summed costs
+    }
+    std::vector<std::string> logs(items.size());
+    m->pool->run(items.size(), 4, [&](size_t x) {
+        const Item &it = items[x];
+        MRead &rd = m->reads[it.read];
+        MChain &ch = rd.chains[0];
+        const uint32_t na = (uint32_t)ch.anchors.size(), nj = it.nj;
+        ch.alignment_score = rawdtw_chain_replay(&m->opt.align, ch.anchors.data(), na, cost.data() + it.job0, -1e10f); // rmap.cpp:306 on the summed costs
         std::string s;
         const uint32_t parts = na - 1;
         char el[96];
@@ -776,11 +799,15 @@ int rawdtw_mapper_finish(rawdtw_mapper *m)
             // sparse: every element offset by its part's start anchor (rmap.cpp:286-289); global: the offsets are added to
             // alignment.back() once per element (rmap.cpp:230-233), i.e. only the last tuple moves
             const rawdtw_anchor_t &s0 = m->opt.align.border_constraint == 0 ? ch.anchors[na - 1] : ch.anchors[parts - k];
-            for (uint32_t q = 0; q < plen[k]; q++) {
-                unsigned long long i = pi[poff[k] + q], j = pj[poff[k] + q];
+            const uint64_t p0 = poff[it.job0 + k];
+            const uint32_t len = plen[it.job0 + k];
+            unsigned long long pi = 0, pj = 0; // (i, j) from the steps: a global path starts at (0, 0)
+            for (uint32_t q = 0; q < len; q++) {
+                pi += step[p0 + q] & 1u; pj += step[p0 + q] >> 1;
+                unsigned long long i = pi, j = pj;
                 if (m->opt.align.border_constraint != 0) { i += s0.query_position; j += s0.target_position; }
-                else if (q + 1 == plen[k]) { i += (unsigned long long)plen[k] * s0.query_position; j += (unsigned long long)plen[k] * s0.target_position; }
-                snprintf(el, sizeof el, "(%llu,%llu,%g)", i, j, (double)pd[poff[k] + q]); // ostream << float == %g (rmap.cpp:580-592)
+                else if (q + 1 == len) { i += (unsigned long long)len * s0.query_position; j += (unsigned long long)len * s0.target_position; }
+                snprintf(el, sizeof el, "(%llu,%llu,%g)", i, j, (double)pd[p0 + q]); // ostream << float == %g (rmap.cpp:580-592)
                 s += el;
             }
         }
@@ -789,9 +816,10 @@ int rawdtw_mapper_finish(rawdtw_mapper *m)
         if (m->opt.flag & 0x8) {
             char line[128];
             snprintf(line, sizeof line, "chaining_score=%f alignment_score=%f\n", (double)ch.chaining_score, (double)ch.alignment_score);
-            m->log += line;
+            logs[x] = line;
         }
-    }
+    });
+    for (const std::string &l : logs) m->log += l; // (read order)
     return RAWDTW_OK;
 }
 

@@ -576,3 +576,52 @@ def test_device_planned_batch_matches_host_planned(oracle, border, fill):
     assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)) and np.array_equal(k0, k1)
     for key in ("n_jobs", "cells", "algorithmic_bytes", "n_lane_jobs", "n_wave_band_jobs", "n_full_jobs"):
         assert i0[key] == i1[key], key
+
+
+def test_traceback_steps_form_equals_ij_arrays(engine):
+    """rawdtw_traceback_batch_steps: a path as one step byte and one distance an element (what leaves the device) must expand
+    to exactly the (i, j, distance) arrays of rawdtw_traceback_batch (which the golden paths pin to the reference) -- with the
+    caller's offsets dense (the stretch comes home whole: through the landing zone, and in place when the arrays are page-
+    locked) and with gaps between the paths (job by job), exclude_last pops included."""
+    import ctypes as C
+
+    rng = np.random.default_rng(41)
+    lib = engine.lib
+    cases = []
+    for k in range(60):
+        n, m = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), -1, k % 3 == 0))
+    jobs, ev, rf = make_arena_jobs(cases)
+    engine.upload_reference([rf], [rf])
+    jobs["ref_off"] += engine.reference_offset(0, 1)
+    want = engine.traceback_batch(jobs, ev)
+    caps = jobs["n"].astype(np.uint64) + jobs["m"].astype(np.uint64) - 1
+    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    for gaps, pinned in ((0, False), (0, True), (7, False)):
+        off = np.zeros(len(jobs), np.uint64)
+        off[1:] = np.cumsum(caps + np.uint64(gaps))[:-1]
+        total = int(off[-1] + caps[-1]) + 8
+        ptrs = []
+        if pinned:
+            def alloc(nbytes):
+                p = C.c_void_p()
+                assert lib.rawdtw_host_alloc(nbytes, C.byref(p)) == 0
+                ptrs.append(p)
+                return p
+            step = np.frombuffer((C.c_char * total).from_address(alloc(total).value), np.uint8, total)
+            dist = np.frombuffer((C.c_char * (4 * total)).from_address(alloc(4 * total).value), np.float32, total)
+        else:
+            step, dist = np.zeros(total, np.uint8), np.zeros(total, np.float32)
+        step[:] = 0xEE
+        cost, plen = np.zeros(len(jobs), np.float32), np.zeros(len(jobs), np.uint32)
+        engine._check(lib.rawdtw_traceback_batch_steps(engine._ctx, vp(jobs), len(jobs), vp(ev), len(ev), vp(cost), vp(off), vp(plen), vp(step), vp(dist)))
+        for k, w in enumerate(want):
+            s, n = int(off[k]), int(plen[k])
+            assert n == len(w) and bits(cost[k]) == bits(w.cost)
+            st = step[s:s + n]
+            assert st[0] == 0 and np.array_equal(np.cumsum(st & 1), w.i) and np.array_equal(np.cumsum(st >> 1), w.j)
+            assert np.array_equal(dist[s:s + n].view(np.uint32), w.difference.view(np.uint32))
+            if gaps:
+                assert np.all(step[s + int(caps[k]):s + int(caps[k]) + gaps] == 0xEE)   # (nothing written between the paths)
+        for p in ptrs:
+            lib.rawdtw_host_free(p)
