@@ -37,6 +37,8 @@ def seq_to_sig(codes: np.ndarray, pore: np.ndarray, k: int = 6, strand: int = 0)
     """ri_seq_to_sig (src/rsig.cpp:7-41) for an unambiguous sequence given as 0..3 codes."""
     seq = (3 - codes[::-1]) if strand else codes  # rsig.cpp:15,22: reverse traversal, complemented base
     n = len(seq) - k + 1
+    if n > (1 << 26):
+        return _seq_to_sig_chunked(seq, pore, k, n)
     idx = np.zeros(n, np.int64)
     for j in range(k):
         idx = (idx << 2) | seq[j:j + n].astype(np.int64)
@@ -44,6 +46,28 @@ def seq_to_sig(codes: np.ndarray, pore: np.ndarray, k: int = 6, strand: int = 0)
     mean = vals.sum() / n                # rsig.cpp:34
     std = np.sqrt((vals * vals).sum() / n - mean * mean)
     return ((pore[idx].astype(np.float32).astype(np.float64) - mean) / std).astype(np.float32)  # rsig.cpp:37-38
+
+
+def _seq_to_sig_chunked(seq, pore, k, n, chunk=1 << 25):
+    """The same for a human-size sequence (gigabases): two passes over chunks, so that the k-mer indices and the doubles of one
+    chunk are all that is alive at a time (the sums of a chunked pass differ from one pairwise sum in their last bits: the
+    whole-array form above stays the one the small fixtures use)."""
+    def levels(lo, hi):
+        idx = np.zeros(hi - lo, np.int32)
+        for j in range(k):
+            idx = (idx << 2) | seq[lo + j:hi + j].astype(np.int32)
+        return pore[idx]
+    s1 = s2 = 0.0
+    for lo in range(0, n, chunk):
+        v = levels(lo, min(n, lo + chunk)).astype(np.float64)
+        s1 += float(v.sum()); s2 += float((v * v).sum())
+    mean = s1 / n
+    std = np.sqrt(s2 / n - mean * mean)
+    out = np.empty(n, np.float32)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        out[lo:hi] = ((levels(lo, hi).astype(np.float64) - mean) / std).astype(np.float32)
+    return out
 
 
 @dataclass
@@ -58,12 +82,25 @@ class Reference:
 
 
 def make_reference(seq_lengths, seed: int, k: int = 6) -> Reference:
+    """RAWDTW_SYNTH_CACHE=<dir>: keep the signal arrays of references of 10^8 bases and more there (a gigabase reference takes
+    minutes to make; the profiling passes of one GPU-box call make the same one several times)."""
+    import os
+
     pore = make_pore_model(k)
     fwd, rev, names = [], [], []
+    cache = os.environ.get("RAWDTW_SYNTH_CACHE")
     for s, n in enumerate(seq_lengths):
-        g = make_genome(int(n), seed + 1000 * s)
-        fwd.append(seq_to_sig(g, pore, k, 0))
-        rev.append(seq_to_sig(g, pore, k, 1))
+        path = os.path.join(cache, "ref_%d_%d_%d_%d.npy" % (int(n), seed, s, k)) if cache and int(n) >= 10 ** 8 else None
+        if path and os.path.exists(path):
+            both = np.load(path, mmap_mode="r")
+            fwd.append(np.ascontiguousarray(both[0])); rev.append(np.ascontiguousarray(both[1]))
+        else:
+            g = make_genome(int(n), seed + 1000 * s)
+            fwd.append(seq_to_sig(g, pore, k, 0))
+            rev.append(seq_to_sig(g, pore, k, 1))
+            if path:
+                os.makedirs(cache, exist_ok=True)
+                np.save(path, np.stack([fwd[-1], rev[-1]]))
         names.append(f"synth_{s}")
     return Reference(fwd, rev, names)
 

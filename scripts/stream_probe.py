@@ -15,7 +15,7 @@ from rawalign_amd import synth  # noqa: E402
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 configs = sys.argv[2:] or [""]
-ref = synth.make_reference([4_600_000], seed=20231007)
+ref = synth.make_reference([int(os.environ.get("RAWDTW_PROBE_GENOME", 4_600_000))], seed=20231007)  # (RAWDTW_PROBE_GENOME: a reference beyond the Infinity Cache)
 eng0 = ra.Engine(0)
 eng0.upload_reference(ref.forward, ref.reverse)
 offs = {(0, st): eng0.reference_offset(0, st) for st in (0, 1)}
