@@ -1,30 +1,37 @@
-// rawdtw_runs.hip -- the sync-free candidate-batch pipeline (rawdtw_batch_create/run for sparse + banded batches).
+// rawdtw_runs.hip -- the sync-free candidate-batch pipeline (rawdtw_batch_create / submit / run for sparse + banded batches).
 //
 // What it replaces: the DTW block of gen_chains (src/rmap.cpp:509-530) for every read of a mini-batch, i.e. all the calls
-// of DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520) that align_chain (src/rmap.cpp:238-300) issues.
+// of DTW_global_slantedbanded_antidiagonalwise (src/dtw.cpp:273-520) that align_chain (src/rmap.cpp:238-300) issues, the
+// fold of their costs (rmap.cpp:279-280, 306) and the per-read accept / cut loop (rmap.cpp:515-524).
 //
-// Round 2 planned a batch JOB BY JOB: a planning kernel wrote a 16-byte record and two running sums for every DTW job to
-// HBM (143 MB a batch), a scan and a search kernel cut them into tiles, and the DTW launch read all of it back and marked
-// every 16-byte chunk of its LDS image job by job.  But a chain's consecutive parts are ONE contiguous piece of each arena
-// (part p runs from anchors[parts - p] to anchors[parts - p - 1], rmap.cpp:248-293: it starts on the element the part
-// before it ends on), and the anchors' positions ARE the running sums of the window lengths.  So here the unit is a run:
+// The unit is a RUN: a chain's consecutive parts are ONE contiguous piece of each arena (part p runs from anchors[parts - p]
+// to anchors[parts - p - 1], rmap.cpp:248-293: it starts on the element the part before it ends on), and the anchors'
+// positions ARE the running sums of the window lengths.  A batch is these launches on the context's stream, none of which
+// the host waits for (rawdtw_batch.cpp: batch_create_stream, batch_enqueue_one):
 //
-//   k_scan     one workgroup per 8192 anchors: finds the range's first chain (a 64-way search of the chains' offsets by
-//              one wave), checks every part's anchors, and appends the parts the lane-per-job bodies do not take
-//              (radius > 3, longer side > 73: one part in two hundred) to a side list.  Its other workgroups write the
-//              fold's chain records and sort the chains by part count.  Writes 4 bytes per TILE (its first chain).
-//   k_side     the side list into class order (wave-per-job first, longest first), as before
-//   k_runs     ONE persistent launch per batch: every wave first takes its share of the side list's items, then
-//              workgroups pull tiles from an eight-headed queue.  Per tile: load the range's anchors (coalesced, each
-//              once), derive every part's windows, radius (rmap.cpp:276, dtw.cpp:298-300) and class in registers, lay
-//              the runs out in the LDS image with one workgroup scan, stage each run's two windows with plain coalesced
-//              16-byte copies, sort the parts by (radius class, longer side) in LDS, score them a lane each
-//              (rawdtw_dp.h).  The cost of part i goes to out[i].  Nothing else about a job or a tile touches HBM.
+//   k_scan         one workgroup per 8192 anchors: finds the range's first chain (a 64-way search of the chains' offsets by one
+//                  wave), checks every part's anchors, classifies it (radius rmap.cpp:276 + slant dtw.cpp:298-300), appends the
+//                  one part in two hundred the lane-per-job bodies do not take (radius > 3, longer side > 73) to a side list and
+//                  writes the tile list (tile, its first chain) of every tile that has a part for the lane bodies; its other
+//                  workgroups write the fold's chain records.  k_scan_compact: the same with the anchor lists in the compact
+//                  hand-over form, decoded unit by unit first (k_scan_desc then writes the chain records).
+//   k_side         the side list into class order (wave-per-job first, longest first)
+//   k_wide         the side list's jobs: wave-cooperative bodies (rawdtw_dp.h: wband_gen, grp_wave, lane_dp_k8), dealt to the
+//                  workgroups like a snake, pulled by a workgroup's waves from an LDS counter
+//   k_plan         a wave a listed tile (512 consecutive anchors): lays the tile's LDS image out (runs: one contiguous piece of
+//                  each arena a run), sorts its jobs into the order the lanes take them, and leaves per PASS the job records
+//                  (8 bytes a job), the copy orders (16 bytes a run and arena) and the list entry in memory
+//   k_runs         a persistent grid over the passes: stage the pass's image by LDS-DMA, one lane per job (four lanes for the
+//                  radius-3 jobs), the cost of part i to out[i]; two barriers a pass
+//   k_gather       chunk rounds only (rawdtw_batch_submit_carry): the lists above are then the round's SHORT lists (new entries +
+//                  one junction a chain); this launch lays every chain's costs out in full -- the stretch taken over from the
+//                  previous batch's cost array, then the new parts' -- for the fold
+//   k_fold_select  fold (rmap.cpp:279-280, 306) and accept / cut loop (rmap.cpp:515-524) out of LDS, a wave per 8 reads
 //
 // No step needs a number on the host: grids are sized by the anchor count or are persistent, every count lives in a
 // device counter block.  rawdtw_batch_create only enqueues; errors and the rare shapes this path does not take (band wider
-// than 256 offsets, chains without anchors) surface in the counters, which rawdtw_batch_fetch reads together with the
-// results and which make k_runs leave at once.
+// than 256 slots, chains without anchors, a list over a capacity) surface in the counters, which rawdtw_batch_fetch reads
+// together with the results and which make the later launches leave at once: such a batch is redone through the job list.
 
 #include "rawdtw_dp.h"
 
@@ -974,7 +981,7 @@ __device__ __forceinline__ uint32_t next_tile(const StreamArgs &a, const uint32_
 // its own (inside k_runs its waves kept a third of the workgroups from the tiles for a third of the launch): wave-
 // cooperative jobs, longest first, dealt over the waves of the grid.  It needs no LDS and ends with its longest job
 // (a wave per job: 163 ns a column).  In line on the batch's stream, between the scan and the pass planning
-// (rawdtw_capi.cpp: stream_wide_fork; on a second stream beside the tiles it cost more in fork / join than it hid).
+// (rawdtw_batch.cpp: stream_wide_fork; on a second stream beside the tiles it cost more in fork / join than it hid).
 __global__ __launch_bounds__(256) void k_wide(const StreamArgs a)
 {
     const uint32_t dbg = a.debug;

@@ -146,9 +146,10 @@ def test_stream_path_shapes_against_oracle(oracle, shapes, opts):
 
 @pytest.mark.parametrize("n_reads,parts_range", [(900, (1, 4)), (12, (300, 500)), (200, (1, 120)), (700, (0, 3))])
 def test_stream_path_chain_lengths_against_oracle(oracle, n_reads, parts_range):
-    """k_pre finds a job's chain in LDS when its unit of 1024 jobs spans at most 62 chains and in memory otherwise:
-    batches of very short chains (hundreds a unit), very long ones (a chain over several units), a mix, and chains of a
-    single anchor (no part, no job: rmap.cpp:251 does not enter its loop) between the others."""
+    """The scan and the planner find an anchor's chain from a chain-start bit mask of its unit / tile (k_scan: 8192 anchors,
+    k_plan: 512), built from the chains' offsets in as many rounds of loads as the range has chains to 64: batches of very
+    short chains (hundreds a tile, several passes a tile for the 32-entry run table), very long ones (a chain over several
+    units), a mix, and chains of a single anchor (no part, no job: rmap.cpp:251 does not enter its loop) between the others."""
     rng = np.random.default_rng(n_reads)
     ref = [rng.normal(size=60000).astype(np.float32), rng.normal(size=60000).astype(np.float32)]
     eng = ra.Engine(0)
