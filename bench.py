@@ -224,7 +224,8 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
     handed over, the device's scan, planning and DTW launches run on that short list, and one gather launch lays every
     chain's costs out in full for the fold).  One context, rounds in sequence
     (a round needs the one before); wall time per round from submit to fetched scores, (a) with the hand-over arrays in
-    pinned host memory -- what a mapper's round is -- and (b) with them resident in HBM, as in the `value` loop."""
+    pinned host memory -- what a mapper's round is: `scratch_ms` / `carried_ms` -- and (b) with them resident in HBM, as in the
+    `value` loop (`*_resident_ms`)."""
     from rawalign_amd import synth
     import torch
 
@@ -258,8 +259,8 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
     want = [None] * n_rounds
     for resident in (0, 1):
         engine.set_option("resident_arrays", resident)
-        sfx = "" if resident else "_host"
-        for mode in ("warm", "scratch", "carried"):
+        sfx = "_resident" if resident else ""
+        for mode in ("warm", "warm_carried", "scratch", "carried"):  # (both forms once untimed: their workspaces come out of the context's pool afterwards)
             prev = None
             for k, d in enumerate(R):
                 h = C.c_void_p()
@@ -267,7 +268,7 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
                 A = (P(d["t"][0]), P(d["t"][1]), P(d["t"][2])) if resident else (vp(d["anchors"]), vp(d["ref_base"]), vp(d["read_base"]))
                 engine.sync()
                 t0 = time.perf_counter()
-                if mode == "carried" and prev is not None:
+                if mode.endswith("carried") and prev is not None:
                     engine._check(lib.rawdtw_batch_submit_carry(engine._ctx, C.byref(copt), cb.n_reads, vp(d["chain_off"]), vp(d["anchor_off"]), vp(d["anchors"]),
                                                                 vp(d["new_off"]), P(d["t_new"]) if resident else vp(d["new_anchors"]), A[1], A[2], prev,
                                                                 vp(d["carry"]), C.byref(h)))
@@ -281,6 +282,11 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
                     if want[k] is None:
                         want[k] = (score.copy(), keep.copy())
                     same = same and np.array_equal(want[k][0].view(np.uint32), score.view(np.uint32)) and np.array_equal(want[k][1], keep)
+                if mode == "warm_carried":
+                    if prev is not None:
+                        lib.rawdtw_batch_destroy(prev)
+                    prev = h
+                    continue
                 if mode == "carried":
                     sc, ru = C.c_uint64(), C.c_uint64()
                     engine._check(lib.rawdtw_batch_round_stats(engine._ctx, h, C.byref(sc), C.byref(ru)))
@@ -300,15 +306,16 @@ def rounds_block(engine, lib, copt, cb, info, n_rounds, local_rank, pin):
     out.update({"parts_total": sum(r["parts"] for r in pr), "parts_scored": sum(r["parts_scored"] for r in pr),
                 "jobs_reused": sum(r["parts_reused"] for r in pr),
                 "scratch_ms_total": tot("scratch_ms"), "carried_ms_total": tot("carried_ms"),
-                "scratch_host_ms_total": tot("scratch_host_ms"), "carried_host_ms_total": tot("carried_host_ms"),
-                "carried_rounds": {"scratch_ms": tot("scratch_ms", 1), "carried_ms": tot("carried_ms", 1), "scratch_host_ms": tot("scratch_host_ms", 1),
-                                   "carried_host_ms": tot("carried_host_ms", 1),
+                "scratch_resident_ms_total": tot("scratch_resident_ms"), "carried_resident_ms_total": tot("carried_resident_ms"),
+                "carried_rounds": {"scratch_ms": tot("scratch_ms", 1), "carried_ms": tot("carried_ms", 1), "scratch_resident_ms": tot("scratch_resident_ms", 1),
+                                   "carried_resident_ms": tot("carried_resident_ms", 1),
                                    "anchor_list_bytes_scratch": 8 * sum(r["anchors"] for r in pr[1:]),
                                    "anchor_list_bytes_carried": 8 * sum(r["anchors_handed_over"] for r in pr[1:]),
                                    "note": "rounds 2.. only (round 1 has no predecessor and is the same submission in both modes)"},
                 "scores_identical_to_scratch": bool(same),
-                "note": "`*_ms`: hand-over arrays resident in HBM (no PCIe in either mode); `*_host_ms`: from pinned host memory, as a "
-                        "mapper's round hands them over.  A carried round sends its new anchors and a junction a chain "
+                "note": "`scratch_ms` / `carried_ms`: the hand-over arrays come from pinned host memory, as a mapper's round hands them over "
+                        "(the anchors are made on the host every round: rmap.cpp:396-507); `*_resident_ms`: the same with them resident in HBM (no PCIe "
+                        "in either form: what is left is the kernels and the submission's small copies -- round 3's block measured only this).  A carried round sends its new anchors and a junction a chain "
                         "(anchors_handed_over), plans and scores only the parts they bring, and gathers the rest's costs out of the batch before "
                         "(k_gather: one stretch a chain); the host's matching of the "
                         "chains (match_ms_host_1_thread, rawdtw_round_match_chains on one thread; the mapper does it per read on "
@@ -341,8 +348,13 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     first, nch = sc["chunk_first"], sc["n_chunks"]
     ev_off, hit_off = sc["ev_off"].astype(np.int64), sc["hit_off"].astype(np.int64)
 
-    def run(cm, reads, label):
+    def run(cm, reads, label, warm=True):
+        if warm:  # the same reads once untimed on the same mapper (its pinned buffers and the contexts' workspaces reach their sizes), then released
+            w = run(cm, reads, label, warm=False)
+            for i in w.pop("ids"):
+                cm.release_read(int(i))
         ids = np.array([cm.add_read("read_%d" % r, int(sc["qlen"][r]), int(nch[r])) for r in reads], np.uint32)
+        tm0, st0 = cm.timing(), cm.stats()
         done = np.zeros(len(reads), np.int64)
         active = np.ones(len(reads), bool)
         t_rounds, n_rounds, read_rounds = 0.0, 0, 0
@@ -369,11 +381,13 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
                 if fin or done[k] >= nch[reads[k]]:
                     active[k] = False
         assert cm.finish() == 0
+        if not warm:
+            return {"ids": ids}
         lines = [cm.paf(int(i)) for i in ids]
         mapped = sum(1 for ln in lines if ln.split("\t")[4] in "+-")
         h = hashlib.sha1("\n".join(lines).encode()).hexdigest()
-        tm = cm.timing()
-        rounds, scored, reused = cm.stats()
+        tm = {k: v - tm0[k] for k, v in cm.timing().items()}
+        rounds, scored, reused = (a - b for a, b in zip(cm.stats(), st0))
         return {"label": label, "reads": int(len(reads)), "mapped_reads": mapped, "rounds": n_rounds, "read_rounds": read_rounds,
                 "seconds_in_rounds": round(t_rounds, 4), "reads_per_s": len(reads) / t_rounds, "mapped_reads_per_s": mapped / t_rounds,
                 "read_rounds_per_s": read_rounds / t_rounds, "parts_scored": scored, "parts_reused": reused,

@@ -560,8 +560,12 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         ra.carried = false;
         ra.round_id = round_id;
         const RoundArrays &pb = g.buf[g.cur ^ 1];
-        if (on_device && m->opt.carry && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) { pv = &pb; ra.carried = true; }
         const size_t nr = ra.ks.size();
+        if (on_device && m->opt.carry && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) {
+            size_t known = 0; // (a round none of whose reads was in the round before has nothing to take over: submitted whole)
+            for (size_t i = 0; i < nr && !known; i++) known += m->reads[read_ids[ra.ks[i]]].last_round == pb.round_id;
+            if (known) { pv = &pb; ra.carried = true; }
+        }
         ra.n_reads = nr;
         m->pool->run(nr, 16, [&](size_t i) {
             const uint32_t k = ra.ks[i];
