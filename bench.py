@@ -941,12 +941,16 @@ def main():
         dbytes = tile_bytes0  # the passes' jobs: what k_runs moves (the side list's jobs are k_wide's)
         achieved = dbytes / (dms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r03.json")
-        if os.path.exists(tpath):
+        for tname in ("traffic_r04_large.json" if args.genome >= 10 ** 8 else "traffic_r04.json", "traffic_r03.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if not os.path.exists(tpath):
+                continue
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == WORKLOAD and tj.get("reads") == args.reads:
-                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/traffic_r03.json (PMC passes over the same batch, collected separately; not measured by this run)"
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/%s (PMC passes over the same batch, collected separately; not measured by this run)" % tname
+                    break
             except Exception:
                 pass
         out = {
