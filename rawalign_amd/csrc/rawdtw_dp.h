@@ -1452,7 +1452,8 @@ __device__ __forceinline__ void wreg_small_job(const DevJob &jb, int lane, const
     const int K = jb.R + 1;
     if (K <= 64) wband_gen<1>(jb, lane, ev, ref, out, lds, lds_floats);
     else if (K <= 128) wband_gen<2>(jb, lane, ev, ref, out, lds, lds_floats);
-    else wband_gen<4>(jb, lane, ev, ref, out, lds, lds_floats);
+    else if (K <= 192) wband_gen<3>(jb, lane, ev, ref, out, lds, lds_floats); // (odd: a lane's window is C consecutive floats of LDS, and with four the lanes of a
+    else wband_gen<5>(jb, lane, ev, ref, out, lds, lds_floats);               //  read sit on eight of the 32 banks -- see k_band_wband8)
 }
 
 } // namespace rawdtw

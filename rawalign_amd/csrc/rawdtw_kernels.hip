@@ -295,13 +295,20 @@ __global__ __launch_bounds__(64) void k_band_wreg(const DevJob *__restrict__ job
     wreg_body<C>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out);
 }
 
-// bands of 257 .. 512 slots (global-mode chains of a few thousand events at banded=0.10): the LDS-window body with eight registers a lane
-constexpr uint32_t kWband8LdsFloats = 128u * 8u + 2u * 1200u;
+// bands of 257 .. 512 slots (global-mode chains of a few thousand events at banded=0.10): the LDS-window body with an ODD number of registers a
+// lane -- five, seven or nine, the fewest that hold the band.  A lane's window is C consecutive floats of LDS: with eight the lanes of a
+// read sit 8 dwords apart, on four of the 32 banks (16 passes a dword; the launch was LDS-bound at 1.2-1.5 TCUPS, 4 x 16-byte reads
+// or 8 x 2 dwords alike); an odd stride visits every bank.
+constexpr uint32_t kWband8LdsFloats = 128u * 9u + 2u * 1300u;
 __global__ __launch_bounds__(64) void k_band_wband8(const DevJob *__restrict__ jobs, const float *__restrict__ ev, const float *__restrict__ ref,
                                                     float *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) float s_w[kWband8LdsFloats];
-    wband_gen<8>(jobs[blockIdx.x], (int)threadIdx.x, ev, ref, out, s_w, kWband8LdsFloats);
+    const DevJob &jb = jobs[blockIdx.x];
+    const int K = __builtin_amdgcn_readfirstlane(jb.R) + 1;
+    if (K <= 320) wband_gen<5>(jb, (int)threadIdx.x, ev, ref, out, s_w, kWband8LdsFloats);
+    else if (K <= 448) wband_gen<7>(jb, (int)threadIdx.x, ev, ref, out, s_w, kWband8LdsFloats);
+    else wband_gen<9>(jb, (int)threadIdx.x, ev, ref, out, s_w, kWband8LdsFloats);
 }
 
 __global__ __launch_bounds__(64) void k_band_wreg_small(const DevJob *__restrict__ jobs,

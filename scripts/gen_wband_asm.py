@@ -36,13 +36,17 @@ SBASE = 36   # first scratch SGPR of the block (clobbered): the 2 C extent masks
 
 
 def gen(C):
-    nd = 1 if C <= 2 else C // 2          # ds_read instructions per window
-    P = [[VBASE + s * C + c for c in range(C)] for s in range(3)]          # a-window register sets
-    B = [[VBASE + 3 * C + s * C + c for c in range(C)] for s in range(2)]  # b-window register sets
-    t = VBASE + 5 * C
+    Cp = C + (C & 1)                      # registers a set: 64-bit operands (ds_read2, v_pk_add) want even-aligned pairs
+    wide = C >= 4 and C % 4 == 0 and os.environ.get("WBAND_B128", "1") == "1"   # 16-byte reads at any 4-byte boundary (the LDS runs in unaligned mode)
+    npair, odd = C // 2, C & 1
+    nd = (C // 4) if wide else (1 if C == 1 else npair + odd)          # ds_read instructions per window
+    P = [[VBASE + s * Cp + c for c in range(C)] for s in range(3)]          # a-window register sets
+    B = [[VBASE + 3 * Cp + s * Cp + c for c in range(C)] for s in range(2)]  # b-window register sets
+    t = VBASE + 5 * Cp
     DIFF = [t + c for c in range(C)]
-    D0 = [t + C + c for c in range(C)]
-    D1 = [t + 2 * C + c for c in range(C)]
+    D0 = [t + Cp + c for c in range(C)]
+    D1 = [t + 2 * Cp + c for c in range(C)]
+    t = t + 3 * Cp - 3 * C  # (the four singles below sit behind the last set)
     KHI, KLO, KLO2, VINF = t + 3 * C, t + 3 * C + 1, t + 3 * C + 2, t + 3 * C + 3
     last_v = VINF
     MS = [SBASE + 2 * c for c in range(C)]              # s[MS[c] : MS[c] + 1]: the secondaries' mask of register c
@@ -60,17 +64,24 @@ def gen(C):
         """C consecutive dwords at LDS byte address `addr` + 4 * dw_off into registers dst[0..C)"""
         if C == 1:
             e(f"ds_read_b32 {v(dst[0])}, {addr} offset:{4 * dw_off}")
+        elif wide:
+            for q in range(C // 4):
+                e(f"ds_read_b128 v[{dst[4 * q]}:{dst[4 * q + 3]}], {addr} offset:{4 * (dw_off + 4 * q)}")
         else:
-            for q in range(C // 2):
+            for q in range(npair):
                 e(f"ds_read2_b32 v[{dst[2 * q]}:{dst[2 * q + 1]}], {addr} offset0:{dw_off + 2 * q} offset1:{dw_off + 2 * q + 1}")
+            if odd:
+                e(f"ds_read_b32 {v(dst[C - 1])}, {addr} offset:{4 * (dw_off + C - 1)}")
 
     def diffs(e, a, b):
         """DIFF[c] = a[c] - b[c]"""
         if C == 1:
             e(f"v_sub_f32 {v(DIFF[0])}, {v(a[0])}, {v(b[0])}")
         else:
-            for q in range(C // 2):
+            for q in range(npair):
                 e(f"v_pk_add_f32 v[{DIFF[2 * q]}:{DIFF[2 * q + 1]}], v[{a[2 * q]}:{a[2 * q + 1]}], v[{b[2 * q]}:{b[2 * q + 1]}] neg_lo:[0,1] neg_hi:[0,1]")
+            if odd:
+                e(f"v_sub_f32 {v(DIFF[C - 1])}, {v(a[C - 1])}, {v(b[C - 1])}")
 
     def next_adv(e, dst):
         """row advance of the NEXT column: rem += M; adv = rem >= N; rem -= adv ? N : 0; dst = adv ? 4 : 0 (bytes the b-window moves)"""
@@ -168,10 +179,14 @@ def gen(C):
         e(f"ds_write_b32 {op['vst']}, {d0[0]}")
         e(f"ds_write_b32 {op['vst']}, {d1[0]} offset:4")
     else:
-        for q in range(C // 2):
+        for q in range(npair):
             e(f"ds_write2_b32 {op['vst']}, {d0[2 * q]}, {d0[2 * q + 1]} offset0:{2 * q} offset1:{2 * q + 1}")
-        for q in range(C // 2):
+        if odd:
+            e(f"ds_write_b32 {op['vst']}, {d0[C - 1]} offset:{4 * (C - 1)}")
+        for q in range(npair):
             e(f"ds_write2_b32 {op['vst']}, {d1[2 * q]}, {d1[2 * q + 1]} offset0:{C + 2 * q} offset1:{C + 2 * q + 1}")
+        if odd:
+            e(f"ds_write_b32 {op['vst']}, {d1[C - 1]} offset:{4 * (2 * C - 1)}")
     # (the advance computed for the column behind the last one is taken back: rem and vb describe the last column done)
     e(f"v_subrev_u32 {op['vb']}, {op['adv0']}, {op['vb']}")
     e(f"s_cmp_lg_u32 {op['adv0']}, 0")
@@ -208,7 +223,7 @@ def main():
            "struct WbandMasks { unsigned long long sec_lo, sec_hi, prim_lo, prim_hi, prim_0; uint32_t sec_c0, prim_c0; };",
            "template <int C> __device__ __forceinline__ void wband_loop_asm(uint32_t &va, uint32_t &vb, const uint32_t vstate, uint32_t &rem, uint32_t iters,",
            "                                                              const uint32_t M, const uint32_t N, const WbandMasks &m);", ""]
-    for C in (1, 2, 4, 8):
+    for C in (1, 2, 3, 4, 5, 7, 8, 9):
         out.append(gen(C))
     out.append("} // namespace rawdtw")
     path = os.path.join(ROOT, "rawalign_amd", "csrc", "rawdtw_wband_asm.h")
