@@ -80,16 +80,19 @@ template <typename T> struct PinBuf {
         if (p) { if (pinned) rawdtw_host_free(p); else free(p); }
         p = nullptr; cap = 0;
     }
-    bool ensure(size_t n, bool want_pinned)
+    // (`keep`: the first `keep` elements survive a move)
+    bool ensure(size_t n, bool want_pinned, size_t keep = 0)
     {
         if (n <= cap) return true;
-        release();
         const size_t c = n + n / 4 + 64;
         void *q = nullptr;
-        if (want_pinned && rawdtw_host_alloc(c * sizeof(T), &q) == RAWDTW_OK && q) pinned = true;
-        else { q = malloc(c * sizeof(T)); pinned = false; }
+        bool pin = false;
+        if (want_pinned && rawdtw_host_alloc(c * sizeof(T), &q) == RAWDTW_OK && q) pin = true;
+        else q = malloc(c * sizeof(T));
         if (!q) return false;
-        p = static_cast<T *>(q); cap = c;
+        if (p && keep) memcpy(q, p, std::min(keep, cap) * sizeof(T));
+        release();
+        p = static_cast<T *>(q); cap = c; pinned = pin;
         return true;
     }
     T &operator[](size_t i) { return p[i]; }
@@ -119,6 +122,9 @@ struct Group {
     RoundArrays buf[2];
     int cur = 0;          // buf[cur]: the round at hand; buf[cur ^ 1]: the round before (when has_prev)
     bool has_prev = false;
+    // the largest round so far: BOTH buffers are sized to it when it grows (page-locked memory is slow to get -- ~0.2 ms a megabyte --, and a
+    // round that is the first of its size in ITS buffer would pay that again one round after its neighbour did)
+    uint64_t hw_reads = 0, hw_chains = 0, hw_anchors = 0, hw_new = 0, hw_events = 0, hw_seg = 0;
 };
 
 // what the host phase leaves per read of the round
@@ -520,6 +526,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     if (!m || (n_reads && (!read_ids || !event_off || !hit_off)) || (n_reads && event_off[n_reads] && !events) || (n_reads && hit_off[n_reads] && !hits))
         return RAWDTW_ERR_INVALID;
     if (n_reads == 0) return RAWDTW_OK;
+    double t0 = now_ms(); // (the checks and the round's set-up count as host phase, its commit as round end: the five times add up to the call)
     const uint32_t n_seq = (uint32_t)m->seq_len.size();
     const bool runs_dtw = (m->opt.flag & (0x2 | 0x8)) != 0; // rmap.cpp:509
     if (runs_dtw && !m->scorer && !m->ctx) return fail(m, RAWDTW_ERR_NO_DEVICE, "a mapper without a context needs a scorer (rawdtw_mapper_set_scorer)");
@@ -551,7 +558,6 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     int status = RAWDTW_OK;
     std::string status_msg;
     auto set_fail = [&](int st, const std::string &msg) { if (status == RAWDTW_OK) { status = st; status_msg = msg; } };
-    double t0 = now_ms();
     // ---- per group: host phase, lay-out, submit ----
     for (uint32_t gi = 0; gi < G && status == RAWDTW_OK; gi++) {
         Group &g = m->groups[gi];
@@ -594,10 +600,17 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         }
         ra.n_chains = nc; ra.n_anchors = na; ra.n_new = nn; ra.n_new_events = nev; ra.n_seg = nseg;
         const bool pin = on_device;
-        const bool ok = ra.chain_off.ensure(nr + 1, pin) && ra.anchor_off.ensure(nc + 1, pin) && ra.ref_base.ensure(nc + 1, pin) && ra.read_base.ensure(nc + 1, pin) &&
-                        ra.anchors.ensure(na + 1, pin && !ra.carried) && ra.score.ensure(nc + 1, pin) && ra.keep.ensure(nc + 1, pin) &&
-                        (!ra.carried || (ra.new_off.ensure(nc + 1, pin) && ra.new_anchors.ensure(nn + 1, pin) && ra.carry.ensure(nc + 1, pin))) &&
-                        (!on_device || (ra.new_events.ensure(nev + 1, pin) && ra.seg_src.ensure(nseg + 2, pin) && ra.seg_dst.ensure(nseg + 1, pin)));
+        g.hw_reads = std::max<uint64_t>(g.hw_reads, nr); g.hw_chains = std::max(g.hw_chains, nc); g.hw_anchors = std::max(g.hw_anchors, na);
+        g.hw_new = std::max(g.hw_new, nn); g.hw_events = std::max(g.hw_events, nev); g.hw_seg = std::max(g.hw_seg, nseg);
+        auto size_arrays = [&](RoundArrays &x, const bool kept) { // (`kept`: the round before's arrays, read again by the next round's matching)
+            const size_t k_r = kept ? x.n_reads + 1 : 0, k_c = kept ? x.n_chains + 1 : 0, k_a = kept ? x.n_anchors + 1 : 0;
+            return x.chain_off.ensure(g.hw_reads + 1, pin, k_r) && x.anchor_off.ensure(g.hw_chains + 1, pin, k_c) && x.ref_base.ensure(g.hw_chains + 1, pin, k_c) &&
+                   x.read_base.ensure(g.hw_chains + 1, pin, k_c) && x.anchors.ensure(g.hw_anchors + 1, pin && !(m->opt.carry && g.has_prev), k_a) &&
+                   x.score.ensure(g.hw_chains + 1, pin) && x.keep.ensure(g.hw_chains + 1, pin) &&
+                   (!(on_device && m->opt.carry) || (x.new_off.ensure(g.hw_chains + 1, pin) && x.new_anchors.ensure(g.hw_new + 1, pin) && x.carry.ensure(g.hw_chains + 1, pin))) &&
+                   (!on_device || (x.new_events.ensure(g.hw_events + 1, pin) && x.seg_src.ensure(g.hw_seg + 2, pin) && x.seg_dst.ensure(g.hw_seg + 1, pin)));
+        };
+        const bool ok = size_arrays(ra, false) && size_arrays(g.buf[g.cur ^ 1], true);
         if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); continue; }
         if (m->scorer) { ra.chain_seq.resize(nc); ra.chain_strand.resize(nc); }
         ra.chain_off[nr] = nc; ra.anchor_off[nc] = na;
@@ -744,6 +757,9 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         if (high_confidence(m, rd.chains)) { rd.finished = true; rd.broke_early = true; } // rmap.cpp:692
         else if (rd.chunks_done >= std::min(rd.n_chunks, m->opt.max_num_chunk)) rd.finished = true;
     }
+    // (the round's per-read state goes on the pool: ten vectors a read, freed one read after the other they were milliseconds of a large round)
+    m->pool->run(n_reads, 64, [&](size_t k) { RoundRead gone; std::swap(gone, rr[k]); });
+    m->timing[4] += now_ms() - t0;
     return RAWDTW_OK;
 }
 

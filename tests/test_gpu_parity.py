@@ -91,10 +91,18 @@ def test_random_wave_band(engine, oracle):
         m = max(1, int(round(n * rng.uniform(0.5, 1.4))))
         R0 = default_radius(n) if t % 2 else int(rng.integers(13, 90))
         cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), R0, t & 1))
-    # radii on both sides of every registers-per-lane class boundary (K = R+1 = 64, 65, 128, 129, ... 2048, 2049)
-    for K in (64, 65, 128, 129, 256, 257, 512, 513, 1024, 1025, 2048, 2049):
+    # radii on both sides of every registers-per-lane class boundary (K = R+1: one register a lane up to 64 slots, two up to 128, then the odd counts --
+    # three up to 192, five up to 320, seven up to 448, nine up to 512 -- and the register-only body beyond), square and slanted; long enough
+    # for several LDS segments
+    for K in (64, 65, 128, 129, 192, 193, 256, 257, 320, 321, 448, 449, 512, 513, 1024, 1025, 2048, 2049):
         n = int(K * 1.6) + 7
         cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32), K - 1, K & 1))
+    for K in (150, 192, 193, 300, 320, 321, 400, 448, 449, 512):
+        n = 2300 + K
+        m = n - n // 10
+        r0 = max(r for r in range(1, K) if r + ((n - m) * r + n - 1) // n + 1 <= K)  # (the radius that the slant of m = 0.9 n widens to K slots: dtw.cpp:298-300)
+        cases.append((rng.normal(size=n).astype(np.float32), rng.normal(size=m).astype(np.float32), r0, K & 1))
+        cases.append((rng.normal(size=m).astype(np.float32), rng.normal(size=n).astype(np.float32), r0, 1 - (K & 1)))
     for R0 in range(5, 16):  # around the lane-kernel / wave-kernel hand-over
         cases.append((rng.normal(size=150).astype(np.float32), rng.normal(size=140).astype(np.float32), R0, R0 & 1))
     cases.append((rng.normal(size=6000).astype(np.float32), rng.normal(size=5200).astype(np.float32), 600, 0))

@@ -290,9 +290,9 @@ def test_windows_that_end_with_the_arenas(oracle, ref_len, tail):
 
 
 def test_wave_per_job_bands_at_the_register_layouts_edges(oracle):
-    """k_wide's wave-per-job bodies hold a band of K slots in C = 1, 2 or 4 registers a lane (wreg_gen<C>: K <= 64 C).  Parts
-    whose radius puts K on both sides of every change of layout -- radius 63 / 64 (K = 64 fills the one-register wave: its last
-    lane's neighbour is the DPP shift's fill; K = 65 is the first two-register band), 127 / 128, and 255 (K = 256, the widest
+    """k_wide's wave-per-job bodies hold a band of K slots in C = 1, 2, 3 or 5 registers a lane (wband_gen<C>: K <= 64 C; odd beyond two, for the
+    LDS banks).  Parts whose radius puts K on both sides of every change of layout -- radius 63 / 64 (K = 64 fills the one-register wave: its last
+    lane's neighbour is the DPP shift's fill; K = 65 is the first two-register band), 127 / 128, 191 / 192, and 255 (K = 256, the widest
     band the sync-free path takes) -- square and slanted, with the longer side on either arena, between small parts: every part cost and every
     chain score bit for bit against the oracle (dtw.cpp:298-303 for P and S, rmap.cpp:276 for the radius)."""
     rng = np.random.default_rng(4242)
@@ -300,13 +300,13 @@ def test_wave_per_job_bands_at_the_register_layouts_edges(oracle):
     eng = ra.Engine(0)
     eng.upload_reference([ref[0]], [ref[1]])
     # (dq, dt): n = dq + 1, m = dt + 1, r0 = int(0.1 n), R = r0 + ceil((N - M) r0 / N) with N the longer side (dtw.cpp:298-300)
-    edges = [(629, 629), (639, 639), (571, 630), (1269, 1269), (1279, 1279), (1160, 1280), (2549, 2549), (2320, 2570), (700, 630)]
+    edges = [(629, 629), (639, 639), (571, 630), (1269, 1269), (1279, 1279), (1160, 1280), (2549, 2549), (2320, 2570), (700, 630), (1915, 1915), (1925, 1925), (1740, 1926)]
 
     def radius(dq, dt):
         n, m = dq + 1, dt + 1
         r0, N, M = max(1, int(np.float32(n) * np.float32(0.1))), max(n, m), min(n, m)
         return r0 + ((N - M) * r0 + N - 1) // N
-    assert [radius(*e) for e in edges][:8] == [63, 64, 63, 127, 128, 127, 255, 255]
+    assert [radius(*e) for e in edges][:8] == [63, 64, 63, 127, 128, 127, 255, 255] and [radius(*e) for e in edges][9:11] == [191, 192]
     state = {"k": 0}
 
     def shapes(r):
