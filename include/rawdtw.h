@@ -333,6 +333,30 @@ int rawdtw_chain_anchors(const rawdtw_chain_opt_t *opt, const rawdtw_anchor_t *a
  * produces for the comparator a.chaining_score > b.chaining_score (rmap.cpp:512). */
 int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains, uint32_t *perm_out);
 
+/* ---- the same on the device for a whole chunk round (rawdtw_chain.hip): per read the anchor sort
+ * (rmap.cpp:396-401), the chaining DP and traceback_chains per (sequence, strand) list (rmap.cpp:430-507, 130-173) with the
+ * read's running maximum carried from list to list, and the evaluation order (rmap.cpp:512) -- a wave a read -- and all
+ * reads' chains laid out in device memory as ONE candidate batch: what rawdtw_batch_submit_device takes, so the anchors
+ * never cross PCIe on their way into the DTW.
+ *   in  (host): read r's seeds seeds[seed_off[r] .. seed_off[r+1]), UNSORTED (key = sequence * 2 + strand as the caller numbers
+ *        its reference arrays); read_base[r] = the read's first event in the event arena; key_base[key] = the arena offset of
+ *        that key's reference array (rawdtw_reference_offset)
+ *   out (host): chain_off[n_reads + 1]; anchor_off[n_chains + 1] and recs[n_chains] (at most chains_cap chains; 32 a read is the
+ *        device's own limit), chains of a read in evaluation order; anchors[...] (end-first per chain; may be NULL: room for
+ *        seed_off[n_reads] entries)
+ *   out (device, the context's, valid until its next rawdtw_chain_round): *d_anchors, *d_ref_base, *d_read_base
+ * The call returns when the host arrays are filled.  Results equal rawdtw_chain_anchors list by list and
+ * rawdtw_sort_by_chaining_score read by read, bit for bit.  RAWDTW_ERR_UNSUPPORTED (nothing written): a read with more than
+ * 2 048 seeds, with more than 32 chains, or with more than 16 chains two of which have equal scores (std::sort's order of
+ * equal elements is an insertion sort's only up to 16) -- chain that round on the host. */
+typedef struct { uint32_t key, target_position, query_position; } rawdtw_seed_t;                       /* 12 bytes */
+typedef struct { float chaining_score; uint32_t key, start_position, end_position, n_anchors; } rawdtw_chain_rec_t; /* 20 bytes */
+int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off,
+                       const rawdtw_seed_t *seeds, const uint32_t *read_base, uint32_t n_keys, const uint64_t *key_base,
+                       uint64_t *chain_off, uint64_t *anchor_off, rawdtw_chain_rec_t *recs, uint64_t chains_cap,
+                       rawdtw_anchor_t *anchors, const rawdtw_anchor_t **d_anchors, const uint64_t **d_ref_base,
+                       const uint32_t **d_read_base);
+
 /* Batched forms over many reads (what rmap.cpp's per-read worker does for every read of a
  * mini-batch, hoisted around one GPU submission).  Chains are listed read by read, each read's
  * chains already in the reference's evaluation order (std::sort by chaining_score descending,
@@ -501,6 +525,11 @@ int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
                         const uint64_t *anchor_off, const rawdtw_anchor_t *anchors, const uint64_t *ref_base,
                         const uint32_t *read_base, rawdtw_batch **out);
 int rawdtw_batch_fetch_destroy(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep);
+/* rawdtw_batch_submit with anchors / ref_base / read_base in DEVICE memory (rawdtw_chain_round's arrays, or the caller's
+ * own): used in place, they must stay as they are until the batch is fetched.  chain_off / anchor_off are host arrays. */
+int rawdtw_batch_submit_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                               const uint64_t *anchor_off, const rawdtw_anchor_t *d_anchors, const uint64_t *d_ref_base,
+                               const uint32_t *d_read_base, rawdtw_batch **out);
 
 /* ---- the chunk-round mapping loop on the host side of the library: the control flow of map_worker_for / ri_map_frag /
  * gen_chains (src/rmap.cpp:667-822, 545-578, 315-541) turned inside out so that every chunk round makes ONE device
@@ -531,6 +560,10 @@ typedef struct {
     int groups;                /* 1 or 2 read groups, each on a context of its own (the second is created by the mapper and shares
                                   the reference arena): one group's host phase runs while the other's batch is on the device, as the
                                   reference's two pipeline workers overlap (rmap.cpp:1015,1033) */
+    int device_chain;          /* 1: the anchor sort and the chaining DP of a round run on the device too (rawdtw_chain_round) and hand
+                                  their chains to the DTW in device memory; the host phase is then the events and the seed lists.  Costs
+                                  are not carried in this mode (nothing of the anchor lists crosses PCIe either way).  A round the
+                                  device declines is chained on the host: same lines. */
 } rawdtw_mapper_opt_t;
 typedef struct {
     uint32_t ref_seq;

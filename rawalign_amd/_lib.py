@@ -85,7 +85,7 @@ class MapperOpt(C.Structure):
         ("min_bestmap_ratio", C.c_float), ("min_meanmap_ratio", C.c_float), ("min_chain_anchor", C.c_uint32),
         ("bp_per_sec", C.c_uint32), ("sample_rate", C.c_uint32), ("chunk_size", C.c_uint32), ("max_num_chunk", C.c_uint32),
         ("slot_events", C.c_uint32), ("max_reads", C.c_uint32), ("carry", C.c_int), ("min_events", C.c_uint32),
-        ("threads", C.c_int), ("groups", C.c_int),
+        ("threads", C.c_int), ("groups", C.c_int), ("device_chain", C.c_int),
     ]
 
 
@@ -180,6 +180,8 @@ SYMBOLS = {
     "rawdtw_batch_stream_counters": (I32, [VP, VP, VP, U32, VP]),
     "rawdtw_batch_destroy": (I32, [VP]),
     "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_batch_submit_device": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
+    "rawdtw_chain_round": (I32, [VP, C.POINTER(ChainOpt), U64, VP, VP, VP, U32, VP, VP, VP, VP, U64, VP, VP, VP, VP]),
     "rawdtw_batch_fetch_destroy": (I32, [VP, VP, VP, VP]),
     "rawdtw_batch_submit_carry": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_can_carry": (I32, [VP, VP, VP]),

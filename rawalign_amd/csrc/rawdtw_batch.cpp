@@ -1109,6 +1109,18 @@ int rawdtw_batch_submit(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t
     return st;
 }
 
+int rawdtw_batch_submit_device(rawdtw_ctx *ctx, const rawdtw_align_opt_t *opt, uint64_t n_reads, const uint64_t *chain_off,
+                               const uint64_t *anchor_off, const rawdtw_anchor_t *d_anchors, const uint64_t *d_ref_base,
+                               const uint32_t *d_read_base, rawdtw_batch **out)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    const bool was = ctx->resident_arrays; // (the option's meaning, for this one batch: a batch keeps the form it was created under)
+    ctx->resident_arrays = true;
+    const int st = rawdtw_batch_submit(ctx, opt, n_reads, chain_off, anchor_off, d_anchors, d_ref_base, d_read_base, out);
+    ctx->resident_arrays = was;
+    return st;
+}
+
 int rawdtw_batch_fetch_destroy(rawdtw_ctx *ctx, rawdtw_batch *batch, float *score, uint8_t *keep)
 {
     const int st = rawdtw_batch_fetch(ctx, batch, score, keep, nullptr);

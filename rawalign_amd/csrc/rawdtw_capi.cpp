@@ -114,6 +114,7 @@ int rawdtw_destroy(rawdtw_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     drop_reference(ctx);
     if (ctx->own_ev && ctx->d_ev) (void)hipFree(ctx->d_ev);
+    chain_ws_free(ctx);
     for (StreamWs &w : ctx->ws_free) { if (w.d) (void)hipFree(w.d); if (w.h) (void)hipHostFree(w.h); }
     if (ctx->d_append) (void)hipFree(ctx->d_append);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

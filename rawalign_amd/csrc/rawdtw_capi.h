@@ -142,6 +142,7 @@ struct rawdtw_ctx {
     float *d_ev = nullptr;
     uint64_t n_ev = 0, cap_ev = 0;
     bool own_ev = false;
+    struct rawdtw_chain_ws *chain_ws = nullptr; // rawdtw_chain_round's device block (rawdtw_chain.hip), grow-only
     std::string err;
 };
 
@@ -260,6 +261,8 @@ inline int hip_fail(rawdtw_ctx *ctx, hipError_t e, const char *what)
     int st = (e == hipErrorOutOfMemory) ? RAWDTW_ERR_OOM : RAWDTW_ERR_DEVICE;
     return fail(ctx, st, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+void chain_ws_free(rawdtw_ctx *ctx); // rawdtw_chain.hip
 
 #define HIP_TRY(ctx, expr)                                                                            \
     do {                                                                                              \

@@ -490,7 +490,7 @@ class CMapper:
     `set_scorer` only (CPU harnesses)."""
 
     def __init__(self, engine, opt: MapOpt, stop: M.StopOpt, seq_names, seq_lens, slot_events: int, max_reads: int, carry: bool = True,
-                 threads: int = 1, groups: int = 1, e: int = 6):
+                 threads: int = 1, groups: int = 1, e: int = 6, device_chain: bool = False):
         import ctypes as C
 
         from ._lib import MapperOpt, load_library
@@ -504,7 +504,7 @@ class CMapper:
         mo.min_bestmap_ratio, mo.min_meanmap_ratio, mo.min_chain_anchor = stop.min_bestmap_ratio, stop.min_meanmap_ratio, stop.min_chain_anchor
         mo.bp_per_sec, mo.sample_rate, mo.chunk_size, mo.max_num_chunk = stop.bp_per_sec, stop.sample_rate, stop.chunk_size, stop.max_num_chunk
         mo.slot_events, mo.max_reads, mo.carry, mo.min_events = int(slot_events), int(max_reads), int(bool(carry)), int(stop.min_events)
-        mo.threads, mo.groups = int(threads), int(groups)
+        mo.threads, mo.groups, mo.device_chain = int(threads), int(groups), int(bool(device_chain))
         names = (C.c_char_p * len(seq_names))(*[n.encode() for n in seq_names])
         lens = np.ascontiguousarray(seq_lens, np.uint32)
         self._h = C.c_void_p()
