@@ -400,17 +400,21 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     out = {"workload": WORKLOAD + ", synthetic seed hits (hit probability 0.2 per event, 25 false hits a chunk), chunks of 520 events",
            "reads": n_reads, "host_threads": threads, "runs": [], "all_chunks": []}
 
-    def device_run(stop, carry, groups, label, thr=threads):
+    def device_run(stop, carry, groups, label, thr=threads, dev_chain=False):
         eng = ra.Engine(local_rank)
         eng.upload_reference(ref.forward, ref.reverse)
-        cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n_reads, carry=carry, threads=thr, groups=groups)
+        cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n_reads, carry=carry, threads=thr, groups=groups, device_chain=dev_chain)
         r = run(cm, all_reads, label)
         cm.close()
         eng.close()
         return r
+    for groups in (1, 2):  # the anchor sort and the chaining DP on the device too (rawdtw_chain_round): the chains reach the DTW in device memory
+        out["runs"].append(device_run(StopOpt(), 0, groups, "stop rule of the reference, chaining on the device, groups=%d" % groups, dev_chain=True))
+    out["runs"].append(device_run(StopOpt(), 0, 1, "stop rule of the reference, chaining on the device, groups=1, ONE host thread", thr=1, dev_chain=True))
     for carry, groups in ((1, 2), (1, 1), (0, 2), (0, 1)):
         out["runs"].append(device_run(StopOpt(), carry, groups, "stop rule of the reference, carry=%d groups=%d" % (carry, groups)))
     out["runs"].append(device_run(StopOpt(), 1, 2, "stop rule of the reference, carry=1 groups=2, ONE host thread", thr=1))
+    out["all_chunks"].append(device_run(never, 0, 1, "every read through all of its chunks, chaining on the device groups=1", dev_chain=True))
     for carry, groups in ((1, 2), (0, 2), (1, 1), (0, 1)):
         out["all_chunks"].append(device_run(never, carry, groups, "every read through all of its chunks, carry=%d groups=%d" % (carry, groups)))
     out["paf_identical_across_runs"] = len({r["paf_sha1"] for r in out["runs"]}) == 1 and len({r["paf_sha1"] for r in out["all_chunks"]}) == 1

@@ -285,7 +285,7 @@ int materialise_host_arrays(rawdtw_ctx *ctx, rawdtw_batch *b)
     }
     if (!b->in_resident) return RAWDTW_OK;
     const uint64_t nc = b->n_chains, na = b->in_anchor_off[nc];
-    try { b->host_anchors.resize(na); b->host_ref_base.resize(nc); b->host_read_base.resize(nc); }
+    try { b->host_anchors.resize(na + 1); b->host_ref_base.resize(nc + 1); b->host_read_base.resize(nc + 1); } // (+ 1: non-null arrays for a round without chains)
     catch (const std::bad_alloc &) { return fail(ctx, RAWDTW_ERR_OOM, "host allocation failed"); }
     if (na) HIP_TRY(ctx, hipMemcpy(b->host_anchors.data(), b->in_anchors, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost));
     if (nc) HIP_TRY(ctx, hipMemcpy(b->host_ref_base.data(), b->in_ref_base, nc * 8, hipMemcpyDeviceToHost));

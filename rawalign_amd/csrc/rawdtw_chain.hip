@@ -26,6 +26,7 @@
 #include "rawdtw_capi.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace rawdtw {
@@ -324,7 +325,11 @@ int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t 
         if (seed_off[r + 1] < seed_off[r]) return fail(ctx, RAWDTW_ERR_INVALID, "offsets do not ascend");
         most = (uint32_t)std::max<uint64_t>(most, std::min<uint64_t>(seed_off[r + 1] - seed_off[r], 0xffffffffull));
     }
-    if (most > kChainMaxSeeds) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "a read has more seeds than the device chains (2048): chain this round on the host");
+    static const uint32_t seed_cap = [] { // (tests: RAWDTW_CHAIN_MAX_SEEDS lowers the cap, so that small rounds take the declined path)
+        const char *e = getenv("RAWDTW_CHAIN_MAX_SEEDS");
+        return e ? std::min<uint32_t>(kChainMaxSeeds, (uint32_t)std::max(1l, strtol(e, nullptr, 10))) : kChainMaxSeeds;
+    }();
+    if (most > seed_cap) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "a read has more seeds than the device chains (2048): chain this round on the host");
     uint32_t n2 = 64;
     while (n2 < most) n2 <<= 1;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

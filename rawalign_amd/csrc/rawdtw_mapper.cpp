@@ -108,6 +108,10 @@ struct RoundArrays {
     PinBuf<rawdtw_carry_t> carry;
     PinBuf<float> new_events, score;
     PinBuf<uint8_t> keep;
+    PinBuf<uint64_t> seed_off;           // device chaining (opt.device_chain): the reads' seed lists in, the chains' records out
+    PinBuf<rawdtw_seed_t> seeds;
+    PinBuf<rawdtw_chain_rec_t> recs;
+    bool device_chained = false;
     std::vector<uint32_t> chain_seq; // (the external scorer's view)
     std::vector<int32_t> chain_strand;
     uint64_t n_reads = 0, n_chains = 0, n_anchors = 0, n_new = 0, n_new_events = 0, n_seg = 0;
@@ -124,7 +128,7 @@ struct Group {
     bool has_prev = false;
     // the largest round so far: BOTH buffers are sized to it when it grows (page-locked memory is slow to get -- ~0.2 ms a megabyte --, and a
     // round that is the first of its size in ITS buffer would pay that again one round after its neighbour did)
-    uint64_t hw_reads = 0, hw_chains = 0, hw_anchors = 0, hw_new = 0, hw_events = 0, hw_seg = 0;
+    uint64_t hw_reads = 0, hw_chains = 0, hw_anchors = 0, hw_new = 0, hw_events = 0, hw_seg = 0, hw_seeds = 0;
 };
 
 // what the host phase leaves per read of the round
@@ -138,6 +142,8 @@ struct RoundRead {
     uint32_t ev_before = 0, off_before = 0;
     bool skipped = false;                // a chunk below min_events: no chaining, chains and offset stay (rmap.cpp:569-575)
     uint64_t chain0 = 0, anchor0 = 0, new0 = 0, ev0 = 0; // its first chain / anchor / new anchor / new event in the group's arrays
+    uint64_t seed0 = 0, n_seeds = 0;     // device chaining: its seeds in the group's list
+    uint32_t chunk_start = 0;
     int err = RAWDTW_OK;
 };
 
@@ -298,16 +304,30 @@ struct Seed { uint32_t key, t, q; };
 
 // The host phase of one read: the chunk's events, the round's anchors, chaining, evaluation order, carry records.
 // `pv` = the arrays of the round before of the read's group (null: none, or the read was not in it).
-void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev, uint64_t ne, const rawdtw_seed_hit_t *hits, uint64_t n_hits,
-                     const RoundArrays *pv, bool runs_dtw)
+// the chunk's events (rmap.cpp:554-575); false: the chunk is below min_events -- no gen_chains this round
+bool host_phase_events(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev, uint64_t ne)
 {
     rr.ne = ne;
     rr.ev_before = (uint32_t)rd.events.size();
     rr.off_before = rd.offset;
     rd.events.insert(rd.events.end(), ev, ev + ne); // rmap.cpp:554-567
-    if (ne < m->opt.min_events) { rr.skipped = true; return; } // rmap.cpp:569-572: no gen_chains, reg->offset stays
-    const uint32_t chunk_start = rd.offset; // reg->offset (rmap.cpp:574)
-    rd.offset += (uint32_t)ne;               // rmap.cpp:575
+    if (ne < m->opt.min_events) { rr.skipped = true; return false; } // rmap.cpp:569-572: no gen_chains, reg->offset stays
+    rr.chunk_start = rd.offset;  // reg->offset (rmap.cpp:574)
+    rd.offset += (uint32_t)ne;   // rmap.cpp:575
+    return true;
+}
+
+void host_phase_chain(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const rawdtw_seed_hit_t *hits, uint64_t n_hits, const RoundArrays *pv, bool runs_dtw);
+
+void host_phase_read(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev, uint64_t ne, const rawdtw_seed_hit_t *hits, uint64_t n_hits,
+                     const RoundArrays *pv, bool runs_dtw)
+{
+    if (host_phase_events(m, rd, rr, ev, ne)) host_phase_chain(m, rd, rr, hits, n_hits, pv, runs_dtw);
+}
+
+void host_phase_chain(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const rawdtw_seed_hit_t *hits, uint64_t n_hits, const RoundArrays *pv, bool runs_dtw)
+{
+    const uint32_t chunk_start = rr.chunk_start;
     // rmap.cpp:344-357: re-seed with the previous chains' anchors; rmap.cpp:371-391: the chunk's seed hits
     std::vector<Seed> seeds;
     size_t n_prev = 0;
@@ -567,19 +587,123 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         ra.round_id = round_id;
         const RoundArrays &pb = g.buf[g.cur ^ 1];
         const size_t nr = ra.ks.size();
-        if (on_device && m->opt.carry && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) {
+        if (on_device && m->opt.carry && !m->opt.device_chain && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) {
             size_t known = 0; // (a round none of whose reads was in the round before has nothing to take over: submitted whole)
             for (size_t i = 0; i < nr && !known; i++) known += m->reads[read_ids[ra.ks[i]]].last_round == pb.round_id;
             if (known) { pv = &pb; ra.carried = true; }
         }
         ra.n_reads = nr;
-        m->pool->run(nr, 16, [&](size_t i) {
-            const uint32_t k = ra.ks[i];
-            MRead &rd = m->reads[read_ids[k]];
-            const bool in_prev = pv && rd.last_round == pv->round_id;
-            host_phase_read(m, rd, rr[k], events + event_off[k], event_off[k + 1] - event_off[k], hits + hit_off[k], hit_off[k + 1] - hit_off[k],
-                            in_prev ? pv : nullptr, runs_dtw);
-        });
+        ra.device_chained = false;
+        bool events_done = false; // (a round the device declined to chain: its events are appended already, on both sides)
+        // ---- device chaining (opt.device_chain): the host phase is the events and the seed lists; sort, chaining DP, traceback and order run on
+        // the device (rawdtw_chain_round) and hand their chains to the DTW in device memory.  A round it declines is chained below, on the host.
+        if (on_device && m->opt.device_chain) {
+            m->pool->run(nr, 64, [&](size_t i) {
+                const uint32_t k = ra.ks[i];
+                MRead &rd = m->reads[read_ids[k]];
+                RoundRead &r = rr[k];
+                if (!host_phase_events(m, rd, r, events + event_off[k], event_off[k + 1] - event_off[k])) return;
+                uint64_t n = hit_off[k + 1] - hit_off[k];
+                for (const MChain &ch : rd.chains) n += ch.anchors.size(); // rmap.cpp:344-357: re-seeding with the previous chains' anchors
+                r.n_seeds = n;
+            });
+            uint64_t ns = 0, nev = 0, nseg = 0;
+            for (size_t i = 0; i < nr; i++) { RoundRead &r = rr[ra.ks[i]]; r.seed0 = ns; ns += r.n_seeds; r.ev0 = nev; nev += r.ne; nseg += r.ne ? 1 : 0; }
+            g.hw_reads = std::max<uint64_t>(g.hw_reads, nr); g.hw_seeds = std::max(g.hw_seeds, ns); g.hw_events = std::max(g.hw_events, nev); g.hw_seg = std::max(g.hw_seg, nseg);
+            g.hw_chains = std::max<uint64_t>(g.hw_chains, g.hw_reads * 32);
+            bool ok = true;
+            for (RoundArrays *x : {&ra, &g.buf[g.cur ^ 1]})
+                ok = ok && x->seed_off.ensure(g.hw_reads + 1, true) && x->seeds.ensure(g.hw_seeds + 1, true) && x->read_base.ensure(std::max(g.hw_reads, g.hw_chains) + 1, true) &&
+                     x->chain_off.ensure(g.hw_reads + 1, true) && x->anchor_off.ensure(g.hw_chains + 1, true) && x->recs.ensure(g.hw_chains + 1, true) &&
+                     x->anchors.ensure(g.hw_seeds + 1, true) && x->score.ensure(g.hw_chains + 1, true) && x->keep.ensure(g.hw_chains + 1, true) &&
+                     x->new_events.ensure(g.hw_events + 1, true) && x->seg_src.ensure(g.hw_seg + 2, true) && x->seg_dst.ensure(g.hw_seg + 1, true);
+            if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); continue; }
+            {
+                uint64_t sg = 0, at = 0;
+                for (size_t i = 0; i < nr; i++) {
+                    const RoundRead &r = rr[ra.ks[i]];
+                    if (!r.ne) continue;
+                    const MRead &rd = m->reads[read_ids[ra.ks[i]]];
+                    ra.seg_src[sg] = at;
+                    ra.seg_dst[sg] = (rd.slot / G) * m->opt.slot_events + r.ev_before;
+                    at += r.ne; sg++;
+                }
+                ra.seg_src[sg] = at;
+            }
+            ra.seed_off[nr] = ns;
+            m->pool->run(nr, 64, [&](size_t i) {
+                const uint32_t k = ra.ks[i];
+                const RoundRead &r = rr[k];
+                const MRead &rd = m->reads[read_ids[k]];
+                ra.seed_off[i] = r.seed0;
+                ra.read_base[i] = (rd.slot / G) * m->opt.slot_events;
+                rawdtw_seed_t *out = ra.seeds.p + r.seed0;
+                if (r.n_seeds) {
+                    for (const MChain &ch : rd.chains) {
+                        const uint32_t key = ch.ref * 2u + (uint32_t)ch.strand;
+                        for (const rawdtw_anchor_t &an : ch.anchors) *out++ = rawdtw_seed_t{key, an.target_position, an.query_position};
+                    }
+                    for (uint64_t h = hit_off[k]; h < hit_off[k + 1]; h++) // rmap.cpp:371-391
+                        *out++ = rawdtw_seed_t{hits[h].ref_seq * 2u + (uint32_t)(hits[h].strand ? 1 : 0), hits[h].target_position, hits[h].query_position + r.chunk_start};
+                }
+                if (r.ne) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
+            });
+            double td = now_ms();
+            m->timing[0] += td - t0; t0 = td;
+            int st = RAWDTW_OK;
+            if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
+            const rawdtw_anchor_t *d_anchors = nullptr;
+            const uint64_t *d_ref_base = nullptr;
+            const uint32_t *d_read_base = nullptr;
+            if (st == RAWDTW_OK)
+                st = rawdtw_chain_round(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(), ra.chain_off.p,
+                                        ra.anchor_off.p, ra.recs.p, g.hw_chains, ra.anchors.p, &d_anchors, &d_ref_base, &d_read_base);
+            if (st == RAWDTW_OK) {
+                const uint64_t nc = ra.chain_off[nr], na = ra.anchor_off[nc];
+                ra.n_chains = nc; ra.n_anchors = na; ra.n_new = 0; ra.n_new_events = nev; ra.n_seg = nseg;
+                st = rawdtw_batch_submit_device(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, d_anchors, d_ref_base, d_read_base, &ra.batch);
+                if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); continue; }
+                ra.device_chained = true;
+                m->timing[6] += (double)(nev * sizeof(float));
+                m->timing[7] += (double)(ns * sizeof(rawdtw_seed_t) + (nr + 1) * 16 + nr * 4 + (nc + 1) * 8 + nseg * 12);
+                td = now_ms();
+                m->timing[2] += td - t0; t0 = td;
+                // (while the batch runs) the round's chains per read, as the host phase would have left them
+                m->pool->run(nr, 32, [&](size_t i) {
+                    RoundRead &r = rr[ra.ks[i]];
+                    r.chain0 = ra.chain_off[i];
+                    const uint64_t n = ra.chain_off[i + 1] - ra.chain_off[i];
+                    r.chains.resize(n);
+                    for (uint64_t c = 0; c < n; c++) {
+                        const rawdtw_chain_rec_t &rec = ra.recs[r.chain0 + c];
+                        MChain &ch = r.chains[c];
+                        ch.chaining_score = rec.chaining_score; ch.ref = rec.key >> 1; ch.strand = (int32_t)(rec.key & 1u);
+                        ch.start_position = rec.start_position; ch.end_position = rec.end_position;
+                        const rawdtw_anchor_t *an = ra.anchors.p + ra.anchor_off[r.chain0 + c];
+                        ch.anchors.assign(an, an + rec.n_anchors);
+                    }
+                });
+                td = now_ms();
+                m->timing[1] += td - t0; t0 = td;
+                continue;
+            }
+            if (st != RAWDTW_ERR_UNSUPPORTED) { set_fail(st, rawdtw_last_error(g.ctx)); continue; }
+            // declined (a read with too many seeds or chains, or an order only std::sort knows): this round's chains are made on the host; the
+            // events are in place already, on both sides
+            m->pool->run(nr, 16, [&](size_t i) {
+                const uint32_t k = ra.ks[i];
+                RoundRead &r = rr[k];
+                if (!r.skipped) host_phase_chain(m, m->reads[read_ids[k]], r, hits + hit_off[k], hit_off[k + 1] - hit_off[k], nullptr, runs_dtw);
+            });
+            events_done = true;
+        } else
+            m->pool->run(nr, 16, [&](size_t i) {
+                const uint32_t k = ra.ks[i];
+                MRead &rd = m->reads[read_ids[k]];
+                const bool in_prev = pv && rd.last_round == pv->round_id;
+                host_phase_read(m, rd, rr[k], events + event_off[k], event_off[k + 1] - event_off[k], hits + hit_off[k], hit_off[k + 1] - hit_off[k],
+                                in_prev ? pv : nullptr, runs_dtw);
+            });
         double t1 = now_ms();
         m->timing[0] += t1 - t0; t0 = t1;
         for (size_t i = 0; i < nr; i++) if (rr[ra.ks[i]].err != RAWDTW_OK) set_fail(rr[ra.ks[i]].err, "chaining failed (chain output buffers too small)");
@@ -595,8 +719,8 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                 na += n;
                 nn += n - r.carry[c].parts; // (the new entries and, when a stretch is taken over, the junction)
             }
-            nev += r.ne;
-            nseg += r.ne ? 1 : 0;
+            nev += events_done ? 0 : r.ne;
+            nseg += !events_done && r.ne ? 1 : 0;
         }
         ra.n_chains = nc; ra.n_anchors = na; ra.n_new = nn; ra.n_new_events = nev; ra.n_seg = nseg;
         const bool pin = on_device;
@@ -619,7 +743,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         ra.anchors[na] = rawdtw_anchor_t{0, 0};
         {   // the new events' segments (reads with a chunk this round, in order)
             uint64_t s = 0, at = 0;
-            for (size_t i = 0; i < nr && on_device; i++) {
+            for (size_t i = 0; i < nr && on_device && !events_done; i++) {
                 const RoundRead &r = rr[ra.ks[i]];
                 if (!r.ne) continue;
                 const MRead &rd = m->reads[read_ids[ra.ks[i]]];
@@ -652,7 +776,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                 }
                 at += an.size();
             }
-            if (on_device && r.ne) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
+            if (on_device && r.ne && !events_done) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
         });
         t1 = now_ms();
         m->timing[1] += t1 - t0; t0 = t1;
@@ -743,7 +867,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         Group &g = m->groups[gi];
         RoundArrays &ra = g.buf[g.cur], &pb = g.buf[g.cur ^ 1];
         if (pb.batch) { rawdtw_batch_destroy(pb.batch); pb.batch = nullptr; }
-        g.has_prev = on_device && m->opt.carry && ra.batch != nullptr;
+        g.has_prev = on_device && m->opt.carry && !m->opt.device_chain && ra.batch != nullptr;
         if (!g.has_prev && ra.batch) { rawdtw_batch_destroy(ra.batch); ra.batch = nullptr; }
         for (size_t i = 0; i < ra.ks.size(); i++) {
             MRead &rd = m->reads[read_ids[ra.ks[i]]];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The mapper block of bench.py for chosen (groups, threads, carry) combinations: wall time of the round calls and the mapper's own phase times, the
-first round apart.  python scripts/mapper_probe.py [reads] [combo ...]   combo = groups,threads,carry[,all]  (default: 1,16,0 2,16,0 2,12,0 2,8,0)"""
+first round apart.  python scripts/mapper_probe.py [reads] [combo ...]   combo = groups,threads,carry[,all][,dev]  (all: every read through all of its chunks; dev: chaining on the device)"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ if os.environ.get("PROBE_TORCH"):  # (as bench.py's process: torch's runtime, it
     torch.cuda.synchronize()
     y = torch.randn(2000, 2000) @ torch.randn(2000, 2000)
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-combos = sys.argv[2:] or ["1,16,0", "2,16,0", "2,12,0", "2,8,0"]
+combos = sys.argv[2:] or ["1,16,0", "1,16,0,dev", "2,16,0,dev", "1,4,0,dev", "1,16,0,all", "1,16,0,all,dev"]
 ref = synth.make_reference([4_600_000], seed=20231005)
 sc = synth.make_seed_chunks(ref, n_reads, seed=20231005 + 17)
 opt = ra.MapOpt()
@@ -65,10 +65,11 @@ def one_pass(cm, reads):
 for combo in combos:
     f = combo.split(",")
     groups, threads, carry = int(f[0]), int(f[1]), int(f[2])
-    stop = never if len(f) > 3 else StopOpt()
+    stop = never if len(f) > 3 and f[3] == "all" else StopOpt()
+    dev_chain = "dev" in f[3:]
     eng = ra.Engine(0)
     eng.upload_reference(ref.forward, ref.reverse)
-    cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n_reads, carry=bool(carry), threads=threads, groups=groups)
+    cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n_reads, carry=bool(carry), threads=threads, groups=groups, device_chain=dev_chain)
     reads = np.arange(n_reads)
     ids, _ = one_pass(cm, reads)
     for i in ids:

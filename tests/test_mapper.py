@@ -225,3 +225,66 @@ def test_cpp_mapper_lines_do_not_depend_on_threads_groups_or_carry(oracle):
         assert hashlib.sha1("\n".join(want).encode()).hexdigest() == hashes[(1, 1, 1)]
         if stop.min_chain_anchor > 2:   # every read through all of its chunks: the rounds in which costs are taken over
             assert reused[(8, 2, 1)] > 0 and reused[(1, 1, 1)] == reused[(8, 2, 1)] and reused[(8, 1, 0)] == 0
+
+
+@pytest.mark.gpu
+def test_cpp_mapper_with_the_chaining_on_the_device_writes_the_same_lines(oracle):
+    """opt.device_chain: the anchor sort and the chaining DP of every round on the device (rawdtw_chain_round), the chains handed to the DTW in
+    device memory -- the PAF lines' hash equals the host-chained mapper's (which the test above ties to the Python mirror and the rounds further
+    up to the oracle), under the stop rule and with every read through all of its chunks, with one read group and two, flags for the CIGAR and the
+    score log included; no anchor list crosses PCIe on the way in."""
+    import hashlib
+
+    from rawalign_amd.mapping import StopOpt
+
+    ref = synth.make_reference([200_000], seed=77)
+    n = 600
+    seeds = mapper.SyntheticSeeds(ref, n, seed=5, max_chunks=5)
+    names, lens = ["seq0"], [len(ref.forward[0])]
+    slot = max(rd["n_ev"] for rd in seeds.reads) + 8
+    for stop, opt in ((StopOpt(), ra.MapOpt()), (StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6), ra.MapOpt()),
+                      (StopOpt(), ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0, flag=0x2 | 0x4 | 0x8))):
+        hashes, logs = {}, {}
+        for threads, groups, dev in ((8, 1, 0), (8, 1, 1), (3, 2, 1), (1, 2, 1)):
+            eng = ra.Engine(0)
+            eng.upload_reference(ref.forward, ref.reverse)
+            cm = mapper.CMapper(eng, opt, stop, names, lens, slot_events=slot, max_reads=n, carry=True, threads=threads, groups=groups, device_chain=bool(dev))
+            lines, rounds = mapper.map_reads_c(seeds, list(range(n)), cm)
+            hashes[(threads, groups, dev)] = hashlib.sha1("\n".join(lines).encode()).hexdigest()
+            logs[(threads, groups, dev)] = hashlib.sha1(cm.log().encode()).hexdigest()
+            tm = cm.timing()
+            assert (tm["anchor_bytes"] == 0) == bool(dev) and tm["event_bytes"] > 0
+            assert cm.stats()[1] > 0
+            cm.close()
+            eng.close()
+        assert len(set(hashes.values())) == 1, hashes
+        assert len(set(logs.values())) == 1, logs
+
+
+@pytest.mark.gpu
+def test_a_round_the_device_declines_to_chain_is_chained_on_the_host(oracle, monkeypatch):
+    """RAWDTW_CHAIN_MAX_SEEDS=60 makes rawdtw_chain_round decline every round in which some read has more than 60 seeds (a chunk's hits alone are
+    often that many; the previous chains' anchors come on top): those rounds are chained on the host -- their anchor lists go up from there --, any
+    other on the device, and the lines are the host-chained mapper's."""
+    import hashlib
+
+    from rawalign_amd.mapping import StopOpt
+
+    monkeypatch.setenv("RAWDTW_CHAIN_MAX_SEEDS", "60")
+    ref = synth.make_reference([120_000], seed=78)
+    n = 200
+    seeds = mapper.SyntheticSeeds(ref, n, seed=6, max_chunks=5)
+    names, lens = ["seq0"], [len(ref.forward[0])]
+    slot = max(rd["n_ev"] for rd in seeds.reads) + 8
+    stop = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
+    out = {}
+    for dev in (0, 1):
+        eng = ra.Engine(0)
+        eng.upload_reference(ref.forward, ref.reverse)
+        cm = mapper.CMapper(eng, ra.MapOpt(), stop, names, lens, slot_events=slot, max_reads=n, carry=False, threads=4, groups=2, device_chain=bool(dev))
+        lines, rounds = mapper.map_reads_c(seeds, list(range(n)), cm)
+        out[dev] = (hashlib.sha1("\n".join(lines).encode()).hexdigest(), cm.timing()["anchor_bytes"], rounds)
+        cm.close()
+        eng.close()
+    assert out[0][0] == out[1][0]
+    assert 0 < out[1][1] <= out[0][1]  # the declined rounds' anchors went up from the host
