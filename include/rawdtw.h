@@ -346,7 +346,7 @@ int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains
  *        seed_off[n_reads] entries)
  *   out (device, the context's, valid until its next rawdtw_chain_round): *d_anchors, *d_ref_base, *d_read_base
  * The call returns when the host arrays are filled.  Results equal rawdtw_chain_anchors list by list and
- * rawdtw_sort_by_chaining_score read by read, bit for bit.  RAWDTW_ERR_UNSUPPORTED (nothing written): a read with more than
+ * rawdtw_sort_by_chaining_score read by read, bit for bit.  RAWDTW_ERR_UNSUPPORTED (the out arrays hold nothing of use): a read with more than
  * 2 048 seeds, with more than 32 chains, or with more than 16 chains two of which have equal scores (std::sort's order of
  * equal elements is an insertion sort's only up to 16) -- chain that round on the host. */
 typedef struct { uint32_t key, target_position, query_position; } rawdtw_seed_t;                       /* 12 bytes */
@@ -356,6 +356,16 @@ int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t 
                        uint64_t *chain_off, uint64_t *anchor_off, rawdtw_chain_rec_t *recs, uint64_t chains_cap,
                        rawdtw_anchor_t *anchors, const rawdtw_anchor_t **d_anchors, const uint64_t **d_ref_base,
                        const uint32_t **d_read_base);
+/* The same in two halves, for a host that has other work while the device chains: _begin enqueues everything (the input
+ * arrays must stay as they are until _end) and returns; _end waits and reports.  When chain_off, anchor_off, recs and
+ * anchors are page-locked (rawdtw_host_alloc) the device writes them itself and _end is one wait; else they are copied in
+ * _end.  One round at a time a context. */
+int rawdtw_chain_round_begin(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off,
+                             const rawdtw_seed_t *seeds, const uint32_t *read_base, uint32_t n_keys, const uint64_t *key_base,
+                             uint64_t *chain_off, uint64_t *anchor_off, rawdtw_chain_rec_t *recs, uint64_t chains_cap,
+                             rawdtw_anchor_t *anchors);
+int rawdtw_chain_round_end(rawdtw_ctx *ctx, const rawdtw_anchor_t **d_anchors, const uint64_t **d_ref_base,
+                           const uint32_t **d_read_base);
 
 /* Batched forms over many reads (what rmap.cpp's per-read worker does for every read of a
  * mini-batch, hoisted around one GPU submission).  Chains are listed read by read, each read's

@@ -182,6 +182,8 @@ SYMBOLS = {
     "rawdtw_batch_submit": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_submit_device": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP]),
     "rawdtw_chain_round": (I32, [VP, C.POINTER(ChainOpt), U64, VP, VP, VP, U32, VP, VP, VP, VP, U64, VP, VP, VP, VP]),
+    "rawdtw_chain_round_begin": (I32, [VP, C.POINTER(ChainOpt), U64, VP, VP, VP, U32, VP, VP, VP, VP, U64, VP]),
+    "rawdtw_chain_round_end": (I32, [VP, VP, VP, VP]),
     "rawdtw_batch_fetch_destroy": (I32, [VP, VP, VP, VP]),
     "rawdtw_batch_submit_carry": (I32, [VP, VP, U64, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "rawdtw_batch_can_carry": (I32, [VP, VP, VP]),

@@ -272,30 +272,51 @@ __global__ __launch_bounds__(1024) void k_chain_scan(const ChainCnt *__restrict_
 __global__ __launch_bounds__(64) void k_chain_compact(const ChainArgs a, const uint64_t *__restrict__ chain_off, const uint64_t *__restrict__ read_anchor0,
                                                       const uint32_t *__restrict__ read_base, const uint64_t *__restrict__ key_base, const uint32_t n_keys,
                                                       uint64_t *__restrict__ anchor_off, rawdtw_anchor_t *__restrict__ anchors, uint64_t *__restrict__ ref_base,
-                                                      uint32_t *__restrict__ read_base_c, rawdtw_chain_rec_t *__restrict__ recs, const uint64_t *__restrict__ totals)
+                                                      uint32_t *__restrict__ read_base_c, rawdtw_chain_rec_t *__restrict__ recs, const uint64_t *__restrict__ totals,
+                                                      // the caller's page-locked host arrays, written from here (null: they are copied afterwards)
+                                                      uint64_t *__restrict__ h_anchor_off, rawdtw_chain_rec_t *__restrict__ h_recs, rawdtw_anchor_t *__restrict__ h_anchors,
+                                                      const uint64_t h_chains_cap)
 {
     const uint32_t r = blockIdx.x, lane = threadIdx.x;
     const uint32_t nc = min(a.cnt[r].nc, kChainCap);
     const uint64_t c0 = chain_off[r], s0 = a.seed_off[r];
+    const bool host = h_anchor_off && totals[2] == 0 && totals[0] <= h_chains_cap; // (a declined round leaves the host arrays alone)
     uint64_t dst = read_anchor0[r];
     for (uint32_t i = 0; i < nc; i++) {
         const ChainRecDev rec = a.tmp_recs[(uint64_t)r * kChainCap + i];
-        for (uint32_t k = lane; k < rec.n; k += 64) anchors[dst + k] = a.tmp_anchors[s0 + rec.a_off + k];
+        for (uint32_t k = lane; k < rec.n; k += 64) {
+            const rawdtw_anchor_t v = a.tmp_anchors[s0 + rec.a_off + k];
+            anchors[dst + k] = v;
+            if (host && h_anchors) h_anchors[dst + k] = v;
+        }
         if (lane == 0) {
+            const rawdtw_chain_rec_t out{rec.score, rec.key, rec.start, rec.end, rec.n};
             anchor_off[c0 + i] = dst;
             ref_base[c0 + i] = rec.key < n_keys ? key_base[rec.key] : 0ull;
             read_base_c[c0 + i] = read_base[r];
-            recs[c0 + i] = rawdtw_chain_rec_t{rec.score, rec.key, rec.start, rec.end, rec.n};
+            recs[c0 + i] = out;
+            if (host) { h_anchor_off[c0 + i] = dst; h_recs[c0 + i] = out; }
         }
         dst += rec.n;
     }
-    if (r == 0 && lane == 0) anchor_off[totals[0]] = totals[1];
+    if (r == 0 && lane == 0) { anchor_off[totals[0]] = totals[1]; if (host) h_anchor_off[totals[0]] = totals[1]; }
 }
 
 struct ChainWs {
     void *dev = nullptr;
     size_t dev_bytes = 0;
     void *pin = nullptr; // totals
+    // a round begun and not ended
+    bool pending = false, direct = false;
+    uint64_t n_reads = 0, chains_cap = 0;
+    uint64_t *h_anchor_off = nullptr;
+    rawdtw_chain_rec_t *h_recs = nullptr;
+    rawdtw_anchor_t *h_anchors = nullptr;
+    const uint64_t *d_aoff = nullptr;
+    const rawdtw_chain_rec_t *d_recs = nullptr;
+    const rawdtw_anchor_t *d_anch = nullptr;
+    const uint64_t *d_refb = nullptr;
+    const uint32_t *d_rbc = nullptr;
 };
 
 } // namespace
@@ -308,15 +329,14 @@ struct rawdtw_chain_ws { ChainWs w; };
 
 extern "C" {
 
-int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off, const rawdtw_seed_t *seeds,
-                       const uint32_t *read_base, uint32_t n_keys, const uint64_t *key_base, uint64_t *chain_off, uint64_t *anchor_off,
-                       rawdtw_chain_rec_t *recs, uint64_t chains_cap, rawdtw_anchor_t *anchors, const rawdtw_anchor_t **d_anchors,
-                       const uint64_t **d_ref_base, const uint32_t **d_read_base)
+int rawdtw_chain_round_begin(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off, const rawdtw_seed_t *seeds,
+                             const uint32_t *read_base, uint32_t n_keys, const uint64_t *key_base, uint64_t *chain_off, uint64_t *anchor_off,
+                             rawdtw_chain_rec_t *recs, uint64_t chains_cap, rawdtw_anchor_t *anchors)
 {
     if (!ctx) return RAWDTW_ERR_INVALID;
-    if (!opt || !seed_off || (!seeds && n_reads && seed_off[n_reads]) || !read_base || (!key_base && n_keys) || !chain_off || !anchor_off || !recs || !d_anchors ||
-        !d_ref_base || !d_read_base)
+    if (!opt || !seed_off || (!seeds && n_reads && seed_off[n_reads]) || !read_base || (!key_base && n_keys) || !chain_off || !anchor_off || !recs)
         return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (ctx->chain_ws && ctx->chain_ws->w.pending) return fail(ctx, RAWDTW_ERR_INVALID, "a chaining round is begun on this context and not ended");
     if (n_reads == 0 || n_reads > 0xffffffffull) return fail(ctx, RAWDTW_ERR_INVALID, "no reads, or more than 2^32");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint64_t n_seeds = seed_off[n_reads];
@@ -325,10 +345,8 @@ int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t 
         if (seed_off[r + 1] < seed_off[r]) return fail(ctx, RAWDTW_ERR_INVALID, "offsets do not ascend");
         most = (uint32_t)std::max<uint64_t>(most, std::min<uint64_t>(seed_off[r + 1] - seed_off[r], 0xffffffffull));
     }
-    static const uint32_t seed_cap = [] { // (tests: RAWDTW_CHAIN_MAX_SEEDS lowers the cap, so that small rounds take the declined path)
-        const char *e = getenv("RAWDTW_CHAIN_MAX_SEEDS");
-        return e ? std::min<uint32_t>(kChainMaxSeeds, (uint32_t)std::max(1l, strtol(e, nullptr, 10))) : kChainMaxSeeds;
-    }();
+    uint32_t seed_cap = kChainMaxSeeds; // (tests: RAWDTW_CHAIN_MAX_SEEDS lowers the cap, so that small rounds take the declined path)
+    if (const char *e = getenv("RAWDTW_CHAIN_MAX_SEEDS")) seed_cap = std::min<uint32_t>(kChainMaxSeeds, (uint32_t)std::max(1l, strtol(e, nullptr, 10)));
     if (most > seed_cap) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, "a read has more seeds than the device chains (2048): chain this round on the host");
     uint32_t n2 = 64;
     while (n2 < most) n2 <<= 1;
@@ -375,22 +393,59 @@ int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t 
     const size_t lds = (size_t)n2 * 21 + 16;
     hipLaunchKernelGGL(k_chain, dim3((uint32_t)n_reads), dim3(64), lds, s, a);
     hipLaunchKernelGGL(k_chain_scan, dim3(1), dim3(1024), 0, s, d_cnt, (uint32_t)n_reads, d_coff, d_ra0, d_tot);
-    hipLaunchKernelGGL(k_chain_compact, dim3((uint32_t)n_reads), dim3(64), 0, s, a, d_coff, d_ra0, d_rb, d_kb, n_keys, d_aoff, d_anch, d_refb, d_rbc, d_recs, d_tot);
+    // the caller's arrays: written by the compaction launch itself when they are page-locked (rawdtw_host_alloc) -- no copy command, no second
+    // wait for sizes only the device knows; else copied at the round's end
+    auto page_locked = [](const void *q) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool direct = page_locked(anchor_off) && page_locked(recs) && (!anchors || page_locked(anchors)) && page_locked(chain_off);
+    hipLaunchKernelGGL(k_chain_compact, dim3((uint32_t)n_reads), dim3(64), 0, s, a, d_coff, d_ra0, d_rb, d_kb, n_keys, d_aoff, d_anch, d_refb, d_rbc, d_recs, d_tot,
+                       direct ? anchor_off : nullptr, direct ? recs : nullptr, direct ? anchors : nullptr, chains_cap);
     HIP_TRY(ctx, hipGetLastError());
     uint64_t *h_tot = static_cast<uint64_t *>(w.pin);
     HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(chain_off, d_coff, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    w.pending = true; w.direct = direct; w.n_reads = n_reads; w.chains_cap = chains_cap;
+    w.h_anchor_off = anchor_off; w.h_recs = recs; w.h_anchors = anchors;
+    w.d_aoff = d_aoff; w.d_recs = d_recs; w.d_anch = d_anch; w.d_refb = d_refb; w.d_rbc = d_rbc;
+    return RAWDTW_OK;
+}
+
+int rawdtw_chain_round_end(rawdtw_ctx *ctx, const rawdtw_anchor_t **d_anchors, const uint64_t **d_ref_base, const uint32_t **d_read_base)
+{
+    if (!ctx) return RAWDTW_ERR_INVALID;
+    if (!d_anchors || !d_ref_base || !d_read_base) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    if (!ctx->chain_ws || !ctx->chain_ws->w.pending) return fail(ctx, RAWDTW_ERR_INVALID, "no chaining round begun on this context");
+    ChainWs &w = ctx->chain_ws->w;
+    w.pending = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    const uint64_t *h_tot = static_cast<const uint64_t *>(w.pin);
     const uint64_t nc = h_tot[0], na = h_tot[1], flags = h_tot[2];
     if (flags) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, flags & 4 ? "a read with more than 16 chains, two of them with equal scores: chain this round on the host"
                                                                : "a read with more than 32 chains (or more seeds than the device chains): chain this round on the host");
-    if (nc > chains_cap) return fail(ctx, RAWDTW_ERR_RANGE, "chain output arrays too small");
-    HIP_TRY(ctx, hipMemcpyAsync(anchor_off, d_aoff, (nc + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (nc) HIP_TRY(ctx, hipMemcpyAsync(recs, d_recs, nc * sizeof(rawdtw_chain_rec_t), hipMemcpyDeviceToHost, s));
-    if (anchors && na) HIP_TRY(ctx, hipMemcpyAsync(anchors, d_anch, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    *d_anchors = d_anch; *d_ref_base = d_refb; *d_read_base = d_rbc;
+    if (nc > w.chains_cap) return fail(ctx, RAWDTW_ERR_RANGE, "chain output arrays too small");
+    if (!w.direct) {
+        HIP_TRY(ctx, hipMemcpyAsync(w.h_anchor_off, w.d_aoff, (nc + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (nc) HIP_TRY(ctx, hipMemcpyAsync(w.h_recs, w.d_recs, nc * sizeof(rawdtw_chain_rec_t), hipMemcpyDeviceToHost, s));
+        if (w.h_anchors && na) HIP_TRY(ctx, hipMemcpyAsync(w.h_anchors, w.d_anch, na * sizeof(rawdtw_anchor_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    *d_anchors = w.d_anch; *d_ref_base = w.d_refb; *d_read_base = w.d_rbc;
     return RAWDTW_OK;
+}
+
+int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off, const rawdtw_seed_t *seeds,
+                       const uint32_t *read_base, uint32_t n_keys, const uint64_t *key_base, uint64_t *chain_off, uint64_t *anchor_off,
+                       rawdtw_chain_rec_t *recs, uint64_t chains_cap, rawdtw_anchor_t *anchors, const rawdtw_anchor_t **d_anchors,
+                       const uint64_t **d_ref_base, const uint32_t **d_read_base)
+{
+    if (ctx && (!d_anchors || !d_ref_base || !d_read_base)) return fail(ctx, RAWDTW_ERR_INVALID, "null argument");
+    const int st = rawdtw_chain_round_begin(ctx, opt, n_reads, seed_off, seeds, read_base, n_keys, key_base, chain_off, anchor_off, recs, chains_cap, anchors);
+    return st == RAWDTW_OK ? rawdtw_chain_round_end(ctx, d_anchors, d_ref_base, d_read_base) : st;
 }
 
 } // extern "C"

@@ -578,26 +578,16 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     int status = RAWDTW_OK;
     std::string status_msg;
     auto set_fail = [&](int st, const std::string &msg) { if (status == RAWDTW_OK) { status = st; status_msg = msg; } };
-    // ---- per group: host phase, lay-out, submit ----
-    for (uint32_t gi = 0; gi < G && status == RAWDTW_OK; gi++) {
+    // ---- device chaining (opt.device_chain), first half: the host phase is the events and the seed lists; sort, chaining DP, traceback and order
+    // are enqueued (rawdtw_chain_round_begin) and run while the next group's host phase does.  false: the device declined (its cap on seeds a read)
+    // -- the events are in place on both sides, the round is chained on the host.
+    struct DevRound { bool pending = false; uint64_t ns = 0, nev = 0, nseg = 0; };
+    std::vector<DevRound> dev(G);
+    auto device_begin = [&](const uint32_t gi) -> bool {
         Group &g = m->groups[gi];
         RoundArrays &ra = g.buf[g.cur];
-        const RoundArrays *pv = nullptr;
-        ra.carried = false;
-        ra.round_id = round_id;
-        const RoundArrays &pb = g.buf[g.cur ^ 1];
         const size_t nr = ra.ks.size();
-        if (on_device && m->opt.carry && !m->opt.device_chain && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) {
-            size_t known = 0; // (a round none of whose reads was in the round before has nothing to take over: submitted whole)
-            for (size_t i = 0; i < nr && !known; i++) known += m->reads[read_ids[ra.ks[i]]].last_round == pb.round_id;
-            if (known) { pv = &pb; ra.carried = true; }
-        }
-        ra.n_reads = nr;
-        ra.device_chained = false;
-        bool events_done = false; // (a round the device declined to chain: its events are appended already, on both sides)
-        // ---- device chaining (opt.device_chain): the host phase is the events and the seed lists; sort, chaining DP, traceback and order run on
-        // the device (rawdtw_chain_round) and hand their chains to the DTW in device memory.  A round it declines is chained below, on the host.
-        if (on_device && m->opt.device_chain) {
+        {
             m->pool->run(nr, 64, [&](size_t i) {
                 const uint32_t k = ra.ks[i];
                 MRead &rd = m->reads[read_ids[k]];
@@ -617,7 +607,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                      x->chain_off.ensure(g.hw_reads + 1, true) && x->anchor_off.ensure(g.hw_chains + 1, true) && x->recs.ensure(g.hw_chains + 1, true) &&
                      x->anchors.ensure(g.hw_seeds + 1, true) && x->score.ensure(g.hw_chains + 1, true) && x->keep.ensure(g.hw_chains + 1, true) &&
                      x->new_events.ensure(g.hw_events + 1, true) && x->seg_src.ensure(g.hw_seg + 2, true) && x->seg_dst.ensure(g.hw_seg + 1, true);
-            if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); continue; }
+            if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); return true; }
             {
                 uint64_t sg = 0, at = 0;
                 for (size_t i = 0; i < nr; i++) {
@@ -652,51 +642,71 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             m->timing[0] += td - t0; t0 = td;
             int st = RAWDTW_OK;
             if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
-            const rawdtw_anchor_t *d_anchors = nullptr;
-            const uint64_t *d_ref_base = nullptr;
-            const uint32_t *d_read_base = nullptr;
             if (st == RAWDTW_OK)
-                st = rawdtw_chain_round(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(), ra.chain_off.p,
-                                        ra.anchor_off.p, ra.recs.p, g.hw_chains, ra.anchors.p, &d_anchors, &d_ref_base, &d_read_base);
-            if (st == RAWDTW_OK) {
-                const uint64_t nc = ra.chain_off[nr], na = ra.anchor_off[nc];
-                ra.n_chains = nc; ra.n_anchors = na; ra.n_new = 0; ra.n_new_events = nev; ra.n_seg = nseg;
-                st = rawdtw_batch_submit_device(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, d_anchors, d_ref_base, d_read_base, &ra.batch);
-                if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); continue; }
-                ra.device_chained = true;
-                m->timing[6] += (double)(nev * sizeof(float));
-                m->timing[7] += (double)(ns * sizeof(rawdtw_seed_t) + (nr + 1) * 16 + nr * 4 + (nc + 1) * 8 + nseg * 12);
-                td = now_ms();
-                m->timing[2] += td - t0; t0 = td;
-                // (while the batch runs) the round's chains per read, as the host phase would have left them
-                m->pool->run(nr, 32, [&](size_t i) {
-                    RoundRead &r = rr[ra.ks[i]];
-                    r.chain0 = ra.chain_off[i];
-                    const uint64_t n = ra.chain_off[i + 1] - ra.chain_off[i];
-                    r.chains.resize(n);
-                    for (uint64_t c = 0; c < n; c++) {
-                        const rawdtw_chain_rec_t &rec = ra.recs[r.chain0 + c];
-                        MChain &ch = r.chains[c];
-                        ch.chaining_score = rec.chaining_score; ch.ref = rec.key >> 1; ch.strand = (int32_t)(rec.key & 1u);
-                        ch.start_position = rec.start_position; ch.end_position = rec.end_position;
-                        const rawdtw_anchor_t *an = ra.anchors.p + ra.anchor_off[r.chain0 + c];
-                        ch.anchors.assign(an, an + rec.n_anchors);
-                    }
-                });
-                td = now_ms();
-                m->timing[1] += td - t0; t0 = td;
-                continue;
+                st = rawdtw_chain_round_begin(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(),
+                                              ra.chain_off.p, ra.anchor_off.p, ra.recs.p, g.hw_chains, ra.anchors.p);
+            td = now_ms();
+            m->timing[2] += td - t0; t0 = td;
+            if (st == RAWDTW_ERR_UNSUPPORTED) return false;
+            if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); return true; }
+            dev[gi].pending = true; dev[gi].ns = ns; dev[gi].nev = nev; dev[gi].nseg = nseg;
+            return true;
+        }
+    };
+    // second half: the wait, the DTW submission straight from the device's arrays, and -- while that batch runs -- the round's chains per read, as
+    // the host phase would have left them.  false: declined (a read with too many chains, or an order only std::sort knows)
+    auto device_end = [&](const uint32_t gi) -> bool {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur];
+        const size_t nr = ra.ks.size();
+        dev[gi].pending = false;
+        const rawdtw_anchor_t *d_anchors = nullptr;
+        const uint64_t *d_ref_base = nullptr;
+        const uint32_t *d_read_base = nullptr;
+        int st = rawdtw_chain_round_end(g.ctx, &d_anchors, &d_ref_base, &d_read_base);
+        if (st == RAWDTW_ERR_UNSUPPORTED) { double td = now_ms(); m->timing[2] += td - t0; t0 = td; return false; }
+        if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); return true; }
+        const uint64_t nc = ra.chain_off[nr], na = ra.anchor_off[nc];
+        ra.n_chains = nc; ra.n_anchors = na; ra.n_new = 0; ra.n_new_events = dev[gi].nev; ra.n_seg = dev[gi].nseg;
+        st = rawdtw_batch_submit_device(g.ctx, &m->opt.align, nr, ra.chain_off.p, ra.anchor_off.p, d_anchors, d_ref_base, d_read_base, &ra.batch);
+        if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); return true; }
+        ra.device_chained = true;
+        m->timing[6] += (double)(dev[gi].nev * sizeof(float));
+        m->timing[7] += (double)(dev[gi].ns * sizeof(rawdtw_seed_t) + (nr + 1) * 16 + nr * 4 + (nc + 1) * 8 + dev[gi].nseg * 12);
+        double td = now_ms();
+        m->timing[2] += td - t0; t0 = td;
+        m->pool->run(nr, 32, [&](size_t i) {
+            RoundRead &r = rr[ra.ks[i]];
+            r.chain0 = ra.chain_off[i];
+            const uint64_t n = ra.chain_off[i + 1] - ra.chain_off[i];
+            r.chains.resize(n);
+            for (uint64_t c = 0; c < n; c++) {
+                const rawdtw_chain_rec_t &rec = ra.recs[r.chain0 + c];
+                MChain &ch = r.chains[c];
+                ch.chaining_score = rec.chaining_score; ch.ref = rec.key >> 1; ch.strand = (int32_t)(rec.key & 1u);
+                ch.start_position = rec.start_position; ch.end_position = rec.end_position;
+                const rawdtw_anchor_t *an = ra.anchors.p + ra.anchor_off[r.chain0 + c];
+                ch.anchors.assign(an, an + rec.n_anchors);
             }
-            if (st != RAWDTW_ERR_UNSUPPORTED) { set_fail(st, rawdtw_last_error(g.ctx)); continue; }
-            // declined (a read with too many seeds or chains, or an order only std::sort knows): this round's chains are made on the host; the
-            // events are in place already, on both sides
+        });
+        td = now_ms();
+        m->timing[1] += td - t0; t0 = td;
+        return true;
+    };
+    // ---- a group's round with the chains made on the host: host phase, lay-out, submit (`events_done`: a round the device declined to chain --
+    // its events are appended already, on both sides) ----
+    auto host_round = [&](const uint32_t gi, const RoundArrays *pv, const bool events_done) {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur];
+        const RoundArrays &pb = g.buf[g.cur ^ 1];
+        const size_t nr = ra.ks.size();
+        if (events_done)
             m->pool->run(nr, 16, [&](size_t i) {
                 const uint32_t k = ra.ks[i];
                 RoundRead &r = rr[k];
                 if (!r.skipped) host_phase_chain(m, m->reads[read_ids[k]], r, hits + hit_off[k], hit_off[k + 1] - hit_off[k], nullptr, runs_dtw);
             });
-            events_done = true;
-        } else
+        else
             m->pool->run(nr, 16, [&](size_t i) {
                 const uint32_t k = ra.ks[i];
                 MRead &rd = m->reads[read_ids[k]];
@@ -707,7 +717,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         double t1 = now_ms();
         m->timing[0] += t1 - t0; t0 = t1;
         for (size_t i = 0; i < nr; i++) if (rr[ra.ks[i]].err != RAWDTW_OK) set_fail(rr[ra.ks[i]].err, "chaining failed (chain output buffers too small)");
-        if (status != RAWDTW_OK || !runs_dtw) continue;
+        if (status != RAWDTW_OK || !runs_dtw) return;
         // ---- lay-out: offsets by a running sum, then every read copies its own stretch ----
         uint64_t nc = 0, na = 0, nn = 0, nev = 0, nseg = 0;
         for (size_t i = 0; i < nr; i++) {
@@ -735,7 +745,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                    (!on_device || (x.new_events.ensure(g.hw_events + 1, pin) && x.seg_src.ensure(g.hw_seg + 2, pin) && x.seg_dst.ensure(g.hw_seg + 1, pin)));
         };
         const bool ok = size_arrays(ra, false) && size_arrays(g.buf[g.cur ^ 1], true);
-        if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); continue; }
+        if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); return; }
         if (m->scorer) { ra.chain_seq.resize(nc); ra.chain_strand.resize(nc); }
         ra.chain_off[nr] = nc; ra.anchor_off[nc] = na;
         if (ra.carried) ra.new_off[nc] = nn;
@@ -807,6 +817,37 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         }
         t1 = now_ms();
         m->timing[2] += t1 - t0; t0 = t1;
+    };
+    for (uint32_t gi = 0; gi < G && status == RAWDTW_OK; gi++) {
+        Group &g = m->groups[gi];
+        RoundArrays &ra = g.buf[g.cur];
+        const RoundArrays &pb = g.buf[g.cur ^ 1];
+        const RoundArrays *pv = nullptr;
+        const size_t nr = ra.ks.size();
+        ra.carried = false;
+        ra.round_id = round_id;
+        ra.n_reads = nr;
+        ra.device_chained = false;
+        if (on_device && m->opt.device_chain) {
+            if (!device_begin(gi) && status == RAWDTW_OK) host_round(gi, nullptr, true);
+            continue;
+        }
+        if (on_device && m->opt.carry && g.has_prev && pb.batch && rawdtw_batch_can_carry(g.ctx, pb.batch, &m->opt.align)) {
+            size_t known = 0; // (a round none of whose reads was in the round before has nothing to take over: submitted whole)
+            for (size_t i = 0; i < nr && !known; i++) known += m->reads[read_ids[ra.ks[i]]].last_round == pb.round_id;
+            if (known) { pv = &pb; ra.carried = true; }
+        }
+        host_round(gi, pv, false);
+    }
+    for (uint32_t gi = 0; gi < G; gi++) {
+        if (!dev[gi].pending) continue;
+        if (status != RAWDTW_OK) { // (a failure elsewhere: the round begun is ended, nothing of it is used)
+            const rawdtw_anchor_t *x = nullptr; const uint64_t *y = nullptr; const uint32_t *z = nullptr;
+            (void)rawdtw_chain_round_end(m->groups[gi].ctx, &x, &y, &z);
+            dev[gi].pending = false;
+            continue;
+        }
+        if (!device_end(gi) && status == RAWDTW_OK) host_round(gi, nullptr, true);
     }
     // ---- per group: fetch, then the round's end per read ----
     for (uint32_t gi = 0; gi < G; gi++) {
