@@ -587,6 +587,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         Group &g = m->groups[gi];
         RoundArrays &ra = g.buf[g.cur];
         const size_t nr = ra.ks.size();
+        if (nr == 0) return true; // (none of the round's reads is this group's)
         {
             m->pool->run(nr, 64, [&](size_t i) {
                 const uint32_t k = ra.ks[i];

@@ -152,6 +152,7 @@ static int run_map(const char *path)
     if (const char *e = getenv("RAWDTW_SHIM_GROUPS")) mo.groups = atoi(e);
     mo.min_events = 50;
     if (const char *e = getenv("RAWDTW_SHIM_MIN_EVENTS")) mo.min_events = (uint32_t)atoi(e);
+    if (const char *e = getenv("RAWDTW_SHIM_DEVICE_CHAIN")) mo.device_chain = atoi(e); // (the anchor sort and the chaining DP on the device: rawdtw_chain_round)
     rawdtw_mapper *mp = nullptr;
     CHECK(rawdtw_mapper_create(dtw, &mo, n_seq, pn.data(), len.data(), &mp));
     std::vector<uint32_t> ids(n_reads);

@@ -251,11 +251,13 @@ def _write_map_blob(path, ref, seeds, n_reads, opt, carry, stop):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("border,fill,flag,carry,never,threads,groups,min_events",
-                         [(1, 1, 0x2, 1, 0, 1, 1, 50), (1, 1, 0x2, 0, 0, 4, 2, 50), (1, 1, 0x2 | 0x4, 1, 0, 3, 2, 50), (1, 0, 0x2 | 0x4, 0, 0, 1, 1, 50),
-                          (0, 0, 0x2 | 0x4, 0, 0, 2, 1, 50), (1, 1, 0x8, 1, 0, 1, 2, 50), (1, 1, 0x2 | 0x4 | 0x8, 1, 0, 4, 1, 50), (0, 1, 0x2, 0, 0, 1, 1, 50),
-                          (1, 1, 0x2, 1, 1, 4, 2, 50), (1, 1, 0x8, 1, 1, 2, 2, 50), (1, 1, 0x2, 1, 1, 1, 1, 300), (1, 1, 0x2, 1, 0, 4, 2, 300)])
-def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_path, border, fill, flag, carry, never, threads, groups, min_events):
+@pytest.mark.parametrize("border,fill,flag,carry,never,threads,groups,min_events,dev_chain",
+                         [(1, 1, 0x2, 1, 0, 1, 1, 50, 0), (1, 1, 0x2, 0, 0, 4, 2, 50, 0), (1, 1, 0x2 | 0x4, 1, 0, 3, 2, 50, 0), (1, 0, 0x2 | 0x4, 0, 0, 1, 1, 50, 0),
+                          (0, 0, 0x2 | 0x4, 0, 0, 2, 1, 50, 0), (1, 1, 0x8, 1, 0, 1, 2, 50, 0), (1, 1, 0x2 | 0x4 | 0x8, 1, 0, 4, 1, 50, 0), (0, 1, 0x2, 0, 0, 1, 1, 50, 0),
+                          (1, 1, 0x2, 1, 1, 4, 2, 50, 0), (1, 1, 0x8, 1, 1, 2, 2, 50, 0), (1, 1, 0x2, 1, 1, 1, 1, 300, 0), (1, 1, 0x2, 1, 0, 4, 2, 300, 0),
+                          (1, 1, 0x2, 0, 0, 4, 2, 50, 1), (1, 1, 0x2 | 0x4 | 0x8, 1, 0, 1, 1, 50, 1), (0, 0, 0x2 | 0x4, 0, 0, 2, 2, 50, 1), (1, 1, 0x2, 0, 1, 3, 2, 300, 1),
+                          (1, 1, 0x8, 0, 1, 2, 1, 50, 1)])
+def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_path, border, fill, flag, carry, never, threads, groups, min_events, dev_chain):
     """f-2 in C++: the chunk-round loop, chaining, primary chains / MAPQ / stop rule and the PAF line run inside the library
     (rawdtw_mapper_*, rawalign_amd/csrc/rawdtw_mapper.cpp), driven by the compiled shim.  Its PAF lines and --dtw-log-scores
     lines must equal, character for character, those of the Python mirror (rawalign_amd.mapper.map_reads) scored on the
@@ -263,8 +265,9 @@ def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_p
     log-scores alone, with and without costs carried from round to round, under the reference's stop rule and with reads
     that never stop early (every read through all of its chunks: the rounds in which carried costs are taken over), on one
     host thread and several, with one read group and two (two contexts, one group's host phase beside the other's batch),
-    and with --min-events at the reference's 50 and at 300 (chunks that are appended but not chained, rmap.cpp:569-575: most
-    reads' last chunk).  d1-scale reference (configs[0])."""
+    with --min-events at the reference's 50 and at 300 (chunks that are appended but not chained, rmap.cpp:569-575: most
+    reads' last chunk), and with the anchor sort and the chaining DP on the host and on the device (opt.device_chain).  d1-scale
+    reference (configs[0])."""
     from rawalign_amd import mapper
     from rawalign_amd.mapping import StopOpt
     from tests.util import OracleScorer
@@ -279,7 +282,8 @@ def test_cpp_mapper_paf_identical_to_python_mirror_and_oracle_flow(oracle, tmp_p
     blob = os.path.join(str(tmp_path), "map.bin")
     _write_map_blob(blob, ref, seeds, n, opt, carry, stop)
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "rawalign_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
-               RAWDTW_SHIM_THREADS=str(threads), RAWDTW_SHIM_GROUPS=str(groups), RAWDTW_SHIM_MIN_EVENTS=str(min_events))
+               RAWDTW_SHIM_THREADS=str(threads), RAWDTW_SHIM_GROUPS=str(groups), RAWDTW_SHIM_MIN_EVENTS=str(min_events),
+               RAWDTW_SHIM_DEVICE_CHAIN=str(dev_chain))
     run = subprocess.run([exe, blob, "--map"], capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0, run.stderr
     got = run.stdout.rstrip("\n").split("\n")
