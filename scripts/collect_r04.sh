@@ -44,4 +44,9 @@ fi
 if want 8; then
   bash scripts/sensitivity.sh $OUT/sens > $OUT/sens_top.txt; cp $OUT/sens/summary.json $OUT/r04_sensitivity.json; step 8 "sensitivity rc=$?"
 fi
+if want 9; then  # the chunk-round mapper: phases of a round, chaining on the host / on the device; its kernels by rocprofv3
+  timeout -k 10 400 python -u scripts/mapper_probe.py 16384 1,16,0 1,16,0,dev 2,16,0,dev 1,1,0,dev 1,16,0,all 1,16,0,all,dev > $OUT/r04_mapper_probe.txt 2>&1; step 9 "mapper_probe rc=$?"
+  ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p $OUT/mp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mp -o run -- python3 scripts/mapper_probe.py 16384 1,16,0,dev 1,16,0,all,dev > $OUT/mp/out.txt 2> $OUT/mp/err.txt ); step 9 "mapper profile rc=$?"
+  cp $OUT/mp/run_kernel_stats.csv $OUT/r04_mapper_kernel_stats.csv
+fi
 ls $OUT
