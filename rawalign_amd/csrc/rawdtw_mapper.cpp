@@ -57,7 +57,9 @@ struct MRead {
     std::string name;
     uint32_t qlen = 0, n_chunks = 0, chunks_done = 0;
     bool finished = false, broke_early = false, released = false;
-    std::vector<float> events;   // p->events[read].values
+    std::vector<float> events;   // p->events[read].values -- the host's copy: kept for what reads it (an external scorer, --dtw-output-cigar's
+                                 // traceback at the end); a mapper that only scores on the device keeps the count (the events are in the arena)
+    uint32_t n_events = 0;
     uint32_t offset = 0;         // reg->offset: events of the chunks that were chained (rmap.cpp:574; a chunk below min_events does not count)
     std::vector<MChain> chains;  // reg0->chains: the primary chains, best first
     uint32_t slot = 0;           // its place in the mapper's event arenas: group = slot % groups, place there = slot / groups
@@ -141,6 +143,7 @@ struct RoundRead {
     uint64_t ne = 0;
     uint32_t ev_before = 0, off_before = 0;
     bool skipped = false;                // a chunk below min_events: no chaining, chains and offset stay (rmap.cpp:569-575)
+    bool high = false;                   // the round's end: mapped with high confidence (rmap.cpp:692)
     uint64_t chain0 = 0, anchor0 = 0, new0 = 0, ev0 = 0; // its first chain / anchor / new anchor / new event in the group's arrays
     uint64_t seed0 = 0, n_seeds = 0;     // device chaining: its seeds in the group's list
     uint32_t chunk_start = 0;
@@ -251,6 +254,7 @@ struct rawdtw_mapper {
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rawdtw_scorer_fn scorer = nullptr;
     void *scorer_user = nullptr;
+    bool keep_host_events = true; // (false: scored on the device only and no CIGAR asked for -- nothing reads the host's copy of a read's events)
     std::string err;
 };
 
@@ -308,9 +312,10 @@ struct Seed { uint32_t key, t, q; };
 bool host_phase_events(rawdtw_mapper *m, MRead &rd, RoundRead &rr, const float *ev, uint64_t ne)
 {
     rr.ne = ne;
-    rr.ev_before = (uint32_t)rd.events.size();
+    rr.ev_before = rd.n_events;
     rr.off_before = rd.offset;
-    rd.events.insert(rd.events.end(), ev, ev + ne); // rmap.cpp:554-567
+    if (m->keep_host_events) rd.events.insert(rd.events.end(), ev, ev + ne); // rmap.cpp:554-567
+    rd.n_events += (uint32_t)ne;
     if (ne < m->opt.min_events) { rr.skipped = true; return false; } // rmap.cpp:569-572: no gen_chains, reg->offset stays
     rr.chunk_start = rd.offset;  // reg->offset (rmap.cpp:574)
     rd.offset += (uint32_t)ne;   // rmap.cpp:575
@@ -426,6 +431,7 @@ int rawdtw_mapper_create(rawdtw_ctx *ctx, const rawdtw_mapper_opt_t *opt, uint32
     if (!m) return RAWDTW_ERR_OOM;
     m->ctx = ctx; m->opt = *opt;
     m->opt.groups = (ctx && opt->groups >= 2) ? 2 : 1;
+    m->keep_host_events = !ctx || (opt->flag & 0x4) || !(opt->flag & (0x2 | 0x8));
     m->opt.threads = std::max(1, std::min(opt->threads, 256));
     for (uint32_t s = 0; s < n_seq; s++) { m->seq_names.emplace_back(seq_names[s]); m->seq_len.push_back(seq_len[s]); }
     m->ref_off.resize(2ull * n_seq);
@@ -476,6 +482,11 @@ const char *rawdtw_mapper_last_error(const rawdtw_mapper *m) { return m ? m->err
 int rawdtw_mapper_set_scorer(rawdtw_mapper *m, rawdtw_scorer_fn fn, void *user)
 {
     if (!m) return RAWDTW_ERR_INVALID;
+    if (fn && !m->keep_host_events) { // (an external scorer reads the host's copy of the reads' events: from the first round on)
+        for (const MRead &rd : m->reads)
+            if (rd.n_events && !rd.released) return fail(m, RAWDTW_ERR_INVALID, "set the scorer before the first round");
+        m->keep_host_events = true;
+    }
     m->scorer = fn; m->scorer_user = user;
     drop_batches(m); // (a round scored elsewhere leaves nothing to carry from)
     for (Group &g : m->groups) g.has_prev = false;
@@ -565,7 +576,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     for (uint32_t k = 0; k < n_reads; k++) m->reads[read_ids[k]].seen_round = 0; // (a failed round does not count)
     for (uint32_t k = 0; k < n_reads; k++) {
         const MRead &rd = m->reads[read_ids[k]];
-        if ((uint64_t)rd.events.size() + (event_off[k + 1] - event_off[k]) > m->opt.slot_events) return fail(m, RAWDTW_ERR_RANGE, "a read outgrew its slot in the event arena");
+        if ((uint64_t)rd.n_events + (event_off[k + 1] - event_off[k]) > m->opt.slot_events) return fail(m, RAWDTW_ERR_RANGE, "a read outgrew its slot in the event arena");
         for (uint64_t h = hit_off[k]; h < hit_off[k + 1]; h++)
             if (hits[h].ref_seq >= n_seq) return fail(m, RAWDTW_ERR_INVALID, "seed hit on an unknown sequence");
     }
@@ -869,7 +880,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             const uint32_t k = ra.ks[i];
             RoundRead &r = rr[k];
             MRead &rd = m->reads[read_ids[k]];
-            if (r.skipped) return; // rmap.cpp:569-572: the chains stay as they were
+            if (r.skipped) { r.high = high_confidence(m, rd.chains); return; } // rmap.cpp:569-572: the chains stay as they were
             std::vector<MChain> post;
             for (size_t c = 0; c < r.chains.size(); c++) {
                 MChain &ch = r.chains[c];
@@ -887,6 +898,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                 if (!evaluate || !runs_dtw || keep) post.push_back(std::move(ch)); // rmap.cpp:525: replaced only under EVALUATE_CHAINS
             }
             rd.chains = primary_chains(m, post);
+            r.high = high_confidence(m, rd.chains);
         });
         t1 = now_ms();
         m->timing[4] += t1 - t0; t0 = t1;
@@ -894,7 +906,10 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     if (status != RAWDTW_OK) { // put the reads back as they were; nothing of the round stays
         for (uint32_t k = 0; k < n_reads; k++) {
             MRead &rd = m->reads[read_ids[k]];
-            if (rd.events.size() >= rr[k].ev_before && rr[k].ne + rr[k].ev_before == rd.events.size()) { rd.events.resize(rr[k].ev_before); rd.offset = rr[k].off_before; }
+            if (rd.n_events >= rr[k].ev_before && rr[k].ne + rr[k].ev_before == rd.n_events) {
+                rd.n_events = rr[k].ev_before; rd.offset = rr[k].off_before;
+                if (rd.events.size() > rd.n_events) rd.events.resize(rd.n_events);
+            }
         }
         for (Group &g : m->groups) {
             RoundArrays &ra = g.buf[g.cur];
@@ -920,7 +935,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
         MRead &rd = m->reads[read_ids[k]];
         if (!rr[k].log.empty()) m->log += rr[k].log;
         rd.chunks_done++;
-        if (high_confidence(m, rd.chains)) { rd.finished = true; rd.broke_early = true; } // rmap.cpp:692
+        if (rr[k].high) { rd.finished = true; rd.broke_early = true; } // rmap.cpp:692 (evaluated with the round's end, per read on the pool)
         else if (rd.chunks_done >= std::min(rd.n_chunks, m->opt.max_num_chunk)) rd.finished = true;
     }
     // (the round's per-read state goes on the pool: ten vectors a read, freed one read after the other they were milliseconds of a large round)
