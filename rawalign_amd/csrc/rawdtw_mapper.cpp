@@ -159,28 +159,50 @@ public:
     }
     ~Pool()
     {
-        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_.fetch_add(1, std::memory_order_release); }
         cv_.notify_all();
         for (auto &t : th_) t.join();
     }
-    // fn(i) for i in [0, n), dealt in pieces of `grain` from a shared counter (as kt_for deals reads: kthread.c:54-72)
+    // fn(i) for i in [0, n), dealt in pieces of `grain` from a shared counter (as kt_for deals reads: kthread.c:54-72).
+    // A round is half a dozen such loops a few hundred microseconds apart: a worker that has run out of work keeps looking for the next loop
+    // for a short while before it goes to sleep, and the caller for the last worker -- waking sixteen threads through a condition variable
+    // was 50-100 us a loop, most of a small round.
     void run(size_t n, size_t grain, const std::function<void(size_t)> &fn)
     {
         if (n == 0) return;
         if (th_.empty() || n <= grain) { for (size_t i = 0; i < n; i++) fn(i); return; }
+        fn_ = &fn; n_ = n; grain_ = grain; next_.store(0, std::memory_order_relaxed);
+        busy_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn; n_ = n; grain_ = grain; next_.store(0); busy_ = (int)th_.size(); gen_++;
+            if (sleeping_ > 0) cv_.notify_all();
         }
-        cv_.notify_all();
         work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this] { return busy_ == 0; });
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+        while (busy_.load(std::memory_order_acquire) != 0) {
+            if (std::chrono::steady_clock::now() > until) {
+                std::unique_lock<std::mutex> lk(mu_);
+                waiting_ = true;
+                done_.wait(lk, [this] { return busy_.load(std::memory_order_acquire) == 0; });
+                waiting_ = false;
+                break;
+            }
+            relax();
+        }
         fn_ = nullptr;
     }
     int threads() const { return (int)th_.size() + 1; }
 
 private:
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void work()
     {
         for (;;) {
@@ -194,16 +216,24 @@ private:
     {
         uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
+            uint64_t g = gen_.load(std::memory_order_acquire);
+            if (g == seen) { // nothing yet: look for a while, then sleep
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+                while ((g = gen_.load(std::memory_order_acquire)) == seen && std::chrono::steady_clock::now() < until) relax();
+                if (g == seen) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    sleeping_++;
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                    sleeping_--;
+                    g = gen_.load(std::memory_order_acquire);
+                }
             }
+            seen = g;
+            if (stop_) return;
             work();
-            {
+            if (busy_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (--busy_ == 0) done_.notify_one();
+                if (waiting_) done_.notify_one();
             }
         }
     }
@@ -213,9 +243,11 @@ private:
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_ = 0, grain_ = 1;
     std::atomic<size_t> next_{0};
-    int busy_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    std::atomic<int> busy_{0};
+    std::atomic<uint64_t> gen_{0};
+    int sleeping_ = 0;      // (under mu_)
+    bool waiting_ = false;  // (under mu_) the caller sleeps on done_
+    std::atomic<bool> stop_{false};
 };
 
 rawdtw_chain_t record_of(const MChain &c, uint32_t tag)
