@@ -166,3 +166,64 @@ def test_round_arrays_in_device_memory_and_what_the_device_declines():
     ok16 = [np.concatenate(many[:16])]
     compare(lib, copt, ok16, device_round(eng, copt, ok16, n_keys=32))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_the_dtw_batch_straight_from_the_devices_chains_equals_the_batch_from_host_arrays():
+    """rawdtw_chain_round -> rawdtw_batch_submit_device (anchors, ref_base, read_base used where the chaining left them, in device memory) against
+    rawdtw_batch_submit of the same chains from the host copies: every chain's score and keep flag bit for bit -- sparse + banded (the device-planned
+    path) and global + full (the job-list path, which brings the device arrays home first)."""
+    from rawalign_amd import mapper, synth
+
+    ref = synth.make_reference([150_000], seed=31)
+    n = 300
+    seeds = mapper.SyntheticSeeds(ref, n, seed=9, max_chunks=2)
+    eng = ra.Engine(0)
+    lib = eng.lib
+    eng.upload_reference(ref.forward, ref.reverse)
+    copt = M.default_chain_opt(6)
+    # one round: every read's first chunk; the reads' events side by side in the arena
+    evs, per_read, read_base = [], [], np.zeros(n, np.uint32)
+    at = 0
+    for r in range(n):
+        ev, hits = seeds.chunk(r, 0)
+        read_base[r] = at
+        at += len(ev)
+        evs.append(np.asarray(ev, np.float32))
+        s = np.zeros(len(hits), SEED_DTYPE)
+        for k, (sq, st, t, q) in enumerate(hits):
+            s[k] = (sq * 2 + (1 if st else 0), t, q)
+        per_read.append(s)
+    events = np.concatenate(evs)
+    eng.upload_events(events)
+    key_base = np.array([eng.reference_offset(0, 0), eng.reference_offset(0, 1)], np.uint64)
+    seed_off = np.zeros(n + 1, np.uint64)
+    for r, s in enumerate(per_read):
+        seed_off[r + 1] = seed_off[r] + len(s)
+    allseeds = np.concatenate(per_read + [np.zeros(1, SEED_DTYPE)])
+    cap = n * 32
+    chain_off, anchor_off, recs = np.zeros(n + 1, np.uint64), np.zeros(cap + 1, np.uint64), np.zeros(cap, REC_DTYPE)
+    anchors = np.zeros(int(seed_off[-1]) + 1, ANCHOR_DTYPE)
+    d_a, d_rb, d_qb = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert lib.rawdtw_chain_round(eng._ctx, C.byref(copt), n, vp(seed_off), vp(allseeds), vp(read_base), 2, vp(key_base), vp(chain_off), vp(anchor_off), vp(recs), cap,
+                                  vp(anchors), C.byref(d_a), C.byref(d_rb), C.byref(d_qb)) == 0
+    nc = int(chain_off[-1])
+    assert nc > n // 2
+    h_ref_base = key_base[recs["key"][:nc]].astype(np.uint64)
+    h_read_base = np.repeat(read_base, np.diff(chain_off).astype(np.int64)).astype(np.uint32)
+    for opt in (ra.MapOpt(), ra.MapOpt(dtw_border_constraint=0, dtw_fill_method=0)):
+        co = opt.c_struct()
+        out = {}
+        for dev in (1, 0):
+            h = C.c_void_p()
+            if dev:
+                st = lib.rawdtw_batch_submit_device(eng._ctx, C.byref(co), n, vp(chain_off), vp(anchor_off), d_a, d_rb, d_qb, C.byref(h))
+            else:
+                st = lib.rawdtw_batch_submit(eng._ctx, C.byref(co), n, vp(chain_off), vp(anchor_off), vp(anchors), vp(h_ref_base), vp(h_read_base), C.byref(h))
+            assert st == 0, lib.rawdtw_last_error(eng._ctx)
+            score, keep = np.zeros(nc + 1, np.float32), np.zeros(nc + 1, np.uint8)
+            assert lib.rawdtw_batch_fetch_destroy(eng._ctx, h, vp(score), vp(keep)) == 0
+            out[dev] = (score[:nc].copy(), keep[:nc].copy())
+        assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all() and (out[0][1] == out[1][1]).all()
+        assert out[1][1].sum() > 0
+    eng.close()
