@@ -227,3 +227,32 @@ def test_the_dtw_batch_straight_from_the_devices_chains_equals_the_batch_from_ho
         assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all() and (out[0][1] == out[1][1]).all()
         assert out[1][1].sum() > 0
     eng.close()
+
+
+@pytest.mark.gpu
+def test_device_chains_against_the_plain_python_restatement():
+    """The device against the plain-Python restatement of rmap.cpp:430-507 / 130-173 that tests/test_mapping_host.py pins the host function with
+    (test infrastructure, no product code in it): one list a read, so that the running maximum starts at 0 as in py_chain."""
+    from tests.test_mapping_host import f32, py_chain
+
+    rng = np.random.default_rng(21)
+    eng = ra.Engine(0)
+    copt = M.default_chain_opt(6)
+    per_read = [random_read(rng, int(rng.integers(2, 220)), 1, int(rng.integers(300, 6000)), dup=0.1) for _ in range(40)]
+    st, chain_off, anchor_off, recs, anchors, _, _, _ = device_round(eng, copt, per_read)
+    assert st == 0
+    for r, s in enumerate(per_read):
+        a = np.zeros(len(s), ANCHOR_DTYPE)
+        a["target_position"], a["query_position"] = s["target_position"], s["query_position"]
+        a = np.sort(a, order=["target_position", "query_position"])
+        want, _ = py_chain(a)
+        want.sort(key=lambda c: -c[0])  # (stable: the evaluation order of rmap.cpp:512 for fewer than 17 chains)
+        c0, c1 = int(chain_off[r]), int(chain_off[r + 1])
+        assert c1 - c0 == len(want), (r, c1 - c0, len(want))
+        for i, (score, idx) in enumerate(want):
+            rec = recs[c0 + i]
+            assert f32(rec["chaining_score"]) == f32(score) and int(rec["n_anchors"]) == len(idx)
+            got = anchors[int(anchor_off[c0 + i]):int(anchor_off[c0 + i + 1])]
+            assert [int(x) for x in got["target_position"]] == [int(a[k]["target_position"]) for k in idx]
+            assert [int(x) for x in got["query_position"]] == [int(a[k]["query_position"]) for k in idx]
+    eng.close()
