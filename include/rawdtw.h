@@ -348,7 +348,8 @@ int rawdtw_sort_by_chaining_score(const float *chaining_score, uint32_t n_chains
  * The call returns when the host arrays are filled.  Results equal rawdtw_chain_anchors list by list and
  * rawdtw_sort_by_chaining_score read by read, bit for bit.  RAWDTW_ERR_UNSUPPORTED (the out arrays hold nothing of use): a read with more than
  * 2 048 seeds, with more than 32 chains, or with more than 16 chains two of which have equal scores (std::sort's order of
- * equal elements is an insertion sort's only up to 16) -- chain that round on the host. */
+ * equal elements is an insertion sort's only up to 16) -- chain that round on the host.  RAWDTW_ERR_INVALID: a chain on a key
+ * that is not below n_keys. */
 typedef struct { uint32_t key, target_position, query_position; } rawdtw_seed_t;                       /* 12 bytes */
 typedef struct { float chaining_score; uint32_t key, start_position, end_position, n_anchors; } rawdtw_chain_rec_t; /* 20 bytes */
 int rawdtw_chain_round(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uint64_t n_reads, const uint64_t *seed_off,

@@ -55,15 +55,6 @@ __device__ __forceinline__ void lds_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ int dpp_i(const int ident, const int x, const int ctrl, const int rowmask)
-{
-    return ctrl == 0x111 ? __builtin_amdgcn_update_dpp(ident, x, 0x111, 0xf, 0xf, false)
-         : ctrl == 0x112 ? __builtin_amdgcn_update_dpp(ident, x, 0x112, 0xf, 0xf, false)
-         : ctrl == 0x114 ? __builtin_amdgcn_update_dpp(ident, x, 0x114, 0xf, 0xf, false)
-         : ctrl == 0x118 ? __builtin_amdgcn_update_dpp(ident, x, 0x118, 0xf, 0xf, false)
-         : ctrl == 0x142 ? __builtin_amdgcn_update_dpp(ident, x, 0x142, 0xa, 0xf, false)
-                         : __builtin_amdgcn_update_dpp(ident, x, 0x143, 0xc, 0xf, false);
-}
 // inclusive scans over the wave in lane order (rows of 16 by row_shr, then the rows' last lanes into the rows behind them)
 __device__ __forceinline__ int scan_add(int x)
 {
@@ -265,14 +256,14 @@ __global__ __launch_bounds__(1024) void k_chain_scan(const ChainCnt *__restrict_
     }
     uint64_t bc = s_c[t] - c, ba = s_a[t] - x;
     for (uint32_t r = lo; r < hi; r++) { chain_off[r] = bc; read_anchor0[r] = ba; bc += min(cnt[r].nc, kChainCap); ba += cnt[r].na; }
-    if (t == 1023) { chain_off[n_reads] = s_c[t]; totals[0] = s_c[t]; totals[1] = s_a[t]; totals[2] = s_f[t]; }
+    if (t == 1023) { chain_off[n_reads] = s_c[t]; totals[0] = s_c[t]; totals[1] = s_a[t]; totals[2] = s_f[t]; totals[3] = 0; }
 }
 
 // a wave a read: its chains, in evaluation order, into the batch's arrays
 __global__ __launch_bounds__(64) void k_chain_compact(const ChainArgs a, const uint64_t *__restrict__ chain_off, const uint64_t *__restrict__ read_anchor0,
                                                       const uint32_t *__restrict__ read_base, const uint64_t *__restrict__ key_base, const uint32_t n_keys,
                                                       uint64_t *__restrict__ anchor_off, rawdtw_anchor_t *__restrict__ anchors, uint64_t *__restrict__ ref_base,
-                                                      uint32_t *__restrict__ read_base_c, rawdtw_chain_rec_t *__restrict__ recs, const uint64_t *__restrict__ totals,
+                                                      uint32_t *__restrict__ read_base_c, rawdtw_chain_rec_t *__restrict__ recs, uint64_t *__restrict__ totals,
                                                       // the caller's page-locked host arrays, written from here (null: they are copied afterwards)
                                                       uint64_t *__restrict__ h_anchor_off, rawdtw_chain_rec_t *__restrict__ h_recs, rawdtw_anchor_t *__restrict__ h_anchors,
                                                       const uint64_t h_chains_cap)
@@ -293,6 +284,7 @@ __global__ __launch_bounds__(64) void k_chain_compact(const ChainArgs a, const u
             const rawdtw_chain_rec_t out{rec.score, rec.key, rec.start, rec.end, rec.n};
             anchor_off[c0 + i] = dst;
             ref_base[c0 + i] = rec.key < n_keys ? key_base[rec.key] : 0ull;
+            if (rec.key >= n_keys) atomicOr(reinterpret_cast<unsigned long long *>(totals + 3), 1ull); // (a seed on a key the caller gave no base for)
             read_base_c[c0 + i] = read_base[r];
             recs[c0 + i] = out;
             if (host) { h_anchor_off[c0 + i] = dst; h_recs[c0 + i] = out; }
@@ -405,7 +397,7 @@ int rawdtw_chain_round_begin(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uin
                        direct ? anchor_off : nullptr, direct ? recs : nullptr, direct ? anchors : nullptr, chains_cap);
     HIP_TRY(ctx, hipGetLastError());
     uint64_t *h_tot = static_cast<uint64_t *>(w.pin);
-    HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(chain_off, d_coff, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
     w.pending = true; w.direct = direct; w.n_reads = n_reads; w.chains_cap = chains_cap;
     w.h_anchor_off = anchor_off; w.h_recs = recs; w.h_anchors = anchors;
@@ -425,6 +417,7 @@ int rawdtw_chain_round_end(rawdtw_ctx *ctx, const rawdtw_anchor_t **d_anchors, c
     HIP_TRY(ctx, hipStreamSynchronize(s));
     const uint64_t *h_tot = static_cast<const uint64_t *>(w.pin);
     const uint64_t nc = h_tot[0], na = h_tot[1], flags = h_tot[2];
+    if (h_tot[3]) return fail(ctx, RAWDTW_ERR_INVALID, "a seed's key is not below n_keys");
     if (flags) return fail(ctx, RAWDTW_ERR_UNSUPPORTED, flags & 4 ? "a read with more than 16 chains, two of them with equal scores: chain this round on the host"
                                                                : "a read with more than 32 chains (or more seeds than the device chains): chain this round on the host");
     if (nc > w.chains_cap) return fail(ctx, RAWDTW_ERR_RANGE, "chain output arrays too small");

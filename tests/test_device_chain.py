@@ -162,6 +162,9 @@ def test_round_arrays_in_device_memory_and_what_the_device_declines():
     tied = [np.concatenate(many)]
     st = device_round(eng, copt, tied, n_keys=32)[0]
     assert st != 0
+    # a seed on a key the caller gave no base for: refused (4 keys declared, a chain on key 5)
+    bad = [many[5].copy()]
+    assert device_round(eng, copt, bad, n_keys=4)[0] == 1  # RAWDTW_ERR_INVALID
     # 16 such lists are within what an insertion sort orders: the same order as the host's
     ok16 = [np.concatenate(many[:16])]
     compare(lib, copt, ok16, device_round(eng, copt, ok16, n_keys=32))
