@@ -348,6 +348,9 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     first, nch = sc["chunk_first"], sc["n_chunks"]
     ev_off, hit_off = sc["ev_off"].astype(np.int64), sc["hit_off"].astype(np.int64)
 
+    pins = Pinned(lib)
+    ev_pin = pins.empty(int(np.diff(ev_off).max()) * n_reads + 1, np.float32)  # (a round's events: at most one chunk a read)
+
     def run(cm, reads, label, warm=True):
         # the same reads twice untimed on the same mapper (its pinned buffers, the contexts' workspaces and the allocator's arenas reach their
         # sizes: the second pass over a fresh mapper still read 1.5 x the third), then released
@@ -369,7 +372,11 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
             ho = np.concatenate([[0], np.cumsum(hcnt)]).astype(np.uint64)
             eidx = np.repeat(ev_off[ci], ecnt) + (np.arange(int(eo[-1])) - np.repeat(eo[:-1].astype(np.int64), ecnt))
             hidx = np.repeat(hit_off[ci], hcnt) + (np.arange(int(ho[-1])) - np.repeat(ho[:-1].astype(np.int64), hcnt))
-            ev = np.ascontiguousarray(sc["events"][eidx]) if len(eidx) else np.zeros(1, np.float32)
+            if len(eidx):  # the round's events in page-locked memory, as a host that allocates its event buffers with rawdtw_host_alloc has them
+                ev = ev_pin[:len(eidx)]
+                np.take(sc["events"], eidx, out=ev)
+            else:
+                ev = np.zeros(1, np.float32)
             hits = np.ascontiguousarray(sc["hits"][hidx]) if len(hidx) else np.zeros(1, sc["hits"].dtype)
             rid = np.ascontiguousarray(ids[sel])
             t0 = time.perf_counter()
@@ -400,7 +407,8 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     all_reads = np.arange(n_reads)
     never = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
     out = {"workload": WORKLOAD + ", synthetic seed hits (hit probability 0.2 per event, 25 false hits a chunk), chunks of 520 events",
-           "reads": n_reads, "host_threads": threads, "runs": [], "all_chunks": []}
+           "reads": n_reads, "host_threads": threads, "runs": [], "all_chunks": [],
+           "events_are": "handed to rawdtw_mapper_round in page-locked memory (rawdtw_host_alloc): with the chaining on the device and one read group they go to the device as they are"}
 
     def device_run(stop, carry, groups, label, thr=threads, dev_chain=False):
         eng = ra.Engine(local_rank)
@@ -472,6 +480,7 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     for r in out["runs"] + out["all_chunks"]:
         if len(r["per_round"]) > 8:
             r["per_round"] = r["per_round"][:8] + [{"more": len(r["per_round"]) - 8}]
+    pins.free()
     return out
 
 

@@ -145,6 +145,8 @@ int rawdtw_events_append(rawdtw_ctx *ctx, const float *h_new, uint64_t n_new, ui
  * arrays of rawdtw_batch_fetch.  Any host memory works; with pinned memory the copies do not block the caller. */
 int rawdtw_host_alloc(uint64_t bytes, void **out);
 int rawdtw_host_free(void *p);
+/* 1 when p points into page-locked host memory (rawdtw_host_alloc's, or any the HIP runtime knows), else 0 */
+int rawdtw_host_is_page_locked(const void *p);
 
 /* ---- score-only batches: replaces the calls at rmap.cpp:211,215,273,277 ---- */
 /* One shot: upload events, bin + launch, copy costs back (out_cost[k] for jobs[k]). */
@@ -594,6 +596,8 @@ int rawdtw_mapper_release_read(rawdtw_mapper *m, uint32_t read_id);
  * were (a failed round can be repeated). */
 int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read_ids, const uint64_t *event_off,
                         const float *events, const uint64_t *hit_off, const rawdtw_seed_hit_t *hits);
+/* (With device_chain and one read group a page-locked `events` array -- rawdtw_host_alloc -- goes to the device as it is, without a
+ * copy into the mapper's own staging.) */
 int rawdtw_mapper_read_state(const rawdtw_mapper *m, uint32_t read_id, int *finished, uint32_t *chunks_done);
 int rawdtw_mapper_finish(rawdtw_mapper *m);
 /* *len = the line's length; RAWDTW_ERR_RANGE when buf (cap bytes) is too small for it and its terminator */

@@ -140,6 +140,7 @@ SYMBOLS = {
     "rawdtw_events_append": (I32, [VP, VP, U64, U32, VP, VP]),
     "rawdtw_host_alloc": (I32, [U64, C.POINTER(VP)]),
     "rawdtw_host_free": (I32, [VP]),
+    "rawdtw_host_is_page_locked": (I32, [VP]),
     "rawdtw_score_batch": (I32, [VP, VP, U64, VP, U64, VP]),
     "rawdtw_plan_create": (I32, [VP, VP, U64, C.POINTER(VP)]),
     "rawdtw_plan_info": (I32, [VP, C.POINTER(PlanInfo)]),

@@ -292,6 +292,14 @@ int rawdtw_host_alloc(uint64_t bytes, void **out)
     return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? RAWDTW_OK : RAWDTW_ERR_OOM;
 }
 
+int rawdtw_host_is_page_locked(const void *p)
+{
+    if (!p) return 0;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return at.type == hipMemoryTypeHost ? 1 : 0;
+}
+
 int rawdtw_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);

@@ -626,6 +626,9 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
     // -- the events are in place on both sides, the round is chained on the host.
     struct DevRound { bool pending = false; uint64_t ns = 0, nev = 0, nseg = 0; };
     std::vector<DevRound> dev(G);
+    // the caller's event array goes to the device as it is when it is page-locked (rawdtw_host_alloc) and one read group takes the whole round:
+    // its reads' chunks ARE the segments, in order -- no copy into the mapper's own staging (a third of the host phase)
+    const bool events_in_place = on_device && m->opt.device_chain && G == 1 && event_off[n_reads] > 0 && rawdtw_host_is_page_locked(events) == 1;
     auto device_begin = [&](const uint32_t gi) -> bool {
         Group &g = m->groups[gi];
         RoundArrays &ra = g.buf[g.cur];
@@ -650,9 +653,12 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                 ok = ok && x->seed_off.ensure(g.hw_reads + 1, true) && x->seeds.ensure(g.hw_seeds + 1, true) && x->read_base.ensure(std::max(g.hw_reads, g.hw_chains) + 1, true) &&
                      x->chain_off.ensure(g.hw_reads + 1, true) && x->anchor_off.ensure(g.hw_chains + 1, true) && x->recs.ensure(g.hw_chains + 1, true) &&
                      x->anchors.ensure(g.hw_seeds + 1, true) && x->score.ensure(g.hw_chains + 1, true) && x->keep.ensure(g.hw_chains + 1, true) &&
-                     x->new_events.ensure(g.hw_events + 1, true) && x->seg_src.ensure(g.hw_seg + 2, true) && x->seg_dst.ensure(g.hw_seg + 1, true);
+                     x->new_events.ensure((events_in_place ? 0 : g.hw_events) + 1, true) && x->seg_src.ensure(g.hw_seg + 2, true) &&
+                     x->seg_dst.ensure(std::max(g.hw_seg, g.hw_reads) + 1, true);
             if (!ok) { set_fail(RAWDTW_ERR_OOM, "host allocation failed"); return true; }
-            {
+            if (events_in_place) { // (every read a segment, empty ones too: event_off itself is the table of sources)
+                for (size_t i = 0; i < nr; i++) ra.seg_dst[i] = m->reads[read_ids[ra.ks[i]]].slot * m->opt.slot_events + rr[ra.ks[i]].ev_before;
+            } else {
                 uint64_t sg = 0, at = 0;
                 for (size_t i = 0; i < nr; i++) {
                     const RoundRead &r = rr[ra.ks[i]];
@@ -680,12 +686,13 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
                     for (uint64_t h = hit_off[k]; h < hit_off[k + 1]; h++) // rmap.cpp:371-391
                         *out++ = rawdtw_seed_t{hits[h].ref_seq * 2u + (uint32_t)(hits[h].strand ? 1 : 0), hits[h].target_position, hits[h].query_position + r.chunk_start};
                 }
-                if (r.ne) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
+                if (r.ne && !events_in_place) memcpy(ra.new_events.p + r.ev0, events + event_off[k], r.ne * sizeof(float));
             });
             double td = now_ms();
             m->timing[0] += td - t0; t0 = td;
             int st = RAWDTW_OK;
-            if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
+            if (nseg && events_in_place) st = rawdtw_events_append(g.ctx, events, event_off[n_reads], (uint32_t)nr, event_off, ra.seg_dst.p);
+            else if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
             if (st == RAWDTW_OK)
                 st = rawdtw_chain_round_begin(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(),
                                               ra.chain_off.p, ra.anchor_off.p, ra.recs.p, g.hw_chains, ra.anchors.p);

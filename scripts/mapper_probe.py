@@ -33,6 +33,22 @@ ev_off, hit_off = sc["ev_off"].astype(np.int64), sc["hit_off"].astype(np.int64)
 never = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
 
 
+import ctypes as C  # noqa: E402
+
+
+
+def pinned(n, dtype):
+    from rawalign_amd._lib import load_library
+    lib = load_library()
+    p = C.c_void_p()
+    nbytes = max(int(n) * np.dtype(dtype).itemsize, 8)
+    assert lib.rawdtw_host_alloc(nbytes, C.byref(p)) == 0
+    return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype, count=int(n))
+
+
+ev_pin = pinned(int(np.diff(ev_off).max()) * n_reads + 1, np.float32) if os.environ.get("PROBE_PAGEABLE_EVENTS") is None else None
+
+
 def one_pass(cm, reads):
     ids = np.array([cm.add_read("read_%d" % r, int(sc["qlen"][r]), int(nch[r])) for r in reads], np.uint32)
     done = np.zeros(len(reads), np.int64)
@@ -46,7 +62,11 @@ def one_pass(cm, reads):
         ho = np.concatenate([[0], np.cumsum(hcnt)]).astype(np.uint64)
         eidx = np.repeat(ev_off[ci], ecnt) + (np.arange(int(eo[-1])) - np.repeat(eo[:-1].astype(np.int64), ecnt))
         hidx = np.repeat(hit_off[ci], hcnt) + (np.arange(int(ho[-1])) - np.repeat(ho[:-1].astype(np.int64), hcnt))
-        ev = np.ascontiguousarray(sc["events"][eidx]) if len(eidx) else np.zeros(1, np.float32)
+        if len(eidx) and ev_pin is not None:  # (page-locked, as a host that allocates its event buffers with rawdtw_host_alloc has them)
+            ev = ev_pin[:len(eidx)]
+            np.take(sc["events"], eidx, out=ev)
+        else:
+            ev = np.ascontiguousarray(sc["events"][eidx]) if len(eidx) else np.zeros(1, np.float32)
         hits = np.ascontiguousarray(sc["hits"][hidx]) if len(hidx) else np.zeros(1, sc["hits"].dtype)
         tm0 = cm.timing()
         t0 = time.perf_counter()
