@@ -1254,9 +1254,18 @@ __device__ __forceinline__ void wband_gen(const DevJob &jb, const int lane, cons
             return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
         };
         const int Hp = SH + P;
-        wm.sec_lo = lanes_below(S / C); wm.sec_hi = lanes_below(S / C + 1); wm.sec_c0 = (uint32_t)(S % C);
-        wm.prim_lo = lanes_below(Hp / C); wm.prim_hi = lanes_below(Hp / C + 1); wm.prim_c0 = (uint32_t)(Hp % C);
-        wm.prim_0 = lanes_below(0 < Hp % C ? Hp / C + 1 : Hp / C) & (SH ? ~1ull : ~0ull); // (the primaries start at slot SH)
+        if constexpr (C >= 3) {
+            // the hand-scheduled loop forces ONE slot an antidiagonal -- the one right behind its extent (slot S, slot SH + P): register
+            // (slot % C) on every lane but (slot / C) -- and, for primaries that start at slot 1, slot 0 (rawdtw_wband_asm.h: force)
+            auto all_but = [&](const int l) { return ~(lanes_below(l + 1) & ~lanes_below(l)); }; // (l >= 64: every lane)
+            wm.sec_lo = 0; wm.sec_hi = all_but(S / C); wm.sec_c0 = (uint32_t)(S % C);
+            wm.prim_lo = 0; wm.prim_hi = all_but(Hp / C); wm.prim_c0 = (uint32_t)(Hp % C);
+            wm.prim_0 = lanes_below(64) & (SH ? ~1ull : ~0ull);
+        } else {
+            wm.sec_lo = lanes_below(S / C); wm.sec_hi = lanes_below(S / C + 1); wm.sec_c0 = (uint32_t)(S % C);
+            wm.prim_lo = lanes_below(Hp / C); wm.prim_hi = lanes_below(Hp / C + 1); wm.prim_c0 = (uint32_t)(Hp % C);
+            wm.prim_0 = lanes_below(0 < Hp % C ? Hp / C + 1 : Hp / C) & (SH ? ~1ull : ~0ull); // (the primaries start at slot SH)
+        }
         wm.prim_0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wm.prim_0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wm.prim_0);
     }
     int row = 0;

@@ -39,6 +39,7 @@ def gen(C):
     Cp = C + (C & 1)                      # registers a set: 64-bit operands (ds_read2, v_pk_add) want even-aligned pairs
     wide = C >= 4 and C % 4 == 0 and os.environ.get("WBAND_B128", "1") == "1"   # 16-byte reads at any 4-byte boundary (the LDS runs in unaligned mode)
     npair, odd = C // 2, C & 1
+    edge = C >= 3   # only the slot behind an extent is forced to 1e10 (through the VGPR index), not every register: see force()
     nd = (C // 4) if wide else (1 if C == 1 else npair + odd)          # ds_read instructions per window
     P = [[VBASE + s * Cp + c for c in range(C)] for s in range(3)]          # a-window register sets
     B = [[VBASE + 3 * Cp + s * Cp + c for c in range(C)] for s in range(2)]  # b-window register sets
@@ -94,7 +95,7 @@ def gen(C):
     e = main.append
     # ---- prologue: the masks, constants, the DP state, the windows of the first column ----
     e("s_waitcnt lgkmcnt(0)")  # (nothing else of this wave's may be counted by the waits below)
-    for c in range(C):
+    for c in range(C if not edge else 0):
         e(f"s_cmp_lt_u32 {c}, {op['s_c0']}")
         e(f"s_cselect_b64 {sm(MS[c])}, {op['s_hi']}, {op['s_lo']}")
         if c == 0:
@@ -102,6 +103,26 @@ def gen(C):
         else:
             e(f"s_cmp_lt_u32 {c}, {op['p_c0']}")
             e(f"s_cselect_b64 {sm(MP[c])}, {op['p_hi']}, {op['p_lo']}")
+
+    def force(e, regs, kind):
+        """an antidiagonal's cells outside its extent read as 1e10.  C <= 2: every register is selected on its lanes' mask.  C >= 3: a slot outside
+        the extent is read by a slot inside only if it is the one right behind it (a cell's neighbours are its own slot and the slots next to it)
+        or, for the primaries that start at slot 1, slot 0 -- so ONE select, on the register that holds that slot (s_c0 / p_c0: picked through the
+        VGPR index, the mask s_hi / p_hi has every lane but the slot's), and for the primaries one more on register 0 (p_0); what lies further
+        out is never read from inside and may hold anything finite."""
+        if not edge:
+            masks = MS if kind == "s" else MP
+            order = reversed(range(C)) if kind != "tail" else range(C)
+            for c in order:
+                e(f"v_cndmask_b32_e64 {regs[c]}, {v(VINF)}, {regs[c]}, {sm(masks[c])}")
+            return
+        idx, mask = (op["s_c0"], op["s_hi"]) if kind == "s" else (op["p_c0"], op["p_hi"])
+        e(f"s_set_gpr_idx_on {idx}, 0xa")   # dst and src1 relative
+        e("s_nop 0")
+        e(f"v_cndmask_b32_e64 {regs[0]}, {v(VINF)}, {regs[0]}, {mask}")
+        e("s_set_gpr_idx_off")
+        if kind != "s":
+            e(f"v_cndmask_b32_e64 {regs[0]}, {v(VINF)}, {regs[0]}, {op['p_0']}")
     e(f"v_mov_b32 {v(VINF)}, 0x501502f9")
     e(f"v_mov_b32 {v(KHI)}, {v(VINF)}")
     e(f"v_mov_b32 {v(KLO)}, {v(VINF)}")
@@ -135,8 +156,7 @@ def gen(C):
             e(f"v_min3_f32 {d0[c]}, {d1[c]}, {left}, {d0[c]}")
         for c in range(C):
             e(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
-        for c in reversed(range(C)):  # (the last slot first: the shift below reads it)
-            e(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {sm(MS[c])}")
+        force(e, d0, "s")  # (C <= 2: the last slot first -- the shift below reads it)
         diffs(e, pc, bc)
         if C == 1:
             e("s_nop 0")  # (two wait states between the select that wrote d0[C-1] and the DPP that reads it: the subtraction is one)
@@ -146,8 +166,7 @@ def gen(C):
             e(f"v_min3_f32 {d1[c]}, {top}, {d0[c]}, {d1[c]}")
         for c in range(C):
             e(f"v_add_f32 {d1[c]}, |{v(DIFF[c])}|, {d1[c]}")
-        for c in reversed(range(C)):
-            e(f"v_cndmask_b32_e64 {d1[c]}, {v(VINF)}, {d1[c]}, {sm(MP[c])}")
+        force(e, d1, "p")
         e(f"3{kcol}:")
         # ---- a column without (behind the loop): X = d1; the primary (X[p-1], X[p], d0[p-1]) into d0, then d0 <-> d1 ----
         T = tail.append
@@ -161,8 +180,7 @@ def gen(C):
             T(f"v_min3_f32 {d0[c]}, {top}, {d1[c]}, {tl}")
         for c in range(C):
             T(f"v_add_f32 {d0[c]}, |{v(DIFF[c])}|, {d0[c]}")
-        for c in range(C):
-            T(f"v_cndmask_b32_e64 {d0[c]}, {v(VINF)}, {d0[c]}, {sm(MP[c])}")
+        force(T, d0, "tail")
         for c in range(C):
             T(f"v_swap_b32 {d0[c]}, {d1[c]}")
         T(f"s_branch 3{kcol}b")
