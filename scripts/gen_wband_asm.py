@@ -24,6 +24,7 @@ The DP state (d0, d1: 2 C floats a lane) enters and leaves through the wave's pi
 thirty operands -- and the extent masks of the 2 C slot registers are made inside from three lane masks a kind: with the
 blocked layout (lane l holds slots l C .. l C + C - 1) a register's lanes inside an extent [lo, hi) are `lanes <= hi / C` for
 the registers below hi % C and `lanes < hi / C` for the others (and the primaries' lo = 1 takes lane 0 out of register 0).
+From three registers a lane on, only the slot right behind an extent is forced to 1e10 -- one select through the VGPR index (`force`).
 
 Cells, neighbours and masks are those of wband_step<C, false> / wreg_gen_step (dtw.cpp:361-485): bit-identical costs
 (tests/test_gpu_parity.py::test_random_wave_band, tests/test_stream_path.py: the wave-per-job bands at the register layouts'
@@ -238,6 +239,8 @@ def main():
            "#pragma once", "namespace rawdtw {", "",
            "// the extents of a band's antidiagonals as lane masks of the blocked layout (lane l holds slots l C .. l C + C - 1): register c's lanes",
            "// inside the secondaries' [0, S) are sec_hi for c < sec_c0 and sec_lo otherwise; the primaries' [SH, SH + P) likewise, register 0 apart",
+           "// (C >= 3: sec_hi / prim_hi = every lane but the one of the slot right behind the extent, sec_c0 / prim_c0 = that slot's register, prim_0 =",
+           "// every lane but lane 0 when the primaries start at slot 1: gen_wband_asm.py, force)",
            "struct WbandMasks { unsigned long long sec_lo, sec_hi, prim_lo, prim_hi, prim_0; uint32_t sec_c0, prim_c0; };",
            "template <int C> __device__ __forceinline__ void wband_loop_asm(uint32_t &va, uint32_t &vb, const uint32_t vstate, uint32_t &rem, uint32_t iters,",
            "                                                              const uint32_t M, const uint32_t N, const WbandMasks &m);", ""]
