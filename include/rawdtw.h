@@ -608,7 +608,10 @@ int rawdtw_mapper_stats(const rawdtw_mapper *m, uint64_t *rounds, uint64_t *part
 /* where a round's time went, accumulated over the mapper's rounds, in milliseconds of host wall time: 0 the per-read host
  * phase (events, re-seeding, sort, chaining, evaluation order, carry matching), 1 laying the round's arrays out, 2 the
  * submissions (enqueue only), 3 waiting for the device in fetch, 4 the round's end per read (primary chains, MAPQ, stop
- * rule); 5 bytes handed to the device for anchor lists, 6 for events, 7 for everything else (offsets, bases, carry records) */
+ * rule); 5 bytes handed to the device for anchor lists, 6 for events, 7 for everything else (offsets, bases, carry records).
+ * With device_chain: 0 = the events and the seed lists (the checks and the round's set-up count here too), 1 = the round's
+ * chains per read out of the arrays the device wrote, 2 = the submissions and the wait for the device's sort + DP, 5 = 0 (no
+ * anchor list goes up), 7 includes the seed lists. */
 int rawdtw_mapper_timing(const rawdtw_mapper *m, double out[8]);
 /* Harness hook: score a round's chains with `fn` instead of on the device -- for timing or checking the SAME control flow
  * with another DTW implementation (bench.py's cpu_baseline, the CPU-only tests).  fn receives the round's chains read by
