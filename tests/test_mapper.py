@@ -288,3 +288,28 @@ def test_a_round_the_device_declines_to_chain_is_chained_on_the_host(oracle, mon
         eng.close()
     assert out[0][0] == out[1][0]
     assert 0 < out[1][1] <= out[0][1]  # the declined rounds' anchors went up from the host
+
+
+@pytest.mark.gpu
+def test_multi_genome_index_with_the_chaining_on_the_device(oracle):
+    """configs[4]'s shape -- a multi-genome index: seven sequences, fourteen (sequence, strand) lists a read can have seeds on -- through the library's
+    mapper with the chaining on the host and on the device: the same lines, equal to the oracle-scored Python flow's, and the same abundance stop."""
+    from rawalign_amd.mapping import StopOpt
+
+    ref = synth.make_reference([20000, 35000, 12000, 8000, 26000, 15000, 30000], seed=20231005 + 9)
+    n = 150
+    seeds = mapper.SyntheticSeeds(ref, n, seed=13, max_chunks=4)
+    names, lens = [f"seq{s}" for s in range(ref.n_seq)], [len(x) for x in ref.forward]
+    slot = max(rd["n_ev"] for rd in seeds.reads) + 8
+    want, _ = mapper.map_reads(seeds, list(range(n)), OracleScorer(oracle, ref), ra.MapOpt(), StopOpt())
+    out = {}
+    for dev, groups in ((0, 1), (1, 1), (1, 2)):
+        eng = ra.Engine(0)
+        eng.upload_reference(ref.forward, ref.reverse)
+        cm = mapper.CMapper(eng, ra.MapOpt(), StopOpt(), names, lens, slot_events=slot, max_reads=n, carry=False, threads=4, groups=groups, device_chain=bool(dev))
+        out[(dev, groups)], _ = mapper.map_reads_c(seeds, list(range(n)), cm)
+        cm.close()
+        eng.close()
+    assert out[(0, 1)] == want and out[(1, 1)] == want and out[(1, 2)] == want
+    stop, est = _abundance_stop(want, ref.n_seq)
+    assert stop > 0 and est.sum() > 0
