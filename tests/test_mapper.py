@@ -313,3 +313,45 @@ def test_multi_genome_index_with_the_chaining_on_the_device(oracle):
     assert out[(0, 1)] == want and out[(1, 1)] == want and out[(1, 2)] == want
     stop, est = _abundance_stop(want, ref.n_seq)
     assert stop > 0 and est.sum() > 0
+
+
+@pytest.mark.gpu
+def test_a_round_declined_after_the_device_chained_it_is_chained_on_the_host(oracle):
+    """A read whose seeds make twenty equal chains on twenty (sequence, strand) lists: more than sixteen chains with equal scores is an order only
+    std::sort knows (rawdtw_chain_round reports it when the round is ENDED, after the device has chained it) -- the mapper chains that round on
+    the host and writes the lines of the host-chained mapper; the other reads of the round and the rounds behind it are not disturbed."""
+    from rawalign_amd.mapping import StopOpt
+
+    ref = synth.make_reference([9000] * 10, seed=99)
+    rng = np.random.default_rng(5)
+    names, lens = [f"seq{s}" for s in range(ref.n_seq)], [len(x) for x in ref.forward]
+    n, n_chunks = 12, 3
+    stop = StopOpt(min_bestmap_ratio=1e9, min_meanmap_ratio=1e9, min_chain_anchor=10 ** 6)
+    chunks = {}
+    for r in range(n):
+        for c in range(n_chunks):
+            ev = rng.normal(size=300).astype(np.float32)
+            hits = []
+            if r == 3 and c == 1:   # the same little diagonal on every list
+                for s in range(10):
+                    for st in (0, 1):
+                        hits += [(s, st, 1000 + 11 * k, 20 + 10 * k) for k in range(6)]
+            else:
+                s, st, t0 = int(rng.integers(0, 10)), int(rng.integers(0, 2)), int(rng.integers(500, 7000))
+                hits = [(s, st, t0 + 12 * k + int(rng.integers(0, 3)), 10 + 11 * k) for k in range(20)]
+                hits += [(int(rng.integers(0, 10)), int(rng.integers(0, 2)), int(rng.integers(0, 8000)), int(rng.integers(0, 300))) for _ in range(10)]
+            chunks[(r, c)] = (ev, hits)
+    out = {}
+    for dev in (0, 1):
+        eng = ra.Engine(0)
+        eng.upload_reference(ref.forward, ref.reverse)
+        cm = mapper.CMapper(eng, ra.MapOpt(flag=0x2 | 0x8), stop, names, lens, slot_events=1000, max_reads=n, carry=False, threads=3, groups=2, device_chain=bool(dev))
+        ids = [cm.add_read("read_%d" % r, 4000 * n_chunks, n_chunks) for r in range(n)]
+        for c in range(n_chunks):
+            cm.round(ids, [chunks[(r, c)] for r in range(n)])
+        assert cm.finish() == 0
+        out[dev] = ([cm.paf(i) for i in ids], cm.log(), cm.timing()["anchor_bytes"])
+        cm.close()
+        eng.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert 0 < out[1][2] < out[0][2]  # one round (of one group) went up as anchor lists from the host, the others did not
