@@ -298,6 +298,7 @@ struct ChainWs {
     void *dev = nullptr;
     size_t dev_bytes = 0;
     void *pin = nullptr; // totals
+    hipEvent_t done = nullptr; // behind a round's last copy: what rawdtw_chain_round_end waits for (not for what the caller enqueued behind the round)
     // a round begun and not ended
     bool pending = false, direct = false;
     uint64_t n_reads = 0, chains_cap = 0;
@@ -399,6 +400,8 @@ int rawdtw_chain_round_begin(rawdtw_ctx *ctx, const rawdtw_chain_opt_t *opt, uin
     uint64_t *h_tot = static_cast<uint64_t *>(w.pin);
     HIP_TRY(ctx, hipMemcpyAsync(h_tot, d_tot, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(chain_off, d_coff, (n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (!w.done) HIP_TRY(ctx, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(w.done, s));
     w.pending = true; w.direct = direct; w.n_reads = n_reads; w.chains_cap = chains_cap;
     w.h_anchor_off = anchor_off; w.h_recs = recs; w.h_anchors = anchors;
     w.d_aoff = d_aoff; w.d_recs = d_recs; w.d_anch = d_anch; w.d_refb = d_refb; w.d_rbc = d_rbc;
@@ -414,7 +417,7 @@ int rawdtw_chain_round_end(rawdtw_ctx *ctx, const rawdtw_anchor_t **d_anchors, c
     w.pending = false;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipEventSynchronize(w.done)); // (the round's own work: what was enqueued behind it -- the caller's next uploads -- goes on)
     const uint64_t *h_tot = static_cast<const uint64_t *>(w.pin);
     const uint64_t nc = h_tot[0], na = h_tot[1], flags = h_tot[2];
     if (h_tot[3]) return fail(ctx, RAWDTW_ERR_INVALID, "a seed's key is not below n_keys");
@@ -449,6 +452,7 @@ void chain_ws_free(rawdtw_ctx *ctx)
     if (!ctx || !ctx->chain_ws) return;
     if (ctx->chain_ws->w.dev) (void)hipFree(ctx->chain_ws->w.dev);
     if (ctx->chain_ws->w.pin) (void)hipHostFree(ctx->chain_ws->w.pin);
+    if (ctx->chain_ws->w.done) (void)hipEventDestroy(ctx->chain_ws->w.done);
     delete ctx->chain_ws;
     ctx->chain_ws = nullptr;
 }

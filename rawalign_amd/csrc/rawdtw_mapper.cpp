@@ -690,15 +690,23 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             });
             double td = now_ms();
             m->timing[0] += td - t0; t0 = td;
-            int st = RAWDTW_OK;
-            if (nseg && events_in_place) st = rawdtw_events_append(g.ctx, events, event_off[n_reads], (uint32_t)nr, event_off, ra.seg_dst.p);
-            else if (nseg) st = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
-            if (st == RAWDTW_OK)
-                st = rawdtw_chain_round_begin(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(),
+            // the chaining first, the events behind it: the sort + DP does not read them, and rawdtw_chain_round_end waits for the round's own work only
+            // -- the events' upload (the round's largest) runs on while the host goes on
+            int st = rawdtw_chain_round_begin(g.ctx, &m->opt.chain, nr, ra.seed_off.p, ra.seeds.p, ra.read_base.p, (uint32_t)m->ref_off.size(), m->ref_off.data(),
                                               ra.chain_off.p, ra.anchor_off.p, ra.recs.p, g.hw_chains, ra.anchors.p);
+            const bool declined = st == RAWDTW_ERR_UNSUPPORTED;
+            if (st == RAWDTW_OK || declined) {
+                int se = RAWDTW_OK;
+                if (nseg && events_in_place) se = rawdtw_events_append(g.ctx, events, event_off[n_reads], (uint32_t)nr, event_off, ra.seg_dst.p);
+                else if (nseg) se = rawdtw_events_append(g.ctx, ra.new_events.p, nev, (uint32_t)nseg, ra.seg_src.p, ra.seg_dst.p);
+                if (se != RAWDTW_OK) {
+                    if (st == RAWDTW_OK) { const rawdtw_anchor_t *x = nullptr; const uint64_t *y = nullptr; const uint32_t *z = nullptr; (void)rawdtw_chain_round_end(g.ctx, &x, &y, &z); }
+                    st = se;
+                }
+            }
             td = now_ms();
             m->timing[2] += td - t0; t0 = td;
-            if (st == RAWDTW_ERR_UNSUPPORTED) return false;
+            if (declined && st == RAWDTW_ERR_UNSUPPORTED) return false;
             if (st != RAWDTW_OK) { set_fail(st, rawdtw_last_error(g.ctx)); return true; }
             dev[gi].pending = true; dev[gi].ns = ns; dev[gi].nev = nev; dev[gi].nseg = nseg;
             return true;
