@@ -302,11 +302,13 @@ std::vector<MChain> primary_chains(const rawdtw_mapper *m, std::vector<MChain> &
 {
     std::vector<MChain> out;
     if (post.empty()) return out;
-    std::vector<rawdtw_chain_t> rec(post.size());
+    static thread_local std::vector<rawdtw_chain_t> rec; // (scratch of the pool's threads: a round calls this once a read)
+    static thread_local std::vector<uint32_t> kept;
+    rec.resize(post.size()); kept.resize(post.size());
     for (size_t k = 0; k < post.size(); k++) rec[k] = record_of(post[k], (uint32_t)k);
-    std::vector<uint32_t> kept(post.size());
     const rawdtw_select_opt_t so = select_opt(m);
     const uint32_t nk = rawdtw_gen_primary_chains(rec.data(), (uint32_t)rec.size(), &so, kept.data());
+    out.reserve(nk);
     for (uint32_t k = 0; k < nk; k++) out.push_back(std::move(post[rec[kept[k]].tag]));
     if (nk) out[0].mapq = rec[kept[0]].mapq;
     return out;
@@ -315,7 +317,8 @@ std::vector<MChain> primary_chains(const rawdtw_mapper *m, std::vector<MChain> &
 bool high_confidence(const rawdtw_mapper *m, const std::vector<MChain> &primary)
 {
     if (primary.empty()) return false;
-    std::vector<rawdtw_chain_t> rec(primary.size());
+    static thread_local std::vector<rawdtw_chain_t> rec;
+    rec.resize(primary.size());
     for (size_t k = 0; k < primary.size(); k++) rec[k] = record_of(primary[k], (uint32_t)k);
     const rawdtw_select_opt_t so = select_opt(m);
     return rawdtw_is_mapped_with_high_confidence(rec.data(), (uint32_t)rec.size(), &so) != 0;
@@ -929,6 +932,7 @@ int rawdtw_mapper_round(rawdtw_mapper *m, uint32_t n_reads, const uint32_t *read
             MRead &rd = m->reads[read_ids[k]];
             if (r.skipped) { r.high = high_confidence(m, rd.chains); return; } // rmap.cpp:569-572: the chains stay as they were
             std::vector<MChain> post;
+            post.reserve(r.chains.size());
             for (size_t c = 0; c < r.chains.size(); c++) {
                 MChain &ch = r.chains[c];
                 bool keep = true;
