@@ -351,13 +351,26 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
     pins = Pinned(lib)
     ev_pin = pins.empty(int(np.diff(ev_off).max()) * n_reads + 1, np.float32)  # (a round's events: at most one chunk a read)
 
-    def run(cm, reads, label, warm=True):
+    def run(cm, reads, label, warm=True, measured=2):
         # the same reads twice untimed on the same mapper (its pinned buffers, the contexts' workspaces and the allocator's arenas reach their
-        # sizes: the second pass over a fresh mapper still read 1.5 x the third), then released
-        for _ in range(2 if warm else 0):
+        # sizes: the second pass over a fresh mapper still read 1.5 x the third), then released; then `measured` timed passes, of which the
+        # faster counts (the box's host cores are shared with other boxes: a pass now and then reads half as fast) -- for every flow alike, the
+        # cpu_baseline included; the passes' lines must be the same lines
+        for _ in range(2 if warm is True else 0):
             w = run(cm, reads, label, warm=False)
             for i in w.pop("ids"):
                 cm.release_read(int(i))
+        if warm is True:
+            best = None
+            for _ in range(max(measured, 1)):
+                r = run(cm, reads, label, warm="timed")
+                for i in r.pop("ids"):
+                    cm.release_read(int(i))
+                assert best is None or best["paf_sha1"] == r["paf_sha1"]
+                if best is None or r["seconds_in_rounds"] < best["seconds_in_rounds"]:
+                    best = r
+            best["timed_passes"] = measured
+            return best
         ids = np.array([cm.add_read("read_%d" % r, int(sc["qlen"][r]), int(nch[r])) for r in reads], np.uint32)
         tm0, st0 = cm.timing(), cm.stats()
         done = np.zeros(len(reads), np.int64)
@@ -397,7 +410,7 @@ def mapper_block(lib, ref, local_rank, n_reads, threads, cpu_seconds, with_cpu):
         h = hashlib.sha1("\n".join(lines).encode()).hexdigest()
         tm = {k: v - tm0[k] for k, v in cm.timing().items()}
         rounds, scored, reused = (a - b for a, b in zip(cm.stats(), st0))
-        return {"label": label, "reads": int(len(reads)), "mapped_reads": mapped, "rounds": n_rounds, "read_rounds": read_rounds,
+        return {"ids": ids, "label": label, "reads": int(len(reads)), "mapped_reads": mapped, "rounds": n_rounds, "read_rounds": read_rounds,
                 "seconds_in_rounds": round(t_rounds, 4), "reads_per_s": len(reads) / t_rounds, "mapped_reads_per_s": mapped / t_rounds,
                 "read_rounds_per_s": read_rounds / t_rounds, "parts_scored": scored, "parts_reused": reused,
                 "ms_per_round": {k: round(v / max(n_rounds, 1), 3) for k, v in tm.items() if k.endswith("_ms")},
